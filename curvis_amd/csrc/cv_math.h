@@ -1,0 +1,557 @@
+/* cv_math.h -- deterministic double-precision elementary functions shared by the
+ * gfx950 kernels (device) and the host-side code of curvis_amd.
+ *
+ * Why this exists
+ * ---------------
+ * The reference (fragarriss/CurVis, single-threaded Rust) calls f64::sin / cos /
+ * acos / atan / atan2 / ln (src/metrics.rs:68,257,262,470,481; src/algebra.rs:130-131;
+ * src/systems.rs:221,252), which lower to whatever libm the platform provides.
+ * Their last-bit behaviour is therefore platform-defined.  A null geodesic is
+ * integrated with ~2000 dependent Euler steps, so a GPU renderer can only be
+ * compared bit-for-bit with a CPU restatement if both sides evaluate *the same*
+ * sequence of IEEE-754 operations.  This header is that sequence: every function
+ * below is written with explicit, individually rounded +,-,*,/ and fma() only
+ * (compile with -ffp-contract=off), integer bit manipulation, and no table
+ * lookups that depend on the platform.  The same source compiled by gcc for
+ * x86-64 (with hardware FMA) and by hipcc for gfx950 returns bit-identical
+ * results; tests/test_cv_math.py checks that on the GPU and checks the accuracy
+ * (< 1 ulp) against mpmath.
+ *
+ * Algorithms: argument reduction and polynomial/rational kernels follow the
+ * classical Sun fdlibm / FreeBSD msun designs (Cody-Waite pi/2 split in 33-bit
+ * pieces, K.C. Ng's kernels; coefficients are the published minimax values),
+ * evaluated here with fma-Horner; huge-argument reduction is a 192-bit integer
+ * Payne-Hanek written for 64-bit multiplies (v_mul_hi_u32 pairs on gfx950).
+ *
+ * The header is C99 / C++ / HIP clean.  All functions are `static inline`.
+ */
+#ifndef CURVIS_CV_MATH_H
+#define CURVIS_CV_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define CV_HD __host__ __device__ static inline
+#else
+#define CV_HD static inline
+#endif
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#elif defined(__GNUC__)
+#pragma GCC optimize("fp-contract=off")
+#endif
+
+#define CV_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define CV_FABS(a) __builtin_fabs((a))
+#define CV_SQRT(a) __builtin_sqrt((a))
+#define CV_RINT(a) __builtin_rint((a))
+
+#define CV_PI 3.14159265358979311600e+00 /* 0x400921FB54442D18 = Rust std::f64::consts::PI */
+
+CV_HD uint64_t cv_bits(double x) {
+  uint64_t u;
+  __builtin_memcpy(&u, &x, sizeof u);
+  return u;
+}
+CV_HD double cv_from_bits(uint64_t u) {
+  double x;
+  __builtin_memcpy(&x, &u, sizeof x);
+  return x;
+}
+CV_HD uint32_t cv_hi(double x) { return (uint32_t)(cv_bits(x) >> 32); }
+CV_HD uint32_t cv_lo(double x) { return (uint32_t)cv_bits(x); }
+CV_HD double cv_with_hi(double x, uint32_t hi) {
+  return cv_from_bits(((uint64_t)hi << 32) | (cv_bits(x) & 0xffffffffULL));
+}
+CV_HD double cv_copysign(double mag, double sgn) {
+  return cv_from_bits((cv_bits(mag) & 0x7fffffffffffffffULL) | (cv_bits(sgn) & 0x8000000000000000ULL));
+}
+
+/* 64x64 -> 128 multiply pieces */
+CV_HD uint64_t cv_mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * (unsigned __int128)b) >> 64);
+#endif
+}
+CV_HD int cv_clz64(uint64_t a) { /* a != 0 */
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __clzll((long long)a);
+#else
+  return __builtin_clzll(a);
+#endif
+}
+
+/* ------------------------------------------------------------------------- */
+/* sin / cos                                                                  */
+/* ------------------------------------------------------------------------- */
+
+/* sin on [-pi/4, pi/4] of the head/tail pair x+y  (|y| <= ulp(x)/2). */
+CV_HD double cv_ksin(double x, double y) {
+  const double S1 = -1.66666666666666324348e-01, /* 0xBFC5555555555549 */
+      S2 = 8.33333333332248946124e-03,           /* 0x3F8111111110F8A6 */
+      S3 = -1.98412698298579493134e-04,          /* 0xBF2A01A019C161D5 */
+      S4 = 2.75573137070700676789e-06,           /* 0x3EC71DE357B1FE7D */
+      S5 = -2.50507602534068634195e-08,          /* 0xBE5AE5E68A2B9CEB */
+      S6 = 1.58969099521155010221e-10;           /* 0x3DE5D93A5ACFD57C */
+  double z = x * x;
+  double v = z * x;
+  double r = CV_FMA(z, CV_FMA(z, CV_FMA(z, CV_FMA(z, S6, S5), S4), S3), S2);
+  /* x - ((z*(y/2 - v*r) - y) - v*S1) */
+  double t = CV_FMA(-v, r, 0.5 * y);
+  double u = CV_FMA(z, t, -y);
+  return x - CV_FMA(-v, S1, u);
+}
+
+/* cos on [-pi/4, pi/4] of the head/tail pair x+y. */
+CV_HD double cv_kcos(double x, double y) {
+  const double C1 = 4.16666666666666019037e-02, /* 0x3FA555555555554C */
+      C2 = -1.38888888888741095749e-03,         /* 0xBF56C16C16C15177 */
+      C3 = 2.48015872894767294178e-05,          /* 0x3EFA01A019CB1590 */
+      C4 = -2.75573143513906633035e-07,         /* 0xBE927E4F809C52AD */
+      C5 = 2.08757232129817482790e-09,          /* 0x3E21EE9EBDB4B1C4 */
+      C6 = -1.13596475577881948265e-11;         /* 0xBDA8FAE9BE8838D4 */
+  double z = x * x;
+  double r = z * CV_FMA(z, CV_FMA(z, CV_FMA(z, CV_FMA(z, CV_FMA(z, C6, C5), C4), C3), C2), C1);
+  double hz = 0.5 * z;
+  double w = 1.0 - hz;
+  /* w + (((1-w)-hz) + (z*r - x*y)) */
+  double e = CV_FMA(z, r, -(x * y));
+  return w + (((1.0 - w) - hz) + e);
+}
+
+/* 2/pi: 64 zero bits, then 1216 fractional bits (tools/gen_math_tables.py). */
+#if defined(__HIPCC__) || defined(__HIP__)
+__device__ __constant__ static const uint64_t cv_two_over_pi_dev[20] = {
+    0x0000000000000000ULL, 0xA2F9836E4E441529ULL, 0xFC2757D1F534DDC0ULL, 0xDB6295993C439041ULL,
+    0xFE5163ABDEBBC561ULL, 0xB7246E3A424DD2E0ULL, 0x06492EEA09D1921CULL, 0xFE1DEB1CB129A73EULL,
+    0xE88235F52EBB4484ULL, 0xE99C7026B45F7E41ULL, 0x3991D639835339F4ULL, 0x9C845F8BBDF9283BULL,
+    0x1FF897FFDE05980FULL, 0xEF2F118B5A0A6D1FULL, 0x6D367ECF27CB09B7ULL, 0x4F463F669E5FEA2DULL,
+    0x7527BAC7EBE5F17BULL, 0x3D0739F78A5292EAULL, 0x6BFB5FB11F8D5D08ULL, 0x56033046FC7B6BABULL};
+#endif
+static const uint64_t cv_two_over_pi_host[20] = {
+    0x0000000000000000ULL, 0xA2F9836E4E441529ULL, 0xFC2757D1F534DDC0ULL, 0xDB6295993C439041ULL,
+    0xFE5163ABDEBBC561ULL, 0xB7246E3A424DD2E0ULL, 0x06492EEA09D1921CULL, 0xFE1DEB1CB129A73EULL,
+    0xE88235F52EBB4484ULL, 0xE99C7026B45F7E41ULL, 0x3991D639835339F4ULL, 0x9C845F8BBDF9283BULL,
+    0x1FF897FFDE05980FULL, 0xEF2F118B5A0A6D1FULL, 0x6D367ECF27CB09B7ULL, 0x4F463F669E5FEA2DULL,
+    0x7527BAC7EBE5F17BULL, 0x3D0739F78A5292EAULL, 0x6BFB5FB11F8D5D08ULL, 0x56033046FC7B6BABULL};
+
+CV_HD uint64_t cv_two_over_pi_word(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return cv_two_over_pi_dev[i];
+#else
+  return cv_two_over_pi_host[i];
+#endif
+}
+
+/* Payne-Hanek for finite |x| >= 2^20: returns quadrant (mod 4) and y0+y1 = x - n*pi/2,
+ * |y0| <= pi/4 (+ rounding).  Pure 64-bit integer arithmetic up to the final
+ * conversion, so host and device agree bit for bit. */
+CV_HD int cv_rem_pio2_large(double x, double *y0, double *y1) {
+  const uint64_t ux = cv_bits(x);
+  const int neg = (int)(ux >> 63);
+  const int bexp = (int)((ux >> 52) & 0x7ff);
+  const uint64_t M = (ux & 0x000fffffffffffffULL) | 0x0010000000000000ULL; /* 53-bit integer */
+  const int E = bexp - 1075;                                             /* |x| = M * 2^E, E >= -32 here */
+  /* window of 192 bits of 2/pi starting at fractional bit k0 = E-1 (bits k <= 0 are zero);
+   * table bit index i <-> k = i - 63 */
+  const int i0 = E + 62;
+  const int wd = i0 >> 6, off = i0 & 63;
+  uint64_t t0 = cv_two_over_pi_word(wd), t1 = cv_two_over_pi_word(wd + 1), t2 = cv_two_over_pi_word(wd + 2),
+           t3 = cv_two_over_pi_word(wd + 3);
+  uint64_t w0, w1, w2;
+  if (off) {
+    w0 = (t0 << off) | (t1 >> (64 - off));
+    w1 = (t1 << off) | (t2 >> (64 - off));
+    w2 = (t2 << off) | (t3 >> (64 - off));
+  } else {
+    w0 = t0;
+    w1 = t1;
+    w2 = t2;
+  }
+  /* P = M * (w0:w1:w2) mod 2^192, value = P * 2^-190 quarter turns */
+  uint64_t p3 = M * w2;
+  uint64_t h2 = cv_mulhi64(M, w2);
+  uint64_t l1 = M * w1;
+  uint64_t h1 = cv_mulhi64(M, w1);
+  uint64_t l0 = M * w0;
+  uint64_t p2 = l1 + h2;
+  uint64_t c1 = (p2 < l1) ? 1u : 0u;
+  uint64_t p1 = l0 + h1 + c1;
+  int q = (int)(p1 >> 62);
+  /* fraction aligned to the top of a 192-bit word */
+  uint64_t A = (p1 << 2) | (p2 >> 62);
+  uint64_t B = (p2 << 2) | (p3 >> 62);
+  uint64_t C = (p3 << 2);
+  int fneg = 0;
+  if (A >> 63) { /* fraction >= 1/2: round to nearest integer, fraction becomes negative */
+    q += 1;
+    fneg = 1;
+    /* two's complement of A:B:C */
+    C = ~C + 1;
+    uint64_t cb = (C == 0) ? 1u : 0u;
+    B = ~B + cb;
+    uint64_t ca = (cb && B == 0) ? 1u : 0u;
+    A = ~A + ca;
+  }
+  /* normalise the magnitude A:B:C / 2^192 */
+  int sh = 0;
+  if (A == 0) {
+    A = B;
+    B = C;
+    C = 0;
+    sh = 64;
+  }
+  double fh, fl;
+  if (A == 0) {
+    fh = 0.0;
+    fl = 0.0;
+  } else {
+    int lz = cv_clz64(A);
+    if (lz) {
+      A = (A << lz) | (B >> (64 - lz));
+      B = (B << lz) | (C >> (64 - lz));
+    }
+    sh += lz;
+    /* top 53 bits -> fh, next 53 bits -> fl */
+    uint64_t hi53 = A >> 11;
+    uint64_t lo53 = ((A & 0x7ffULL) << 42) | (B >> 22);
+    double sc_h = cv_from_bits((uint64_t)(1023 - 53 - sh) << 52);  /* 2^(-53-sh) */
+    double sc_l = cv_from_bits((uint64_t)(1023 - 106 - sh) << 52); /* 2^(-106-sh) */
+    fh = (double)hi53 * sc_h;
+    fl = (double)lo53 * sc_l;
+  }
+  /* (fh+fl) * pi/2 */
+  const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+  double r0 = fh * PIO2_HI;
+  double e0 = CV_FMA(fh, PIO2_HI, -r0);
+  double r1 = e0 + CV_FMA(fh, PIO2_LO, fl * PIO2_HI);
+  if (fneg) {
+    r0 = -r0;
+    r1 = -r1;
+  }
+  if (neg) {
+    q = -q;
+    r0 = -r0;
+    r1 = -r1;
+  }
+  *y0 = r0;
+  *y1 = r1;
+  return q & 3;
+}
+
+/* x - n*pi/2 as head/tail; returns n mod 4.  x finite, |x| > pi/4. */
+CV_HD int cv_rem_pio2(double x, double *y0, double *y1) {
+  const double INVPIO2 = 6.36619772367581382433e-01, /* 0x3FE45F306DC9C883 */
+      PIO2_1 = 1.57079632673412561417e+00,           /* 0x3FF921FB54400000: first 33 bits of pi/2 */
+      PIO2_1T = 6.07710050650619224932e-11,          /* 0x3DD0B4611A626331: pi/2 - PIO2_1 */
+      PIO2_2 = 6.07710050630396597660e-11,           /* 0x3DD0B4611A600000: second 33 bits */
+      PIO2_2T = 2.02226624879595063154e-21,          /* 0x3BA3198A2E037073 */
+      PIO2_3 = 2.02226624871116645580e-21,           /* 0x3BA3198A2E000000: third 33 bits */
+      PIO2_3T = 8.47842766036889956997e-32;          /* 0x397B839A252049C1 */
+  const uint32_t ix = cv_hi(x) & 0x7fffffffu;
+  if (ix >= 0x41300000u) /* |x| >= 2^20 */
+    return cv_rem_pio2_large(x, y0, y1);
+  double fn = CV_RINT(x * INVPIO2);
+  double r = CV_FMA(-fn, PIO2_1, x); /* fn*PIO2_1 is exact (33+20 bits) */
+  double w = fn * PIO2_1T;
+  double a = r - w;
+  int ediff = (int)(ix >> 20) - (int)((cv_hi(a) >> 20) & 0x7ff);
+  if (ediff > 16) { /* 2nd iteration: good to 118 bits */
+    double t = r;
+    w = fn * PIO2_2;
+    r = t - w;
+    w = CV_FMA(fn, PIO2_2T, -((t - r) - w));
+    a = r - w;
+    ediff = (int)(ix >> 20) - (int)((cv_hi(a) >> 20) & 0x7ff);
+    if (ediff > 49) { /* 3rd iteration: 151 bits, covers every double */
+      t = r;
+      w = fn * PIO2_3;
+      r = t - w;
+      w = CV_FMA(fn, PIO2_3T, -((t - r) - w));
+      a = r - w;
+    }
+  }
+  *y0 = a;
+  *y1 = (r - a) - w;
+  return ((int)fn) & 3;
+}
+
+CV_HD void cv_sincos(double x, double *sn, double *cs) {
+  const uint32_t ix = cv_hi(x) & 0x7fffffffu;
+  if (ix <= 0x3fe921fbu) { /* |x| <= ~pi/4 */
+    *sn = cv_ksin(x, 0.0);
+    *cs = cv_kcos(x, 0.0);
+    return;
+  }
+  if (ix >= 0x7ff00000u) { /* inf / nan */
+    *sn = *cs = x - x;
+    return;
+  }
+  double y0, y1;
+  int n = cv_rem_pio2(x, &y0, &y1);
+  double s = cv_ksin(y0, y1);
+  double c = cv_kcos(y0, y1);
+  double so = (n & 1) ? c : s;
+  double co = (n & 1) ? s : c;
+  if (n & 2) so = -so;
+  if ((n + 1) & 2) co = -co;
+  *sn = so;
+  *cs = co;
+}
+
+CV_HD double cv_sin(double x) {
+  double s, c;
+  cv_sincos(x, &s, &c);
+  return s;
+}
+CV_HD double cv_cos(double x) {
+  double s, c;
+  cv_sincos(x, &s, &c);
+  return c;
+}
+
+/* ------------------------------------------------------------------------- */
+/* atan / atan2                                                               */
+/* ------------------------------------------------------------------------- */
+
+CV_HD double cv_atan(double x) {
+  const double aT0 = 3.33333333333329318027e-01, /* 0x3FD555555555550D */
+      aT1 = -1.99999999998764832476e-01,         /* 0xBFC999999998EBC4 */
+      aT2 = 1.42857142725034663711e-01,          /* 0x3FC24924920083FF */
+      aT3 = -1.11111104054623557880e-01,         /* 0xBFBC71C6FE231671 */
+      aT4 = 9.09088713343650656196e-02,          /* 0x3FB745CDC54C206E */
+      aT5 = -7.69187620504482999495e-02,         /* 0xBFB3B0F2AF749A6D */
+      aT6 = 6.66107313738753120669e-02,          /* 0x3FB10D66A0D03D51 */
+      aT7 = -5.83357013379057348645e-02,         /* 0xBFADDE2D52DEFD9A */
+      aT8 = 4.97687799461593236017e-02,          /* 0x3FA97B4B24760DEB */
+      aT9 = -3.65315727442169155270e-02,         /* 0xBFA2B4442C6A6C2F */
+      aT10 = 1.62858201153657823623e-02;         /* 0x3F90AD3AE322DA11 */
+  const uint32_t hx = cv_hi(x);
+  const uint32_t ix = hx & 0x7fffffffu;
+  const int neg = (int)(hx >> 31);
+  if (ix >= 0x44100000u) { /* |x| >= 2^66 */
+    if (ix > 0x7ff00000u || (ix == 0x7ff00000u && cv_lo(x) != 0)) return x + x; /* nan */
+    double z = 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
+    return neg ? -z : z;
+  }
+  double hi = 0.0, lo = 0.0, t;
+  int id = -1;
+  if (ix < 0x3fdc0000u) { /* |x| < 0.4375 */
+    if (ix < 0x3e400000u) return x; /* |x| < 2^-27 */
+    t = x;
+  } else {
+    double ax = CV_FABS(x);
+    double num, den;
+    if (ix < 0x3ff30000u) {   /* |x| < 1.1875 */
+      if (ix < 0x3fe60000u) { /* 7/16 <= |x| < 11/16 */
+        id = 0;
+        num = CV_FMA(2.0, ax, -1.0);
+        den = 2.0 + ax;
+        hi = 4.63647609000806093515e-01;
+        lo = 2.26987774529616870924e-17;
+      } else { /* 11/16 <= |x| < 19/16 */
+        id = 1;
+        num = ax - 1.0;
+        den = ax + 1.0;
+        hi = 7.85398163397448278999e-01;
+        lo = 3.06161699786838301793e-17;
+      }
+    } else {
+      if (ix < 0x40038000u) { /* |x| < 2.4375 */
+        id = 2;
+        num = ax - 1.5;
+        den = CV_FMA(1.5, ax, 1.0);
+        hi = 9.82793723247329054082e-01;
+        lo = 1.39033110312309984516e-17;
+      } else { /* 2.4375 <= |x| < 2^66 */
+        id = 3;
+        num = -1.0;
+        den = ax;
+        hi = 1.57079632679489655800e+00;
+        lo = 6.12323399573676603587e-17;
+      }
+    }
+    t = num / den;
+  }
+  double z = t * t;
+  double w = z * z;
+  double s1 = z * CV_FMA(w, CV_FMA(w, CV_FMA(w, CV_FMA(w, CV_FMA(w, aT10, aT8), aT6), aT4), aT2), aT0);
+  double s2 = w * CV_FMA(w, CV_FMA(w, CV_FMA(w, CV_FMA(w, aT9, aT7), aT5), aT3), aT1);
+  if (id < 0) return t - t * (s1 + s2);
+  double r = hi - ((t * (s1 + s2) - lo) - t);
+  return neg ? -r : r;
+}
+
+CV_HD double cv_atan2(double y, double x) {
+  const double PI_LO = 1.2246467991473531772E-16; /* 0x3CA1A62633145C07 */
+  const double PI_O_4 = 7.8539816339744827900E-01, PI_O_2 = 1.5707963267948965580E+00;
+  const double TINY = 1.0e-300;
+  const uint32_t hx = cv_hi(x), lx = cv_lo(x), hy = cv_hi(y), ly = cv_lo(y);
+  const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+  if (ix > 0x7ff00000u || (ix == 0x7ff00000u && lx != 0) || iy > 0x7ff00000u || (iy == 0x7ff00000u && ly != 0))
+    return x + y;                                        /* nan */
+  if (hx == 0x3ff00000u && lx == 0) return cv_atan(y);   /* x == 1 */
+  const int m = (int)((hy >> 31) & 1) | (int)((hx >> 30) & 2); /* 2*sign(x) + sign(y) */
+  if ((iy | ly) == 0) { /* y == 0 */
+    switch (m) {
+      case 0:
+      case 1:
+        return y;
+      case 2:
+        return CV_PI + TINY;
+      default:
+        return -CV_PI - TINY;
+    }
+  }
+  if ((ix | lx) == 0) return (hy >> 31) ? -PI_O_2 - TINY : PI_O_2 + TINY; /* x == 0 */
+  if (ix == 0x7ff00000u) { /* x inf */
+    if (iy == 0x7ff00000u) {
+      switch (m) {
+        case 0:
+          return PI_O_4 + TINY;
+        case 1:
+          return -PI_O_4 - TINY;
+        case 2:
+          return 3.0 * PI_O_4 + TINY;
+        default:
+          return -3.0 * PI_O_4 - TINY;
+      }
+    } else {
+      switch (m) {
+        case 0:
+          return 0.0;
+        case 1:
+          return -0.0;
+        case 2:
+          return CV_PI + TINY;
+        default:
+          return -CV_PI - TINY;
+      }
+    }
+  }
+  if (iy == 0x7ff00000u) return (hy >> 31) ? -PI_O_2 - TINY : PI_O_2 + TINY; /* y inf */
+  const int k = (int)(iy >> 20) - (int)(ix >> 20);
+  double z;
+  if (k > 60) { /* |y/x| > 2^60 */
+    z = PI_O_2 + 0.5 * PI_LO;
+  } else if ((hx >> 31) && k < -60) {
+    z = 0.0; /* |y|/x < -2^-60 with x < 0 */
+  } else {
+    z = cv_atan(CV_FABS(y / x));
+  }
+  switch (m) {
+    case 0:
+      return z;
+    case 1:
+      return -z;
+    case 2:
+      return CV_PI - (z - PI_LO);
+    default:
+      return (z - PI_LO) - CV_PI;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* acos                                                                       */
+/* ------------------------------------------------------------------------- */
+
+CV_HD double cv_acos_R(double z) { /* (asin(x)-x)/x^3 as p(z)/q(z), z = x^2 */
+  const double pS0 = 1.66666666666666657415e-01, /* 0x3FC5555555555555 */
+      pS1 = -3.25565818622400915405e-01,         /* 0xBFD4D61203EB6F7D */
+      pS2 = 2.01212532134862925881e-01,          /* 0x3FC9C1550E884455 */
+      pS3 = -4.00555345006794114027e-02,         /* 0xBFA48228B5688F3B */
+      pS4 = 7.91534994289814532176e-04,          /* 0x3F49EFE07501B288 */
+      pS5 = 3.47933107596021167570e-05,          /* 0x3F023DE10DFDF709 */
+      qS1 = -2.40339491173441421878e+00,         /* 0xC0033A271C8A2D4B */
+      qS2 = 2.02094576023350569471e+00,          /* 0x40002AE59C598AC8 */
+      qS3 = -6.88283971605453293030e-01,         /* 0xBFE6066C1B8D0159 */
+      qS4 = 7.70381505559019352791e-02;          /* 0x3FB3B8C5B12E9282 */
+  double p = z * CV_FMA(z, CV_FMA(z, CV_FMA(z, CV_FMA(z, CV_FMA(z, pS5, pS4), pS3), pS2), pS1), pS0);
+  double q = CV_FMA(z, CV_FMA(z, CV_FMA(z, CV_FMA(z, qS4, qS3), qS2), qS1), 1.0);
+  return p / q;
+}
+
+CV_HD double cv_acos(double x) {
+  const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+  const uint32_t hx = cv_hi(x);
+  const uint32_t ix = hx & 0x7fffffffu;
+  if (ix >= 0x3ff00000u) { /* |x| >= 1 */
+    if (((ix - 0x3ff00000u) | cv_lo(x)) == 0) {
+      if (hx >> 31) return 2.0 * PIO2_HI + 2.0 * PIO2_LO; /* acos(-1) = pi */
+      return 0.0;                                         /* acos(1) = 0 */
+    }
+    return (x - x) / (x - x); /* |x| > 1 or nan: NaN */
+  }
+  if (ix < 0x3fe00000u) {                                 /* |x| < 0.5 */
+    if (ix <= 0x3c600000u) return PIO2_HI + PIO2_LO;      /* |x| < 2^-57 */
+    double r = cv_acos_R(x * x);
+    return PIO2_HI - (x - (PIO2_LO - x * r));
+  }
+  if (hx >> 31) { /* x < -0.5 */
+    double z = (1.0 + x) * 0.5;
+    double s = CV_SQRT(z);
+    double r = cv_acos_R(z);
+    double w = CV_FMA(r, s, -PIO2_LO);
+    return CV_PI - 2.0 * (s + w);
+  }
+  /* x > 0.5 */
+  double z = (1.0 - x) * 0.5;
+  double s = CV_SQRT(z);
+  double df = cv_from_bits(cv_bits(s) & 0xffffffff00000000ULL);
+  double c = CV_FMA(-df, df, z) / (s + df);
+  double r = cv_acos_R(z);
+  double w = CV_FMA(r, s, c);
+  return 2.0 * (df + w);
+}
+
+/* ------------------------------------------------------------------------- */
+/* natural logarithm                                                          */
+/* ------------------------------------------------------------------------- */
+
+CV_HD double cv_log(double x) {
+  const double LN2_HI = 6.93147180369123816490e-01, /* 0x3FE62E42FEE00000 */
+      LN2_LO = 1.90821492927058770002e-10,          /* 0x3DEA39EF35793C76 */
+      Lg1 = 6.666666666666735130e-01,               /* 0x3FE5555555555593 */
+      Lg2 = 3.999999999940941908e-01,               /* 0x3FD999999997FA04 */
+      Lg3 = 2.857142874366239149e-01,               /* 0x3FD2492494229359 */
+      Lg4 = 2.222219843214978396e-01,               /* 0x3FCC71C51D8E78AF */
+      Lg5 = 1.818357216161805012e-01,               /* 0x3FC7466496CB03DE */
+      Lg6 = 1.531383769920937332e-01,               /* 0x3FC39A09D078C69F */
+      Lg7 = 1.479819860511658591e-01;               /* 0x3FC2F112DF3E5244 */
+  uint64_t ux = cv_bits(x);
+  uint32_t hx = (uint32_t)(ux >> 32);
+  int k = 0;
+  if (hx < 0x00100000u || (hx >> 31)) {          /* x < 2^-1022, zero, or negative */
+    if ((ux << 1) == 0) return -1.0 / (x * x);   /* log(+-0) = -inf */
+    if (hx >> 31) return (x - x) / 0.0;          /* log(-#) = NaN */
+    k -= 54;
+    x *= 1.80143985094819840000e+16; /* 2^54: scale up subnormal */
+    ux = cv_bits(x);
+    hx = (uint32_t)(ux >> 32);
+  } else if (hx >= 0x7ff00000u) {
+    return x + x; /* inf or nan */
+  } else if (hx == 0x3ff00000u && (uint32_t)ux == 0) {
+    return 0.0; /* log(1) = +0 */
+  }
+  /* reduce x into [sqrt(2)/2, sqrt(2)) */
+  hx += 0x3ff00000u - 0x3fe6a09eu;
+  k += (int)(hx >> 20) - 0x3ff;
+  hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+  x = cv_from_bits(((uint64_t)hx << 32) | (ux & 0xffffffffULL));
+  double f = x - 1.0;
+  double hfsq = 0.5 * f * f;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double w = z * z;
+  double t1 = w * CV_FMA(w, CV_FMA(w, Lg6, Lg4), Lg2);
+  double t2 = z * CV_FMA(w, CV_FMA(w, CV_FMA(w, Lg7, Lg5), Lg3), Lg1);
+  double R = t2 + t1;
+  double dk = (double)k;
+  /* s*(hfsq+R) + dk*ln2_lo - hfsq + f + dk*ln2_hi */
+  return CV_FMA(s, hfsq + R, dk * LN2_LO) - hfsq + f + dk * LN2_HI;
+}
+
+#endif /* CURVIS_CV_MATH_H */
