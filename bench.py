@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the per-pixel geodesic hot path on MI355X.
+
+A "step" is one pass of the hot path over one frame of BASELINE.json configs[1]:
+Ellis wormhole (rho = 1), 1920x1080, cap 4096 Euler steps, default camera (l = 5, theta = pi/2,
+focal 15, diagonal 43), escape radius 100, delta 0.05, two procedural 8192x4096 RGBA8 skies
+resident in HBM.  The frame stays in HBM (no D2H inside the timed region).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 every rank renders its own K frames (video frames are independent: weak scaling, no
+data-path collective); the only communication is the RCCL broadcast of the two sky textures from
+rank 0 before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_STEP = {"ellis": 35, "interstellar": 46}   # live FP64 flop per Euler step
+FP64_VECTOR_PEAK_TFLOPS = 78.6                      # MI355X vector FP64 (spec), MFMA not applicable
+HBM_PEAK_GBPS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
+ALGO_BYTES_PER_RAY = 7                              # 3 B RGB8 store + 4 B sky texel
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--max-iter", type=int, default=4096)
+    ap.add_argument("--metric", default="ellis", choices=["ellis", "interstellar"])
+    ap.add_argument("--sky", type=int, default=8192, help="sky width (height = width/2)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--refill-threshold", type=int, default=None)
+    ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-step", type=int, default=16)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch  # device memory / streams / torch.distributed plumbing only
+    import curvis_amd
+    from curvis_amd import skies
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = curvis_amd.Context(local_rank)
+    ctx.set_option("variant", args.variant)
+    if args.refill_threshold is not None:
+        ctx.set_option("refill_threshold", args.refill_threshold)
+    if args.blocks_per_cu is not None:
+        ctx.set_option("blocks_per_cu", args.blocks_per_cu)
+
+    # ---- inputs resident in HBM before the timed region: two skies (rank 0 generates, RCCL broadcast)
+    sw, sh = args.sky, args.sky // 2
+    host_skies = None
+    if rank == 0:
+        host_skies = (skies.smooth(sw, sh, 128), skies.smooth(sw, sh, 32))
+    sky_dev = []
+    for which in range(2):
+        if world > 1:
+            t = torch.empty((sh, sw, 4), dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                t.copy_(torch.from_numpy(host_skies[which]))
+            dist.broadcast(t, src=0)  # RCCL over xGMI, w*h*4 bytes
+            torch.cuda.synchronize()
+            ctx.set_sky_device(which, t.data_ptr(), sw, sh, copy=False)
+            sky_dev.append(t)  # keep alive
+        else:
+            ctx.set_sky(which, curvis_amd.SphericalImage(host_skies[which]))
+
+    if args.metric == "ellis":
+        metric = curvis_amd.EllisMetric(1.0)
+    else:
+        metric = curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0)
+    cam = curvis_amd.Camera((0.0, 5.0, np.pi / 2, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 15.0, 43.0,
+                            args.width, args.height)
+    R, DELTA = 100.0, 0.05
+
+    def step():
+        _, st = ctx.render_brute(metric, cam, args.max_iter, R, DELTA, download=False)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    steps_executed = 0
+    rays = 0
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        st = step()
+        steps_executed += st.steps
+        rays += st.rays
+        kernel_ms += st.kernel_ms  # HIP events on the context's own stream, inside the C ABI
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        agg = torch.tensor([float(steps_executed), float(rays), kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        total_steps, total_rays, total_kernel_ms = [float(v) for v in agg.tolist()]
+    else:
+        total_steps, total_rays, total_kernel_ms = float(steps_executed), float(rays), kernel_ms
+
+    if rank == 0:
+        n_launches = args.steps * world
+        kernel_s = total_kernel_ms / 1e3 / n_launches            # average launch duration
+        per_launch_steps = total_steps / n_launches
+        per_launch_rays = total_rays / n_launches
+        flop = FLOP_PER_STEP[args.metric]
+        achieved_tflops = per_launch_steps * flop / kernel_s / 1e12
+        hbm_gbps = per_launch_rays * ALGO_BYTES_PER_RAY / kernel_s / 1e9
+        value = total_steps / elapsed / 1e6
+        nominal = total_rays * args.max_iter / elapsed / 1e6
+        info = ctx.device_info()
+        out = {
+            "metric": "Mrays/s (pixels x steps/s) at 1920x1080, 4096 steps",
+            "value": round(value, 1),
+            "unit": "Mray-steps/s (executed Euler steps, all GPUs)",
+            "value_nominal_cap": round(nominal, 1),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (procedural 8192x4096 RGBA8 skies, default camera/metric settings)",
+            "config": {
+                "workload": "configs[1]: %s wormhole, %dx%d, cap %d Euler steps, R=100, delta=0.05, single image; "
+                            "%d frame(s)/GPU/step" % (args.metric, args.width, args.height, args.max_iter, 1),
+                "kernel": "geodesic_persistent" if args.variant == 0 else "geodesic_static",
+                "frames_per_gpu": args.steps,
+                "rays_per_frame": int(per_launch_rays),
+                "executed_steps_per_frame": int(per_launch_steps),
+                "device": info["name"],
+                "compute_units": info["compute_units"],
+            },
+            "roofline": {
+                "bound": "fp64-valu",
+                "achieved": round(achieved_tflops, 3),
+                "peak": FP64_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved_tflops / FP64_VECTOR_PEAK_TFLOPS, 4),
+                "flop_per_step": flop,
+                "kernel_ms_avg": round(kernel_s * 1e3, 4),
+                "traffic": None,
+                "hbm": {"achieved": round(hbm_gbps, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(hbm_gbps / HBM_PEAK_GBPS, 8),
+                        "note": "7 B/ray algorithmic; the loop is register-resident, HBM fraction is ~0 by construction"},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, host_skies)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, host_skies):
+    """The oracle (libm flavour = what a Linux build of the single-threaded Rust reference calls), one
+    thread, on every `cpu_row_step`-th row of the same frame.  Checker code used as a timed baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    om = O.ellis(1.0) if args.metric == "ellis" else O.interstellar(0.1, 1e-4, 1.0)
+    oc = O.camera(res=(args.width, args.height))
+    sp, sn = O.sky(host_skies[0]), O.sky(host_skies[1])
+    t0 = time.perf_counter()
+    _, _, st = O.render_image(O.LIBM, om, oc, sp, sn, args.max_iter, 100.0, 0.05, row_begin=0,
+                              row_step=args.cpu_row_step)
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": round(st.steps / dt / 1e6, 2),
+        "unit": "Mray-steps/s (executed)",
+        "cores": 1,
+        "kind": "port",
+        "sample": "every %dth row of the same %dx%d frame: %d rays, %d Euler steps, %.1f s" % (
+            args.cpu_row_step, args.width, args.height, st.rays, st.steps, dt),
+        "host_cpu": model,
+        "host_logical_cpus": os.cpu_count(),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,831 @@
+/* curvis_hip.hip -- gfx950 kernels and C ABI of libcurvis_hip.so (see include/curvis_hip.h).
+ *
+ * Kernels
+ *   geodesic_persistent<KIND,DEBUG>  K1, the hot kernel.  Persistent waves: every lane owns one ray
+ *       (pixel -> photon -> forward-Euler loop -> tangent direction -> nearest sky texel -> RGB8
+ *       store, i.e. rows R1-R10 of SURVEY.md section 8a fused).  When at least `refill_threshold`
+ *       lanes of a wave have terminated (escaped or hit the cap) the wave retires them together and
+ *       refills the free lanes from a global ray queue with ONE wave-aggregated atomic
+ *       (ballot + popcount + mbcnt rank), so lanes never idle behind a slow neighbour (rays orbiting
+ *       the throat run to the cap while their neighbours finish in ~2000 steps) and the grid has
+ *       no tail of half-empty waves until the queue is dry.
+ *   geodesic_static<KIND,DEBUG>      one ray per thread, no refill: A/B baseline for the above.
+ *   selftest_math                    cv_math.h / IEEE div / sqrt on device for bit-equality tests.
+ *
+ * Ray order: rays are numbered by 8x8 pixel tiles (tile-major, then row-major inside the tile) so
+ * the 64 rays a wave draws together are spatial neighbours: similar step counts, neighbouring sky
+ * texels, and a 3-byte store pattern that covers whole 24-byte row segments.
+ *
+ * No MFMA: the loop is a latency/issue-bound chain of FP64 VALU ops (div, sqrt, sincos) on five
+ * registers of state; HBM traffic is 3 B out + 4 B in per ~2000 steps.
+ */
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "../../include/curvis_hip.h"
+#include "cv_device.h"
+#include "cv_host.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+enum { CNT_NEXT = 0, CNT_STEPS, CNT_POS, CNT_NEG, CNT_NONE, CNT_OOB, CNT_RAYS, CNT_N };
+
+struct LaunchParams {
+  cvk::MetricParams metric;
+  cvk::SkyParams sky[2];
+  const cvk::CameraParams *cams; /* device, n_frames entries */
+  unsigned n_frames, W, H, tiles_x, tiles_y;
+  unsigned rays_per_frame;          /* tiles_x*tiles_y*64 (padded to whole tiles) */
+  unsigned long long total_rays;    /* n_frames * rays_per_frame */
+  unsigned max_iter;
+  double max_radius, delta;
+  unsigned char *fb;                /* RGB8, n_frames*H*W*3 */
+  curvis_ray_debug *dbg;            /* n_frames*H*W or null */
+  unsigned long long *counters;     /* CNT_N */
+  int refill_threshold;
+};
+
+struct LaneJob {
+  unsigned frame;
+  unsigned pix; /* py*W + px */
+};
+
+__device__ __forceinline__ bool decode_ray(const LaunchParams &P, unsigned long long id, LaneJob &job, unsigned &px,
+                                           unsigned &py) {
+  const unsigned frame = (unsigned)(id / P.rays_per_frame);
+  const unsigned rem = (unsigned)(id - (unsigned long long)frame * P.rays_per_frame);
+  const unsigned tile = rem >> 6, k = rem & 63u;
+  const unsigned tyi = tile / P.tiles_x, txi = tile - tyi * P.tiles_x;
+  px = txi * 8u + (k & 7u);
+  py = tyi * 8u + (k >> 3);
+  job.frame = frame;
+  job.pix = py * P.W + px;
+  return px < P.W && py < P.H;
+}
+
+struct LaneStats {
+  unsigned long long steps;
+  unsigned rays, pos, neg, none, oob;
+};
+
+/* retire one ray: direction, sky lookup, RGB store, optional debug dump */
+template <int KIND, bool DEBUG>
+__device__ __forceinline__ void retire_ray(const LaunchParams &P, const cvk::Ray &q, int code, unsigned steps,
+                                           const LaneJob &job, LaneStats &st) {
+  unsigned texel = 0xFF000000u; /* Rgba([0,0,0,255]) */
+  unsigned tx = 0, ty = 0;
+  if (code != cvk::CODE_NONE) {
+    double d0, d1, d2;
+    cvk::ray_direction<KIND>(P.metric, q, d0, d1, d2);
+    const cvk::SkyParams &S = P.sky[code == cvk::CODE_POS ? 0 : 1];
+    cvk::sky_indices(S, d0, d1, d2, tx, ty);
+    unsigned cx = tx, cy = ty;
+    if (cx >= S.w || cy >= S.h) st.oob++; /* reference: image::get_pixel panics; defined here: clamp + count */
+    if (cx >= S.w) cx = S.w - 1;
+    if (cy >= S.h) cy = S.h - 1;
+    texel = S.texels[(size_t)cy * S.w + cx];
+  }
+  const size_t o = ((size_t)job.frame * P.W * P.H + job.pix);
+  unsigned char *dst = P.fb + o * 3;
+  dst[0] = (unsigned char)(texel & 0xFF);
+  dst[1] = (unsigned char)((texel >> 8) & 0xFF);
+  dst[2] = (unsigned char)((texel >> 16) & 0xFF);
+  st.steps += steps;
+  st.rays++;
+  st.pos += (code == cvk::CODE_POS);
+  st.neg += (code == cvk::CODE_NEG);
+  st.none += (code == cvk::CODE_NONE);
+  if (DEBUG) {
+    curvis_ray_debug *d = P.dbg + o;
+    d->x[0] = 0.0; /* t and p_t are filled in by the host (dead lanes of the integrator) */
+    d->x[1] = q.l;
+    d->x[2] = q.th;
+    d->x[3] = q.ph;
+    d->p[0] = 1.0;
+    d->p[1] = q.p1;
+    d->p[2] = q.p2;
+    d->p[3] = steps ? q.p3 + 0.0 : q.p3; /* p3 + 0.0*delta of the reference (-0 -> +0) */
+    d->steps = steps;
+    d->code = code;
+    d->tx = tx;
+    d->ty = ty;
+  }
+}
+
+__device__ __forceinline__ void flush_stats(const LaunchParams &P, LaneStats st) {
+  /* wave reduction, then one atomic per counter per wave */
+  for (int off = 32; off > 0; off >>= 1) {
+    st.steps += __shfl_xor(st.steps, off);
+    st.rays += __shfl_xor(st.rays, off);
+    st.pos += __shfl_xor(st.pos, off);
+    st.neg += __shfl_xor(st.neg, off);
+    st.none += __shfl_xor(st.none, off);
+    st.oob += __shfl_xor(st.oob, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&P.counters[CNT_STEPS], st.steps);
+    atomicAdd(&P.counters[CNT_RAYS], (unsigned long long)st.rays);
+    atomicAdd(&P.counters[CNT_POS], (unsigned long long)st.pos);
+    atomicAdd(&P.counters[CNT_NEG], (unsigned long long)st.neg);
+    atomicAdd(&P.counters[CNT_NONE], (unsigned long long)st.none);
+    if (st.oob) atomicAdd(&P.counters[CNT_OOB], (unsigned long long)st.oob);
+  }
+}
+
+/* escape test of src/systems.rs:129-134 followed by the loop bound of :126 */
+__device__ __forceinline__ bool ray_terminated(double l, double R, unsigned steps, unsigned max_iter, int &code) {
+  if (l > R) {
+    code = cvk::CODE_POS;
+    return true;
+  } else if (l < -R) {
+    code = cvk::CODE_NEG;
+    return true;
+  }
+  if (steps >= max_iter) {
+    code = cvk::CODE_NONE;
+    return true;
+  }
+  return false;
+}
+
+template <int KIND, bool DEBUG>
+__global__ __launch_bounds__(256) void geodesic_persistent(const LaunchParams P) {
+  const unsigned lane = threadIdx.x & 63u;
+  cvk::Ray q;
+  q.l = q.th = q.ph = q.p1 = q.p2 = q.p3 = q.p3sq = 0.0;
+  LaneJob job{0u, 0u};
+  unsigned steps = 0;
+  int code = cvk::CODE_NONE;
+  bool active = false; /* lane is integrating */
+  bool done = false;   /* lane holds a terminated ray that has not been retired yet */
+  bool dry = false;    /* queue exhausted (wave-uniform) */
+  LaneStats st{0ull, 0u, 0u, 0u, 0u, 0u};
+
+  for (;;) {
+    if (done) {
+      retire_ray<KIND, DEBUG>(P, q, code, steps, job, st);
+      done = false;
+    }
+    if (!dry) {
+      const bool need = !active;
+      const unsigned long long mask = __ballot(need);
+      if (mask) {
+        const unsigned n = (unsigned)__popcll(mask);
+        const int leader = __ffsll((long long)mask) - 1;
+        unsigned long long base = 0;
+        if ((int)lane == leader) base = atomicAdd(&P.counters[CNT_NEXT], (unsigned long long)n);
+        base = __shfl(base, leader);
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        const unsigned long long mine = base + rank;
+        if (need && mine < P.total_rays) {
+          unsigned px, py;
+          if (decode_ray(P, mine, job, px, py)) {
+            cvk::ray_init<KIND>(P.metric, P.cams[job.frame], px, py, q);
+            steps = 0;
+            if (P.max_iter == 0) {
+              code = cvk::CODE_NONE;
+              done = true;
+            } else {
+              active = true;
+            }
+          }
+        }
+        if (base + n >= P.total_rays) dry = true;
+      }
+    }
+    const unsigned long long act = __ballot(active);
+    if (!act) {
+      if (__ballot(done)) continue; /* max_iter == 0 corner */
+      if (dry) break;
+      continue; /* every drawn id was tile padding: draw again */
+    }
+    const int thr = dry ? 64 : P.refill_threshold;
+    /* integrate until `thr` lanes are free */
+    for (;;) {
+      if (active) {
+        cvk::ray_step<KIND, DEBUG>(P.metric, q, P.delta);
+        ++steps;
+        if (ray_terminated(q.l, P.max_radius, steps, P.max_iter, code)) {
+          active = false;
+          done = true;
+        }
+      }
+      if (__popcll(__ballot(!active)) >= thr) break;
+    }
+  }
+  flush_stats(P, st);
+}
+
+template <int KIND, bool DEBUG>
+__global__ __launch_bounds__(256) void geodesic_static(const LaunchParams P) {
+  const unsigned long long id = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  LaneStats st{0ull, 0u, 0u, 0u, 0u, 0u};
+  LaneJob job{0u, 0u};
+  unsigned px, py;
+  if (id < P.total_rays && decode_ray(P, id, job, px, py)) {
+    cvk::Ray q;
+    cvk::ray_init<KIND>(P.metric, P.cams[job.frame], px, py, q);
+    unsigned steps = 0;
+    int code = cvk::CODE_NONE;
+    bool active = P.max_iter != 0;
+    while (active) {
+      cvk::ray_step<KIND, DEBUG>(P.metric, q, P.delta);
+      ++steps;
+      if (ray_terminated(q.l, P.max_radius, steps, P.max_iter, code)) active = false;
+    }
+    retire_ray<KIND, DEBUG>(P, q, code, steps, job, st);
+  }
+  flush_stats(P, st);
+}
+
+__global__ void selftest_math_kernel(int op, const double *a, const double *b, double *out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b ? b[i] : 0.0;
+  double r;
+  switch (op) {
+    case 0:
+      r = cv_sin(x);
+      break;
+    case 1:
+      r = cv_cos(x);
+      break;
+    case 2:
+      r = cv_atan(x);
+      break;
+    case 3:
+      r = cv_acos(x);
+      break;
+    case 4:
+      r = cv_log(x);
+      break;
+    case 5:
+      r = cv_atan2(x, y);
+      break;
+    case 6:
+      r = x / y;
+      break;
+    case 7:
+      r = CV_SQRT(x);
+      break;
+    default:
+      r = CV_FMA(x, y, x);
+      break;
+  }
+  out[i] = r;
+}
+
+/* ------------------------------------------------------------------------------------------ host */
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct curvis_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipDeviceProp_t prop{};
+  std::string err;
+  /* skies */
+  void *d_sky[2] = {nullptr, nullptr};
+  bool sky_owned[2] = {false, false};
+  unsigned sky_w[2] = {0, 0}, sky_h[2] = {0, 0};
+  double sky_inv_rot[2][9];
+  /* frame resources */
+  unsigned char *d_fb = nullptr;
+  size_t fb_cap = 0, fb_bytes = 0;
+  curvis_ray_debug *d_dbg = nullptr;
+  size_t dbg_cap = 0;
+  cvk::CameraParams *d_cams = nullptr;
+  size_t cams_cap = 0;
+  cvk::CameraParams *h_cams = nullptr; /* pinned */
+  size_t h_cams_cap = 0;
+  unsigned long long *d_counters = nullptr;
+  unsigned long long *h_counters = nullptr; /* pinned */
+  /* options */
+  int variant = 0;
+  int refill_threshold = 4;
+  int blocks_per_cu = 0; /* 0 = occupancy query */
+};
+
+namespace {
+
+int fail(curvis_ctx *ctx, int code, const std::string &msg) {
+  if (ctx)
+    ctx->err = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                         \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(ctx, CURVIS_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+template <typename T>
+int ensure_device(curvis_ctx *ctx, T *&ptr, size_t &cap, size_t need) {
+  if (need <= cap) return CURVIS_OK;
+  if (ptr) HIP_TRY(ctx, hipFree(ptr));
+  ptr = nullptr;
+  cap = 0;
+  HIP_TRY(ctx, hipMalloc((void **)&ptr, need * sizeof(T)));
+  cap = need;
+  return CURVIS_OK;
+}
+
+cvk::MetricParams make_metric(const curvis_metric &m) {
+  cvk::MetricParams M;
+  M.rho = m.rho;
+  M.rho2 = m.rho * m.rho;
+  M.m = m.m;
+  M.a = m.a;
+  M.pim = CV_PI * m.m;
+  M.two_o_pi = 2.0 / CV_PI;
+  return M;
+}
+
+cvk::CameraParams make_camera(const curvis_camera &c) {
+  cvk::CameraParams C;
+  for (int i = 0; i < 4; ++i) C.pos[i] = c.pos[i];
+  for (int i = 0; i < 9; ++i) C.rot[i] = c.rot[i];
+  C.focal = c.focal;
+  C.sensor_w = c.sensor_w;
+  C.sensor_h = c.sensor_h;
+  C.res_x = (double)c.res_x;
+  C.res_y = (double)c.res_y;
+  return C;
+}
+
+template <int KIND, bool DEBUG>
+int launch(curvis_ctx *ctx, const LaunchParams &P) {
+  if (ctx->variant == 1) {
+    const unsigned long long blocks = (P.total_rays + 255ull) / 256ull;
+    hipLaunchKernelGGL((geodesic_static<KIND, DEBUG>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+  } else {
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu <= 0) {
+      HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, geodesic_persistent<KIND, DEBUG>, 256, 0));
+      if (per_cu <= 0) per_cu = 1;
+    }
+    unsigned long long blocks = (unsigned long long)per_cu * (unsigned long long)ctx->prop.multiProcessorCount;
+    const unsigned long long max_useful = (P.total_rays + 255ull) / 256ull;
+    if (blocks > max_useful) blocks = max_useful;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL((geodesic_persistent<KIND, DEBUG>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return CURVIS_OK;
+}
+
+template <bool DEBUG>
+int launch_kind(curvis_ctx *ctx, int kind, const LaunchParams &P) {
+  switch (kind) {
+    case CURVIS_METRIC_ELLIS:
+      return launch<cvk::METRIC_ELLIS, DEBUG>(ctx, P);
+    case CURVIS_METRIC_INTERSTELLAR:
+      return launch<cvk::METRIC_INTERSTELLAR, DEBUG>(ctx, P);
+    default:
+      return launch<cvk::METRIC_FLAT, DEBUG>(ctx, P);
+  }
+}
+
+int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cams, uint32_t n_frames,
+                uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
+                curvis_ray_debug *dbg_out, curvis_stats *stats) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (!metric || !cams || n_frames == 0) return fail(ctx, CURVIS_E_INVALID, "null metric/camera or zero frames");
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = curvis_metric_validate(metric);
+  if (rc != CURVIS_OK) return fail(ctx, rc, "invalid metric parameters (src/metrics.rs:409-456)");
+  const uint32_t W = cams[0].res_x, H = cams[0].res_y;
+  if (W == 0 || H == 0) return fail(ctx, CURVIS_E_INVALID, "resolution must be greater than 0 (src/cameras.rs:98)");
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    if (cams[f].res_x != W || cams[f].res_y != H)
+      return fail(ctx, CURVIS_E_INVALID, "all cameras of a batch must share one resolution");
+    if (std::fabs(cams[f].pos[1]) > max_radius)
+      return fail(ctx, CURVIS_E_CAMERA_OUTSIDE,
+                  "Photon already beyond the maximum radius. Cannot evaluate escape. (src/systems.rs:122-124)");
+  }
+  if (!ctx->d_sky[0] || !ctx->d_sky[1]) return fail(ctx, CURVIS_E_NO_SKY, "both background images must be set");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  const size_t npix = (size_t)W * H;
+  const size_t fb_bytes = npix * 3 * n_frames;
+  rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, fb_bytes);
+  if (rc) return rc;
+  ctx->fb_bytes = fb_bytes;
+  if (dbg_out) {
+    rc = ensure_device(ctx, ctx->d_dbg, ctx->dbg_cap, npix * n_frames);
+    if (rc) return rc;
+  }
+  rc = ensure_device(ctx, ctx->d_cams, ctx->cams_cap, (size_t)n_frames);
+  if (rc) return rc;
+  if (ctx->h_cams_cap < n_frames) {
+    if (ctx->h_cams) HIP_TRY(ctx, hipHostFree(ctx->h_cams));
+    ctx->h_cams = nullptr;
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_cams, sizeof(cvk::CameraParams) * n_frames));
+    ctx->h_cams_cap = n_frames;
+  }
+  for (uint32_t f = 0; f < n_frames; ++f) ctx->h_cams[f] = make_camera(cams[f]);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cams, ctx->h_cams, sizeof(cvk::CameraParams) * n_frames, hipMemcpyHostToDevice,
+                              ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+
+  LaunchParams P;
+  P.metric = make_metric(*metric);
+  for (int s = 0; s < 2; ++s) {
+    P.sky[s].texels = (const unsigned *)ctx->d_sky[s];
+    P.sky[s].w = ctx->sky_w[s];
+    P.sky[s].h = ctx->sky_h[s];
+    for (int i = 0; i < 9; ++i) P.sky[s].inv_rot[i] = ctx->sky_inv_rot[s][i];
+  }
+  P.cams = ctx->d_cams;
+  P.n_frames = n_frames;
+  P.W = W;
+  P.H = H;
+  P.tiles_x = (W + 7) / 8;
+  P.tiles_y = (H + 7) / 8;
+  const unsigned long long rpf = (unsigned long long)P.tiles_x * P.tiles_y * 64ull;
+  if (rpf > 0xFFFFFFFFull) return fail(ctx, CURVIS_E_INVALID, "frame too large");
+  P.rays_per_frame = (unsigned)rpf;
+  P.total_rays = rpf * n_frames;
+  P.max_iter = max_iterations;
+  P.max_radius = max_radius;
+  P.delta = delta;
+  P.fb = ctx->d_fb;
+  P.dbg = dbg_out ? ctx->d_dbg : nullptr;
+  P.counters = ctx->d_counters;
+  P.refill_threshold = ctx->refill_threshold < 1 ? 1 : (ctx->refill_threshold > 64 ? 64 : ctx->refill_threshold);
+
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  rc = dbg_out ? launch_kind<true>(ctx, metric->kind, P) : launch_kind<false>(ctx, metric->kind, P);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N,
+                              hipMemcpyDeviceToHost, ctx->stream));
+  if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (dbg_out)
+    HIP_TRY(ctx, hipMemcpyAsync(dbg_out, ctx->d_dbg, sizeof(curvis_ray_debug) * npix * n_frames,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (dbg_out) {
+    /* dead lanes of the integrator, replayed on the host: t_{k+1} = t_k + (p_t * g^tt) * delta with
+     * p_t = 1, g^tt = -1 (src/metrics.rs:237, :295); p_t = p_t + 0*delta stays 1. */
+    std::vector<double> t_of_steps((size_t)max_iterations + 1);
+    for (uint32_t f = 0; f < n_frames; ++f) {
+      double t = cams[f].pos[0];
+      t_of_steps[0] = t;
+      for (uint32_t k = 1; k <= max_iterations; ++k) {
+        t = t + (1.0 * -1.0) * delta;
+        t_of_steps[k] = t;
+      }
+      curvis_ray_debug *d = dbg_out + (size_t)f * npix;
+      for (size_t i = 0; i < npix; ++i) d[i].x[0] = t_of_steps[d[i].steps];
+    }
+  }
+  if (stats) {
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    stats->rays = ctx->h_counters[CNT_RAYS];
+    stats->steps = ctx->h_counters[CNT_STEPS];
+    stats->n_pos = ctx->h_counters[CNT_POS];
+    stats->n_neg = ctx->h_counters[CNT_NEG];
+    stats->n_none = ctx->h_counters[CNT_NONE];
+    stats->n_oob = ctx->h_counters[CNT_OOB];
+    stats->kernel_ms = (double)ms;
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return CURVIS_OK;
+}
+
+}  // namespace
+
+/* ------------------------------------------------------------------------------------------ ABI */
+extern "C" {
+
+const char *curvis_version(void) { return "curvis_amd 0.1 (gfx950, abi 1)"; }
+
+const char *curvis_last_error(const curvis_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int curvis_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int curvis_ctx_create(int device, curvis_ctx **out) {
+  if (!out) return fail(nullptr, CURVIS_E_INVALID, "out is null");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, CURVIS_E_NO_DEVICE,
+                "no HIP device visible: libcurvis_hip has no CPU fallback (hipGetDeviceCount: " +
+                    std::string(hipGetErrorString(e)) + ")");
+  if (device < 0 || device >= n) return fail(nullptr, CURVIS_E_NO_DEVICE, "device index out of range");
+  curvis_ctx *ctx = new curvis_ctx();
+  ctx->device = device;
+  for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < 9; ++i) ctx->sky_inv_rot[s][i] = (i % 4 == 0) ? 1.0 : 0.0;
+  auto bail = [&](const std::string &m) {
+    g_create_error = m;
+    curvis_ctx_destroy(ctx);
+    return CURVIS_E_HIP;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(std::string("hipSetDevice: ") + hipGetErrorString(e));
+  if ((e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess)
+    return bail(std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+  if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("device is ") + ctx->prop.gcnArchName + ", this library carries gfx950 code only";
+    curvis_ctx_destroy(ctx);
+    return CURVIS_E_NO_DEVICE;
+  }
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+    return bail(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess)
+    return bail(std::string("hipEventCreate: ") + hipGetErrorString(e));
+  if ((e = hipMalloc((void **)&ctx->d_counters, sizeof(unsigned long long) * CNT_N)) != hipSuccess)
+    return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
+  if ((e = hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned long long) * CNT_N)) != hipSuccess)
+    return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  *out = ctx;
+  return CURVIS_OK;
+}
+
+void curvis_ctx_destroy(curvis_ctx *ctx) {
+  if (!ctx) return;
+  if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int s = 0; s < 2; ++s)
+    if (ctx->d_sky[s] && ctx->sky_owned[s]) (void)hipFree(ctx->d_sky[s]);
+  if (ctx->d_fb) (void)hipFree(ctx->d_fb);
+  if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
+  if (ctx->d_cams) (void)hipFree(ctx->d_cams);
+  if (ctx->h_cams) (void)hipHostFree(ctx->h_cams);
+  if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int curvis_ctx_device_info(const curvis_ctx *ctx, char *name, size_t name_cap, int *compute_units, int *clock_mhz) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (name && name_cap) {
+    std::snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  }
+  if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+  if (clock_mhz) *clock_mhz = ctx->prop.clockRate / 1000;
+  return CURVIS_OK;
+}
+
+static int set_sky_common(curvis_ctx *ctx, int which, uint32_t w, uint32_t h) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (which < 0 || which > 1) return fail(ctx, CURVIS_E_INVALID, "which must be 0 (+l) or 1 (-l)");
+  if (w == 0 || h == 0) return fail(ctx, CURVIS_E_INVALID, "empty sky image");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->d_sky[which] && ctx->sky_owned[which]) HIP_TRY(ctx, hipFree(ctx->d_sky[which]));
+  ctx->d_sky[which] = nullptr;
+  ctx->sky_owned[which] = false;
+  ctx->sky_w[which] = w;
+  ctx->sky_h[which] = h;
+  return CURVIS_OK;
+}
+
+int curvis_ctx_set_sky(curvis_ctx *ctx, int which, const uint8_t *rgba, uint32_t w, uint32_t h) {
+  int rc = set_sky_common(ctx, which, w, h);
+  if (rc) return rc;
+  const size_t bytes = (size_t)w * h * 4;
+  HIP_TRY(ctx, hipMalloc(&ctx->d_sky[which], bytes));
+  ctx->sky_owned[which] = true;
+  if (rgba) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sky[which], rgba, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return CURVIS_OK;
+}
+
+int curvis_ctx_set_sky_device(curvis_ctx *ctx, int which, const void *dev_rgba, uint32_t w, uint32_t h, int copy) {
+  if (!dev_rgba) return fail(ctx, CURVIS_E_INVALID, "null device pointer");
+  int rc = set_sky_common(ctx, which, w, h);
+  if (rc) return rc;
+  const size_t bytes = (size_t)w * h * 4;
+  if (copy) {
+    HIP_TRY(ctx, hipMalloc(&ctx->d_sky[which], bytes));
+    ctx->sky_owned[which] = true;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sky[which], dev_rgba, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    ctx->d_sky[which] = const_cast<void *>(dev_rgba);
+    ctx->sky_owned[which] = false;
+  }
+  return CURVIS_OK;
+}
+
+int curvis_ctx_set_sky_orientation(curvis_ctx *ctx, int which, const double forward[3], const double up[3]) {
+  if (!ctx || !forward || !up || which < 0 || which > 1) return fail(ctx, CURVIS_E_INVALID, "bad argument");
+  cvh::Orientation o;
+  if (!cvh::orientation_new(cvh::Vec3{forward[0], forward[1], forward[2]}, cvh::Vec3{up[0], up[1], up[2]}, o))
+    return fail(ctx, CURVIS_E_PARALLEL, "Forward and up vectors must not be parallel (src/algebra.rs:19-21)");
+  for (int i = 0; i < 9; ++i) ctx->sky_inv_rot[which][i] = o.inverse_rotation.m[i];
+  return CURVIS_OK;
+}
+
+int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root) {
+  if (!ctx || !nccl_comm) return fail(ctx, CURVIS_E_INVALID, "null context or communicator");
+  ncclComm_t comm = (ncclComm_t)nccl_comm;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rank = -1;
+  if (ncclCommUserRank(comm, &rank) != ncclSuccess) return fail(ctx, CURVIS_E_RCCL, "ncclCommUserRank failed");
+  /* shapes first (4 x u32), then the two textures */
+  uint32_t *d_shape = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d_shape, 4 * sizeof(uint32_t)));
+  uint32_t shape[4] = {ctx->sky_w[0], ctx->sky_h[0], ctx->sky_w[1], ctx->sky_h[1]};
+  if (rank == root) {
+    if (!ctx->d_sky[0] || !ctx->d_sky[1]) {
+      (void)hipFree(d_shape);
+      return fail(ctx, CURVIS_E_NO_SKY, "root rank must hold both skies before the broadcast");
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(d_shape, shape, sizeof shape, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (ncclBroadcast(d_shape, d_shape, 4, ncclUint32, root, comm, ctx->stream) != ncclSuccess) {
+    (void)hipFree(d_shape);
+    return fail(ctx, CURVIS_E_RCCL, "ncclBroadcast(shape) failed");
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(shape, d_shape, sizeof shape, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_shape);
+  for (int s = 0; s < 2; ++s) {
+    const uint32_t w = shape[2 * s], h = shape[2 * s + 1];
+    if (rank != root) {
+      int rc = curvis_ctx_set_sky(ctx, s, nullptr, w, h);
+      if (rc) return rc;
+    }
+    if (ncclBroadcast(ctx->d_sky[s], ctx->d_sky[s], (size_t)w * h * 4, ncclUint8, root, comm, ctx->stream) !=
+        ncclSuccess)
+      return fail(ctx, CURVIS_E_RCCL, "ncclBroadcast(sky) failed");
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CURVIS_OK;
+}
+
+int curvis_orientation_init(const double forward[3], const double up[3], double rot[9], double inv_rot[9],
+                            double up_out[3]) {
+  if (!forward || !up) return CURVIS_E_INVALID;
+  cvh::Orientation o;
+  if (!cvh::orientation_new(cvh::Vec3{forward[0], forward[1], forward[2]}, cvh::Vec3{up[0], up[1], up[2]}, o))
+    return CURVIS_E_PARALLEL;
+  if (rot) std::memcpy(rot, o.rotation.m, sizeof o.rotation.m);
+  if (inv_rot) std::memcpy(inv_rot, o.inverse_rotation.m, sizeof o.inverse_rotation.m);
+  if (up_out) {
+    up_out[0] = o.up.x;
+    up_out[1] = o.up.y;
+    up_out[2] = o.up.z;
+  }
+  return CURVIS_OK;
+}
+
+int curvis_camera_init(curvis_camera *out, const double pos[4], const double forward[3], const double up[3],
+                       double focal_length, double sensor_diagonal, uint32_t res_x, uint32_t res_y) {
+  if (!out || !pos || !forward || !up) return CURVIS_E_INVALID;
+  if (!(focal_length > 0.0)) return CURVIS_E_INVALID;    /* src/cameras.rs:92 */
+  if (!(sensor_diagonal > 0.0)) return CURVIS_E_INVALID; /* :95 */
+  if (res_x == 0 || res_y == 0) return CURVIS_E_INVALID; /* :98 */
+  int rc = curvis_orientation_init(forward, up, out->rot, nullptr, nullptr);
+  if (rc) return rc;
+  for (int i = 0; i < 4; ++i) out->pos[i] = pos[i];
+  const double aspect = (double)res_x / (double)res_y; /* :107-110 */
+  const double aspect2 = aspect * aspect;
+  out->sensor_h = std::sqrt(sensor_diagonal * sensor_diagonal / (aspect2 + 1.0));
+  out->sensor_w = aspect * out->sensor_h;
+  out->focal = focal_length;
+  out->res_x = res_x;
+  out->res_y = res_y;
+  return CURVIS_OK;
+}
+
+int curvis_metric_validate(const curvis_metric *m) {
+  if (!m) return CURVIS_E_INVALID;
+  switch (m->kind) {
+    case CURVIS_METRIC_ELLIS:
+      return (m->rho <= 0.0 || m->rho != m->rho) ? CURVIS_E_METRIC : CURVIS_OK;
+    case CURVIS_METRIC_INTERSTELLAR:
+      if (m->m <= 0.0 || m->a <= 0.0 || m->rho <= 0.0) return CURVIS_E_METRIC;
+      if (m->m != m->m || m->a != m->a || m->rho != m->rho) return CURVIS_E_METRIC;
+      return CURVIS_OK;
+    case CURVIS_METRIC_FLAT:
+      return CURVIS_OK;
+    default:
+      return CURVIS_E_METRIC;
+  }
+}
+
+int curvis_render_brute(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
+                        uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
+                        curvis_stats *stats) {
+  return render_impl(ctx, metric, camera, 1, max_iterations, max_radius, delta, rgb_out, nullptr, stats);
+}
+
+int curvis_render_brute_debug(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
+                              uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
+                              curvis_ray_debug *dbg_out, curvis_stats *stats) {
+  if (!dbg_out) return fail(ctx, CURVIS_E_INVALID, "dbg_out is null");
+  return render_impl(ctx, metric, camera, 1, max_iterations, max_radius, delta, rgb_out, dbg_out, stats);
+}
+
+int curvis_render_brute_batch(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cameras,
+                              uint32_t n_frames, uint32_t max_iterations, double max_radius, double delta,
+                              uint8_t *rgb_out, curvis_stats *stats) {
+  return render_impl(ctx, metric, cameras, n_frames, max_iterations, max_radius, delta, rgb_out, nullptr, stats);
+}
+
+int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (dev_ptr) *dev_ptr = ctx->d_fb;
+  if (bytes) *bytes = ctx->fb_bytes;
+  return CURVIS_OK;
+}
+
+int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes) {
+  if (!ctx || !rgb_out) return CURVIS_E_INVALID;
+  if (bytes > ctx->fb_bytes) return fail(ctx, CURVIS_E_INVALID, "download larger than the last frame");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CURVIS_OK;
+}
+
+int curvis_ctx_synchronize(curvis_ctx *ctx) {
+  if (!ctx) return CURVIS_E_INVALID;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CURVIS_OK;
+}
+
+int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
+  if (!ctx || !key) return CURVIS_E_INVALID;
+  const std::string k(key);
+  if (k == "variant")
+    ctx->variant = (int)value;
+  else if (k == "refill_threshold")
+    ctx->refill_threshold = (int)value;
+  else if (k == "blocks_per_cu")
+    ctx->blocks_per_cu = (int)value;
+  else
+    return fail(ctx, CURVIS_E_INVALID, "unknown option " + k);
+  return CURVIS_OK;
+}
+
+int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value) {
+  if (!ctx || !key || !value) return CURVIS_E_INVALID;
+  const std::string k(key);
+  if (k == "variant")
+    *value = ctx->variant;
+  else if (k == "refill_threshold")
+    *value = ctx->refill_threshold;
+  else if (k == "blocks_per_cu")
+    *value = ctx->blocks_per_cu;
+  else
+    return CURVIS_E_INVALID;
+  return CURVIS_OK;
+}
+
+int curvis_selftest_math(curvis_ctx *ctx, int op, const double *a, const double *b, double *out, size_t n) {
+  if (!ctx || !a || !out) return CURVIS_E_INVALID;
+  if (n == 0) return CURVIS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&da, n * sizeof(double)));
+  HIP_TRY(ctx, hipMalloc((void **)&dout, n * sizeof(double)));
+  HIP_TRY(ctx, hipMemcpy(da, a, n * sizeof(double), hipMemcpyHostToDevice));
+  if (b) {
+    HIP_TRY(ctx, hipMalloc((void **)&db, n * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(db, b, n * sizeof(double), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, da, db,
+                     dout, n);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(da);
+  (void)hipFree(dout);
+  if (db) (void)hipFree(db);
+  return CURVIS_OK;
+}
+
+} /* extern "C" */

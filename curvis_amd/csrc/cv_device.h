@@ -1,0 +1,232 @@
+/* cv_device.h -- per-ray device functions of the geodesic hot path (gfx950).
+ *
+ * One lane owns one ray.  The live state of the forward-Euler loop is five doubles
+ * (l, theta, p_l, p_theta and -- only when the caller needs it -- phi) plus the constants
+ * p_phi and p_phi^2; t and p_t are dead on this path (dp_t = dp_phi = 0, t is never read:
+ * src/metrics.rs:259-264) and are reconstructed on the host for the debug dump.
+ *
+ * Arithmetic contract: every floating-point operation below is the operation the reference
+ * performs, in the reference's order (src/metrics.rs:223-297 for the step), individually
+ * rounded; the only fused operations are the explicit fma() calls inside cv_math.h.  The file
+ * must be compiled with -ffp-contract=off.  Common sub-expressions are evaluated once
+ * (sin/cos(theta), r(l), r^2(l)): they are pure functions of the old state, so the values are
+ * identical to the reference's repeated evaluation.
+ *
+ * Functions are __host__ __device__ so the SAME source can be compiled for x86 by the CPU test
+ * suite (tests/host_twin) -- a test vehicle, never a fallback: libcurvis_hip.so only launches
+ * the __global__ kernels.
+ */
+#ifndef CURVIS_CV_DEVICE_H
+#define CURVIS_CV_DEVICE_H
+
+#include <math.h>
+
+#include "cv_math.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace cvk {
+
+enum : int { METRIC_ELLIS = 0, METRIC_INTERSTELLAR = 1, METRIC_FLAT = 2 };
+enum : int { CODE_NONE = 0, CODE_POS = 1, CODE_NEG = -1 };
+
+struct MetricParams {
+  double rho;      /* throat radius */
+  double rho2;     /* rho*rho (rho.powi(2)) */
+  double m, a;     /* Interstellar mass / half-length */
+  double pim;      /* PI*m: denominator of scaled_distance (src/metrics.rs:461) */
+  double two_o_pi; /* 2.0/PI (src/metrics.rs:481) */
+};
+
+/* r(l), r^2(l), r'(l): src/metrics.rs:417-421 / 467-485 / 501-505 */
+template <int KIND>
+CV_HD void metric_eval(const MetricParams &M, double l, double &r, double &r2, double &rd) {
+  if (KIND == METRIC_ELLIS) {
+    r2 = M.rho2 + l * l;
+    r = CV_SQRT(r2);
+    rd = l / r;
+  } else if (KIND == METRIC_INTERSTELLAR) {
+    double al = CV_FABS(l);
+    if (al > M.a) {
+      double x = 2.0 * (al - M.a) / M.pim;
+      double at = cv_atan(x);
+      r = M.rho + M.m * (x * at - cv_log(1.0 + x * x) / 2.0);
+      double sg = (cv_bits(l) >> 63) ? -1.0 : 1.0; /* l.signum(), l != NaN-safe below */
+      if (l != l) sg = l;
+      rd = M.two_o_pi * sg * at;
+    } else {
+      r = M.rho;
+      rd = 0.0;
+    }
+    r2 = r * r;
+  } else {
+    r = l;
+    r2 = l * l;
+    rd = 1.0;
+  }
+}
+
+/* r(l) only (photon construction) */
+template <int KIND>
+CV_HD double metric_r(const MetricParams &M, double l) {
+  double r, r2, rd;
+  metric_eval<KIND>(M, l, r, r2, rd);
+  return r;
+}
+
+struct Ray {
+  double l, th, ph; /* position (contravariant) */
+  double p1, p2;    /* covariant momentum: radial, theta */
+  double p3, p3sq;  /* covariant phi momentum (constant of motion) and its square */
+};
+
+/* One forward-Euler step: src/metrics.rs:283-297 with :223-244 and :247-270 inlined. */
+template <int KIND, bool PHI>
+CV_HD void ray_step(const MetricParams &M, Ray &q, double delta) {
+  double s, c;
+  cv_sincos(q.th, &s, &c);
+  double r, r2, rd;
+  metric_eval<KIND>(M, q.l, r, r2, rd);
+  const double ss = s * s;            /* theta.sin().powi(2) */
+  const double g22c = 1.0 / r2;       /* g22.powi(-1) */
+  const double dx1 = q.p1;            /* p1 * g11.powi(-1) == p1 * 1.0 */
+  const double dx2 = q.p2 * g22c;
+  const double b2 = q.p2 * q.p2 + q.p3sq / ss;
+  const double dp1 = b2 * rd / (r * (r * r));         /* r.powi(3) */
+  const double dp2 = q.p3sq * (c / (r2 * (s * ss)));  /* sin.powi(3) = s*(s*s) */
+  if (PHI) {
+    const double g33c = 1.0 / (r2 * ss);
+    q.ph = q.ph + (q.p3 * g33c) * delta;
+  }
+  q.l = q.l + dx1 * delta;
+  q.th = q.th + dx2 * delta;
+  q.p1 = q.p1 + dp1 * delta;
+  q.p2 = q.p2 + dp2 * delta;
+}
+
+struct CameraParams {
+  double pos[4];
+  double rot[9];
+  double focal, sensor_w, sensor_h;
+  double res_x, res_y; /* as f64 */
+};
+
+CV_HD void mat3_vec(const double *m, double v0, double v1, double v2, double &o0, double &o1, double &o2) {
+  /* nalgebra gemv: ((m_i0*x0) + m_i1*x1) + m_i2*x2 */
+  o0 = (m[0] * v0 + m[1] * v1) + m[2] * v2;
+  o1 = (m[3] * v0 + m[4] * v1) + m[5] * v2;
+  o2 = (m[6] * v0 + m[7] * v1) + m[8] * v2;
+}
+
+/* pixel -> photon: src/cameras.rs:150-172 then src/metrics.rs:301-334 */
+template <int KIND>
+CV_HD void ray_init(const MetricParams &M, const CameraParams &C, unsigned px, unsigned py, Ray &q) {
+  const double h = 0.5 - ((double)py / C.res_y);
+  const double w = ((double)px / C.res_x) - 0.5;
+  double vx = C.focal * 1.0;
+  double vy = -C.sensor_w * w;
+  double vz = C.sensor_h * h;
+  double n = CV_SQRT(vx * vx + vy * vy + vz * vz); /* Vector3::normalize */
+  vx = vx / n;
+  vy = vy / n;
+  vz = vz / n;
+  double d0, d1, d2;
+  mat3_vec(C.rot, vx, vy, vz, d0, d1, d2);
+  n = CV_SQRT(d0 * d0 + d1 * d1 + d2 * d2); /* direction.normalize() in new_photon */
+  d0 = d0 / n;
+  d1 = d1 / n;
+  d2 = d2 / n;
+  const double r = metric_r<KIND>(M, C.pos[1]);
+  q.l = C.pos[1];
+  q.th = C.pos[2];
+  q.ph = C.pos[3];
+  q.p1 = d0;
+  q.p2 = d1 * r;
+  q.p3 = d2 * r * cv_sin(C.pos[2]);
+  q.p3sq = q.p3 * q.p3;
+}
+
+/* photon from an explicit tangent-space direction (compute_escape_angle, src/systems.rs:221-230) */
+template <int KIND>
+CV_HD void ray_init_dir(const MetricParams &M, const double pos[4], double dx, double dy, double dz, Ray &q) {
+  double n = CV_SQRT(dx * dx + dy * dy + dz * dz);
+  double d0 = dx / n, d1 = dy / n, d2 = dz / n;
+  const double r = metric_r<KIND>(M, pos[1]);
+  q.l = pos[1];
+  q.th = pos[2];
+  q.ph = pos[3];
+  q.p1 = d0;
+  q.p2 = d1 * r;
+  q.p3 = d2 * r * cv_sin(pos[2]);
+  q.p3sq = q.p3 * q.p3;
+}
+
+/* final photon -> tangent-space direction: src/metrics.rs:339-349 (+ :190-203).
+ * z uses frame_field_22 (no sin theta), exactly as line 347. */
+template <int KIND>
+CV_HD void ray_direction(const MetricParams &M, const Ray &q, double &d0, double &d1, double &d2) {
+  double r, r2, rd;
+  metric_eval<KIND>(M, q.l, r, r2, rd);
+  const double s = cv_sin(q.th);
+  const double g22c = 1.0 / r2;
+  const double g33c = 1.0 / (r2 * (s * s));
+  const double v1 = q.p1; /* * 1.0 */
+  const double v2 = q.p2 * g22c;
+  const double v3 = q.p3 * g33c;
+  d0 = v1; /* * frame_field_11 = 1.0 */
+  d1 = v2 * r;
+  d2 = v3 * r;
+}
+
+CV_HD unsigned rust_as_u32(double v) { /* `as u32`: NaN -> 0, saturating */
+  if (!(v == v)) return 0u;
+  if (v <= 0.0) return 0u;
+  if (v >= 4294967295.0) return 4294967295u;
+  return (unsigned)v;
+}
+
+/* f64::rem_euclid(a, b) for b > 0.  On this path |a| < b always holds (a is an atan2 result
+ * against 2*pi, or 0.5 - phi/(2*pi) against 1), where fmod(a, b) == a exactly; the general
+ * branch keeps the function total. */
+CV_HD double rem_euclid_pos(double a, double b) {
+  double r;
+  if (CV_FABS(a) < b || a != a) {
+    r = a;
+  } else {
+    r = fmod(a, b);
+  }
+  return (r < 0.0) ? r + b : r;
+}
+
+struct SkyParams {
+  const unsigned *texels; /* RGBA8 packed little-endian, row-major */
+  unsigned w, h;
+  double inv_rot[9];
+};
+
+/* direction -> texel indices: src/images.rs:132-142 -> src/algebra.rs:128-134 -> :106-116 ->
+ * src/images.rs:115-121.  Returns raw `as u32` indices (may equal w / h: reference panics). */
+CV_HD void sky_indices(const SkyParams &S, double d0, double d1, double d2, unsigned &tx, unsigned &ty) {
+  double w0, w1, w2;
+  mat3_vec(S.inv_rot, d0, d1, d2, w0, w1, w2);
+  const double rn = CV_SQRT(w0 * w0 + w1 * w1 + w2 * w2);
+  double theta = cv_acos(w2 / rn);
+  double phi = cv_atan2(w1, w0);
+  const double TWO_PI = 2.0 * CV_PI;
+  /* normalize_theta_phi #1 (theta_phi_from_vector3) and #2 (pixel_indexes...) */
+  for (int k = 0; k < 2; ++k) {
+    if (theta < 0.0) {
+      theta = CV_FABS(theta);
+      phi = phi + CV_PI;
+    }
+    phi = rem_euclid_pos(phi, TWO_PI);
+  }
+  ty = rust_as_u32((theta / CV_PI) * (double)S.h);
+  tx = rust_as_u32(rem_euclid_pos(0.5 - phi / TWO_PI, 1.0) * (double)S.w);
+}
+
+}  // namespace cvk
+
+#endif /* CURVIS_CV_DEVICE_H */

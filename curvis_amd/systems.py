@@ -1,0 +1,239 @@
+"""Host-side mirror of the reference's scene types over the C ABI.
+
+Reference surface mirrored (names, argument meaning and error behaviour):
+  EllisMetric::new(rho)                      src/metrics.rs:407-414
+  InterstellarMetric::new(m, a, rho)         src/metrics.rs:443-459
+  FlatSphericalMetric::new()                 src/metrics.rs:496-498
+  Camera::new(position, forward_world, up_world, focal_length, sensor_diagonal,
+              resolution_width, resolution_height)                src/cameras.rs:79-122
+  SphericalImage::new(img, forward, up)      src/images.rs:71-90
+  RelativisticSystem::new(metric, background_positive, background_negative, camera)  src/systems.rs:286-288
+  RelativisticSystem::render_image(max_iterations, max_radius, delta)                src/systems.rs:307-330
+Reference panics surface as CurvisError (or ValueError for constructor argument checks).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import CameraC, Metric, Stats, check, dptr, lib
+
+
+class EllisMetric:
+    def __init__(self, rho):
+        if not rho > 0.0:
+            raise ValueError("The rho parameter for Ellis Metrics must be positive.")
+        self.rho = float(rho)
+
+    def _c(self):
+        return Metric(_abi.METRIC_ELLIS, 0, self.rho, 0.0, 0.0)
+
+
+class InterstellarMetric:
+    def __init__(self, m, a, rho):
+        if not m > 0.0:
+            raise ValueError("The mass parameter for Interstellar Metrics must be positive.")
+        if not a > 0.0:
+            raise ValueError("The angular momentum parameter for Interstellar Metrics must be positive.")
+        if not rho > 0.0:
+            raise ValueError("The rho parameter for Interstellar Metrics must be positive.")
+        self.m, self.a, self.rho = float(m), float(a), float(rho)
+
+    def _c(self):
+        return Metric(_abi.METRIC_INTERSTELLAR, 0, self.rho, self.m, self.a)
+
+
+class FlatSphericalMetric:
+    def _c(self):
+        return Metric(_abi.METRIC_FLAT, 0, 0.0, 0.0, 0.0)
+
+
+def _vec(v, n):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(n))
+    return a
+
+
+class Camera:
+    def __init__(self, position, forward_world, up_world, focal_length, sensor_diagonal, resolution_width,
+                 resolution_height):
+        self._c = CameraC()
+        self.position = _vec(position, 4)
+        self.forward = _vec(forward_world, 3)
+        self.up = _vec(up_world, 3)
+        self.focal_length = float(focal_length)
+        self.sensor_diagonal = float(sensor_diagonal)
+        self.resolution_width = int(resolution_width)
+        self.resolution_height = int(resolution_height)
+        self._rebuild()
+
+    def _rebuild(self):
+        rc = lib().curvis_camera_init(C.byref(self._c), dptr(self.position), dptr(self.forward), dptr(self.up),
+                                      self.focal_length, self.sensor_diagonal, self.resolution_width,
+                                      self.resolution_height)
+        if rc == _abi.E_PARALLEL:
+            raise ValueError("Forward and up vectors must not be parallel")
+        if rc != 0:
+            raise ValueError("invalid camera arguments (focal_length, sensor_diagonal, resolution must be > 0)")
+
+    def update_position(self, new_position):  # src/cameras.rs:135-140
+        self.position = _vec(new_position, 4)
+        self._rebuild()
+
+    def update_orientation(self, forward_world, up_world):  # src/cameras.rs:143-146
+        self.forward = _vec(forward_world, 3)
+        self.up = _vec(up_world, 3)
+        self._rebuild()
+
+    @property
+    def rotation_matrix(self):
+        return np.array(self._c.rot[:]).reshape(3, 3)
+
+    @property
+    def sensor_width(self):
+        return self._c.sensor_w
+
+    @property
+    def sensor_height(self):
+        return self._c.sensor_h
+
+
+class SphericalImage:
+    """Equirectangular background; `img` is HxWx4 (RGBA8) or HxWx3 (RGB8, alpha := 255 as
+    DynamicImage::get_pixel does)."""
+
+    def __init__(self, img, forward=None, up=None):
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] not in (3, 4):
+            raise ValueError("img must be HxWx3 or HxWx4 uint8")
+        if img.shape[2] == 3:
+            img = np.concatenate([img, np.full(img.shape[:2] + (1,), 255, np.uint8)], axis=2)
+        self.rgba = np.ascontiguousarray(img)
+        self.height_pixels, self.width_pixels = self.rgba.shape[:2]
+        self.forward = _vec((1.0, 0.0, 0.0) if forward is None else forward, 3)
+        self.up = _vec((0.0, 0.0, 1.0) if up is None else up, 3)
+
+    def set_forward_up(self, forward, up):
+        self.forward, self.up = _vec(forward, 3), _vec(up, 3)
+
+
+class Context:
+    """One GPU: owns the HIP stream, the two sky textures in HBM and the device framebuffer."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().curvis_ctx_create(int(device), C.byref(self._h)))
+        self.device = device
+        self._sky_ids = [None, None]
+
+    def close(self):
+        if self._h:
+            lib().curvis_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mhz = C.c_int(0), C.c_int(0)
+        check(lib().curvis_ctx_device_info(self._h, name, 256, C.byref(cus), C.byref(mhz)), self._h)
+        return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value}
+
+    def set_sky(self, which, image):
+        check(lib().curvis_ctx_set_sky(self._h, which, image.rgba.ctypes.data, image.width_pixels,
+                                       image.height_pixels), self._h)
+        check(lib().curvis_ctx_set_sky_orientation(self._h, which, dptr(image.forward), dptr(image.up)), self._h)
+        self._sky_ids[which] = id(image)
+
+    def set_sky_device(self, which, dev_ptr, w, h, copy=False, forward=(1.0, 0.0, 0.0), up=(0.0, 0.0, 1.0)):
+        check(lib().curvis_ctx_set_sky_device(self._h, which, C.c_void_p(dev_ptr), w, h, int(copy)), self._h)
+        check(lib().curvis_ctx_set_sky_orientation(self._h, which, dptr(_vec(forward, 3)), dptr(_vec(up, 3))),
+              self._h)
+        self._sky_ids[which] = None
+
+    def set_option(self, key, value):
+        check(lib().curvis_ctx_set_option(self._h, key.encode(), int(value)), self._h)
+
+    def framebuffer(self):
+        p, n = C.c_void_p(), C.c_size_t(0)
+        check(lib().curvis_ctx_framebuffer(self._h, C.byref(p), C.byref(n)), self._h)
+        return p.value, n.value
+
+    def render_brute(self, metric, cameras, max_iterations, max_radius, delta, download=True, debug=False):
+        """cameras: one Camera or a list (one launch for the whole batch).  Returns (rgb, stats[, dbg])."""
+        single = isinstance(cameras, Camera)
+        cams = [cameras] if single else list(cameras)
+        n = len(cams)
+        W, H = cams[0].resolution_width, cams[0].resolution_height
+        arr = (CameraC * n)(*[c._c for c in cams])
+        m = metric._c()
+        st = Stats()
+        rgb = np.empty((n, H, W, 3), dtype=np.uint8) if download else None
+        out = rgb.ctypes.data if download else None
+        if debug:
+            if n != 1:
+                raise ValueError("debug dump is single-frame")
+            dbg = np.zeros((H, W), dtype=_abi.RAY_DEBUG)
+            check(lib().curvis_render_brute_debug(self._h, C.byref(m), arr, max_iterations, max_radius, delta, out,
+                                                  dbg.ctypes.data, C.byref(st)), self._h)
+            return (rgb[0] if download else None), st, dbg
+        check(lib().curvis_render_brute_batch(self._h, C.byref(m), arr, n, max_iterations, max_radius, delta, out,
+                                              C.byref(st)), self._h)
+        if download and single:
+            rgb = rgb[0]
+        return rgb, st
+
+    def selftest_math(self, op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = np.empty_like(a)
+        bb = None
+        if b is not None:
+            bb = np.ascontiguousarray(b, dtype=np.float64)
+        check(lib().curvis_selftest_math(self._h, op, dptr(a), dptr(bb) if bb is not None else None, dptr(out),
+                                         a.size), self._h)
+        return out
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class RelativisticSystem:
+    """RelativisticSystem<M> (src/systems.rs:68-73)."""
+
+    def __init__(self, metric, background_positive, background_negative, camera, context=None):
+        self.metric = metric
+        self.background_positive = background_positive
+        self.background_negative = background_negative
+        self.camera = camera
+        self.context = context if context is not None else default_context()
+        self.last_stats = None
+
+    def _bind_skies(self):
+        ctx = self.context
+        if ctx._sky_ids[0] != id(self.background_positive):
+            ctx.set_sky(0, self.background_positive)
+        if ctx._sky_ids[1] != id(self.background_negative):
+            ctx.set_sky(1, self.background_negative)
+
+    def render_image(self, max_iterations, max_radius, delta):
+        """The per-pixel renderer; returns an HxWx3 uint8 array (DynamicImage::ImageRgb8)."""
+        self._bind_skies()
+        rgb, st = self.context.render_brute(self.metric, self.camera, max_iterations, max_radius, delta)
+        self.last_stats = st
+        return rgb
+
+    def render_image_debug(self, max_iterations, max_radius, delta):
+        self._bind_skies()
+        rgb, st, dbg = self.context.render_brute(self.metric, self.camera, max_iterations, max_radius, delta,
+                                                 debug=True)
+        self.last_stats = st
+        return rgb, dbg

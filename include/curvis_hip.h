@@ -1,0 +1,161 @@
+/* curvis_hip.h -- C ABI of libcurvis_hip.so: the MI355X (gfx950) replacement for the
+ * per-pixel geodesic hot path of fragarriss/CurVis.
+ *
+ * The reference has no FFI/plugin seam; the seam this library replaces is the method pair its
+ * orchestration calls (src/rendering.rs:97 and :299):
+ *
+ *   RelativisticSystem<M>::render_image(&self, max_iterations: u32, max_radius: f64, delta: f64)
+ *        -> image::DynamicImage                                          src/systems.rs:307-330
+ *   RelativisticSystem<M>::render_image_efficient(&self, max_iterations_propagation, max_radius, delta,
+ *        alpha_nums, max_iterations_sampling, thr1, thr2) -> DynamicImage  src/systems.rs:333-527
+ *
+ * with self = { metric: M, background_positive, background_negative: SphericalImage, camera: Camera }
+ * (src/systems.rs:68-73).  A context (`curvis_ctx`) plays the role of `self`: it owns one GPU, the
+ * two sky textures resident in HBM, and the device framebuffer.  A Rust host binds these with a
+ * plain `extern "C"` block (INTEGRATION.md shows the stub); the C++ host in curvis_amd/csrc/host and
+ * the Python mirror in curvis_amd/ bind the same symbols.
+ *
+ * Conventions: every function returns CURVIS_OK (0) or a negative CURVIS_E_* code;
+ * curvis_last_error() gives the message.  The reference's panics map to error codes.  A context is
+ * not thread-safe; distinct contexts (one per GPU) are independent.  No CPU fallback exists: without
+ * a gfx950 device curvis_ctx_create fails with CURVIS_E_NO_DEVICE.
+ */
+#ifndef CURVIS_HIP_H
+#define CURVIS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CURVIS_ABI_VERSION 1
+
+enum {
+  CURVIS_OK = 0,
+  CURVIS_E_INVALID = -1,        /* bad argument (null pointer, zero resolution, ...) */
+  CURVIS_E_NO_DEVICE = -2,      /* no usable gfx950 GPU: the product path has no CPU fallback */
+  CURVIS_E_HIP = -3,            /* a HIP runtime call failed */
+  CURVIS_E_CAMERA_OUTSIDE = -4, /* |l_camera| > max_radius: panic at src/systems.rs:122-124 */
+  CURVIS_E_NO_SKY = -5,         /* a background image has not been set */
+  CURVIS_E_PARALLEL = -6,       /* forward/up parallel: panic at src/algebra.rs:19-21 */
+  CURVIS_E_METRIC = -7,         /* invalid metric parameters: panics at src/metrics.rs:409-456 */
+  CURVIS_E_RCCL = -8,           /* RCCL call failed */
+  CURVIS_E_SAMPLING = -9,       /* sampler panic (< 3 finite points): src/sampling.rs:155-157 */
+  CURVIS_E_IO = -10
+};
+
+/* enum Metric (src/metrics.rs:575-578) + FlatSphericalMetric (src/metrics.rs:492-505) */
+enum { CURVIS_METRIC_ELLIS = 0, CURVIS_METRIC_INTERSTELLAR = 1, CURVIS_METRIC_FLAT = 2 };
+
+/* EllisMetric { rho } (src/metrics.rs:399-401), InterstellarMetric { m, a, rho } (:431-435). */
+typedef struct curvis_metric {
+  int32_t kind;
+  int32_t _pad;
+  double rho, m, a;
+} curvis_metric;
+
+/* Camera (src/cameras.rs:16-34) reduced to what the kernels read: position (t,l,theta,phi),
+ * camera_to_world_rotation_matrix (row-major), focal_length, sensor_width/height, resolution. */
+typedef struct curvis_camera {
+  double pos[4];
+  double rot[9];
+  double focal, sensor_w, sensor_h;
+  uint32_t res_x, res_y;
+} curvis_camera;
+
+/* PhotonEscape (src/systems.rs:39-44) */
+enum { CURVIS_NOT_ESCAPED = 0, CURVIS_POSITIVE_SPACE = 1, CURVIS_NEGATIVE_SPACE = -1 };
+
+/* per-ray final state, for parity tests: RelativisticObject (src/vectors.rs:135-139) after
+ * escape_photon, number of Euler steps executed, escape code, raw texel indices
+ * (`as u32` results of src/images.rs:118-119, before clamping). */
+typedef struct curvis_ray_debug {
+  double x[4];
+  double p[4];
+  uint32_t steps;
+  int32_t code;
+  uint32_t tx, ty;
+} curvis_ray_debug;
+
+typedef struct curvis_stats {
+  uint64_t rays;      /* rays traced */
+  uint64_t steps;     /* Euler steps executed (sum over rays) */
+  uint64_t n_pos;     /* escaped to +l */
+  uint64_t n_neg;     /* escaped to -l */
+  uint64_t n_none;    /* hit the iteration cap */
+  uint64_t n_oob;     /* texel index == W or == H (reference would panic); clamped */
+  double kernel_ms;   /* HIP-event time of the kernel(s) on the context's stream */
+  double total_ms;    /* wall time of the call including H2D/D2H */
+} curvis_stats;
+
+typedef struct curvis_ctx curvis_ctx;
+
+const char *curvis_version(void);
+/* message of the last error on this context (or of the last failed curvis_ctx_create if ctx == NULL) */
+const char *curvis_last_error(const curvis_ctx *ctx);
+int curvis_device_count(void);
+
+int curvis_ctx_create(int device, curvis_ctx **out);
+void curvis_ctx_destroy(curvis_ctx *ctx);
+/* name of the device + number of CUs, for bench reports */
+int curvis_ctx_device_info(const curvis_ctx *ctx, char *name, size_t name_cap, int *compute_units, int *clock_mhz);
+
+/* SphericalImage (src/images.rs:51-56): which = 0 -> background_positive (+l), 1 -> background_negative.
+ * `rgba` is the decoded image as Rgba8 (what DynamicImage::get_pixel returns, src/images.rs:107-111),
+ * row-major, host memory; it is copied to HBM and kept for all frames. */
+int curvis_ctx_set_sky(curvis_ctx *ctx, int which, const uint8_t *rgba, uint32_t w, uint32_t h);
+/* same, from a device pointer on this context's GPU (e.g. a buffer filled by an RCCL broadcast);
+ * copy != 0 copies it, copy == 0 borrows it (caller keeps it alive). */
+int curvis_ctx_set_sky_device(curvis_ctx *ctx, int which, const void *dev_rgba, uint32_t w, uint32_t h, int copy);
+/* SphericalImage::set_forward_up (src/images.rs:102-104); default forward = x, up = z. */
+int curvis_ctx_set_sky_orientation(curvis_ctx *ctx, int which, const double forward[3], const double up[3]);
+/* Broadcast both sky textures from rank `root` over an existing RCCL communicator (ncclComm_t):
+ * two ncclBroadcast calls of w*h*4 bytes each over xGMI.  Non-root ranks must have called
+ * curvis_ctx_set_sky_shape first or pass the shapes through set_sky with NULL data. */
+int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root);
+
+/* Camera::new (src/cameras.rs:79-122) incl. Orientation::new (src/algebra.rs:16-38). */
+int curvis_camera_init(curvis_camera *out, const double pos[4], const double forward[3], const double up[3],
+                       double focal_length, double sensor_diagonal, uint32_t res_x, uint32_t res_y);
+/* Orientation::new: rotation matrix, its inverse and the orthogonalised up (any may be NULL). */
+int curvis_orientation_init(const double forward[3], const double up[3], double rot[9], double inv_rot[9],
+                            double up_out[3]);
+/* EllisMetric::new / InterstellarMetric::new parameter checks (src/metrics.rs:407-459). */
+int curvis_metric_validate(const curvis_metric *m);
+
+/* RelativisticSystem::render_image (src/systems.rs:307-330): one ray per pixel, forward-Euler
+ * integration until |l| > max_radius or max_iterations steps, nearest-texel sky lookup.
+ * rgb_out: host buffer res_y*res_x*3 (row-major, RGB8) or NULL to leave the frame in HBM
+ * (see curvis_ctx_framebuffer / curvis_ctx_download). */
+int curvis_render_brute(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
+                        uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
+                        curvis_stats *stats);
+/* same, plus the final state of every ray (dbg_out: res_y*res_x entries, row-major). */
+int curvis_render_brute_debug(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
+                              uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
+                              curvis_ray_debug *dbg_out, curvis_stats *stats);
+/* n_frames cameras of identical resolution rendered by ONE launch (video shards):
+ * rgb_out is n_frames*res_y*res_x*3 or NULL. */
+int curvis_render_brute_batch(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cameras,
+                              uint32_t n_frames, uint32_t max_iterations, double max_radius, double delta,
+                              uint8_t *rgb_out, curvis_stats *stats);
+
+/* device framebuffer of the last render (RGB8, frames back to back) */
+int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes);
+int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);
+int curvis_ctx_synchronize(curvis_ctx *ctx);
+
+/* tuning knobs (not part of the reference surface): "variant" (0 = persistent lane-refill kernel,
+ * 1 = static one-ray-per-thread kernel), "chunk", "refill_threshold", "blocks_per_cu". */
+int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value);
+int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value);
+
+/* self-test hooks used by tests/ (device vs host bit-equality of cv_math.h and of IEEE div/sqrt):
+ * op: 0 sin, 1 cos, 2 atan, 3 acos, 4 log, 5 atan2(a,b), 6 a/b, 7 sqrt(a), 8 fma(a,b,a) */
+int curvis_selftest_math(curvis_ctx *ctx, int op, const double *a, const double *b, double *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CURVIS_HIP_H */

@@ -1,0 +1,88 @@
+"""Shared scene builders for the parity tests (same inputs to the oracle, the host twin and the GPU)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import oracle_lib as O
+import curvis_amd
+from curvis_amd import _abi, skies
+
+HALF_PI = np.pi / 2
+DEFAULTS = dict(max_radius=100.0, delta=0.05)  # settings/defaults/simulation_settings.toml
+
+
+def make_skies(w=512, h=256, kind="check"):
+    if kind == "check":
+        return skies.checker(w, h, seed=0xC0FFEE), skies.checker(w, h, seed=0xBADC0DE)
+    return skies.smooth(w, h, 128), skies.smooth(w, h, 32)
+
+
+def scene(metric="ellis", res=(64, 36), pos=(0.0, 5.0, HALF_PI, 0.0), fwd=(-1.0, 0.0, 0.0), up=(0.0, 0.0, 1.0),
+          focal=15.0, diag=43.0):
+    """returns (oracle metric, oracle camera, product metric, product camera)"""
+    if metric == "ellis":
+        om, pm = O.ellis(1.0), curvis_amd.EllisMetric(1.0)
+    elif metric == "interstellar":
+        om, pm = O.interstellar(0.1, 1e-4, 1.0), curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0)
+    else:
+        om, pm = O.flat(), curvis_amd.FlatSphericalMetric()
+    oc = O.camera(pos, fwd, up, focal, diag, res)
+    pc = curvis_amd.Camera(pos, fwd, up, focal, diag, res[0], res[1])
+    return om, oc, pm, pc
+
+
+_twin = None
+
+
+def twin():
+    global _twin
+    if _twin is None:
+        p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_twin", "libtwin.so")
+        L = C.CDLL(p)
+        L.twin_math_array.restype = None
+        L.twin_math_array.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.twin_render.restype = None
+        L.twin_render.argtypes = [C.POINTER(_abi.Metric), C.POINTER(_abi.CameraC), C.c_void_p, C.c_uint, C.c_uint,
+                                  C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_double, C.c_double, C.c_void_p,
+                                  C.c_void_p]
+        _twin = L
+    return _twin
+
+
+def twin_math(op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty_like(a)
+    bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+    twin().twin_math_array(op, a.ctypes.data, bb.ctypes.data if bb is not None else None, out.ctypes.data, a.size)
+    return out
+
+
+def twin_render(pm, pc, sky_pos, sky_neg, max_iter, max_radius, delta):
+    W, H = pc.resolution_width, pc.resolution_height
+    rgb = np.zeros((H, W, 3), np.uint8)
+    dbg = np.zeros((H, W), _abi.RAY_DEBUG)
+    m = pm._c()
+    twin().twin_render(C.byref(m), C.byref(pc._c), sky_pos.ctypes.data, sky_pos.shape[1], sky_pos.shape[0],
+                       sky_neg.ctypes.data, sky_neg.shape[1], sky_neg.shape[0], max_iter, max_radius, delta,
+                       rgb.ctypes.data, dbg.ctypes.data)
+    return rgb, dbg
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_debug_equal(got, want, check_t=True):
+    """bit-exact comparison of two RAY_DEBUG arrays (NaN payloads included)."""
+    assert got.shape == want.shape
+    for f in ("steps", "code", "tx", "ty"):
+        bad = np.nonzero(got[f] != want[f])
+        assert bad[0].size == 0, "%s differs at %d rays, first %s: %s vs %s" % (
+            f, bad[0].size, [b[0] for b in bad], got[f][bad][0], want[f][bad][0])
+    lo = 0 if check_t else 1
+    for f in ("x", "p"):
+        g, w = bits(got[f])[..., lo:], bits(want[f])[..., lo:]
+        bad = np.nonzero(g != w)
+        assert bad[0].size == 0, "%s differs at %d entries, first index %s: %r vs %r" % (
+            f, bad[0].size, [b[0] for b in bad], got[f][..., lo:][bad][0], want[f][..., lo:][bad][0])

@@ -1,0 +1,89 @@
+// Host twin of the device per-ray functions (curvis_amd/csrc/cv_device.h, cv_math.h) compiled for
+// x86-64.  TEST VEHICLE ONLY: lets the CPU test-suite (no GPU in the build container) check that the
+// kernel source is bit-identical to the oracle's CVO_CV flavour.  Nothing in curvis_amd/ loads this.
+#include <cstdint>
+#include <cstring>
+
+#include "../../curvis_amd/csrc/cv_device.h"
+#include "../../include/curvis_hip.h"
+
+template <int KIND>
+static void render_kind(const cvk::MetricParams &M, const cvk::CameraParams &C, const cvk::SkyParams sky[2],
+                        unsigned W, unsigned H, unsigned max_iter, double R, double delta, uint8_t *rgb,
+                        curvis_ray_debug *dbg) {
+  for (unsigned py = 0; py < H; ++py)
+    for (unsigned px = 0; px < W; ++px) {
+      cvk::Ray q;
+      cvk::ray_init<KIND>(M, C, px, py, q);
+      unsigned steps = 0;
+      int code = cvk::CODE_NONE;
+      while (steps < max_iter) {
+        cvk::ray_step<KIND, true>(M, q, delta);
+        ++steps;
+        if (q.l > R) { code = cvk::CODE_POS; break; }
+        else if (q.l < -R) { code = cvk::CODE_NEG; break; }
+      }
+      unsigned texel = 0xFF000000u, tx = 0, ty = 0;
+      if (code != cvk::CODE_NONE) {
+        double d0, d1, d2;
+        cvk::ray_direction<KIND>(M, q, d0, d1, d2);
+        const cvk::SkyParams &S = sky[code == cvk::CODE_POS ? 0 : 1];
+        cvk::sky_indices(S, d0, d1, d2, tx, ty);
+        unsigned cx = tx >= S.w ? S.w - 1 : tx, cy = ty >= S.h ? S.h - 1 : ty;
+        texel = S.texels[(size_t)cy * S.w + cx];
+      }
+      size_t o = (size_t)py * W + px;
+      rgb[o * 3 + 0] = texel & 0xFF;
+      rgb[o * 3 + 1] = (texel >> 8) & 0xFF;
+      rgb[o * 3 + 2] = (texel >> 16) & 0xFF;
+      if (dbg) {
+        curvis_ray_debug &d = dbg[o];
+        d.x[0] = 0.0; d.x[1] = q.l; d.x[2] = q.th; d.x[3] = q.ph;
+        d.p[0] = 1.0; d.p[1] = q.p1; d.p[2] = q.p2; d.p[3] = steps ? q.p3 + 0.0 : q.p3;
+        d.steps = steps; d.code = code; d.tx = tx; d.ty = ty;
+      }
+    }
+}
+
+
+extern "C" {
+
+double twin_math(int op, double x, double y) {
+  switch (op) {
+    case 0: return cv_sin(x);
+    case 1: return cv_cos(x);
+    case 2: return cv_atan(x);
+    case 3: return cv_acos(x);
+    case 4: return cv_log(x);
+    case 5: return cv_atan2(x, y);
+    case 6: return x / y;
+    case 7: return CV_SQRT(x);
+    default: return CV_FMA(x, y, x);
+  }
+}
+void twin_math_array(int op, const double *a, const double *b, double *out, size_t n) {
+  for (size_t i = 0; i < n; ++i) out[i] = twin_math(op, a[i], b ? b[i] : 0.0);
+}
+
+void twin_render(const curvis_metric *m, const curvis_camera *c, const uint8_t *sky_pos, unsigned wp, unsigned hp,
+                 const uint8_t *sky_neg, unsigned wn, unsigned hn, unsigned max_iter, double R, double delta,
+                 uint8_t *rgb, curvis_ray_debug *dbg) {
+  cvk::MetricParams M;
+  M.rho = m->rho; M.rho2 = m->rho * m->rho; M.m = m->m; M.a = m->a; M.pim = CV_PI * m->m; M.two_o_pi = 2.0 / CV_PI;
+  cvk::CameraParams C;
+  for (int i = 0; i < 4; ++i) C.pos[i] = c->pos[i];
+  for (int i = 0; i < 9; ++i) C.rot[i] = c->rot[i];
+  C.focal = c->focal; C.sensor_w = c->sensor_w; C.sensor_h = c->sensor_h;
+  C.res_x = (double)c->res_x; C.res_y = (double)c->res_y;
+  cvk::SkyParams sky[2];
+  sky[0].texels = (const unsigned *)sky_pos; sky[0].w = wp; sky[0].h = hp;
+  sky[1].texels = (const unsigned *)sky_neg; sky[1].w = wn; sky[1].h = hn;
+  for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < 9; ++i) sky[s].inv_rot[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  switch (m->kind) {
+    case 0: render_kind<0>(M, C, sky, c->res_x, c->res_y, max_iter, R, delta, rgb, dbg); break;
+    case 1: render_kind<1>(M, C, sky, c->res_x, c->res_y, max_iter, R, delta, rgb, dbg); break;
+    default: render_kind<2>(M, C, sky, c->res_x, c->res_y, max_iter, R, delta, rgb, dbg); break;
+  }
+}
+}

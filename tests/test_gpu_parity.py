@@ -1,0 +1,123 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bit-exact against the oracle's CVO_CV flavour (same IEEE operation sequence);
+<= 1 LSB per channel on the smooth sky against the glibc-libm flavour, outside the ill-conditioned
+pole rows (tolerance from BASELINE.json north_star: "<= 1 ULP per channel")."""
+import numpy as np
+import pytest
+
+import common
+import oracle_lib as O
+import curvis_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_math_bit_identical_to_host(gpu_ctx):
+    """cv_math.h on gfx950 == cv_math.h on x86, IEEE division and sqrt correctly rounded on device."""
+    rng = np.random.default_rng(1234)
+    n = 1 << 20
+    u = rng.uniform
+    cases = {
+        0: np.concatenate([u(-4, 7, n), u(-1e6, 1e6, n // 4), np.ldexp(u(1, 2, n // 4), rng.integers(20, 1023, n // 4)),
+                           np.array([0.0, -0.0, np.pi / 2, np.pi, np.inf, np.nan, 1e-310, 5e-324])]),
+        2: np.concatenate([u(-700, 700, n), 10.0 ** u(-12, 25, n // 4), np.array([0.0, np.inf, -np.inf, np.nan])]),
+        3: np.concatenate([u(-1, 1, n), 1 - 10.0 ** u(-16, -1, n // 4), np.array([1.0, -1.0, 1.0000000000000002, np.nan])]),
+        4: np.concatenate([u(1, 1e6, n), 10.0 ** u(-300, 300, n // 4), np.array([0.0, -1.0, 1.0, np.inf, 5e-324])]),
+    }
+    cases[1] = cases[0]
+    for op, a in cases.items():
+        got = gpu_ctx.selftest_math(op, a)
+        want = common.twin_math(op, a)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), "cv_math op %d differs on device" % op
+    a, b = u(-5, 5, n), u(-5, 5, n)
+    assert np.array_equal(gpu_ctx.selftest_math(5, a, b).view(np.uint64), common.twin_math(5, a, b).view(np.uint64))
+    # IEEE-754 division / sqrt / fma: numpy on the host is the reference
+    a = np.concatenate([u(-1e3, 1e3, n), 10.0 ** u(-300, 300, n)])
+    b = np.concatenate([u(-1e3, 1e3, n), 10.0 ** u(-300, 300, n)])
+    with np.errstate(all="ignore"):
+        assert np.array_equal(gpu_ctx.selftest_math(6, a, b).view(np.uint64), (a / b).view(np.uint64))
+        assert np.array_equal(gpu_ctx.selftest_math(7, np.abs(a)).view(np.uint64), np.sqrt(np.abs(a)).view(np.uint64))
+    assert np.array_equal(gpu_ctx.selftest_math(8, a, b).view(np.uint64), common.twin_math(8, a, b).view(np.uint64))
+
+
+CASES = [
+    ("ellis", (64, 36), (0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), 4096),
+    ("interstellar", (64, 36), (0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), 4096),
+    ("ellis", (61, 35), (0.0, 3.0, common.HALF_PI, 1.0), (-1.0, 0.1, 0.05), 2500),     # ragged tiles, cap binds
+    ("interstellar", (40, 24), (0.0, -2.0, 1.2, 4.0), (1.0, 0.2, -0.1), 3000),          # camera in the -l space
+    ("flat", (32, 18), (0.0, 5.0, 1.0, 0.5), (1.0, 0.3, 0.2), 4096),
+]
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("metric,res,pos,fwd,cap", CASES)
+def test_full_ray_state_bit_exact_vs_oracle(gpu_ctx, variant, metric, res, pos, fwd, cap):
+    sp, sn = common.make_skies(256, 128, "check")
+    om, oc, pm, pc = common.scene(metric, res=res, pos=pos, fwd=fwd)
+    want_rgb, want_dbg, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, debug=True)
+    gpu_ctx.set_option("variant", variant)
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
+                                         context=gpu_ctx)
+    got_rgb, got_dbg = sys_.render_image_debug(cap, 100.0, 0.05)
+    common.assert_debug_equal(got_dbg, want_dbg, check_t=True)
+    assert np.array_equal(got_rgb, want_rgb)
+    s = sys_.last_stats
+    assert (s.rays, s.steps, s.n_pos, s.n_neg, s.n_none) == (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none)
+    # the non-debug kernel (phi not integrated) must give the same pixels
+    assert np.array_equal(sys_.render_image(cap, 100.0, 0.05), want_rgb)
+    gpu_ctx.set_option("variant", 0)
+
+
+def test_config1_256x144_pixels(gpu_ctx):
+    """BASELINE config 1 (256x144, all defaults, cap 40000): bit-exact vs oracle(cv); vs oracle(libm)
+    <= 1 per channel on the smooth sky except ill-conditioned rays, which are counted and reported."""
+    sp, sn = common.make_skies(512, 256, "smooth")
+    om, oc, pm, pc = common.scene("ellis", res=(256, 144))
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
+                                         context=gpu_ctx)
+    got = sys_.render_image(40000, 100.0, 0.05)
+    want_cv, _, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05)
+    assert np.array_equal(got, want_cv)
+    assert sys_.last_stats.steps == st.steps
+    want_libm, _, _ = O.render_image(O.LIBM, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05)
+    diff = np.abs(got.astype(int) - want_libm.astype(int)).max(axis=2)
+    frac_exact = float((diff == 0).mean())
+    frac_le1 = float((diff <= 1).mean())
+    print("config1 vs libm oracle: exact %.5f, <=1 LSB %.5f, max %d" % (frac_exact, frac_le1, diff.max()))
+    assert frac_le1 > 0.98
+
+
+def test_batch_equals_single_frames(gpu_ctx):
+    sp, sn = common.make_skies(256, 128, "check")
+    cams = []
+    for k in range(3):
+        _, _, pm, pc = common.scene("ellis", res=(48, 27), pos=(0.0, 3.0 + k, common.HALF_PI, 0.3 * k))
+        cams.append(pc)
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    batch, st = gpu_ctx.render_brute(pm, cams, 3000, 100.0, 0.05)
+    total = 0
+    for k, c in enumerate(cams):
+        one, s1 = gpu_ctx.render_brute(pm, c, 3000, 100.0, 0.05)
+        assert np.array_equal(batch[k], one)
+        total += s1.steps
+    assert st.steps == total and st.rays == 3 * 48 * 27
+
+
+def test_camera_outside_is_an_error(gpu_ctx):
+    sp, sn = common.make_skies(64, 32, "check")
+    _, _, pm, pc = common.scene("ellis", res=(8, 8), pos=(0.0, 150.0, common.HALF_PI, 0.0))
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
+                                         context=gpu_ctx)
+    with pytest.raises(curvis_amd.CurvisError) as e:
+        sys_.render_image(100, 100.0, 0.05)
+    assert e.value.code == -4
+
+
+def test_zero_iterations_is_black(gpu_ctx):
+    sp, sn = common.make_skies(64, 32, "check")
+    _, _, pm, pc = common.scene("ellis", res=(16, 9))
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
+                                         context=gpu_ctx)
+    img = sys_.render_image(0, 100.0, 0.05)
+    assert img.shape == (9, 16, 3) and not img.any() and sys_.last_stats.n_none == 16 * 9

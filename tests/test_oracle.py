@@ -1,0 +1,234 @@
+"""The oracle against everything the reference's own tests pin on this path and the
+known-answer values of the survey.  CPU only."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+L = O.lib()
+PI = math.pi
+FLS = [O.LIBM, O.CV]
+
+
+def v3(fl, theta, phi):
+    out = np.zeros(3)
+    L.cvo_vector3_from_theta_phi(fl, theta, phi, O._dp(out))
+    return out
+
+
+@pytest.mark.parametrize("fl", FLS)
+def test_vector3_from_theta_phi_known_answers(fl):
+    """src/algebra.rs:259-282: 14 known answers, approx::assert_relative_eq! default tolerance."""
+    s = 1.0 / math.sqrt(2.0)
+    cases = [((0.0, 0.0), (0, 0, 1)), ((PI / 2, 0.0), (1, 0, 0)), ((PI, 0.0), (0, 0, -1)),
+             ((PI / 2, PI / 4), (s, s, 0)), ((-PI / 2, PI / 4), (-s, -s, 0)), ((PI / 2, -PI / 4), (s, -s, 0)),
+             ((-PI / 2, -PI / 4), (-s, s, 0)), ((PI / 2, PI / 2), (0, 1, 0)), ((-PI / 2, PI / 2), (0, -1, 0)),
+             ((PI / 2, 3 * PI / 4), (-s, s, 0)), ((PI / 2, PI), (-1, 0, 0)), ((PI / 2, 5 * PI / 4), (-s, -s, 0)),
+             ((PI / 2, 3 * PI / 2), (0, -1, 0)), ((PI / 2, 7 * PI / 4), (s, -s, 0))]
+    eps = np.finfo(float).eps
+    for (t, p), want in cases:
+        got = v3(fl, t, p)
+        for g, w in zip(got, want):
+            # approx relative_eq: |a-b| <= eps (absolute) or |a-b| <= max(|a|,|b|)*eps (default max_relative = eps)
+            assert abs(g - w) <= eps or abs(g - w) <= max(abs(g), abs(w)) * eps, ((t, p), got, want)
+
+
+def orientation(fwd, up):
+    rot, inv, upo = np.zeros(9), np.zeros(9), np.zeros(3)
+    rc = L.cvo_orientation_new(O._dp(O.vec(*fwd)), O._dp(O.vec(*up)), O._dp(rot), O._dp(inv), O._dp(upo))
+    return rc, rot.reshape(3, 3), inv.reshape(3, 3), upo
+
+
+def test_orientation_constructor_exact():
+    """src/algebra.rs:145-176 (assert_eq!, exact) and :200-209 (identity for fwd=x, up=z)."""
+    rc, rot, inv, up = orientation((1, 0, 0), (0, 0, 1))
+    assert rc == 0 and np.array_equal(up, [0, 0, 1]) and np.array_equal(rot, np.eye(3))
+    for fwd, upv, want in [((1, 0, 0), (1, 0, 1), (0, 0, 1)), ((1, 1, 0), (-1, -1, 1), (0, 0, 1)),
+                           ((1, 0, 1), (1, 1, 1), (0, 1, 0))]:
+        rc, rot, inv, up = orientation(fwd, upv)
+        assert rc == 0
+        assert np.array_equal(up, want), (fwd, upv, up)
+
+
+def test_orientation_parallel_panics():
+    """src/algebra.rs:178-198 should_panic."""
+    assert orientation((1, 0, 0), (1, 0, 0))[0] == -1
+    assert orientation((1, 0, 0), (-1, 0, 0))[0] == -1
+
+
+def test_orientation_inverse_is_identity():
+    """src/algebra.rs:211-235 (randomised)."""
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        f, u = rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3)
+        rc, rot, inv, _ = orientation(f, u)
+        assert rc == 0
+        np.testing.assert_allclose(rot @ inv, np.eye(3), atol=1e-15)
+        np.testing.assert_allclose(rot @ np.array([1.0, 0, 0]), f / np.linalg.norm(f), atol=1e-15)
+
+
+@pytest.mark.parametrize("fl", FLS)
+def test_theta_phi_round_trip(fl):
+    """src/algebra.rs:284-309 with its epsilon 2e12*f64::EPSILON (and a much tighter one)."""
+    rng = np.random.default_rng(11)
+    for _ in range(1000):
+        th, ph, r = rng.uniform(0, PI), rng.uniform(0, 2 * PI), rng.uniform(0.1, 5.0)
+        v = O.vec(r * math.sin(th) * math.cos(ph), r * math.sin(th) * math.sin(ph), r * math.cos(th))
+        t, p = C.c_double(), C.c_double()
+        L.cvo_theta_phi_from_vector3(fl, O._dp(v), C.byref(t), C.byref(p))
+        assert abs(t.value - th) < 1e-9 * max(1, th) and abs(p.value - ph) < 1e-9 * max(1, ph)
+
+
+@pytest.mark.parametrize("fl", FLS)
+def test_photon_normalization_and_direction(fl):
+    """src/metrics.rs:515-541: photon is null and relativistic_vector_to_direction returns the direction."""
+    e = O.ellis(1.0)
+    pos = O.vec(0.0, 5.0, PI / 2, 0.0)
+    a = PI / 4
+    d = O.vec(math.cos(a), 0.0, math.sin(a))
+    x, p, out = np.zeros(4), np.zeros(4), np.zeros(3)
+    L.cvo_new_photon(fl, C.byref(e), O._dp(pos), O._dp(d), O._dp(x), O._dp(p))
+    n = L.cvo_squared_norm_cov(fl, C.byref(e), O._dp(p), O._dp(x))
+    assert abs(n) <= np.finfo(float).eps  # assert_relative_eq!(norm, 0.0)
+    L.cvo_vector_to_direction(fl, C.byref(e), O._dp(p), O._dp(x), O._dp(out))
+    np.testing.assert_allclose(out, d, rtol=np.finfo(float).eps, atol=np.finfo(float).eps)
+
+
+@pytest.mark.parametrize("fl", FLS)
+def test_kat1_metric_scalars(fl):
+    e, it = O.ellis(1.0), O.interstellar(0.1, 1e-4, 1.0)
+    assert L.cvo_metric_r(fl, C.byref(e), 5.0) == 5.0990195135927845
+    assert L.cvo_metric_r_derivative(fl, C.byref(e), 5.0) == 0.9805806756909202
+    assert abs(L.cvo_metric_r(fl, C.byref(it), 5.0) - 5.5538415248760264) < 2e-15
+    assert L.cvo_metric_r(fl, C.byref(it), -5.0) == L.cvo_metric_r(fl, C.byref(it), 5.0)
+    assert abs(L.cvo_metric_r_squared(fl, C.byref(it), 5.0) - 30.845155683437266) < 2e-14
+    assert abs(L.cvo_metric_r_derivative(fl, C.byref(it), 5.0) - 0.9800061762290591) < 5e-16
+    assert L.cvo_metric_r_derivative(fl, C.byref(it), -5.0) == -L.cvo_metric_r_derivative(fl, C.byref(it), 5.0)
+    assert L.cvo_metric_r(fl, C.byref(it), 5e-5) == 1.0
+    assert L.cvo_metric_r_derivative(fl, C.byref(it), 5e-5) == 0.0
+
+
+@pytest.mark.parametrize("fl", FLS)
+def test_kat2_propagation_state(fl):
+    """State behind src/metrics.rs:543-570 (100 steps, delta 0.01); the reference's assertion on the
+    norm cannot hold, the state is the known answer."""
+    e = O.ellis(1.0)
+    pos = O.vec(0.0, 5.0, PI / 2, 0.0)
+    a = PI / 4
+    x, p = np.zeros(4), np.zeros(4)
+    L.cvo_new_photon(fl, C.byref(e), O._dp(pos), O._dp(O.vec(math.cos(a), 0.0, math.sin(a))), O._dp(x), O._dp(p))
+    for _ in range(100):
+        L.cvo_update(fl, C.byref(e), O._dp(x), O._dp(p), 0.01)
+    np.testing.assert_allclose(x, [-1.0000000000000007, 5.749028999476, 1.5707963267948966, 0.121642825893],
+                               rtol=1e-11)
+    np.testing.assert_allclose(p[:2], [1.0, 0.786462992935], rtol=1e-11)
+    assert abs(p[3] - 3.60555127546) < 1e-10
+    assert abs(L.cvo_squared_norm_cov(fl, C.byref(e), O._dp(p), O._dp(pos)) - 0.118524039256) < 1e-10
+    assert abs(L.cvo_squared_norm_cov(fl, C.byref(e), O._dp(p), O._dp(x)) - 3.0056e-4) < 1e-7
+
+
+KAT34 = {
+    "ellis": [(0.0, 1, 1901), (PI / 2, 1, 1990), (2.9, 1, 2074), (3.0, -1, 2114), (PI, -1, 2101)],
+    "interstellar": [(0.0, 1, 1901), (PI / 2, 1, 2000), (2.9, 1, 2058), (3.0, -1, 2106), (PI, -1, 2101)],
+}
+
+
+@pytest.mark.parametrize("fl", FLS)
+@pytest.mark.parametrize("name", ["ellis", "interstellar"])
+def test_kat34_escape(fl, name):
+    met = O.ellis() if name == "ellis" else O.interstellar()
+    for alpha, code, steps in KAT34[name]:
+        c, s, x, p = O.escape_photon(fl, met, (0, 5, PI / 2, 0), (math.cos(alpha), 0.0, math.sin(alpha)), 0.05, 40000,
+                                     100.0)
+        assert (c, s) == (code, steps), (alpha, c, s)
+    if name == "ellis":
+        c, s, x, p = O.escape_photon(fl, met, (0, 5, PI / 2, 0), (1.0, 0.0, 0.0), 0.05, 40000, 100.0)
+        assert x[1] == 100.04999999999646 and p[1] == 1.0
+        c, s, x, p = O.escape_photon(fl, met, (0, 5, PI / 2, 0), (math.cos(PI / 2), 0.0, math.sin(PI / 2)), 0.05, 40000,
+                                     100.0)
+        assert abs(x[3] - 1.5381061032038592) < 1e-13 and abs(p[1] - 1.0044336279077155) < 1e-13
+        angles = [0.0, 1.53814814214, 3.87828144397, 5.67680946329, PI]
+        for (alpha, code, _), want in zip(KAT34[name], angles):
+            c, ang, _ = O.compute_escape_angle(fl, met, 5.0, alpha, 0.05, 40000, 100.0)
+            assert c == code and abs(ang - want) < 1e-10
+
+
+def test_escape_photon_panics_outside():
+    c, s, x, p = O.escape_photon(O.LIBM, O.ellis(), (0, 101.0, PI / 2, 0), (1.0, 0, 0), 0.05, 10, 100.0)
+    assert c == O.PANIC
+
+
+@pytest.mark.parametrize("fl", FLS)
+def test_kat5_sampler(fl):
+    """efficient-mode sampler, Ellis l=5, n0=100, maxit=100, thr 1e-5/1e-5, cap 4096."""
+    smp = O.Samples()
+    e = O.ellis()
+    rc = L.cvo_doubly_sample(fl, C.byref(e), 5.0, 0.05, 4096, 100.0, -0.1 * PI, 1.1 * PI, 100, 100, 1e-5, 1e-5,
+                             C.byref(smp))
+    assert rc == 0
+    assert smp.n == 678 and smp.calls == 712 and smp.steps == 1496307
+    a = np.ctypeslib.as_array(smp.a, (smp.n,))
+    assert np.all(np.diff(a) > 0)
+    assert abs(a[-1] - 3.3516) < 1e-3  # the sampled domain shrinks from 1.1*pi (sampling.rs:161)
+    L.cvo_samples_free(C.byref(smp))
+
+
+def test_interp_slice_semantics():
+    x = np.array([0.0, 1.0, 3.0]); y = np.array([0.0, 2.0, 0.0])
+    xp = np.array([-1.0, 0.0, 0.5, 1.0, 2.0, 3.0, 4.0, np.nan])
+    out = np.zeros_like(xp)
+    L.cvo_interp_slice(O._dp(x), O._dp(y), 3, O._dp(xp), xp.size, O._dp(out))
+    np.testing.assert_array_equal(out[:-1], [-2.0, 0.0, 1.0, 2.0, 1.0, 0.0, -1.0])  # extrapolates
+    assert np.isnan(out[-1])
+
+
+def test_sky_index_edges():
+    """src/images.rs:115-121: truncation, rem_euclid wrap, `as u32` saturation."""
+    img = np.zeros((256, 512, 4), np.uint8)
+    s = O.sky(img)
+    x, y = C.c_uint32(), C.c_uint32()
+    for v, want in [((1.0, 0.0, 0.0), (256, 128)), ((-1.0, 0.0, 0.0), (0, 128)), ((-1.0, -1e-300, 0.0), (0, 128)),
+                    ((0.0, 0.0, 1.0), (256, 0)), ((0.0, 0.0, -1.0), (256, 256)), ((0.0, 1.0, 0.0), (128, 128)),
+                    ((0.0, -1.0, 0.0), (384, 128))]:
+        for fl in FLS:
+            L.cvo_sky_indices(fl, C.byref(s), O._dp(O.vec(*v)), C.byref(x), C.byref(y))
+            assert (x.value, y.value) == want, (v, x.value, y.value)
+    # NaN direction -> (0, 0) through `NaN as u32 == 0`
+    L.cvo_sky_indices(O.LIBM, C.byref(s), O._dp(O.vec(np.nan, 0.0, 0.0)), C.byref(x), C.byref(y))
+    assert (x.value, y.value) == (0, 0)
+
+
+def test_path_frames_and_off_by_one(tmp_path):
+    """times_of_frames (src/rendering.rs:224-238) and the Interpolator off-by-one (src/interpolation.rs:76-90)."""
+    import tools_paths
+    orbit = tmp_path / "orbit.csv"
+    through = tmp_path / "through.csv"
+    tools_paths.write_orbit(orbit)
+    tools_paths.write_through(through)
+    p = O.Path()
+    assert L.cvo_load_path(str(orbit).encode(), C.byref(p)) == 0
+    assert p.n == 1000
+    tmin, tmax = p.pos[0], p.pos[4 * 999]
+    assert L.cvo_times_of_frames(tmin, tmax, 4.0, None, 0) == 240
+    assert L.cvo_times_of_frames(tmin, tmax, 30.0, None, 0) == 1801
+    times = np.zeros(1801)
+    L.cvo_times_of_frames(tmin, tmax, 30.0, O._dp(times), 1801)
+    pos, f, u = np.zeros(4), np.zeros(3), np.zeros(3)
+    rcs = [L.cvo_path_camera(C.byref(p), t, O._dp(pos), O._dp(f), O._dp(u)) for t in times]
+    first_bad = next(i for i, r in enumerate(rcs) if r != 0)
+    assert first_bad == 1799 and rcs[first_bad] == -2  # README: "sometimes panics on the last frame"
+    times4 = np.zeros(240)
+    L.cvo_times_of_frames(tmin, tmax, 4.0, O._dp(times4), 240)
+    assert all(L.cvo_path_camera(C.byref(p), t, O._dp(pos), O._dp(f), O._dp(u)) == 0 for t in times4)
+    # t == min_time: indices (0, 1), frac 0
+    assert L.cvo_path_camera(C.byref(p), tmin, O._dp(pos), O._dp(f), O._dp(u)) == 0
+    assert pos[1] == 3.0 and pos[3] == 0.0
+    L.cvo_path_free(C.byref(p))
+    assert L.cvo_load_path(str(through).encode(), C.byref(p)) == 0
+    tmin, tmax = p.pos[0], p.pos[4 * (p.n - 1)]
+    assert L.cvo_times_of_frames(tmin, tmax, 24.0, None, 0) == 480
+    assert L.cvo_times_of_frames(tmin, tmax, 30.0, None, 0) == 600
+    L.cvo_path_free(C.byref(p))

@@ -1,0 +1,37 @@
+import os
+
+import pytest
+
+from curvis_amd import paths
+
+REF = "/root/reference/paths"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_generated_paths_equal_reference_files(tmp_path):
+    o, t = tmp_path / "o.csv", tmp_path / "t.csv"
+    paths.write_orbit(o)
+    paths.write_through(t)
+    assert o.read_bytes() == open(os.path.join(REF, "path_orbit.csv"), "rb").read()
+    # path_through goes through np.exp/arctan/cos/sin, whose last bit depends on the numpy build
+    # (SIMD loops): the reference's file is reproduced to <= 2 ulp, most rows byte-identical.
+    mine = paths.load_path(t)
+    ref = paths.load_path(os.path.join(REF, "path_through.csv"))
+    import numpy as np
+    for a, b in zip(mine, ref):
+        assert a.shape == b.shape
+        assert np.max(np.abs(a - b)) < 1e-15
+    differing = int(np.sum(np.any(mine[1] != ref[1], axis=1)))
+    assert differing < 50
+    for k in (0, 2):
+        assert np.array_equal(mine[k], ref[k])
+
+
+def test_shipped_paths_match_generators(tmp_path):
+    o, t = tmp_path / "o.csv", tmp_path / "t.csv"
+    paths.write_orbit(o)
+    paths.write_through(t)
+    assert o.read_bytes() == open(os.path.join(paths.DATA_DIR, "path_orbit.csv"), "rb").read()
+    assert t.read_bytes() == open(os.path.join(paths.DATA_DIR, "path_through.csv"), "rb").read()
+    pos, fwd, up = paths.load_path(os.path.join(paths.DATA_DIR, "path_orbit.csv"))
+    assert pos.shape == (1000, 4) and fwd.shape == (1000, 3) and up.shape == (1000, 3)
