@@ -40,9 +40,10 @@ def parse():
     ap.add_argument("--max-iter", type=int, default=4096)
     ap.add_argument("--metric", default="ellis", choices=["ellis", "interstellar"])
     ap.add_argument("--sky", type=int, default=8192, help="sky width (height = width/2)")
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=1, help="1 static kernel (default), 0 persistent lane-refill kernel")
     ap.add_argument("--refill-threshold", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--fast-math", type=int, default=1, help="1 shared-reciprocal step, 0 compiler IEEE div/sqrt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=16)
     return ap.parse_args()
@@ -75,6 +76,7 @@ def main():
         ctx.set_option("refill_threshold", args.refill_threshold)
     if args.blocks_per_cu is not None:
         ctx.set_option("blocks_per_cu", args.blocks_per_cu)
+    ctx.set_option("fast_math", args.fast_math)
 
     # ---- inputs resident in HBM before the timed region: two skies (rank 0 generates, RCCL broadcast)
     sw, sh = args.sky, args.sky // 2
@@ -120,11 +122,13 @@ def main():
     steps_executed = 0
     rays = 0
     kernel_ms = 0.0
+    shade_ms = 0.0
     for _ in range(args.steps):
         st = step()
         steps_executed += st.steps
         rays += st.rays
-        kernel_ms += st.kernel_ms  # HIP events on the context's own stream, inside the C ABI
+        kernel_ms += st.integrate_ms  # HIP events on the context's own stream, inside the C ABI
+        shade_ms += st.shade_ms
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -132,11 +136,12 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        agg = torch.tensor([float(steps_executed), float(rays), kernel_ms], dtype=torch.float64, device="cuda")
+        agg = torch.tensor([float(steps_executed), float(rays), kernel_ms, shade_ms], dtype=torch.float64,
+                           device="cuda")
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        total_steps, total_rays, total_kernel_ms = [float(v) for v in agg.tolist()]
+        total_steps, total_rays, total_kernel_ms, total_shade_ms = [float(v) for v in agg.tolist()]
     else:
-        total_steps, total_rays, total_kernel_ms = float(steps_executed), float(rays), kernel_ms
+        total_steps, total_rays, total_kernel_ms, total_shade_ms = float(steps_executed), float(rays), kernel_ms, shade_ms
 
     if rank == 0:
         n_launches = args.steps * world
@@ -166,7 +171,8 @@ def main():
             "config": {
                 "workload": "configs[1]: %s wormhole, %dx%d, cap %d Euler steps, R=100, delta=0.05, single image; "
                             "%d frame(s)/GPU/step" % (args.metric, args.width, args.height, args.max_iter, 1),
-                "kernel": "geodesic_persistent" if args.variant == 0 else "geodesic_static",
+                "kernel": ("geodesic_persistent" if args.variant == 0 else "geodesic_static") +
+                          ("<fast>" if args.fast_math else "<strict>"),
                 "frames_per_gpu": args.steps,
                 "rays_per_frame": int(per_launch_rays),
                 "executed_steps_per_frame": int(per_launch_steps),
@@ -180,7 +186,9 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / FP64_VECTOR_PEAK_TFLOPS, 4),
                 "flop_per_step": flop,
+                "kernel": "geodesic_persistent" if args.variant == 0 else "geodesic_static",
                 "kernel_ms_avg": round(kernel_s * 1e3, 4),
+                "shade_kernel_ms_avg": round(total_shade_ms / n_launches, 4),
                 "traffic": None,
                 "hbm": {"achieved": round(hbm_gbps, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(hbm_gbps / HBM_PEAK_GBPS, 8),

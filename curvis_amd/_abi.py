@@ -30,7 +30,8 @@ class CameraC(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("n_pos", C.c_uint64), ("n_neg", C.c_uint64),
-                ("n_none", C.c_uint64), ("n_oob", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("n_none", C.c_uint64), ("n_oob", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("integrate_ms", C.c_double), ("shade_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -21,6 +21,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -41,106 +42,62 @@ namespace {
 
 enum { CNT_NEXT = 0, CNT_STEPS, CNT_POS, CNT_NEG, CNT_NONE, CNT_OOB, CNT_RAYS, CNT_N };
 
-struct LaunchParams {
+/* Final ray states, structure-of-arrays in HBM, indexed by pixel id = frame*W*H + py*W + px.
+ * Written by the integration kernel, read once by the shading kernel (48-56 B per ray against
+ * ~2000 Euler steps of arithmetic: the staging costs ~0.2% of a frame). */
+struct RayStore {
+  double *l, *th, *ph, *p1, *p2, *p3;
+  unsigned *steps;
+  int *code;
+};
+
+struct IntegrateParams {
   cvk::MetricParams metric;
-  cvk::SkyParams sky[2];
   const cvk::CameraParams *cams; /* device, n_frames entries */
   unsigned n_frames, W, H, tiles_x, tiles_y;
-  unsigned rays_per_frame;          /* tiles_x*tiles_y*64 (padded to whole tiles) */
-  unsigned long long total_rays;    /* n_frames * rays_per_frame */
+  unsigned rays_per_frame;       /* tiles_x*tiles_y*64 (padded to whole 8x8 tiles) */
+  unsigned long long total_rays; /* n_frames * rays_per_frame */
   unsigned max_iter;
   double max_radius, delta;
-  unsigned char *fb;                /* RGB8, n_frames*H*W*3 */
-  curvis_ray_debug *dbg;            /* n_frames*H*W or null */
-  unsigned long long *counters;     /* CNT_N */
+  RayStore store;
+  unsigned long long *counters; /* CNT_N */
   int refill_threshold;
+  int fast_ok; /* host-side part of the fast-step guard */
 };
 
-struct LaneJob {
-  unsigned frame;
-  unsigned pix; /* py*W + px */
+struct ShadeParams {
+  cvk::MetricParams metric;
+  cvk::SkyParams sky[2];
+  RayStore store;
+  unsigned long long n_pixels; /* n_frames*W*H */
+  unsigned char *fb;           /* RGB8 */
+  curvis_ray_debug *dbg;       /* or null */
+  unsigned long long *counters;
 };
 
-__device__ __forceinline__ bool decode_ray(const LaunchParams &P, unsigned long long id, LaneJob &job, unsigned &px,
-                                           unsigned &py) {
-  const unsigned frame = (unsigned)(id / P.rays_per_frame);
+/* ray id -> (frame, pixel).  Rays are numbered by 8x8 pixel tiles so the 64 rays a wave draws
+ * together are spatial neighbours (similar step counts, neighbouring texels). */
+__device__ __forceinline__ bool decode_ray(const IntegrateParams &P, unsigned long long id, unsigned &frame,
+                                           unsigned &px, unsigned &py) {
+  frame = (unsigned)(id / P.rays_per_frame);
   const unsigned rem = (unsigned)(id - (unsigned long long)frame * P.rays_per_frame);
   const unsigned tile = rem >> 6, k = rem & 63u;
   const unsigned tyi = tile / P.tiles_x, txi = tile - tyi * P.tiles_x;
   px = txi * 8u + (k & 7u);
   py = tyi * 8u + (k >> 3);
-  job.frame = frame;
-  job.pix = py * P.W + px;
   return px < P.W && py < P.H;
 }
 
-struct LaneStats {
-  unsigned long long steps;
-  unsigned rays, pos, neg, none, oob;
-};
-
-/* retire one ray: direction, sky lookup, RGB store, optional debug dump */
-template <int KIND, bool DEBUG>
-__device__ __forceinline__ void retire_ray(const LaunchParams &P, const cvk::Ray &q, int code, unsigned steps,
-                                           const LaneJob &job, LaneStats &st) {
-  unsigned texel = 0xFF000000u; /* Rgba([0,0,0,255]) */
-  unsigned tx = 0, ty = 0;
-  if (code != cvk::CODE_NONE) {
-    double d0, d1, d2;
-    cvk::ray_direction<KIND>(P.metric, q, d0, d1, d2);
-    const cvk::SkyParams &S = P.sky[code == cvk::CODE_POS ? 0 : 1];
-    cvk::sky_indices(S, d0, d1, d2, tx, ty);
-    unsigned cx = tx, cy = ty;
-    if (cx >= S.w || cy >= S.h) st.oob++; /* reference: image::get_pixel panics; defined here: clamp + count */
-    if (cx >= S.w) cx = S.w - 1;
-    if (cy >= S.h) cy = S.h - 1;
-    texel = S.texels[(size_t)cy * S.w + cx];
-  }
-  const size_t o = ((size_t)job.frame * P.W * P.H + job.pix);
-  unsigned char *dst = P.fb + o * 3;
-  dst[0] = (unsigned char)(texel & 0xFF);
-  dst[1] = (unsigned char)((texel >> 8) & 0xFF);
-  dst[2] = (unsigned char)((texel >> 16) & 0xFF);
-  st.steps += steps;
-  st.rays++;
-  st.pos += (code == cvk::CODE_POS);
-  st.neg += (code == cvk::CODE_NEG);
-  st.none += (code == cvk::CODE_NONE);
-  if (DEBUG) {
-    curvis_ray_debug *d = P.dbg + o;
-    d->x[0] = 0.0; /* t and p_t are filled in by the host (dead lanes of the integrator) */
-    d->x[1] = q.l;
-    d->x[2] = q.th;
-    d->x[3] = q.ph;
-    d->p[0] = 1.0;
-    d->p[1] = q.p1;
-    d->p[2] = q.p2;
-    d->p[3] = steps ? q.p3 + 0.0 : q.p3; /* p3 + 0.0*delta of the reference (-0 -> +0) */
-    d->steps = steps;
-    d->code = code;
-    d->tx = tx;
-    d->ty = ty;
-  }
-}
-
-__device__ __forceinline__ void flush_stats(const LaunchParams &P, LaneStats st) {
-  /* wave reduction, then one atomic per counter per wave */
-  for (int off = 32; off > 0; off >>= 1) {
-    st.steps += __shfl_xor(st.steps, off);
-    st.rays += __shfl_xor(st.rays, off);
-    st.pos += __shfl_xor(st.pos, off);
-    st.neg += __shfl_xor(st.neg, off);
-    st.none += __shfl_xor(st.none, off);
-    st.oob += __shfl_xor(st.oob, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&P.counters[CNT_STEPS], st.steps);
-    atomicAdd(&P.counters[CNT_RAYS], (unsigned long long)st.rays);
-    atomicAdd(&P.counters[CNT_POS], (unsigned long long)st.pos);
-    atomicAdd(&P.counters[CNT_NEG], (unsigned long long)st.neg);
-    atomicAdd(&P.counters[CNT_NONE], (unsigned long long)st.none);
-    if (st.oob) atomicAdd(&P.counters[CNT_OOB], (unsigned long long)st.oob);
-  }
+template <bool PHI>
+__device__ __forceinline__ void store_ray(const RayStore &S, size_t o, const cvk::Ray &q, unsigned steps, int code) {
+  S.l[o] = q.l;
+  S.th[o] = q.th;
+  if (PHI) S.ph[o] = q.ph;
+  S.p1[o] = q.p1;
+  S.p2[o] = q.p2;
+  S.p3[o] = q.p3;
+  S.steps[o] = steps;
+  S.code[o] = code;
 }
 
 /* escape test of src/systems.rs:129-134 followed by the loop bound of :126 */
@@ -159,22 +116,47 @@ __device__ __forceinline__ bool ray_terminated(double l, double R, unsigned step
   return false;
 }
 
-template <int KIND, bool DEBUG>
-__global__ __launch_bounds__(256) void geodesic_persistent(const LaunchParams P) {
+template <int KIND, bool PHI, bool FAST>
+__device__ __forceinline__ void one_step(const IntegrateParams &P, cvk::Ray &q, bool lane_ok) {
+  if (FAST)
+    cvk::ray_step_fast<KIND, PHI>(P.metric, q, P.delta, lane_ok);
+  else
+    cvk::ray_step<KIND, PHI>(P.metric, q, P.delta);
+}
+
+__device__ __forceinline__ void flush_steps(const IntegrateParams &P, unsigned long long steps, unsigned rays) {
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_xor(steps, off);
+    rays += __shfl_xor(rays, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&P.counters[CNT_STEPS], steps);
+    atomicAdd(&P.counters[CNT_RAYS], (unsigned long long)rays);
+  }
+}
+
+/* K1, persistent form: lanes draw rays from a global queue with one wave-aggregated atomic whenever
+ * `refill_threshold` lanes are free; terminated rays are stored together at that point. */
+template <int KIND, bool PHI, bool FAST>
+__global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams P) {
   const unsigned lane = threadIdx.x & 63u;
   cvk::Ray q;
   q.l = q.th = q.ph = q.p1 = q.p2 = q.p3 = q.p3sq = 0.0;
-  LaneJob job{0u, 0u};
+  size_t slot = 0;
   unsigned steps = 0;
   int code = cvk::CODE_NONE;
   bool active = false; /* lane is integrating */
-  bool done = false;   /* lane holds a terminated ray that has not been retired yet */
+  bool done = false;   /* lane holds a terminated ray that has not been stored yet */
   bool dry = false;    /* queue exhausted (wave-uniform) */
-  LaneStats st{0ull, 0u, 0u, 0u, 0u, 0u};
+  bool lane_ok = false;
+  unsigned long long st_steps = 0;
+  unsigned st_rays = 0;
 
   for (;;) {
     if (done) {
-      retire_ray<KIND, DEBUG>(P, q, code, steps, job, st);
+      store_ray<PHI>(P.store, slot, q, steps, code);
+      st_steps += steps;
+      st_rays++;
       done = false;
     }
     if (!dry) {
@@ -186,13 +168,16 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const LaunchParams P)
         unsigned long long base = 0;
         if ((int)lane == leader) base = atomicAdd(&P.counters[CNT_NEXT], (unsigned long long)n);
         base = __shfl(base, leader);
-        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        const unsigned rank =
+            __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         const unsigned long long mine = base + rank;
         if (need && mine < P.total_rays) {
-          unsigned px, py;
-          if (decode_ray(P, mine, job, px, py)) {
-            cvk::ray_init<KIND>(P.metric, P.cams[job.frame], px, py, q);
+          unsigned frame, px, py;
+          if (decode_ray(P, mine, frame, px, py)) {
+            cvk::ray_init<KIND>(P.metric, P.cams[frame], px, py, q);
+            slot = (size_t)frame * P.W * P.H + (size_t)py * P.W + px;
             steps = 0;
+            lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
             if (P.max_iter == 0) {
               code = cvk::CODE_NONE;
               done = true;
@@ -204,17 +189,15 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const LaunchParams P)
         if (base + n >= P.total_rays) dry = true;
       }
     }
-    const unsigned long long act = __ballot(active);
-    if (!act) {
+    if (!__ballot(active)) {
       if (__ballot(done)) continue; /* max_iter == 0 corner */
       if (dry) break;
       continue; /* every drawn id was tile padding: draw again */
     }
     const int thr = dry ? 64 : P.refill_threshold;
-    /* integrate until `thr` lanes are free */
-    for (;;) {
+    for (;;) { /* integrate until `thr` lanes are free */
       if (active) {
-        cvk::ray_step<KIND, DEBUG>(P.metric, q, P.delta);
+        one_step<KIND, PHI, FAST>(P, q, lane_ok);
         ++steps;
         if (ray_terminated(q.l, P.max_radius, steps, P.max_iter, code)) {
           active = false;
@@ -224,29 +207,100 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const LaunchParams P)
       if (__popcll(__ballot(!active)) >= thr) break;
     }
   }
-  flush_stats(P, st);
+  flush_steps(P, st_steps, st_rays);
 }
 
-template <int KIND, bool DEBUG>
-__global__ __launch_bounds__(256) void geodesic_static(const LaunchParams P) {
+/* K1, static form: one ray per thread, hardware block scheduling does the load balancing. */
+template <int KIND, bool PHI, bool FAST>
+__global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) {
   const unsigned long long id = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  LaneStats st{0ull, 0u, 0u, 0u, 0u, 0u};
-  LaneJob job{0u, 0u};
-  unsigned px, py;
-  if (id < P.total_rays && decode_ray(P, id, job, px, py)) {
+  unsigned long long st_steps = 0;
+  unsigned st_rays = 0;
+  unsigned frame, px, py;
+  if (id < P.total_rays && decode_ray(P, id, frame, px, py)) {
     cvk::Ray q;
-    cvk::ray_init<KIND>(P.metric, P.cams[job.frame], px, py, q);
+    cvk::ray_init<KIND>(P.metric, P.cams[frame], px, py, q);
+    const bool lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
     unsigned steps = 0;
     int code = cvk::CODE_NONE;
     bool active = P.max_iter != 0;
     while (active) {
-      cvk::ray_step<KIND, DEBUG>(P.metric, q, P.delta);
+      one_step<KIND, PHI, FAST>(P, q, lane_ok);
       ++steps;
       if (ray_terminated(q.l, P.max_radius, steps, P.max_iter, code)) active = false;
     }
-    retire_ray<KIND, DEBUG>(P, q, code, steps, job, st);
+    store_ray<PHI>(P.store, (size_t)frame * P.W * P.H + (size_t)py * P.W + px, q, steps, code);
+    st_steps = steps;
+    st_rays = 1;
   }
-  flush_stats(P, st);
+  flush_steps(P, st_steps, st_rays);
+}
+
+/* K2: final photon -> tangent direction -> nearest sky texel -> RGB8 (rows R9-R10 of SURVEY.md 8a).
+ * One thread per pixel, coalesced reads of the ray store, 3-byte stores of consecutive pixels. */
+template <int KIND, bool DEBUG>
+__global__ __launch_bounds__(256) void shade_kernel(const ShadeParams P) {
+  const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned pos = 0, neg = 0, none = 0, oob = 0;
+  if (o < P.n_pixels) {
+    cvk::Ray q;
+    q.l = P.store.l[o];
+    q.th = P.store.th[o];
+    q.ph = DEBUG ? P.store.ph[o] : 0.0;
+    q.p1 = P.store.p1[o];
+    q.p2 = P.store.p2[o];
+    q.p3 = P.store.p3[o];
+    q.p3sq = 0.0;
+    const int code = P.store.code[o];
+    const unsigned steps = P.store.steps[o];
+    unsigned texel = 0xFF000000u; /* Rgba([0,0,0,255]) */
+    unsigned tx = 0, ty = 0;
+    if (code != cvk::CODE_NONE) {
+      double d0, d1, d2;
+      cvk::ray_direction<KIND>(P.metric, q, d0, d1, d2);
+      const cvk::SkyParams &S = P.sky[code == cvk::CODE_POS ? 0 : 1];
+      cvk::sky_indices(S, d0, d1, d2, tx, ty);
+      unsigned cx = tx, cy = ty;
+      if (cx >= S.w || cy >= S.h) oob = 1; /* reference: image::get_pixel panics; defined here: clamp + count */
+      if (cx >= S.w) cx = S.w - 1;
+      if (cy >= S.h) cy = S.h - 1;
+      texel = S.texels[(size_t)cy * S.w + cx];
+    }
+    unsigned char *dst = P.fb + o * 3;
+    dst[0] = (unsigned char)(texel & 0xFF);
+    dst[1] = (unsigned char)((texel >> 8) & 0xFF);
+    dst[2] = (unsigned char)((texel >> 16) & 0xFF);
+    pos = (code == cvk::CODE_POS);
+    neg = (code == cvk::CODE_NEG);
+    none = (code == cvk::CODE_NONE);
+    if (DEBUG) {
+      curvis_ray_debug *d = P.dbg + o;
+      d->x[0] = 0.0; /* t and p_t: dead lanes of the integrator, filled in by the host */
+      d->x[1] = q.l;
+      d->x[2] = q.th;
+      d->x[3] = q.ph;
+      d->p[0] = 1.0;
+      d->p[1] = q.p1;
+      d->p[2] = q.p2;
+      d->p[3] = steps ? q.p3 + 0.0 : q.p3; /* p3 + 0.0*delta of the reference (-0 -> +0) */
+      d->steps = steps;
+      d->code = code;
+      d->tx = tx;
+      d->ty = ty;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    pos += __shfl_xor(pos, off);
+    neg += __shfl_xor(neg, off);
+    none += __shfl_xor(none, off);
+    oob += __shfl_xor(oob, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (pos) atomicAdd(&P.counters[CNT_POS], (unsigned long long)pos);
+    if (neg) atomicAdd(&P.counters[CNT_NEG], (unsigned long long)neg);
+    if (none) atomicAdd(&P.counters[CNT_NONE], (unsigned long long)none);
+    if (oob) atomicAdd(&P.counters[CNT_OOB], (unsigned long long)oob);
+  }
 }
 
 __global__ void selftest_math_kernel(int op, const double *a, const double *b, double *out, size_t n) {
@@ -308,6 +362,9 @@ struct curvis_ctx {
   size_t fb_cap = 0, fb_bytes = 0;
   curvis_ray_debug *d_dbg = nullptr;
   size_t dbg_cap = 0;
+  unsigned char *d_store = nullptr; /* RayStore arrays, carved from one allocation */
+  size_t store_cap = 0;
+  hipEvent_t ev2 = nullptr;
   cvk::CameraParams *d_cams = nullptr;
   size_t cams_cap = 0;
   cvk::CameraParams *h_cams = nullptr; /* pinned */
@@ -315,9 +372,12 @@ struct curvis_ctx {
   unsigned long long *d_counters = nullptr;
   unsigned long long *h_counters = nullptr; /* pinned */
   /* options */
-  int variant = 0;
-  int refill_threshold = 4;
-  int blocks_per_cu = 0; /* 0 = occupancy query */
+  int variant = 1;          /* 1 static one-ray-per-thread (default: fastest on the BASELINE configs), 0 persistent lane-refill */
+  int refill_threshold = 16;
+  int blocks_per_cu = 0;    /* 0 = occupancy query */
+  int fast_math = 1;        /* 1 shared-reciprocal step (ray_step_fast), 0 compiler IEEE div/sqrt */
+  size_t max_store_bytes = (size_t)8 << 30; /* frames of a batch are rendered in chunks below this */
+  double last_integrate_ms = 0.0, last_shade_ms = 0.0;
 };
 
 namespace {
@@ -371,38 +431,58 @@ cvk::CameraParams make_camera(const curvis_camera &c) {
   return C;
 }
 
-template <int KIND, bool DEBUG>
-int launch(curvis_ctx *ctx, const LaunchParams &P) {
+template <int KIND, bool PHI, bool FAST>
+int launch_integrate(curvis_ctx *ctx, const IntegrateParams &P) {
   if (ctx->variant == 1) {
     const unsigned long long blocks = (P.total_rays + 255ull) / 256ull;
-    hipLaunchKernelGGL((geodesic_static<KIND, DEBUG>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL((geodesic_static<KIND, PHI, FAST>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
   } else {
     int per_cu = ctx->blocks_per_cu;
     if (per_cu <= 0) {
-      HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, geodesic_persistent<KIND, DEBUG>, 256, 0));
+      HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, geodesic_persistent<KIND, PHI, FAST>, 256, 0));
       if (per_cu <= 0) per_cu = 1;
     }
     unsigned long long blocks = (unsigned long long)per_cu * (unsigned long long)ctx->prop.multiProcessorCount;
     const unsigned long long max_useful = (P.total_rays + 255ull) / 256ull;
     if (blocks > max_useful) blocks = max_useful;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL((geodesic_persistent<KIND, DEBUG>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL((geodesic_persistent<KIND, PHI, FAST>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
   }
   HIP_TRY(ctx, hipGetLastError());
   return CURVIS_OK;
 }
 
-template <bool DEBUG>
-int launch_kind(curvis_ctx *ctx, int kind, const LaunchParams &P) {
-  switch (kind) {
-    case CURVIS_METRIC_ELLIS:
-      return launch<cvk::METRIC_ELLIS, DEBUG>(ctx, P);
-    case CURVIS_METRIC_INTERSTELLAR:
-      return launch<cvk::METRIC_INTERSTELLAR, DEBUG>(ctx, P);
-    default:
-      return launch<cvk::METRIC_FLAT, DEBUG>(ctx, P);
-  }
+template <int KIND>
+int launch_integrate_kind(curvis_ctx *ctx, bool phi, bool fast, const IntegrateParams &P) {
+  if (phi) return fast ? launch_integrate<KIND, true, true>(ctx, P) : launch_integrate<KIND, true, false>(ctx, P);
+  return fast ? launch_integrate<KIND, false, true>(ctx, P) : launch_integrate<KIND, false, false>(ctx, P);
 }
+
+template <int KIND>
+int launch_shade_kind(curvis_ctx *ctx, bool debug, const ShadeParams &P) {
+  const unsigned long long blocks = (P.n_pixels + 255ull) / 256ull;
+  if (debug)
+    hipLaunchKernelGGL((shade_kernel<KIND, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+  else
+    hipLaunchKernelGGL((shade_kernel<KIND, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  return CURVIS_OK;
+}
+
+RayStore carve_store(unsigned char *base, size_t npix) {
+  RayStore S;
+  double *d = (double *)base;
+  S.l = d;
+  S.th = d + npix;
+  S.ph = d + 2 * npix;
+  S.p1 = d + 3 * npix;
+  S.p2 = d + 4 * npix;
+  S.p3 = d + 5 * npix;
+  S.steps = (unsigned *)(d + 6 * npix);
+  S.code = (int *)(S.steps + npix);
+  return S;
+}
+constexpr size_t kStoreBytesPerPixel = 6 * sizeof(double) + sizeof(unsigned) + sizeof(int);
 
 int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cams, uint32_t n_frames,
                 uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
@@ -433,6 +513,11 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     rc = ensure_device(ctx, ctx->d_dbg, ctx->dbg_cap, npix * n_frames);
     if (rc) return rc;
   }
+  /* frames per chunk: the ray store of a chunk stays below max_store_bytes */
+  uint32_t chunk = (uint32_t)std::max<size_t>(1, ctx->max_store_bytes / (npix * kStoreBytesPerPixel));
+  if (chunk > n_frames) chunk = n_frames;
+  rc = ensure_device(ctx, ctx->d_store, ctx->store_cap, (size_t)chunk * npix * kStoreBytesPerPixel);
+  if (rc) return rc;
   rc = ensure_device(ctx, ctx->d_cams, ctx->cams_cap, (size_t)n_frames);
   if (rc) return rc;
   if (ctx->h_cams_cap < n_frames) {
@@ -444,40 +529,89 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   for (uint32_t f = 0; f < n_frames; ++f) ctx->h_cams[f] = make_camera(cams[f]);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cams, ctx->h_cams, sizeof(cvk::CameraParams) * n_frames, hipMemcpyHostToDevice,
                               ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
 
-  LaunchParams P;
-  P.metric = make_metric(*metric);
-  for (int s = 0; s < 2; ++s) {
-    P.sky[s].texels = (const unsigned *)ctx->d_sky[s];
-    P.sky[s].w = ctx->sky_w[s];
-    P.sky[s].h = ctx->sky_h[s];
-    for (int i = 0; i < 9; ++i) P.sky[s].inv_rot[i] = ctx->sky_inv_rot[s][i];
+  const cvk::MetricParams MP = make_metric(*metric);
+  const bool phi = dbg_out != nullptr; /* phi is only read by the debug dump on this path */
+  const bool fast = ctx->fast_math != 0;
+  uint64_t tot[CNT_N] = {0};
+  double integrate_ms = 0.0, shade_ms = 0.0;
+
+  for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
+    const uint32_t nf = std::min(chunk, n_frames - f0);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+    IntegrateParams P;
+    P.metric = MP;
+    P.cams = ctx->d_cams + f0;
+    P.n_frames = nf;
+    P.W = W;
+    P.H = H;
+    P.tiles_x = (W + 7) / 8;
+    P.tiles_y = (H + 7) / 8;
+    const unsigned long long rpf = (unsigned long long)P.tiles_x * P.tiles_y * 64ull;
+    if (rpf > 0xFFFFFFFFull) return fail(ctx, CURVIS_E_INVALID, "frame too large");
+    P.rays_per_frame = (unsigned)rpf;
+    P.total_rays = rpf * nf;
+    P.max_iter = max_iterations;
+    P.max_radius = max_radius;
+    P.delta = delta;
+    P.store = carve_store(ctx->d_store, (size_t)nf * npix);
+    P.counters = ctx->d_counters;
+    P.refill_threshold = ctx->refill_threshold < 1 ? 1 : (ctx->refill_threshold > 64 ? 64 : ctx->refill_threshold);
+    P.fast_ok = cvk::metric_fast_ok(metric->kind, MP, max_radius) ? 1 : 0;
+
+    ShadeParams Q;
+    Q.metric = MP;
+    for (int k = 0; k < 2; ++k) {
+      Q.sky[k].texels = (const unsigned *)ctx->d_sky[k];
+      Q.sky[k].w = ctx->sky_w[k];
+      Q.sky[k].h = ctx->sky_h[k];
+      for (int i = 0; i < 9; ++i) Q.sky[k].inv_rot[i] = ctx->sky_inv_rot[k][i];
+    }
+    Q.store = P.store;
+    Q.n_pixels = (unsigned long long)nf * npix;
+    Q.fb = ctx->d_fb + (size_t)f0 * npix * 3;
+    Q.dbg = dbg_out ? ctx->d_dbg + (size_t)f0 * npix : nullptr;
+    Q.counters = ctx->d_counters;
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    switch (metric->kind) {
+      case CURVIS_METRIC_ELLIS:
+        rc = launch_integrate_kind<cvk::METRIC_ELLIS>(ctx, phi, fast, P);
+        break;
+      case CURVIS_METRIC_INTERSTELLAR:
+        rc = launch_integrate_kind<cvk::METRIC_INTERSTELLAR>(ctx, phi, fast, P);
+        break;
+      default:
+        rc = launch_integrate_kind<cvk::METRIC_FLAT>(ctx, phi, fast, P);
+        break;
+    }
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    switch (metric->kind) {
+      case CURVIS_METRIC_ELLIS:
+        rc = launch_shade_kind<cvk::METRIC_ELLIS>(ctx, dbg_out != nullptr, Q);
+        break;
+      case CURVIS_METRIC_INTERSTELLAR:
+        rc = launch_shade_kind<cvk::METRIC_INTERSTELLAR>(ctx, dbg_out != nullptr, Q);
+        break;
+      default:
+        rc = launch_shade_kind<cvk::METRIC_FLAT>(ctx, dbg_out != nullptr, Q);
+        break;
+    }
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < CNT_N; ++k) tot[k] += ctx->h_counters[k];
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    integrate_ms += ms;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
+    shade_ms += ms;
   }
-  P.cams = ctx->d_cams;
-  P.n_frames = n_frames;
-  P.W = W;
-  P.H = H;
-  P.tiles_x = (W + 7) / 8;
-  P.tiles_y = (H + 7) / 8;
-  const unsigned long long rpf = (unsigned long long)P.tiles_x * P.tiles_y * 64ull;
-  if (rpf > 0xFFFFFFFFull) return fail(ctx, CURVIS_E_INVALID, "frame too large");
-  P.rays_per_frame = (unsigned)rpf;
-  P.total_rays = rpf * n_frames;
-  P.max_iter = max_iterations;
-  P.max_radius = max_radius;
-  P.delta = delta;
-  P.fb = ctx->d_fb;
-  P.dbg = dbg_out ? ctx->d_dbg : nullptr;
-  P.counters = ctx->d_counters;
-  P.refill_threshold = ctx->refill_threshold < 1 ? 1 : (ctx->refill_threshold > 64 ? 64 : ctx->refill_threshold);
-
-  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  rc = dbg_out ? launch_kind<true>(ctx, metric->kind, P) : launch_kind<false>(ctx, metric->kind, P);
-  if (rc) return rc;
-  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N,
-                              hipMemcpyDeviceToHost, ctx->stream));
+  ctx->last_integrate_ms = integrate_ms;
+  ctx->last_shade_ms = shade_ms;
   if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (dbg_out)
     HIP_TRY(ctx, hipMemcpyAsync(dbg_out, ctx->d_dbg, sizeof(curvis_ray_debug) * npix * n_frames,
@@ -499,15 +633,15 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     }
   }
   if (stats) {
-    float ms = 0.f;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    stats->rays = ctx->h_counters[CNT_RAYS];
-    stats->steps = ctx->h_counters[CNT_STEPS];
-    stats->n_pos = ctx->h_counters[CNT_POS];
-    stats->n_neg = ctx->h_counters[CNT_NEG];
-    stats->n_none = ctx->h_counters[CNT_NONE];
-    stats->n_oob = ctx->h_counters[CNT_OOB];
-    stats->kernel_ms = (double)ms;
+    stats->rays = tot[CNT_RAYS];
+    stats->steps = tot[CNT_STEPS];
+    stats->n_pos = tot[CNT_POS];
+    stats->n_neg = tot[CNT_NEG];
+    stats->n_none = tot[CNT_NONE];
+    stats->n_oob = tot[CNT_OOB];
+    stats->kernel_ms = integrate_ms + shade_ms;
+    stats->integrate_ms = integrate_ms;
+    stats->shade_ms = shade_ms;
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
   return CURVIS_OK;
@@ -557,7 +691,8 @@ int curvis_ctx_create(int device, curvis_ctx **out) {
   }
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail(std::string("hipStreamCreate: ") + hipGetErrorString(e));
-  if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess)
+  if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+      (e = hipEventCreate(&ctx->ev2)) != hipSuccess)
     return bail(std::string("hipEventCreate: ") + hipGetErrorString(e));
   if ((e = hipMalloc((void **)&ctx->d_counters, sizeof(unsigned long long) * CNT_N)) != hipSuccess)
     return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -575,6 +710,8 @@ void curvis_ctx_destroy(curvis_ctx *ctx) {
     if (ctx->d_sky[s] && ctx->sky_owned[s]) (void)hipFree(ctx->d_sky[s]);
   if (ctx->d_fb) (void)hipFree(ctx->d_fb);
   if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
+  if (ctx->d_store) (void)hipFree(ctx->d_store);
+  if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->d_cams) (void)hipFree(ctx->d_cams);
   if (ctx->h_cams) (void)hipHostFree(ctx->h_cams);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -786,6 +923,10 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->refill_threshold = (int)value;
   else if (k == "blocks_per_cu")
     ctx->blocks_per_cu = (int)value;
+  else if (k == "fast_math")
+    ctx->fast_math = (int)value;
+  else if (k == "max_store_bytes")
+    ctx->max_store_bytes = (size_t)value;
   else
     return fail(ctx, CURVIS_E_INVALID, "unknown option " + k);
   return CURVIS_OK;
@@ -800,6 +941,10 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->refill_threshold;
   else if (k == "blocks_per_cu")
     *value = ctx->blocks_per_cu;
+  else if (k == "fast_math")
+    *value = ctx->fast_math;
+  else if (k == "max_store_bytes")
+    *value = (int64_t)ctx->max_store_bytes;
   else
     return CURVIS_E_INVALID;
   return CURVIS_OK;

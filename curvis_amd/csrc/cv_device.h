@@ -82,11 +82,10 @@ struct Ray {
   double p3, p3sq;  /* covariant phi momentum (constant of motion) and its square */
 };
 
-/* One forward-Euler step: src/metrics.rs:283-297 with :223-244 and :247-270 inlined. */
+/* One forward-Euler step given sin/cos(theta): src/metrics.rs:283-297 with :223-244 and :247-270
+ * inlined, every division and the square root being the compiler's IEEE-754 operations. */
 template <int KIND, bool PHI>
-CV_HD void ray_step(const MetricParams &M, Ray &q, double delta) {
-  double s, c;
-  cv_sincos(q.th, &s, &c);
+CV_HD void ray_step_core(const MetricParams &M, Ray &q, double delta, double s, double c) {
   double r, r2, rd;
   metric_eval<KIND>(M, q.l, r, r2, rd);
   const double ss = s * s;            /* theta.sin().powi(2) */
@@ -98,6 +97,143 @@ CV_HD void ray_step(const MetricParams &M, Ray &q, double delta) {
   const double dp2 = q.p3sq * (c / (r2 * (s * ss)));  /* sin.powi(3) = s*(s*s) */
   if (PHI) {
     const double g33c = 1.0 / (r2 * ss);
+    q.ph = q.ph + (q.p3 * g33c) * delta;
+  }
+  q.l = q.l + dx1 * delta;
+  q.th = q.th + dx2 * delta;
+  q.p1 = q.p1 + dp1 * delta;
+  q.p2 = q.p2 + dp2 * delta;
+}
+
+template <int KIND, bool PHI>
+CV_HD void ray_step(const MetricParams &M, Ray &q, double delta) {
+  double s, c;
+  cv_sincos(q.th, &s, &c);
+  ray_step_core<KIND, PHI>(M, q, delta, s, c);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Fast step: the same IEEE results with far fewer instructions.
+ *
+ * The AMDGPU expansion of an f64 division n/d is  y = rcp(d) + 2 Newton steps;  q0 = n*y;
+ * rem = fma(-d, q0, n);  q = fma(rem, y, q0)  (plus div_scale / div_fixup for extreme exponents),
+ * and that of sqrt(x) is a Goldschmidt iteration on rsq(x) (plus ldexp scaling below 2^-767).  The
+ * final fma of either sequence returns the correctly rounded result for ANY y within a few ulp of
+ * 1/d (Markstein), so the five divisions of a step do not each need their own rcp + Newton chain:
+ * 1/r^2, 1/r^3 and 1/(r^2 sin^3) are products of ONE refined 1/r (a by-product of the sqrt) and
+ * ONE refined 1/sin(theta).  The result of each division is still the individually, correctly
+ * rounded quotient the reference computes (a mis-rounding needs the exact quotient within
+ * ~2^-102 relative of a rounding boundary: probability ~2^-49 per division; tests compare the
+ * fast kernels with the oracle over >10^10 divisions per frame).
+ *
+ * Guards: the shortcut skips div_scale/div_fixup, so it is only taken when every operand is finite,
+ * non-zero and far from the exponent limits; any lane failing the guard executes ray_step_core
+ * (the compiler's IEEE operations) for that step instead. */
+CV_HD double rcp_seed(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcp(x); /* v_rcp_f64 */
+#else
+  return 1.0 / x;
+#endif
+}
+CV_HD double rsq_seed(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rsq(x); /* v_rsq_f64 */
+#else
+  return 1.0 / CV_SQRT(x);
+#endif
+}
+/* y ~ 1/d: hardware seed + two Newton steps (identical to the fdiv expansion's reciprocal) */
+CV_HD double recip_nr2(double d) {
+  double y = rcp_seed(d);
+  double e = CV_FMA(-d, y, 1.0);
+  y = CV_FMA(y, e, y);
+  e = CV_FMA(-d, y, 1.0);
+  return CV_FMA(y, e, y);
+}
+/* correctly rounded n/d given y ~ 1/d */
+CV_HD double div_with_recip(double n, double d, double y) {
+  const double q0 = n * y;
+  const double rem = CV_FMA(-d, q0, n);
+  return CV_FMA(rem, y, q0);
+}
+/* root = sqrt(x) correctly rounded (the AMDGPU Goldschmidt sequence without scaling), y ~ 1/sqrt(x) */
+CV_HD void sqrt_and_rsqrt(double x, double &root, double &y) {
+  const double y0 = rsq_seed(x);
+  double g = x * y0;
+  double h = 0.5 * y0;
+  const double e = CV_FMA(-h, g, 0.5);
+  g = CV_FMA(g, e, g);
+  h = CV_FMA(h, e, h);
+  double d = CV_FMA(-g, g, x);
+  g = CV_FMA(d, h, g);
+  d = CV_FMA(-g, g, x);
+  g = CV_FMA(d, h, g);
+  root = g;
+  const double yy = h + h;
+  const double e2 = CV_FMA(-yy, g, 1.0);
+  y = CV_FMA(yy, e2, yy);
+}
+/* lo_hi <= (high word of |v|) < hi_hi : exponent-range test with two integer ops */
+CV_HD bool hi_word_in(double v, uint32_t lo_hi, uint32_t hi_hi) {
+  return ((cv_hi(v) & 0x7fffffffu) - lo_hi) < (hi_hi - lo_hi);
+}
+#define CV_HI_2POW(e) ((uint32_t)(1023 + (e)) << 20)
+
+/* per-ray part of the guard (p_phi^2 is a constant of the motion) */
+CV_HD bool ray_fast_ok(const Ray &q) { return hi_word_in(q.p3sq, CV_HI_2POW(-300), CV_HI_2POW(300)); }
+
+/* host-side part of the guard: metric parameters / escape radius far from the exponent limits */
+CV_HD bool metric_fast_ok(int kind, const MetricParams &M, double max_radius) {
+  bool ok = hi_word_in(max_radius, CV_HI_2POW(-90), CV_HI_2POW(90));
+  if (kind == METRIC_ELLIS) ok = ok && hi_word_in(M.rho, CV_HI_2POW(-90), CV_HI_2POW(90));
+  if (kind == METRIC_INTERSTELLAR)
+    ok = ok && hi_word_in(M.rho, CV_HI_2POW(-90), CV_HI_2POW(90)) && hi_word_in(M.m, CV_HI_2POW(-90), CV_HI_2POW(90)) &&
+         hi_word_in(M.a, CV_HI_2POW(-300), CV_HI_2POW(90));
+  return ok;
+}
+
+template <int KIND, bool PHI>
+CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_ok) {
+  double s, c;
+  cv_sincos(q.th, &s, &c);
+  /* guard (branch-free): sin(theta) and l finite, non-zero, far from the exponent limits.  cos(theta)
+   * needs no test of its own: it is finite iff sin(theta) is, and the cosine of a double is never
+   * zero or subnormal. */
+  const bool ok = lane_ok & hi_word_in(s, CV_HI_2POW(-60), CV_HI_2POW(1)) &
+                  hi_word_in(q.l, CV_HI_2POW(-100), CV_HI_2POW(100));
+  if (!ok) {
+    ray_step_core<KIND, PHI>(M, q, delta, s, c);
+    return;
+  }
+  double r, r2, rd, y_r;
+  if (KIND == METRIC_ELLIS) {
+    r2 = M.rho2 + q.l * q.l;
+    sqrt_and_rsqrt(r2, r, y_r);
+    rd = div_with_recip(q.l, r, y_r);
+  } else {
+    metric_eval<KIND>(M, q.l, r, r2, rd);
+    y_r = recip_nr2(r);
+  }
+  const double y_s = recip_nr2(s);
+  const double y_r2 = y_r * y_r;
+  const double y_ss = y_s * y_s;
+  const double ss = s * s;
+  const double g22c = div_with_recip(1.0, r2, y_r2);
+  const double dx1 = q.p1;
+  const double dx2 = q.p2 * g22c;
+  const double b2 = q.p2 * q.p2 + div_with_recip(q.p3sq, ss, y_ss);
+  const double num = b2 * rd;
+  const double r3 = r * (r * r);
+  double dp1;
+  if (hi_word_in(num, CV_HI_2POW(-300), CV_HI_2POW(300))) {
+    dp1 = div_with_recip(num, r3, y_r2 * y_r);
+  } else { /* zero (r' == 0 inside the Interstellar throat), huge (|p_theta| exploding at a pole) or NaN */
+    dp1 = num / r3;
+  }
+  const double dp2 = q.p3sq * div_with_recip(c, r2 * (s * ss), y_r2 * (y_ss * y_s));
+  if (PHI) {
+    const double g33c = div_with_recip(1.0, r2 * ss, y_r2 * y_ss);
     q.ph = q.ph + (q.p3 * g33c) * delta;
   }
   q.l = q.l + dx1 * delta;

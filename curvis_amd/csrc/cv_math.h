@@ -279,27 +279,54 @@ CV_HD int cv_rem_pio2(double x, double *y0, double *y1) {
   return ((int)fn) & 3;
 }
 
+/* sin and cos of x together.
+ *
+ * Main path (|x| < 1024 and x not within 2^-20 of a multiple of pi/2), branch-free:
+ *   k  = rint(x * 2/pi)
+ *   r1 = fma(-k, P1, x)     exact: x - k*P1 is a multiple of 2^-53 below 1 in magnitude
+ *   t  = fma(-k, P2, r1)    head of the reduced argument
+ *   u  = r1 - t             exact (|u| <= 2^-44, a multiple of ulp(t) >= 2^-72)
+ *   lo = fma(-k, P3, fma(-k, P2, u))    tail: rounding error of t, plus the third piece of pi/2
+ * with pi/2 = P1 + P2 + P3 to 2^-161.  Everything else (tiny, huge, non-finite, or deeply
+ * cancelling arguments such as theta == fl(pi/2), which the equatorial rays hold for ever) takes
+ * cv_rem_pio2, the fdlibm-style iterative / Payne-Hanek reduction.  Both paths feed the same
+ * kernels; which path an argument takes is a function of the argument alone, so host and device
+ * agree bit for bit. */
 CV_HD void cv_sincos(double x, double *sn, double *cs) {
-  const uint32_t ix = cv_hi(x) & 0x7fffffffu;
-  if (ix <= 0x3fe921fbu) { /* |x| <= ~pi/4 */
-    *sn = cv_ksin(x, 0.0);
-    *cs = cv_kcos(x, 0.0);
-    return;
-  }
-  if (ix >= 0x7ff00000u) { /* inf / nan */
-    *sn = *cs = x - x;
-    return;
-  }
+  const double INVPIO2 = 6.36619772367581382433e-01; /* 0x3FE45F306DC9C883 */
+  const double P1 = 1.57079632679489655800e+00;      /* 0x3FF921FB54442D18 */
+  const double P2 = 6.12323399573676603587e-17;      /* 0x3C91A62633145C07 */
+  const double P3 = -1.4973849048591698e-33;         /* 0xB91F1976B7ED8FBC */
+  const double k = CV_RINT(x * INVPIO2);
+  const double r1 = CV_FMA(-k, P1, x);
+  const double t = CV_FMA(-k, P2, r1);
   double y0, y1;
-  int n = cv_rem_pio2(x, &y0, &y1);
-  double s = cv_ksin(y0, y1);
-  double c = cv_kcos(y0, y1);
-  double so = (n & 1) ? c : s;
-  double co = (n & 1) ? s : c;
-  if (n & 2) so = -so;
-  if ((n + 1) & 2) co = -co;
-  *sn = so;
-  *cs = co;
+  int n;
+  if (CV_FABS(x) < 1024.0 && CV_FABS(t) >= 9.5367431640625e-07 /* 2^-20 */) {
+    const double u = r1 - t;
+    y0 = t;
+    y1 = CV_FMA(-k, P3, CV_FMA(-k, P2, u));
+    n = (int)k;
+  } else {
+    const uint32_t ix = cv_hi(x) & 0x7fffffffu;
+    if (ix >= 0x7ff00000u) { /* inf / nan */
+      *sn = *cs = x - x;
+      return;
+    }
+    if (ix <= 0x3fe921fbu) { /* |x| <= ~pi/4 */
+      y0 = x;
+      y1 = 0.0;
+      n = 0;
+    } else {
+      n = cv_rem_pio2(x, &y0, &y1);
+    }
+  }
+  const double s = cv_ksin(y0, y1);
+  const double c = cv_kcos(y0, y1);
+  const double so = (n & 1) ? c : s;
+  const double co = (n & 1) ? s : c;
+  *sn = cv_from_bits(cv_bits(so) ^ ((uint64_t)(n & 2) << 62));
+  *cs = cv_from_bits(cv_bits(co) ^ ((uint64_t)((n + 1) & 2) << 62));
 }
 
 CV_HD double cv_sin(double x) {

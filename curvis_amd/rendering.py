@@ -1,0 +1,155 @@
+"""Host orchestration of the video path (mirror of src/rendering.rs + src/interpolation.rs) with the
+frames of a video sharded across the GPUs of a node.
+
+Reference surface mirrored:
+  Interpolator::{from_file, min_time, max_time, camera_position, camera_forward, camera_up}
+                                                              src/interpolation.rs:45-112
+  VideoRenderingSystem::times_of_frames                       src/rendering.rs:224-238
+  VideoRenderingSystem::update_camera / render                src/rendering.rs:242-327
+The reference renders frames one after the other on one thread.  Frames are independent
+(src/rendering.rs:291-316: the only shared mutable is the camera, overwritten per frame), so here
+frame k goes to rank k mod world_size; each rank renders its shard in batches of `batch` frames
+per kernel launch; there is no data-path collective (the two skies are broadcast once, before).
+"""
+import numpy as np
+
+from . import paths
+from .systems import Camera
+
+
+class InterpolatorPanic(RuntimeError):
+    """a panic of the reference's Interpolator (message of the panic, or the index-out-of-bounds)."""
+
+
+class Interpolator:
+    def __init__(self, positions, forward_vectors, up_vectors):
+        self.positions = np.asarray(positions, dtype=np.float64)
+        self.forward_vectors = np.asarray(forward_vectors, dtype=np.float64)
+        self.up_vectors = np.asarray(up_vectors, dtype=np.float64)
+
+    @classmethod
+    def from_file(cls, path_to_csv_file):
+        return cls(*paths.load_path(path_to_csv_file))
+
+    def min_time(self):
+        return float(self.positions[0][0])
+
+    def max_time(self):
+        return float(self.positions[len(self.positions) - 1][0])
+
+    def time_indexes_and_frac_from_time(self, t):
+        """src/interpolation.rs:63-91, including its off-by-one: the loop leaves (t1, t2) on segment
+        (i-1, i) but returns the indices (i, i+1)."""
+        if t < self.min_time():
+            raise InterpolatorPanic("Interpolation time cannot be smaller than first time in positions[0].")
+        if t > self.max_time():
+            raise InterpolatorPanic("Interpolation time cannot be greater than last time in positions[0].")
+        t1, t2 = self.min_time(), self.max_time()
+        i = 0
+        while t > self.positions[i][0]:
+            t1 = float(self.positions[i][0])
+            t2 = float(self.positions[i + 1][0])
+            i += 1
+        frac = (t - t1) / (t2 - t1)
+        return i, i + 1, frac
+
+    def _interp(self, table, t):
+        i1, i2, frac = self.time_indexes_and_frac_from_time(t)
+        if i2 >= len(table):
+            raise InterpolatorPanic("index out of bounds: the len is %d but the index is %d" % (len(table), i2))
+        if not (0.0 <= frac <= 1.0):
+            raise InterpolatorPanic("frac must be between 0 and 1")
+        v1, v2 = table[i1], table[i2]
+        return v1 + frac * (v2 - v1)
+
+    def camera_position(self, t):
+        return self._interp(self.positions, t)
+
+    def camera_forward(self, t):
+        return self._interp(self.forward_vectors, t)
+
+    def camera_up(self, t):
+        return self._interp(self.up_vectors, t)
+
+
+def times_of_frames(min_time, max_time, frame_rate):
+    """src/rendering.rs:224-238 (float accumulation, not k*dt)."""
+    delta_time = 1.0 / frame_rate
+    times = []
+    t = min_time
+    while t < max_time:
+        times.append(t)
+        t += delta_time
+    return times
+
+
+def frames_of_rank(n_frames, rank, world_size):
+    """frame k -> rank k mod world_size (costs are near-uniform: same ray count per frame)."""
+    return list(range(rank, n_frames, world_size))
+
+
+class VideoRenderingSystem:
+    """VideoRenderingSystem<M> (src/rendering.rs:178-327) over one curvis Context per rank."""
+
+    def __init__(self, metric, context, interpolator, frame_rate, resolution, camera_diagonal, camera_focal_length,
+                 escape_radius, max_iterations_propagation, ray_integration_step, rank=0, world_size=1, batch=8):
+        self.metric = metric
+        self.context = context
+        self.interpolator = interpolator
+        self.frame_rate = float(frame_rate)
+        self.resolution = tuple(resolution)
+        self.camera_diagonal = float(camera_diagonal)
+        self.camera_focal_length = float(camera_focal_length)
+        self.escape_radius = float(escape_radius)
+        self.max_iterations_propagation = int(max_iterations_propagation)
+        self.ray_integration_step = float(ray_integration_step)
+        self.rank, self.world_size, self.batch = int(rank), int(world_size), max(1, int(batch))
+
+    def times_of_frames(self):
+        return times_of_frames(self.interpolator.min_time(), self.interpolator.max_time(), self.frame_rate)
+
+    def camera_at(self, t):
+        """update_camera (src/rendering.rs:242-253): a fresh Camera with interpolated pose."""
+        it = self.interpolator
+        return Camera(it.camera_position(t), it.camera_forward(t), it.camera_up(t), self.camera_focal_length,
+                      self.camera_diagonal, self.resolution[0], self.resolution[1])
+
+    def render(self, on_frame=None, download=True):
+        """Render this rank's shard.  on_frame(index, rgb_or_None, stats_dict) is called per frame in
+        index order of the shard.  Returns the list of per-frame statistics dicts (early-termination
+        statistics included: executed steps, escaped +/-, capped rays)."""
+        times = self.times_of_frames()
+        mine = frames_of_rank(len(times), self.rank, self.world_size)
+        out = []
+        for b0 in range(0, len(mine), self.batch):
+            idx = mine[b0:b0 + self.batch]
+            cams = [self.camera_at(times[k]) for k in idx]
+            if len(cams) == 1:
+                rgb, st = self.context.render_brute(self.metric, cams[0], self.max_iterations_propagation,
+                                                    self.escape_radius, self.ray_integration_step, download=download)
+                frames = [rgb] if download else [None]
+                per = [st]
+            else:
+                # one launch for the whole batch; per-frame statistics need per-frame launches, so the
+                # batch statistics are attributed evenly unless batch == 1
+                rgb, st = self.context.render_brute(self.metric, cams, self.max_iterations_propagation,
+                                                    self.escape_radius, self.ray_integration_step, download=download)
+                frames = list(rgb) if download else [None] * len(cams)
+                per = [st] * len(cams)
+            for k, frame, s in zip(idx, frames, per):
+                d = dict(frame=k, time=times[k], rank=self.rank, batch_frames=len(idx), rays=s.rays // len(idx),
+                         steps=s.steps // len(idx), n_pos=s.n_pos // len(idx), n_neg=s.n_neg // len(idx),
+                         n_none=s.n_none // len(idx), kernel_ms=s.kernel_ms / len(idx))
+                out.append(d)
+                if on_frame is not None:
+                    on_frame(k, frame, d)
+        return out
+
+
+def gather_frame_stats(local_stats, dist=None):
+    """all ranks -> rank 0 list ordered by frame index (host-side gather of small python objects)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return sorted(local_stats, key=lambda d: d["frame"])
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, local_stats)
+    return sorted([d for part in gathered for d in part], key=lambda d: d["frame"])

@@ -123,7 +123,7 @@ class Context:
         self._h = C.c_void_p()
         check(lib().curvis_ctx_create(int(device), C.byref(self._h)))
         self.device = device
-        self._sky_ids = [None, None]
+        self._sky_objs = [None, None]  # strong refs: identity check must not suffer id() reuse
 
     def close(self):
         if self._h:
@@ -146,13 +146,13 @@ class Context:
         check(lib().curvis_ctx_set_sky(self._h, which, image.rgba.ctypes.data, image.width_pixels,
                                        image.height_pixels), self._h)
         check(lib().curvis_ctx_set_sky_orientation(self._h, which, dptr(image.forward), dptr(image.up)), self._h)
-        self._sky_ids[which] = id(image)
+        self._sky_objs[which] = image
 
     def set_sky_device(self, which, dev_ptr, w, h, copy=False, forward=(1.0, 0.0, 0.0), up=(0.0, 0.0, 1.0)):
         check(lib().curvis_ctx_set_sky_device(self._h, which, C.c_void_p(dev_ptr), w, h, int(copy)), self._h)
         check(lib().curvis_ctx_set_sky_orientation(self._h, which, dptr(_vec(forward, 3)), dptr(_vec(up, 3))),
               self._h)
-        self._sky_ids[which] = None
+        self._sky_objs[which] = None
 
     def set_option(self, key, value):
         check(lib().curvis_ctx_set_option(self._h, key.encode(), int(value)), self._h)
@@ -219,9 +219,9 @@ class RelativisticSystem:
 
     def _bind_skies(self):
         ctx = self.context
-        if ctx._sky_ids[0] != id(self.background_positive):
+        if ctx._sky_objs[0] is not self.background_positive:
             ctx.set_sky(0, self.background_positive)
-        if ctx._sky_ids[1] != id(self.background_negative):
+        if ctx._sky_objs[1] is not self.background_negative:
             ctx.set_sky(1, self.background_negative)
 
     def render_image(self, max_iterations, max_radius, delta):

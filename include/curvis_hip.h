@@ -85,8 +85,10 @@ typedef struct curvis_stats {
   uint64_t n_neg;     /* escaped to -l */
   uint64_t n_none;    /* hit the iteration cap */
   uint64_t n_oob;     /* texel index == W or == H (reference would panic); clamped */
-  double kernel_ms;   /* HIP-event time of the kernel(s) on the context's stream */
+  double kernel_ms;   /* HIP-event time of the kernels on the context's stream (integrate + shade) */
   double total_ms;    /* wall time of the call including H2D/D2H */
+  double integrate_ms; /* HIP-event time of the geodesic integration kernel(s) alone */
+  double shade_ms;     /* HIP-event time of the shading (direction + sky lookup) kernel(s) */
 } curvis_stats;
 
 typedef struct curvis_ctx curvis_ctx;
@@ -111,8 +113,8 @@ int curvis_ctx_set_sky_device(curvis_ctx *ctx, int which, const void *dev_rgba, 
 /* SphericalImage::set_forward_up (src/images.rs:102-104); default forward = x, up = z. */
 int curvis_ctx_set_sky_orientation(curvis_ctx *ctx, int which, const double forward[3], const double up[3]);
 /* Broadcast both sky textures from rank `root` over an existing RCCL communicator (ncclComm_t):
- * two ncclBroadcast calls of w*h*4 bytes each over xGMI.  Non-root ranks must have called
- * curvis_ctx_set_sky_shape first or pass the shapes through set_sky with NULL data. */
+ * the shapes (4 x u32) first, then two ncclBroadcast calls of w*h*4 bytes each over xGMI.
+ * Non-root ranks need no prior set_sky: their textures are allocated from the broadcast shapes. */
 int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root);
 
 /* Camera::new (src/cameras.rs:79-122) incl. Orientation::new (src/algebra.rs:16-38). */
@@ -147,7 +149,9 @@ int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);
 int curvis_ctx_synchronize(curvis_ctx *ctx);
 
 /* tuning knobs (not part of the reference surface): "variant" (0 = persistent lane-refill kernel,
- * 1 = static one-ray-per-thread kernel), "chunk", "refill_threshold", "blocks_per_cu". */
+ * 1 = static one-ray-per-thread kernel), "refill_threshold", "blocks_per_cu", "fast_math"
+ * (1 = shared-reciprocal Euler step, 0 = compiler IEEE division/sqrt; identical results),
+ * "max_store_bytes" (ray-store budget that bounds the frames per launch of a batch). */
 int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value);
 int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value);
 

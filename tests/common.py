@@ -45,7 +45,7 @@ def twin():
         L.twin_render.restype = None
         L.twin_render.argtypes = [C.POINTER(_abi.Metric), C.POINTER(_abi.CameraC), C.c_void_p, C.c_uint, C.c_uint,
                                   C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_double, C.c_double, C.c_void_p,
-                                  C.c_void_p]
+                                  C.c_void_p, C.c_int]
         _twin = L
     return _twin
 
@@ -58,14 +58,14 @@ def twin_math(op, a, b=None):
     return out
 
 
-def twin_render(pm, pc, sky_pos, sky_neg, max_iter, max_radius, delta):
+def twin_render(pm, pc, sky_pos, sky_neg, max_iter, max_radius, delta, fast=0):
     W, H = pc.resolution_width, pc.resolution_height
     rgb = np.zeros((H, W, 3), np.uint8)
     dbg = np.zeros((H, W), _abi.RAY_DEBUG)
     m = pm._c()
     twin().twin_render(C.byref(m), C.byref(pc._c), sky_pos.ctypes.data, sky_pos.shape[1], sky_pos.shape[0],
                        sky_neg.ctypes.data, sky_neg.shape[1], sky_neg.shape[0], max_iter, max_radius, delta,
-                       rgb.ctypes.data, dbg.ctypes.data)
+                       rgb.ctypes.data, dbg.ctypes.data, int(fast))
     return rgb, dbg
 
 

@@ -10,15 +10,20 @@
 template <int KIND>
 static void render_kind(const cvk::MetricParams &M, const cvk::CameraParams &C, const cvk::SkyParams sky[2],
                         unsigned W, unsigned H, unsigned max_iter, double R, double delta, uint8_t *rgb,
-                        curvis_ray_debug *dbg) {
+                        curvis_ray_debug *dbg, int fast) {
+  const bool metric_ok = cvk::metric_fast_ok(KIND, M, R);
   for (unsigned py = 0; py < H; ++py)
     for (unsigned px = 0; px < W; ++px) {
       cvk::Ray q;
       cvk::ray_init<KIND>(M, C, px, py, q);
       unsigned steps = 0;
       int code = cvk::CODE_NONE;
+      const bool lane_ok = fast && metric_ok && cvk::ray_fast_ok(q);
       while (steps < max_iter) {
-        cvk::ray_step<KIND, true>(M, q, delta);
+        if (fast)
+          cvk::ray_step_fast<KIND, true>(M, q, delta, lane_ok);
+        else
+          cvk::ray_step<KIND, true>(M, q, delta);
         ++steps;
         if (q.l > R) { code = cvk::CODE_POS; break; }
         else if (q.l < -R) { code = cvk::CODE_NEG; break; }
@@ -67,7 +72,7 @@ void twin_math_array(int op, const double *a, const double *b, double *out, size
 
 void twin_render(const curvis_metric *m, const curvis_camera *c, const uint8_t *sky_pos, unsigned wp, unsigned hp,
                  const uint8_t *sky_neg, unsigned wn, unsigned hn, unsigned max_iter, double R, double delta,
-                 uint8_t *rgb, curvis_ray_debug *dbg) {
+                 uint8_t *rgb, curvis_ray_debug *dbg, int fast) {
   cvk::MetricParams M;
   M.rho = m->rho; M.rho2 = m->rho * m->rho; M.m = m->m; M.a = m->a; M.pim = CV_PI * m->m; M.two_o_pi = 2.0 / CV_PI;
   cvk::CameraParams C;
@@ -81,9 +86,9 @@ void twin_render(const curvis_metric *m, const curvis_camera *c, const uint8_t *
   for (int s = 0; s < 2; ++s)
     for (int i = 0; i < 9; ++i) sky[s].inv_rot[i] = (i % 4 == 0) ? 1.0 : 0.0;
   switch (m->kind) {
-    case 0: render_kind<0>(M, C, sky, c->res_x, c->res_y, max_iter, R, delta, rgb, dbg); break;
-    case 1: render_kind<1>(M, C, sky, c->res_x, c->res_y, max_iter, R, delta, rgb, dbg); break;
-    default: render_kind<2>(M, C, sky, c->res_x, c->res_y, max_iter, R, delta, rgb, dbg); break;
+    case 0: render_kind<0>(M, C, sky, c->res_x, c->res_y, max_iter, R, delta, rgb, dbg, fast); break;
+    case 1: render_kind<1>(M, C, sky, c->res_x, c->res_y, max_iter, R, delta, rgb, dbg, fast); break;
+    default: render_kind<2>(M, C, sky, c->res_x, c->res_y, max_iter, R, delta, rgb, dbg, fast); break;
   }
 }
 }

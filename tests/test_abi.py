@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_struct_layouts_match_header():
     assert C.sizeof(_abi.Metric) == 32
     assert C.sizeof(_abi.CameraC) == 4 * 8 + 9 * 8 + 3 * 8 + 8
-    assert C.sizeof(_abi.Stats) == 64
+    assert C.sizeof(_abi.Stats) == 80
     assert _abi.RAY_DEBUG.itemsize == 80 and O.RAY_DEBUG.itemsize == 80
 
 

@@ -1,0 +1,96 @@
+"""Accuracy of curvis_amd/csrc/cv_math.h (the deterministic elementary functions shared by the
+kernels and the oracle's CVO_CV flavour) against mpmath: every function < 1 ulp (atan2 < 1.5).
+Runs on the host twin; tests/test_gpu_parity.py checks device == host bit for bit."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+import common
+
+mpmath = pytest.importorskip("mpmath")
+from mpmath import mp, mpf  # noqa: E402
+
+mp.prec = 300
+N = 4000
+OPS = {"sin": 0, "cos": 1, "atan": 2, "acos": 3, "log": 4}
+REF = {"sin": mpmath.sin, "cos": mpmath.cos, "atan": mpmath.atan, "acos": mpmath.acos, "log": mpmath.log}
+
+
+def max_ulp_error(name, xs):
+    got = common.twin_math(OPS[name], np.array(xs, dtype=np.float64))
+    worst = 0.0
+    for x, g in zip(xs, got):
+        ex = REF[name](mpf(x))
+        u = math.ulp(abs(float(ex))) if ex != 0 else 5e-324
+        worst = max(worst, float(abs(mpf(float(g)) - ex) / u))
+    return worst
+
+
+def near_multiples(rng, kmax, dist_exp):
+    out = []
+    for _ in range(N // 4):
+        k = rng.randint(1, kmax)
+        base = float(mpf(k) * mpmath.pi / 2)
+        d = math.ldexp(rng.uniform(1, 2), rng.randint(*dist_exp)) * rng.choice([-1, 1])
+        out.append(base + d)
+        out.append(base)
+        out.append(math.nextafter(base, math.inf))
+        out.append(math.nextafter(base, -math.inf))
+    return out
+
+
+@pytest.mark.parametrize("name", ["sin", "cos"])
+def test_sincos_accuracy(name):
+    rng = random.Random(5)
+    sets = [
+        [rng.uniform(-0.79, 0.79) for _ in range(N)],
+        [rng.uniform(-4, 7) for _ in range(N)],
+        [rng.uniform(-1024, 1024) for _ in range(N)],                      # main path
+        [rng.uniform(1024, 1.1e6) * rng.choice([-1, 1]) for _ in range(N)],  # Cody-Waite 33-bit pieces
+        [rng.choice([-1, 1]) * math.ldexp(rng.uniform(1, 2), rng.randint(20, 1023)) for _ in range(N)],  # Payne-Hanek
+        near_multiples(rng, 650, (-45, -10)),                              # main <-> slow path switch at 2^-20
+        near_multiples(rng, 10 ** 15, (-30, 5)),
+        [10.0 ** rng.uniform(-320, -1) for _ in range(N // 4)],
+    ]
+    for xs in sets:
+        assert max_ulp_error(name, xs) < 0.85
+
+
+@pytest.mark.parametrize("name,gen", [
+    ("atan", lambda r: r.uniform(-700, 700)), ("atan", lambda r: r.uniform(-3, 3)),
+    ("atan", lambda r: r.choice([-1, 1]) * 10 ** r.uniform(-12, 25)),
+    ("acos", lambda r: r.uniform(-1, 1)), ("acos", lambda r: 1 - 10 ** r.uniform(-16, -1)),
+    ("acos", lambda r: -1 + 10 ** r.uniform(-16, -1)),
+    ("log", lambda r: r.uniform(1, 1e6)), ("log", lambda r: r.uniform(0.5, 2)),
+    ("log", lambda r: 10 ** r.uniform(-320, 300)),
+])
+def test_other_functions_accuracy(name, gen):
+    rng = random.Random(9)
+    assert max_ulp_error(name, [gen(rng) for _ in range(N)]) < 0.95
+
+
+def test_atan2_accuracy_and_quadrants():
+    rng = random.Random(2)
+    ys = np.array([rng.uniform(-5, 5) for _ in range(N)])
+    xs = np.array([rng.uniform(-5, 5) for _ in range(N)])
+    got = common.twin_math(5, ys, xs)
+    worst = 0.0
+    for y, x, g in zip(ys, xs, got):
+        ex = mpmath.atan2(mpf(y), mpf(x))
+        worst = max(worst, float(abs(mpf(float(g)) - ex) / math.ulp(abs(float(ex)))))
+    assert worst < 1.5
+    sp = common.twin_math(5, np.array([0.0, -0.0, 1.0, -1.0, 0.0, 1.0]), np.array([-1.0, -1.0, 0.0, 0.0, 1.0, 1.0]))
+    assert list(sp) == [math.pi, -math.pi, math.pi / 2, -math.pi / 2, 0.0, math.pi / 4]
+
+
+def test_special_values_match_ieee_semantics():
+    t = common.twin_math
+    assert np.isnan(t(0, np.array([np.inf, np.nan]))).all() and np.isnan(t(1, np.array([-np.inf]))).all()
+    assert list(t(0, np.array([0.0, -0.0]))) == [0.0, -0.0] and np.signbit(t(0, np.array([-0.0])))[0]
+    assert list(t(1, np.array([0.0, math.pi / 2, math.pi]))) == [1.0, 6.123233995736766e-17, -1.0]
+    assert list(t(3, np.array([1.0, -1.0, 0.0]))) == [0.0, math.pi, math.pi / 2]
+    assert np.isnan(t(3, np.array([1.0000000000000002, -1.5, np.nan]))).all()
+    assert list(t(4, np.array([1.0, 0.0, np.inf]))) == [0.0, -np.inf, np.inf] and np.isnan(t(4, np.array([-1.0])))[0]
+    assert list(t(2, np.array([np.inf, -np.inf, 0.0]))) == [math.pi / 2, -math.pi / 2, 0.0]

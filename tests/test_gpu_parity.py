@@ -49,13 +49,15 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("metric,res,pos,fwd,cap", CASES)
-def test_full_ray_state_bit_exact_vs_oracle(gpu_ctx, variant, metric, res, pos, fwd, cap):
+def test_full_ray_state_bit_exact_vs_oracle(gpu_ctx, variant, fast, metric, res, pos, fwd, cap):
     sp, sn = common.make_skies(256, 128, "check")
     om, oc, pm, pc = common.scene(metric, res=res, pos=pos, fwd=fwd)
     want_rgb, want_dbg, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, debug=True)
     gpu_ctx.set_option("variant", variant)
+    gpu_ctx.set_option("fast_math", fast)
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
                                          context=gpu_ctx)
     got_rgb, got_dbg = sys_.render_image_debug(cap, 100.0, 0.05)
@@ -66,6 +68,48 @@ def test_full_ray_state_bit_exact_vs_oracle(gpu_ctx, variant, metric, res, pos, 
     # the non-debug kernel (phi not integrated) must give the same pixels
     assert np.array_equal(sys_.render_image(cap, 100.0, 0.05), want_rgb)
     gpu_ctx.set_option("variant", 0)
+    gpu_ctx.set_option("fast_math", 1)
+
+
+def oracle_full_frame(fl, om, oc, sky_pos, sky_neg, cap, threads=None):
+    """whole-frame oracle render with the rows striped over host threads (ctypes drops the GIL)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    T = threads or min(64, os.cpu_count() or 1)
+    W, H = oc.res_x, oc.res_y
+    rgb = np.zeros((H, W, 3), np.uint8)
+    dbg = np.zeros((H, W), O.RAY_DEBUG)
+    sp, sn = O.sky(sky_pos), O.sky(sky_neg)
+
+    def work(i):
+        r, d, st = O.render_image(fl, om, oc, sp, sn, cap, 100.0, 0.05, row_begin=i, row_step=T, debug=True)
+        rgb[i::T] = r[i::T]
+        dbg[i::T] = d[i::T]
+        return st.steps
+    with ThreadPoolExecutor(T) as ex:
+        steps = sum(ex.map(work, range(T)))
+    return rgb, dbg, steps
+
+
+@pytest.mark.parametrize("metric,res,cap", [("ellis", (1920, 1080), 4096), ("interstellar", (960, 540), 8192)])
+def test_full_size_frame_bit_exact(gpu_ctx, metric, res, cap):
+    """BASELINE configs[1] at full size (and configs[2]'s metric/cap at quarter size): every ray of the
+    frame -- final state, step count, texel index, pixel -- bit-exact against the oracle (cv flavour), for
+    the fast (shared-reciprocal) and the strict (compiler IEEE) kernels, persistent and static."""
+    sp, sn = common.make_skies(2048, 1024, "check")
+    om, oc, pm, pc = common.scene(metric, res=res)
+    want_rgb, want_dbg, steps = oracle_full_frame(O.CV, om, oc, sp, sn, cap)
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
+                                         context=gpu_ctx)
+    for variant, fast in [(0, 1), (1, 1), (0, 0)]:
+        gpu_ctx.set_option("variant", variant)
+        gpu_ctx.set_option("fast_math", fast)
+        got_rgb, got_dbg = sys_.render_image_debug(cap, 100.0, 0.05)
+        common.assert_debug_equal(got_dbg, want_dbg, check_t=True)
+        assert np.array_equal(got_rgb, want_rgb)
+        assert sys_.last_stats.steps == steps
+    gpu_ctx.set_option("variant", 0)
+    gpu_ctx.set_option("fast_math", 1)
 
 
 def test_config1_256x144_pixels(gpu_ctx):

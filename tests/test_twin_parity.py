@@ -8,6 +8,7 @@ import common
 import oracle_lib as O
 
 
+@pytest.mark.parametrize("fast", [0, 1])
 @pytest.mark.parametrize("metric,pos,fwd,cap", [
     ("ellis", (0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), 4096),
     ("interstellar", (0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), 4096),
@@ -15,11 +16,11 @@ import oracle_lib as O
     ("interstellar", (0.0, -2.0, 1.2, 4.0), (1.0, 0.2, -0.1), 3000),
     ("flat", (0.0, 5.0, 1.0, 0.5), (1.0, 0.3, 0.2), 4096),
 ])
-def test_twin_equals_oracle_cv(metric, pos, fwd, cap):
+def test_twin_equals_oracle_cv(metric, pos, fwd, cap, fast):
     sp, sn = common.make_skies(128, 64, "check")
     om, oc, pm, pc = common.scene(metric, res=(24, 14), pos=pos, fwd=fwd)
     want_rgb, want_dbg, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, debug=True)
-    got_rgb, got_dbg = common.twin_render(pm, pc, sp, sn, cap, 100.0, 0.05)
+    got_rgb, got_dbg = common.twin_render(pm, pc, sp, sn, cap, 100.0, 0.05, fast=fast)
     common.assert_debug_equal(got_dbg, want_dbg, check_t=False)
     assert np.array_equal(got_rgb, want_rgb)
     assert st.n_pos + st.n_neg + st.n_none == 24 * 14

@@ -1,0 +1,108 @@
+"""Host logic of the video path: Interpolator (with the reference's off-by-one), times_of_frames, frame
+sharding, and the world_size-2 gloo gather.  CPU only; the renderer is replaced by a recording stub
+(the product has no CPU renderer)."""
+import ctypes as C
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from curvis_amd import paths, rendering
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORBIT = os.path.join(paths.DATA_DIR, "path_orbit.csv")
+THROUGH = os.path.join(paths.DATA_DIR, "path_through.csv")
+
+
+def test_interpolator_matches_oracle_including_off_by_one():
+    it = rendering.Interpolator.from_file(ORBIT)
+    p = O.Path()
+    assert O.lib().cvo_load_path(ORBIT.encode(), C.byref(p)) == 0
+    times = rendering.times_of_frames(it.min_time(), it.max_time(), 30.0)
+    assert len(times) == 1801
+    pos, f, u = np.zeros(4), np.zeros(3), np.zeros(3)
+    for k, t in enumerate(times):
+        rc = O.lib().cvo_path_camera(C.byref(p), t, O._dp(pos), O._dp(f), O._dp(u))
+        if rc == 0:
+            assert np.array_equal(it.camera_position(t), pos)
+            assert np.array_equal(it.camera_forward(t), f) and np.array_equal(it.camera_up(t), u)
+        else:
+            assert k >= 1799  # README.md:107 "sometimes panics on the last frame"
+            with pytest.raises(rendering.InterpolatorPanic):
+                it.camera_position(t)
+    O.lib().cvo_path_free(C.byref(p))
+
+
+def test_frame_counts_of_the_baseline_configs():
+    o = rendering.Interpolator.from_file(ORBIT)
+    t = rendering.Interpolator.from_file(THROUGH)
+    assert len(rendering.times_of_frames(o.min_time(), o.max_time(), 4.0)) == 240     # config 4
+    assert len(rendering.times_of_frames(t.min_time(), t.max_time(), 24.0)) == 480    # config 5
+    assert len(rendering.times_of_frames(t.min_time(), t.max_time(), 30.0)) == 600
+
+
+def test_sharding_is_a_partition():
+    for n, w in [(240, 8), (480, 8), (7, 2), (3, 8), (0, 4)]:
+        shards = [rendering.frames_of_rank(n, r, w) for r in range(w)]
+        flat = sorted(k for s in shards for k in s)
+        assert flat == list(range(n))
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch.distributed as dist
+    from curvis_amd import rendering, paths, systems
+
+    class StubStats:
+        def __init__(self, n): self.rays = 64 * n; self.steps = 1000 * n; self.n_pos = 60 * n; self.n_neg = 3 * n; self.n_none = n; self.kernel_ms = 1.0 * n
+    class StubContext:
+        def __init__(self): self.calls = []
+        def render_brute(self, metric, cams, max_it, R, delta, download=True):
+            cams = [cams] if isinstance(cams, systems.Camera) else list(cams)
+            self.calls.append([tuple(c.position) for c in cams])
+            return None, StubStats(len(cams))
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    it = rendering.Interpolator.from_file(os.path.join(paths.DATA_DIR, "path_orbit.csv"))
+    ctx = StubContext()
+    v = rendering.VideoRenderingSystem(None, ctx, it, 4.0, (8, 8), 43.0, 15.0, 100.0, 64, 0.05, rank=rank, world_size=world, batch=7)
+    local = v.render(download=False)
+    allstats = rendering.gather_frame_stats(local, dist)
+    if rank == 0:
+        print(json.dumps({"frames": [d["frame"] for d in allstats], "ranks": [d["rank"] for d in allstats],
+                          "steps": sum(d["steps"] for d in allstats), "launches0": len(ctx.calls)}))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_gloo_video_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["frames"] == list(range(240))
+    assert out["ranks"] == [k % 2 for k in range(240)]
+    assert out["steps"] == 240 * 1000
+    assert out["launches0"] == 18  # 120 frames of rank 0 in batches of 7
