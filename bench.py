@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--refill-threshold", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     ap.add_argument("--fast-math", type=int, default=1, help="1 shared-reciprocal step, 0 compiler IEEE div/sqrt")
+    ap.add_argument("--download", action="store_true",
+                    help="copy every frame to host memory inside the timed region (PCIe-inclusive rate, "
+                         "reported in DESIGN.md; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=16)
     return ap.parse_args()
@@ -105,7 +108,7 @@ def main():
     R, DELTA = 100.0, 0.05
 
     def step():
-        _, st = ctx.render_brute(metric, cam, args.max_iter, R, DELTA, download=False)
+        _, st = ctx.render_brute(metric, cam, args.max_iter, R, DELTA, download=args.download)
         return st
 
     for _ in range(args.warmup):
@@ -167,7 +170,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (procedural 8192x4096 RGBA8 skies, default camera/metric settings)",
+            "data": "synthetic (procedural 8192x4096 RGBA8 skies, default camera/metric settings)" +
+                    ("; frames copied to host inside the timed region" if args.download else ""),
             "config": {
                 "workload": "configs[1]: %s wormhole, %dx%d, cap %d Euler steps, R=100, delta=0.05, single image; "
                             "%d frame(s)/GPU/step" % (args.metric, args.width, args.height, args.max_iter, 1),
