@@ -37,6 +37,11 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class SamplingInfo(C.Structure):
+    _fields_ = [("n_samples", C.c_uint32), ("rounds", C.c_uint32), ("calls", C.c_uint64), ("steps", C.c_uint64),
+                ("warned_max_iterations", C.c_int32), ("_pad", C.c_int32)]
+
+
 RAY_DEBUG = np.dtype([("x", "<f8", 4), ("p", "<f8", 4), ("steps", "<u4"), ("code", "<i4"), ("tx", "<u4"),
                       ("ty", "<u4")])
 
@@ -63,6 +68,14 @@ SYMBOLS = {
                                             C.c_double, _vp, _vp, C.POINTER(Stats)]),
     "curvis_render_brute_batch": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_uint32,
                                             C.c_double, C.c_double, _vp, C.POINTER(Stats)]),
+    "curvis_render_efficient": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_double,
+                                          C.c_double, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _vp,
+                                          C.POINTER(Stats)]),
+    "curvis_render_efficient_batch": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_uint32,
+                                                C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_double,
+                                                C.c_double, _vp, C.POINTER(Stats)]),
+    "curvis_ctx_sampling_info": (C.c_int, [_vp, C.c_uint32, C.POINTER(SamplingInfo)]),
+    "curvis_ctx_samples": (C.c_int, [_vp, C.c_uint32, _dp, _dp, _dp, C.c_size_t]),
     "curvis_ctx_framebuffer": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "curvis_ctx_download": (C.c_int, [_vp, _vp, C.c_size_t]),
     "curvis_ctx_synchronize": (C.c_int, [_vp]),

@@ -34,7 +34,9 @@
 
 #include "../../include/curvis_hip.h"
 #include "cv_device.h"
+#include "cv_efficient.h"
 #include "cv_host.h"
+#include "cv_sampler.h"
 
 #pragma clang fp contract(off)
 
@@ -100,21 +102,11 @@ __device__ __forceinline__ void store_ray(const RayStore &S, size_t o, const cvk
   S.code[o] = code;
 }
 
-/* escape test of src/systems.rs:129-134 followed by the loop bound of :126 */
-__device__ __forceinline__ bool ray_terminated(double l, double R, unsigned steps, unsigned max_iter, int &code) {
-  if (l > R) {
-    code = cvk::CODE_POS;
-    return true;
-  } else if (l < -R) {
-    code = cvk::CODE_NEG;
-    return true;
-  }
-  if (steps >= max_iter) {
-    code = cvk::CODE_NONE;
-    return true;
-  }
-  return false;
-}
+/* Escape test of src/systems.rs:129-134: `l > R` -> PositiveSpace, else `l < -R` -> NegativeSpace.
+ * One compare per step: |l| > R is true exactly when one of the two is (false for NaN, like both);
+ * which one is decided once, after the loop. */
+__device__ __forceinline__ bool ray_escaped(double l, double R) { return __builtin_fabs(l) > R; }
+__device__ __forceinline__ int escape_code(double l) { return l > 0.0 ? cvk::CODE_POS : cvk::CODE_NEG; }
 
 template <int KIND, bool PHI, bool FAST>
 __device__ __forceinline__ void one_step(const IntegrateParams &P, cvk::Ray &q, bool lane_ok) {
@@ -199,7 +191,9 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
       if (active) {
         one_step<KIND, PHI, FAST>(P, q, lane_ok);
         ++steps;
-        if (ray_terminated(q.l, P.max_radius, steps, P.max_iter, code)) {
+        const bool esc = ray_escaped(q.l, P.max_radius);
+        if (esc | (steps >= P.max_iter)) { /* loop bound of src/systems.rs:126 */
+          code = esc ? escape_code(q.l) : cvk::CODE_NONE;
           active = false;
           done = true;
         }
@@ -217,19 +211,37 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
   unsigned long long st_steps = 0;
   unsigned st_rays = 0;
   unsigned frame, px, py;
+  cvk::Ray q;
+  q.l = q.th = q.ph = q.p1 = q.p2 = q.p3 = q.p3sq = 0.0;
+  bool valid = false, active = false, lane_ok_w = false;
+  size_t slot = 0;
+  unsigned steps = 0;
+  int code = cvk::CODE_NONE;
   if (id < P.total_rays && decode_ray(P, id, frame, px, py)) {
-    cvk::Ray q;
     cvk::ray_init<KIND>(P.metric, P.cams[frame], px, py, q);
-    const bool lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
-    unsigned steps = 0;
-    int code = cvk::CODE_NONE;
-    bool active = P.max_iter != 0;
-    while (active) {
-      one_step<KIND, PHI, FAST>(P, q, lane_ok);
-      ++steps;
-      if (ray_terminated(q.l, P.max_radius, steps, P.max_iter, code)) active = false;
+    lane_ok_w = FAST && P.fast_ok && cvk::ray_fast_ok(q);
+    valid = true;
+    active = P.max_iter != 0;
+    slot = (size_t)frame * P.W * P.H + (size_t)py * P.W + px;
+  }
+  /* All lanes of a wave start together, so the step counter is wave-uniform (an SGPR): a lane records
+   * it when it escapes; lanes still active when the counter reaches max_iterations are NotEscaped. */
+  unsigned k = 0;
+  while (__any(active)) {
+    ++k;
+    if (active) {
+      one_step<KIND, PHI, FAST>(P, q, lane_ok_w);
+      if (ray_escaped(q.l, P.max_radius)) {
+        active = false;
+        steps = k;
+        code = escape_code(q.l);
+      }
     }
-    store_ray<PHI>(P.store, (size_t)frame * P.W * P.H + (size_t)py * P.W + px, q, steps, code);
+    if (k >= P.max_iter) break;
+  }
+  if (active) steps = k; /* == max_iter, code stays CODE_NONE */
+  if (valid) {
+    store_ray<PHI>(P.store, slot, q, steps, code);
     st_steps = steps;
     st_rays = 1;
   }
@@ -288,6 +300,127 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams P) {
       d->tx = tx;
       d->ty = ty;
     }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    pos += __shfl_xor(pos, off);
+    neg += __shfl_xor(neg, off);
+    none += __shfl_xor(none, off);
+    oob += __shfl_xor(oob, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (pos) atomicAdd(&P.counters[CNT_POS], (unsigned long long)pos);
+    if (neg) atomicAdd(&P.counters[CNT_NEG], (unsigned long long)neg);
+    if (none) atomicAdd(&P.counters[CNT_NONE], (unsigned long long)none);
+    if (oob) atomicAdd(&P.counters[CNT_OOB], (unsigned long long)oob);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Efficient renderer (render_image_efficient, src/systems.rs:333-527): the CLI's variant. */
+
+struct EscapeAngleParams {
+  cvk::MetricParams metric;
+  const double *alpha; /* n */
+  const double *l_cam; /* n: radial coordinate of the camera the sample belongs to */
+  double *angle;       /* n: escape angle, NaN when not escaped */
+  double *space;       /* n: +1 / -1, NaN when not escaped */
+  unsigned *steps;     /* n */
+  int *status;         /* n: escape code, or ESC_PANIC */
+  unsigned n;
+  unsigned max_iter;
+  double max_radius, delta;
+  int fast_ok;
+};
+
+/* K2: compute_escape_angle (src/systems.rs:203-261) for a batch of alphas: photon at (0, l, pi/2, 0)
+ * with tangent direction (cos a, 0, sin a), Euler loop WITH phi, world direction, angle. */
+template <int KIND, bool FAST>
+__global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParams P) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const double alpha = P.alpha[i];
+  double sa, ca;
+  cv_sincos(alpha, &sa, &ca);
+  const double pos[4] = {0.0, P.l_cam[i], CV_PI / 2.0, 0.0};
+  cvk::Ray q;
+  cvk::ray_init_dir<KIND>(P.metric, pos, ca, 0.0, sa, q);
+  const bool lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
+  unsigned steps = 0;
+  int code = cvk::CODE_NONE;
+  while (steps < P.max_iter) {
+    if (FAST)
+      cvk::ray_step_fast<KIND, true>(P.metric, q, P.delta, lane_ok);
+    else
+      cvk::ray_step<KIND, true>(P.metric, q, P.delta);
+    ++steps;
+    if (q.l > P.max_radius) {
+      code = cvk::CODE_POS;
+      break;
+    } else if (q.l < -P.max_radius) {
+      code = cvk::CODE_NEG;
+      break;
+    }
+  }
+  const double nan = __builtin_nan("");
+  double angle = nan, space = nan;
+  int status = code;
+  if (code != cvk::CODE_NONE) {
+    if (cvk::escape_angle_of<KIND>(P.metric, q, angle)) {
+      space = (code == cvk::CODE_POS) ? 1.0 : -1.0;
+    } else {
+      angle = nan;
+      status = cvk::ESC_PANIC;
+    }
+  }
+  P.angle[i] = angle;
+  P.space[i] = space;
+  P.steps[i] = steps;
+  P.status[i] = status;
+}
+
+struct EfficientPixelParams {
+  cvk::SkyParams sky[2];
+  const cvk::CameraParams *cams;      /* n_frames */
+  const cvk::EfficientFrame *frames;  /* n_frames */
+  const unsigned *tab_off;            /* n_frames: offset of the frame's tables in sx/m/c */
+  const unsigned *tab_n;              /* n_frames: number of samples */
+  const double *sx, *m_e, *c_e, *m_s, *c_s;
+  unsigned n_frames, W, H;
+  unsigned char *fb;
+  unsigned long long *counters;
+};
+
+/* K3: steps 2, 4, 5 of render_image_efficient + sky lookup, one thread per pixel. */
+__global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPixelParams P) {
+  const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long npix = (unsigned long long)P.W * P.H;
+  unsigned pos = 0, neg = 0, none = 0, oob = 0;
+  if (o < npix * P.n_frames) {
+    const unsigned f = (unsigned)(o / npix);
+    const unsigned pix = (unsigned)(o - (unsigned long long)f * npix);
+    const unsigned py = pix / P.W, px = pix - py * P.W;
+    const unsigned off = P.tab_off[f], n = P.tab_n[f];
+    double fin[3], space;
+    cvk::efficient_pixel(P.cams[f], P.frames[f], px, py, P.sx + off, P.m_e + off, P.c_e + off, P.m_s + off,
+                         P.c_s + off, n, fin, space);
+    unsigned texel = 0xFF000000u;
+    if (space == 1.0 || space == -1.0) { /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black } */
+      const cvk::SkyParams &S = P.sky[space == 1.0 ? 0 : 1];
+      unsigned tx, ty;
+      cvk::sky_indices(S, fin[0], fin[1], fin[2], tx, ty);
+      if (tx >= S.w || ty >= S.h) oob = 1;
+      if (tx >= S.w) tx = S.w - 1;
+      if (ty >= S.h) ty = S.h - 1;
+      texel = S.texels[(size_t)ty * S.w + tx];
+      pos = (space == 1.0);
+      neg = (space == -1.0);
+    } else {
+      none = 1;
+    }
+    unsigned char *dst = P.fb + o * 3;
+    dst[0] = (unsigned char)(texel & 0xFF);
+    dst[1] = (unsigned char)((texel >> 8) & 0xFF);
+    dst[2] = (unsigned char)((texel >> 16) & 0xFF);
   }
   for (int off = 32; off > 0; off >>= 1) {
     pos += __shfl_xor(pos, off);
@@ -365,6 +498,12 @@ struct curvis_ctx {
   unsigned char *d_store = nullptr; /* RayStore arrays, carved from one allocation */
   size_t store_cap = 0;
   hipEvent_t ev2 = nullptr;
+  /* efficient mode scratch (device) */
+  unsigned char *d_eff = nullptr;
+  size_t eff_cap = 0;
+  /* sample tables of the last efficient render, per frame (for tests / statistics) */
+  std::vector<std::vector<cvs::BiPoint>> last_samples;
+  std::vector<curvis_sampling_info> last_sampling_info;
   cvk::CameraParams *d_cams = nullptr;
   size_t cams_cap = 0;
   cvk::CameraParams *h_cams = nullptr; /* pinned */
@@ -647,6 +786,280 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   return CURVIS_OK;
 }
 
+/* ---- efficient mode ------------------------------------------------------------------------- */
+
+template <int KIND>
+int launch_escape_kind(curvis_ctx *ctx, bool fast, const EscapeAngleParams &P) {
+  const unsigned blocks = (P.n + 63u) / 64u;
+  if (fast)
+    hipLaunchKernelGGL((escape_angle_kernel<KIND, true>), dim3(blocks), dim3(64), 0, ctx->stream, P);
+  else
+    hipLaunchKernelGGL((escape_angle_kernel<KIND, false>), dim3(blocks), dim3(64), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  return CURVIS_OK;
+}
+
+/* evaluate compute_escape_angle for a batch on the GPU */
+int eval_escape_batch(curvis_ctx *ctx, const curvis_metric *metric, const cvk::MetricParams &MP,
+                      const std::vector<double> &alpha, const std::vector<double> &lcam, uint32_t max_iter,
+                      double max_radius, double delta, std::vector<double> &angle, std::vector<double> &space,
+                      std::vector<uint32_t> &steps, std::vector<int> &status, double *ms_acc) {
+  const size_t n = alpha.size();
+  angle.resize(n);
+  space.resize(n);
+  steps.resize(n);
+  status.resize(n);
+  if (n == 0) return CURVIS_OK;
+  /* layout: alpha | l | angle | space (f64) | steps (u32) | status (i32) */
+  const size_t bytes = n * (4 * sizeof(double) + sizeof(unsigned) + sizeof(int));
+  int rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, bytes);
+  if (rc) return rc;
+  double *d_alpha = (double *)ctx->d_eff, *d_l = d_alpha + n, *d_angle = d_l + n, *d_space = d_angle + n;
+  unsigned *d_steps = (unsigned *)(d_space + n);
+  int *d_status = (int *)(d_steps + n);
+  HIP_TRY(ctx, hipMemcpyAsync(d_alpha, alpha.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_l, lcam.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  EscapeAngleParams P;
+  P.metric = MP;
+  P.alpha = d_alpha;
+  P.l_cam = d_l;
+  P.angle = d_angle;
+  P.space = d_space;
+  P.steps = d_steps;
+  P.status = d_status;
+  P.n = (unsigned)n;
+  P.max_iter = max_iter;
+  P.max_radius = max_radius;
+  P.delta = delta;
+  P.fast_ok = cvk::metric_fast_ok(metric->kind, MP, max_radius) ? 1 : 0;
+  const bool fast = ctx->fast_math != 0;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  switch (metric->kind) {
+    case CURVIS_METRIC_ELLIS:
+      rc = launch_escape_kind<cvk::METRIC_ELLIS>(ctx, fast, P);
+      break;
+    case CURVIS_METRIC_INTERSTELLAR:
+      rc = launch_escape_kind<cvk::METRIC_INTERSTELLAR>(ctx, fast, P);
+      break;
+    default:
+      rc = launch_escape_kind<cvk::METRIC_FLAT>(ctx, fast, P);
+      break;
+  }
+  if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(angle.data(), d_angle, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(space.data(), d_space, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(steps.data(), d_steps, n * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(status.data(), d_status, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (ms_acc) *ms_acc += ms;
+  return CURVIS_OK;
+}
+
+int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cams, uint32_t n_frames,
+                          uint32_t max_iter, double max_radius, double delta, uint32_t alpha_nums,
+                          uint32_t max_iterations_sampling, double thr1, double thr2, uint8_t *rgb_out,
+                          curvis_stats *stats) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (!metric || !cams || n_frames == 0) return fail(ctx, CURVIS_E_INVALID, "null metric/camera or zero frames");
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = curvis_metric_validate(metric);
+  if (rc != CURVIS_OK) return fail(ctx, rc, "invalid metric parameters (src/metrics.rs:409-456)");
+  const uint32_t W = cams[0].res_x, H = cams[0].res_y;
+  if (W == 0 || H == 0) return fail(ctx, CURVIS_E_INVALID, "resolution must be greater than 0 (src/cameras.rs:98)");
+  if (alpha_nums < 3) return fail(ctx, CURVIS_E_SAMPLING, "alpha_nums < 3: the sampler panics (src/sampling.rs:155-157)");
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    if (cams[f].res_x != W || cams[f].res_y != H)
+      return fail(ctx, CURVIS_E_INVALID, "all cameras of a batch must share one resolution");
+    if (std::fabs(cams[f].pos[1]) > max_radius)
+      return fail(ctx, CURVIS_E_CAMERA_OUTSIDE,
+                  "Photon already beyond the maximum radius. Cannot evaluate escape. (src/systems.rs:122-124)");
+  }
+  if (!ctx->d_sky[0] || !ctx->d_sky[1]) return fail(ctx, CURVIS_E_NO_SKY, "both background images must be set");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const cvk::MetricParams MP = make_metric(*metric);
+
+  /* step 1 (host): camera direction on the background space and the tangent->background rotation */
+  std::vector<cvk::EfficientFrame> eframes(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    cvk::vector3_from_theta_phi(cams[f].pos[2], cams[f].pos[3], eframes[f].cam_bg);
+    const double ex[3] = {1.0, 0.0, 0.0};
+    if (!cvk::rotation_from_two_vectors(ex, eframes[f].cam_bg, eframes[f].rot_bg))
+      return fail(ctx, CURVIS_E_PARALLEL, "v1 and v2 must not be parallel (src/algebra.rs:95-97, camera on the x axis)");
+  }
+
+  /* step 3: one sampler per frame, advanced in lock step; every round is ONE kernel launch */
+  std::vector<cvs::Sampler> smp(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    smp[f].a_min = -0.1 * CV_PI; /* src/systems.rs:437-438 */
+    smp[f].a_max = 1.1 * CV_PI;
+    smp[f].n0 = alpha_nums;
+    smp[f].max_iterations = max_iterations_sampling;
+    smp[f].thr1 = thr1;
+    smp[f].thr2 = thr2;
+  }
+  double sample_ms = 0.0;
+  std::vector<double> b_alpha, b_l, r_angle, r_space;
+  std::vector<uint32_t> r_steps;
+  std::vector<int> r_status;
+  std::vector<size_t> b_off(n_frames + 1);
+  bool panic = false;
+  for (;;) {
+    b_alpha.clear();
+    b_l.clear();
+    bool any = false;
+    for (uint32_t f = 0; f < n_frames; ++f) {
+      b_off[f] = b_alpha.size();
+      if (smp[f].plan()) {
+        any = true;
+        b_alpha.insert(b_alpha.end(), smp[f].pending.begin(), smp[f].pending.end());
+        b_l.insert(b_l.end(), smp[f].pending.size(), cams[f].pos[1]);
+      }
+    }
+    b_off[n_frames] = b_alpha.size();
+    if (!any) break;
+    rc = eval_escape_batch(ctx, metric, MP, b_alpha, b_l, max_iter, max_radius, delta, r_angle, r_space, r_steps,
+                           r_status, &sample_ms);
+    if (rc) return rc;
+    for (size_t k = 0; k < r_status.size(); ++k)
+      if (r_status[k] == cvk::ESC_PANIC) panic = true;
+    for (uint32_t f = 0; f < n_frames; ++f) {
+      if (smp[f].finished) continue;
+      const size_t o = b_off[f];
+      smp[f].consume(r_angle.data() + o, r_space.data() + o, r_steps.data() + o);
+    }
+  }
+  ctx->last_samples.assign(n_frames, {});
+  ctx->last_sampling_info.assign(n_frames, curvis_sampling_info{});
+  uint64_t total_steps = 0;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    if (smp[f].panicked) panic = true;
+    ctx->last_samples[f] = smp[f].pts;
+    curvis_sampling_info &si = ctx->last_sampling_info[f];
+    si.n_samples = (uint32_t)smp[f].pts.size();
+    si.rounds = smp[f].rounds;
+    si.calls = smp[f].calls;
+    si.steps = smp[f].steps;
+    si.warned_max_iterations = smp[f].warned ? 1 : 0;
+    total_steps += smp[f].steps;
+  }
+  if (panic)
+    return fail(ctx, CURVIS_E_SAMPLING,
+                "sampler panic: fewer than 3 finite samples (src/sampling.rs:155-157) or undefined tangent rotation "
+                "(src/algebra.rs:95-97)");
+
+  /* step 4 tables (interp 1.0.3) */
+  std::vector<double> sx, m_e, c_e, m_s, c_s, x, ye, ys, m, c;
+  std::vector<unsigned> tab_off(n_frames), tab_n(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const auto &pts = smp[f].pts;
+    x.clear();
+    ye.clear();
+    ys.clear();
+    for (const auto &b : pts) {
+      x.push_back(b.a);
+      ye.push_back(b.e);
+      ys.push_back(b.s);
+    }
+    tab_off[f] = (unsigned)sx.size();
+    tab_n[f] = (unsigned)pts.size();
+    const size_t slots = std::max<size_t>(pts.size(), 1);
+    cvs::interp_tables(x, ye, m, c);
+    m.resize(slots, 0.0);
+    c.resize(slots, 0.0);
+    m_e.insert(m_e.end(), m.begin(), m.end());
+    c_e.insert(c_e.end(), c.begin(), c.end());
+    cvs::interp_tables(x, ys, m, c);
+    m.resize(slots, 0.0);
+    c.resize(slots, 0.0);
+    m_s.insert(m_s.end(), m.begin(), m.end());
+    c_s.insert(c_s.end(), c.begin(), c.end());
+    x.resize(slots, 0.0);
+    sx.insert(sx.end(), x.begin(), x.end());
+  }
+
+  /* device buffers for K3 */
+  const size_t npix = (size_t)W * H;
+  const size_t fb_bytes = npix * 3 * n_frames;
+  rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, fb_bytes);
+  if (rc) return rc;
+  ctx->fb_bytes = fb_bytes;
+  const size_t T = sx.size();
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 15) & ~(size_t)15;
+    return o;
+  };
+  const size_t o_cams = carve(sizeof(cvk::CameraParams) * n_frames), o_fr = carve(sizeof(cvk::EfficientFrame) * n_frames),
+               o_to = carve(sizeof(unsigned) * n_frames), o_tn = carve(sizeof(unsigned) * n_frames),
+               o_sx = carve(sizeof(double) * T), o_me = carve(sizeof(double) * T), o_ce = carve(sizeof(double) * T),
+               o_ms = carve(sizeof(double) * T), o_cs = carve(sizeof(double) * T);
+  rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, off);
+  if (rc) return rc;
+  std::vector<unsigned char> stage(off);
+  std::vector<cvk::CameraParams> cp(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) cp[f] = make_camera(cams[f]);
+  std::memcpy(stage.data() + o_cams, cp.data(), sizeof(cvk::CameraParams) * n_frames);
+  std::memcpy(stage.data() + o_fr, eframes.data(), sizeof(cvk::EfficientFrame) * n_frames);
+  std::memcpy(stage.data() + o_to, tab_off.data(), sizeof(unsigned) * n_frames);
+  std::memcpy(stage.data() + o_tn, tab_n.data(), sizeof(unsigned) * n_frames);
+  std::memcpy(stage.data() + o_sx, sx.data(), sizeof(double) * T);
+  std::memcpy(stage.data() + o_me, m_e.data(), sizeof(double) * T);
+  std::memcpy(stage.data() + o_ce, c_e.data(), sizeof(double) * T);
+  std::memcpy(stage.data() + o_ms, m_s.data(), sizeof(double) * T);
+  std::memcpy(stage.data() + o_cs, c_s.data(), sizeof(double) * T);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eff, stage.data(), off, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+  EfficientPixelParams Q;
+  for (int k = 0; k < 2; ++k) {
+    Q.sky[k].texels = (const unsigned *)ctx->d_sky[k];
+    Q.sky[k].w = ctx->sky_w[k];
+    Q.sky[k].h = ctx->sky_h[k];
+    for (int i = 0; i < 9; ++i) Q.sky[k].inv_rot[i] = ctx->sky_inv_rot[k][i];
+  }
+  Q.cams = (const cvk::CameraParams *)(ctx->d_eff + o_cams);
+  Q.frames = (const cvk::EfficientFrame *)(ctx->d_eff + o_fr);
+  Q.tab_off = (const unsigned *)(ctx->d_eff + o_to);
+  Q.tab_n = (const unsigned *)(ctx->d_eff + o_tn);
+  Q.sx = (const double *)(ctx->d_eff + o_sx);
+  Q.m_e = (const double *)(ctx->d_eff + o_me);
+  Q.c_e = (const double *)(ctx->d_eff + o_ce);
+  Q.m_s = (const double *)(ctx->d_eff + o_ms);
+  Q.c_s = (const double *)(ctx->d_eff + o_cs);
+  Q.n_frames = n_frames;
+  Q.W = W;
+  Q.H = H;
+  Q.fb = ctx->d_fb;
+  Q.counters = ctx->d_counters;
+  const unsigned long long blocks = ((unsigned long long)npix * n_frames + 255ull) / 256ull;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, Q);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N,
+                              hipMemcpyDeviceToHost, ctx->stream));
+  if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (stats) {
+    stats->rays = (uint64_t)npix * n_frames;
+    stats->steps = total_steps;
+    stats->n_pos = ctx->h_counters[CNT_POS];
+    stats->n_neg = ctx->h_counters[CNT_NEG];
+    stats->n_none = ctx->h_counters[CNT_NONE];
+    stats->n_oob = ctx->h_counters[CNT_OOB];
+    stats->integrate_ms = sample_ms;
+    stats->shade_ms = ms;
+    stats->kernel_ms = sample_ms + ms;
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return CURVIS_OK;
+}
+
 }  // namespace
 
 /* ------------------------------------------------------------------------------------------ ABI */
@@ -711,6 +1124,7 @@ void curvis_ctx_destroy(curvis_ctx *ctx) {
   if (ctx->d_fb) (void)hipFree(ctx->d_fb);
   if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
   if (ctx->d_store) (void)hipFree(ctx->d_store);
+  if (ctx->d_eff) (void)hipFree(ctx->d_eff);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->d_cams) (void)hipFree(ctx->d_cams);
   if (ctx->h_cams) (void)hipHostFree(ctx->h_cams);
@@ -890,6 +1304,44 @@ int curvis_render_brute_batch(curvis_ctx *ctx, const curvis_metric *metric, cons
                               uint32_t n_frames, uint32_t max_iterations, double max_radius, double delta,
                               uint8_t *rgb_out, curvis_stats *stats) {
   return render_impl(ctx, metric, cameras, n_frames, max_iterations, max_radius, delta, rgb_out, nullptr, stats);
+}
+
+int curvis_render_efficient(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
+                            uint32_t max_iterations_propagation, double max_radius, double delta, uint32_t alpha_nums,
+                            uint32_t max_iterations_sampling, double sampling_convergence_threshold_1,
+                            double sampling_convergence_threshold_2, uint8_t *rgb_out, curvis_stats *stats) {
+  return render_efficient_impl(ctx, metric, camera, 1, max_iterations_propagation, max_radius, delta, alpha_nums,
+                               max_iterations_sampling, sampling_convergence_threshold_1,
+                               sampling_convergence_threshold_2, rgb_out, stats);
+}
+
+int curvis_render_efficient_batch(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cameras,
+                                  uint32_t n_frames, uint32_t max_iterations_propagation, double max_radius,
+                                  double delta, uint32_t alpha_nums, uint32_t max_iterations_sampling,
+                                  double sampling_convergence_threshold_1, double sampling_convergence_threshold_2,
+                                  uint8_t *rgb_out, curvis_stats *stats) {
+  return render_efficient_impl(ctx, metric, cameras, n_frames, max_iterations_propagation, max_radius, delta,
+                               alpha_nums, max_iterations_sampling, sampling_convergence_threshold_1,
+                               sampling_convergence_threshold_2, rgb_out, stats);
+}
+
+int curvis_ctx_sampling_info(const curvis_ctx *ctx, uint32_t frame, curvis_sampling_info *info) {
+  if (!ctx || !info || frame >= ctx->last_sampling_info.size()) return CURVIS_E_INVALID;
+  *info = ctx->last_sampling_info[frame];
+  return CURVIS_OK;
+}
+
+int curvis_ctx_samples(const curvis_ctx *ctx, uint32_t frame, double *alpha, double *escape_angle,
+                       double *escape_space, size_t cap) {
+  if (!ctx || frame >= ctx->last_samples.size()) return CURVIS_E_INVALID;
+  const auto &pts = ctx->last_samples[frame];
+  if (cap < pts.size()) return CURVIS_E_INVALID;
+  for (size_t i = 0; i < pts.size(); ++i) {
+    if (alpha) alpha[i] = pts[i].a;
+    if (escape_angle) escape_angle[i] = pts[i].e;
+    if (escape_space) escape_space[i] = pts[i].s;
+  }
+  return CURVIS_OK;
 }
 
 int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes) {

@@ -200,8 +200,8 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
   /* guard (branch-free): sin(theta) and l finite, non-zero, far from the exponent limits.  cos(theta)
    * needs no test of its own: it is finite iff sin(theta) is, and the cosine of a double is never
    * zero or subnormal. */
-  const bool ok = lane_ok & hi_word_in(s, CV_HI_2POW(-60), CV_HI_2POW(1)) &
-                  hi_word_in(q.l, CV_HI_2POW(-100), CV_HI_2POW(100));
+  const bool ok = (int)lane_ok & (int)hi_word_in(s, CV_HI_2POW(-60), CV_HI_2POW(1)) &
+                  (int)hi_word_in(q.l, CV_HI_2POW(-100), CV_HI_2POW(100));
   if (!ok) {
     ray_step_core<KIND, PHI>(M, q, delta, s, c);
     return;

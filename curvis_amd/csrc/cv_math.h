@@ -84,6 +84,19 @@ CV_HD int cv_clz64(uint64_t a) { /* a != 0 */
 #endif
 }
 
+/* Horner step acc*z + C with a loop-invariant constant C.  On gfx950 LLVM lowers fma(z, acc, C)
+ * to v_mov_b64 tmp, C ; v_fmac_f64 tmp, z, acc (two-address form, one extra full-rate move per
+ * coefficient); the three-address VOP3 form needs no copy.  Same IEEE operation either way. */
+CV_HD double cv_fma_c(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CV_NO_ASM_FMA)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+#else
+  return CV_FMA(a, b, c);
+#endif
+}
+
 /* ------------------------------------------------------------------------- */
 /* sin / cos                                                                  */
 /* ------------------------------------------------------------------------- */
@@ -98,7 +111,7 @@ CV_HD double cv_ksin(double x, double y) {
       S6 = 1.58969099521155010221e-10;           /* 0x3DE5D93A5ACFD57C */
   double z = x * x;
   double v = z * x;
-  double r = CV_FMA(z, CV_FMA(z, CV_FMA(z, CV_FMA(z, S6, S5), S4), S3), S2);
+  double r = cv_fma_c(z, cv_fma_c(z, cv_fma_c(z, cv_fma_c(z, S6, S5), S4), S3), S2);
   /* x - ((z*(y/2 - v*r) - y) - v*S1) */
   double t = CV_FMA(-v, r, 0.5 * y);
   double u = CV_FMA(z, t, -y);
@@ -114,7 +127,7 @@ CV_HD double cv_kcos(double x, double y) {
       C5 = 2.08757232129817482790e-09,          /* 0x3E21EE9EBDB4B1C4 */
       C6 = -1.13596475577881948265e-11;         /* 0xBDA8FAE9BE8838D4 */
   double z = x * x;
-  double r = z * CV_FMA(z, CV_FMA(z, CV_FMA(z, CV_FMA(z, CV_FMA(z, C6, C5), C4), C3), C2), C1);
+  double r = z * cv_fma_c(z, cv_fma_c(z, cv_fma_c(z, cv_fma_c(z, cv_fma_c(z, C6, C5), C4), C3), C2), C1);
   double hz = 0.5 * z;
   double w = 1.0 - hz;
   /* w + (((1-w)-hz) + (z*r - x*y)) */

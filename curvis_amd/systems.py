@@ -186,6 +186,35 @@ class Context:
             rgb = rgb[0]
         return rgb, st
 
+    def render_efficient(self, metric, cameras, max_iterations_propagation, max_radius, delta, alpha_nums,
+                         max_iterations_sampling, thr1, thr2, download=True):
+        """render_image_efficient for one Camera or a list (samplers advance in lock step)."""
+        single = isinstance(cameras, Camera)
+        cams = [cameras] if single else list(cameras)
+        n = len(cams)
+        W, H = cams[0].resolution_width, cams[0].resolution_height
+        arr = (CameraC * n)(*[c._c for c in cams])
+        m = metric._c()
+        st = Stats()
+        rgb = np.empty((n, H, W, 3), dtype=np.uint8) if download else None
+        check(lib().curvis_render_efficient_batch(self._h, C.byref(m), arr, n, max_iterations_propagation, max_radius,
+                                                  delta, alpha_nums, max_iterations_sampling, thr1, thr2,
+                                                  rgb.ctypes.data if download else None, C.byref(st)), self._h)
+        if download and single:
+            rgb = rgb[0]
+        return rgb, st
+
+    def sampling_info(self, frame=0):
+        info = _abi.SamplingInfo()
+        check(lib().curvis_ctx_sampling_info(self._h, frame, C.byref(info)), self._h)
+        return info
+
+    def samples(self, frame=0):
+        n = self.sampling_info(frame).n_samples
+        a, e, s = np.zeros(n), np.zeros(n), np.zeros(n)
+        check(lib().curvis_ctx_samples(self._h, frame, dptr(a), dptr(e), dptr(s), n), self._h)
+        return a, e, s
+
     def selftest_math(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float64)
         out = np.empty_like(a)
@@ -228,6 +257,17 @@ class RelativisticSystem:
         """The per-pixel renderer; returns an HxWx3 uint8 array (DynamicImage::ImageRgb8)."""
         self._bind_skies()
         rgb, st = self.context.render_brute(self.metric, self.camera, max_iterations, max_radius, delta)
+        self.last_stats = st
+        return rgb
+
+    def render_image_efficient(self, max_iterations_propagation, max_radius, delta, alpha_nums,
+                               max_iterations_sampling, sampling_convergence_threshold_1,
+                               sampling_convergence_threshold_2):
+        """src/systems.rs:333-343: the renderer behind `curvis image` / `curvis video`."""
+        self._bind_skies()
+        rgb, st = self.context.render_efficient(self.metric, self.camera, max_iterations_propagation, max_radius, delta,
+                                                alpha_nums, max_iterations_sampling, sampling_convergence_threshold_1,
+                                                sampling_convergence_threshold_2)
         self.last_stats = st
         return rgb
 

@@ -143,6 +143,36 @@ int curvis_render_brute_batch(curvis_ctx *ctx, const curvis_metric *metric, cons
                               uint32_t n_frames, uint32_t max_iterations, double max_radius, double delta,
                               uint8_t *rgb_out, curvis_stats *stats);
 
+/* RelativisticSystem::render_image_efficient (src/systems.rs:333-527) -- what `curvis image` and
+ * `curvis video` call (src/rendering.rs:97-106, :299-307): adaptive 1-D sampling of the escape angle over
+ * alpha in [-0.1 pi, 1.1 pi] on the equatorial plane (src/sampling.rs), linear interpolation per pixel
+ * (interp 1.0.3), axis-angle rotation of the camera direction, nearest-texel lookup.  Argument names and
+ * order are the reference's.  Reproduces the reference's behaviour including the shrinking sample domain
+ * (src/sampling.rs:161), extrapolation beyond the last sample and black +/- transitions. */
+int curvis_render_efficient(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
+                            uint32_t max_iterations_propagation, double max_radius, double delta, uint32_t alpha_nums,
+                            uint32_t max_iterations_sampling, double sampling_convergence_threshold_1,
+                            double sampling_convergence_threshold_2, uint8_t *rgb_out, curvis_stats *stats);
+/* n_frames cameras: the per-frame samplers advance in lock step, one kernel launch per refinement round
+ * for the whole batch, one per-pixel launch for all frames. */
+int curvis_render_efficient_batch(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cameras,
+                                  uint32_t n_frames, uint32_t max_iterations_propagation, double max_radius,
+                                  double delta, uint32_t alpha_nums, uint32_t max_iterations_sampling,
+                                  double sampling_convergence_threshold_1, double sampling_convergence_threshold_2,
+                                  uint8_t *rgb_out, curvis_stats *stats);
+/* sampler bookkeeping of the last efficient render (per frame): final table size, refinement rounds,
+ * integrator calls, Euler steps, and whether the "maximum number of iterations" warning fired. */
+typedef struct curvis_sampling_info {
+  uint32_t n_samples, rounds;
+  uint64_t calls, steps;
+  int32_t warned_max_iterations;
+  int32_t _pad;
+} curvis_sampling_info;
+int curvis_ctx_sampling_info(const curvis_ctx *ctx, uint32_t frame, curvis_sampling_info *info);
+/* the (alpha, escape angle, escape space) table of a frame of the last efficient render; cap >= n_samples */
+int curvis_ctx_samples(const curvis_ctx *ctx, uint32_t frame, double *alpha, double *escape_angle,
+                       double *escape_space, size_t cap);
+
 /* device framebuffer of the last render (RGB8, frames back to back) */
 int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes);
 int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);

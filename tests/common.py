@@ -46,6 +46,13 @@ def twin():
         L.twin_render.argtypes = [C.POINTER(_abi.Metric), C.POINTER(_abi.CameraC), C.c_void_p, C.c_uint, C.c_uint,
                                   C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_double, C.c_double, C.c_void_p,
                                   C.c_void_p, C.c_int]
+        L.twin_render_efficient.restype = C.c_int
+        L.twin_render_efficient.argtypes = [C.POINTER(_abi.Metric), C.POINTER(_abi.CameraC), C.c_void_p, C.c_uint,
+                                            C.c_uint, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_double,
+                                            C.c_double, C.c_uint, C.c_uint, C.c_double, C.c_double, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                            C.c_int]
         _twin = L
     return _twin
 
@@ -86,3 +93,21 @@ def assert_debug_equal(got, want, check_t=True):
         bad = np.nonzero(g != w)
         assert bad[0].size == 0, "%s differs at %d entries, first index %s: %r vs %r" % (
             f, bad[0].size, [b[0] for b in bad], got[f][..., lo:][bad][0], want[f][..., lo:][bad][0])
+
+
+def twin_render_efficient(pm, pc, sky_pos, sky_neg, max_iter, max_radius, delta, alpha_nums, max_it_sampling, thr1, thr2,
+                          fast=0, cap=8192):
+    W, H = pc.resolution_width, pc.resolution_height
+    rgb = np.zeros((H, W, 3), np.uint8)
+    a, e, s = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    n, calls, steps = C.c_size_t(0), C.c_uint64(0), C.c_uint64(0)
+    m = pm._c()
+    rc = twin().twin_render_efficient(C.byref(m), C.byref(pc._c), sky_pos.ctypes.data, sky_pos.shape[1], sky_pos.shape[0],
+                                      sky_neg.ctypes.data, sky_neg.shape[1], sky_neg.shape[0], max_iter, max_radius,
+                                      delta, alpha_nums, max_it_sampling, thr1, thr2, rgb.ctypes.data, a.ctypes.data,
+                                      e.ctypes.data, s.ctypes.data, cap, C.byref(n), C.byref(calls), C.byref(steps),
+                                      int(fast))
+    if rc != 0:
+        raise RuntimeError("twin efficient render failed: %d" % rc)
+    k = n.value
+    return rgb, dict(a=a[:k].copy(), e=e[:k].copy(), s=s[:k].copy(), calls=calls.value, steps=steps.value)

@@ -4,7 +4,11 @@
 #include <cstdint>
 #include <cstring>
 
+#include <vector>
+
 #include "../../curvis_amd/csrc/cv_device.h"
+#include "../../curvis_amd/csrc/cv_efficient.h"
+#include "../../curvis_amd/csrc/cv_sampler.h"
 #include "../../include/curvis_hip.h"
 
 template <int KIND>
@@ -91,4 +95,106 @@ void twin_render(const curvis_metric *m, const curvis_camera *c, const uint8_t *
     default: render_kind<2>(M, C, sky, c->res_x, c->res_y, max_iter, R, delta, rgb, dbg, fast); break;
   }
 }
+}
+
+// ---- efficient renderer on the host: cvs::Sampler + cv_efficient.h (the code the GPU path runs, on x86)
+template <int KIND>
+static int escape_angle_host(const cvk::MetricParams &M, double l, double alpha, double delta, unsigned max_iter,
+                             double R, int fast, double &angle, double &space, uint32_t &steps) {
+  double sa, ca;
+  cv_sincos(alpha, &sa, &ca);
+  const double pos[4] = {0.0, l, CV_PI / 2.0, 0.0};
+  cvk::Ray q;
+  cvk::ray_init_dir<KIND>(M, pos, ca, 0.0, sa, q);
+  const bool lane_ok = fast && cvk::metric_fast_ok(KIND, M, R) && cvk::ray_fast_ok(q);
+  steps = 0;
+  int code = cvk::CODE_NONE;
+  while (steps < max_iter) {
+    if (fast) cvk::ray_step_fast<KIND, true>(M, q, delta, lane_ok);
+    else cvk::ray_step<KIND, true>(M, q, delta);
+    ++steps;
+    if (q.l > R) { code = cvk::CODE_POS; break; }
+    else if (q.l < -R) { code = cvk::CODE_NEG; break; }
+  }
+  angle = space = __builtin_nan("");
+  if (code == cvk::CODE_NONE) return code;
+  if (!cvk::escape_angle_of<KIND>(M, q, angle)) { angle = __builtin_nan(""); return cvk::ESC_PANIC; }
+  space = (code == cvk::CODE_POS) ? 1.0 : -1.0;
+  return code;
+}
+
+static int escape_angle_any(int kind, const cvk::MetricParams &M, double l, double alpha, double delta,
+                            unsigned max_iter, double R, int fast, double &angle, double &space, uint32_t &steps) {
+  switch (kind) {
+    case 0: return escape_angle_host<0>(M, l, alpha, delta, max_iter, R, fast, angle, space, steps);
+    case 1: return escape_angle_host<1>(M, l, alpha, delta, max_iter, R, fast, angle, space, steps);
+    default: return escape_angle_host<2>(M, l, alpha, delta, max_iter, R, fast, angle, space, steps);
+  }
+}
+
+extern "C" int twin_render_efficient(const curvis_metric *m, const curvis_camera *c, const uint8_t *sky_pos, unsigned wp,
+                                     unsigned hp, const uint8_t *sky_neg, unsigned wn, unsigned hn, unsigned max_iter,
+                                     double R, double delta, unsigned alpha_nums, unsigned max_it_sampling, double thr1,
+                                     double thr2, uint8_t *rgb, double *sa, double *se, double *ss, size_t cap,
+                                     size_t *n_out, uint64_t *calls, uint64_t *steps_out, int fast) {
+  cvk::MetricParams M;
+  M.rho = m->rho; M.rho2 = m->rho * m->rho; M.m = m->m; M.a = m->a; M.pim = CV_PI * m->m; M.two_o_pi = 2.0 / CV_PI;
+  cvk::CameraParams C;
+  for (int i = 0; i < 4; ++i) C.pos[i] = c->pos[i];
+  for (int i = 0; i < 9; ++i) C.rot[i] = c->rot[i];
+  C.focal = c->focal; C.sensor_w = c->sensor_w; C.sensor_h = c->sensor_h;
+  C.res_x = (double)c->res_x; C.res_y = (double)c->res_y;
+  cvk::SkyParams sky[2];
+  sky[0].texels = (const unsigned *)sky_pos; sky[0].w = wp; sky[0].h = hp;
+  sky[1].texels = (const unsigned *)sky_neg; sky[1].w = wn; sky[1].h = hn;
+  for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < 9; ++i) sky[s].inv_rot[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  cvk::EfficientFrame F;
+  cvk::vector3_from_theta_phi(c->pos[2], c->pos[3], F.cam_bg);
+  const double ex[3] = {1.0, 0.0, 0.0};
+  if (!cvk::rotation_from_two_vectors(ex, F.cam_bg, F.rot_bg)) return -2;
+  cvs::Sampler S;
+  S.a_min = -0.1 * CV_PI; S.a_max = 1.1 * CV_PI; S.n0 = alpha_nums; S.max_iterations = max_it_sampling;
+  S.thr1 = thr1; S.thr2 = thr2;
+  bool panic = false;
+  std::vector<double> e, s;
+  std::vector<uint32_t> st;
+  while (S.plan()) {
+    const size_t n = S.pending.size();
+    e.resize(n); s.resize(n); st.resize(n);
+    for (size_t k = 0; k < n; ++k)
+      if (escape_angle_any(m->kind, M, c->pos[1], S.pending[k], delta, max_iter, R, fast, e[k], s[k], st[k]) == cvk::ESC_PANIC)
+        panic = true;
+    S.consume(e.data(), s.data(), st.data());
+  }
+  if (panic || S.panicked) return -2;
+  *n_out = S.pts.size();
+  *calls = S.calls;
+  *steps_out = S.steps;
+  if (S.pts.size() > cap) return -3;
+  std::vector<double> x, ye, ys, m_e, c_e, m_s, c_s;
+  for (size_t i = 0; i < S.pts.size(); ++i) {
+    sa[i] = S.pts[i].a; se[i] = S.pts[i].e; ss[i] = S.pts[i].s;
+    x.push_back(S.pts[i].a); ye.push_back(S.pts[i].e); ys.push_back(S.pts[i].s);
+  }
+  cvs::interp_tables(x, ye, m_e, c_e);
+  cvs::interp_tables(x, ys, m_s, c_s);
+  const unsigned W = c->res_x, H = c->res_y;
+  for (unsigned py = 0; py < H; ++py)
+    for (unsigned px = 0; px < W; ++px) {
+      double fin[3], space;
+      cvk::efficient_pixel(C, F, px, py, x.data(), m_e.data(), c_e.data(), m_s.data(), c_s.data(), (unsigned)x.size(), fin, space);
+      unsigned texel = 0xFF000000u;
+      if (space == 1.0 || space == -1.0) {
+        const cvk::SkyParams &Sk = sky[space == 1.0 ? 0 : 1];
+        unsigned tx, ty;
+        cvk::sky_indices(Sk, fin[0], fin[1], fin[2], tx, ty);
+        if (tx >= Sk.w) tx = Sk.w - 1;
+        if (ty >= Sk.h) ty = Sk.h - 1;
+        texel = Sk.texels[(size_t)ty * Sk.w + tx];
+      }
+      size_t o = (size_t)py * W + px;
+      rgb[o * 3 + 0] = texel & 0xFF; rgb[o * 3 + 1] = (texel >> 8) & 0xFF; rgb[o * 3 + 2] = (texel >> 16) & 0xFF;
+    }
+  return 0;
 }

@@ -165,3 +165,72 @@ def test_zero_iterations_is_black(gpu_ctx):
                                          context=gpu_ctx)
     img = sys_.render_image(0, 100.0, 0.05)
     assert img.shape == (9, 16, 3) and not img.any() and sys_.last_stats.n_none == 16 * 9
+
+
+EFF_CASES = [
+    ("ellis", (96, 54), (0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), 4096, 100),
+    ("ellis", (64, 36), (0.0, 3.0, common.HALF_PI, 0.9), (-1.0, 0.0, 0.0), 4096, 100),
+    ("interstellar", (64, 36), (0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), 4096, 100),
+    ("ellis", (40, 30), (0.0, -2.5, 1.1, 2.0), (1.0, 0.3, 0.1), 3000, 60),
+]
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("metric,res,pos,fwd,cap,n0", EFF_CASES)
+def test_efficient_mode_bit_exact_vs_oracle(gpu_ctx, fast, metric, res, pos, fwd, cap, n0):
+    """render_image_efficient (what `curvis image` / `curvis video` call): the adaptive sample table
+    (alphas, escape angles, escape spaces), the sampler bookkeeping and every pixel, bit for bit."""
+    sp, sn = common.make_skies(512, 256, "check")
+    om, oc, pm, pc = common.scene(metric, res=res, pos=pos, fwd=fwd)
+    want_rgb, want, st = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, n0, n0, 1e-5,
+                                                  1e-5)
+    gpu_ctx.set_option("fast_math", fast)
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
+                                         context=gpu_ctx)
+    got_rgb = sys_.render_image_efficient(cap, 100.0, 0.05, n0, n0, 1e-5, 1e-5)
+    a, e, s = gpu_ctx.samples(0)
+    info = gpu_ctx.sampling_info(0)
+    gpu_ctx.set_option("fast_math", 1)
+    assert (info.n_samples, info.calls, info.steps) == (len(want["a"]), want["calls"], want["steps"])
+    assert np.array_equal(common.bits(a), common.bits(want["a"]))
+    assert np.array_equal(common.bits(e), common.bits(want["e"]))
+    assert np.array_equal(common.bits(s), common.bits(want["s"]))
+    assert np.array_equal(got_rgb, want_rgb)
+    assert sys_.last_stats.steps == want["steps"]
+
+
+def test_efficient_batch_equals_single_frames(gpu_ctx):
+    sp, sn = common.make_skies(256, 128, "check")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    cams = []
+    for k in range(4):
+        _, _, pm, pc = common.scene("ellis", res=(40, 24), pos=(0.0, 3.0, common.HALF_PI, 0.4 * k))
+        cams.append(pc)
+    batch, st = gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+    tables = [gpu_ctx.samples(k) for k in range(4)]
+    for k, c in enumerate(cams):
+        one, _ = gpu_ctx.render_efficient(pm, c, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+        assert np.array_equal(batch[k], one)
+        a, e, s = gpu_ctx.samples(0)
+        assert np.array_equal(common.bits(a), common.bits(tables[k][0]))
+        assert np.array_equal(common.bits(e), common.bits(tables[k][1]))
+
+
+def test_efficient_default_960x540_vs_oracle(gpu_ctx):
+    """the reference's default image (settings/defaults: 960x540, cap 40000, n0 = 100, thr 1e-5) through
+    the CLI's renderer."""
+    sp, sn = common.make_skies(2048, 1024, "smooth")
+    om, oc, pm, pc = common.scene("ellis", res=(960, 540))
+    want_rgb, want, st = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05, 100, 100,
+                                                  1e-5, 1e-5)
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
+                                         context=gpu_ctx)
+    got = sys_.render_image_efficient(40000, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+    assert np.array_equal(got, want_rgb)
+    # against the glibc-libm flavour (what a Linux build of the reference computes): <= 1 LSB on the smooth sky
+    libm_rgb, _, _ = O.render_image_efficient(O.LIBM, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05, 100, 100, 1e-5,
+                                              1e-5)
+    d = np.abs(got.astype(int) - libm_rgb.astype(int)).max(axis=2)
+    print("efficient 960x540 vs libm oracle: exact %.5f, <=1 LSB %.5f, max %d" % ((d == 0).mean(), (d <= 1).mean(), d.max()))
+    assert (d <= 1).mean() > 0.999

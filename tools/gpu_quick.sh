@@ -1,0 +1,11 @@
+#!/bin/bash
+# quick loop: gpu tests + bench both variants + SQ counters of the default kernel
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT; cd $GRAFT_REPO_ROOT
+python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
+for v in 1 0; do python bench.py --steps 10 --warmup 2 --variant $v --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/q_bench_v${v}.json; done
+python bench.py --steps 5 --warmup 2 --metric interstellar --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/q_bench_interstellar.json
+python bench.py --steps 10 --warmup 2 --download --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/q_bench_download.json
+cd /tmp
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/q_pmc -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/q_pmc.log 2>&1
