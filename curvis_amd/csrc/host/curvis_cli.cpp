@@ -1,0 +1,714 @@
+/* curvis_cli.cpp -- `curvis image | video | custom`: the reference's command line (src/cli.rs:35-122,
+ * src/main.rs:135-235) over libcurvis_hip.so.
+ *
+ *   curvis image <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-i toml] [-m toml] [-c toml] [-s toml]
+ *   curvis video <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-v toml] [-m toml] [-c toml] [-s toml]
+ *   curvis custom
+ *
+ * Same positional arguments, flags, TOML keys (including `ray_integration_max_itarations`,
+ * src/settings.rs:121), defaults (settings/defaults/\*.toml), validation messages, output names
+ * (`<out>/<image_name>.png`, `<out>/tmp/frame_{k}.png`, src/rendering.rs:108, :296) and the reference's
+ * observable quirks: max_iterations_sampling is wired to sampling_initial_nums (src/main.rs:47, :107),
+ * the video path passes sampling_convergence_threshold_1 twice (src/rendering.rs:305-306), and the
+ * camera-path interpolator reads one row too far in the last CSV segment (src/interpolation.rs:76-90:
+ * the reference panics there; this binary reports the same condition and exits with status 101).
+ *
+ * Extensions (do not exist in the reference): --mode efficient|brute (default efficient = what the
+ * reference renders; brute = RelativisticSystem::render_image, the per-pixel integrator),
+ * --devices N (frames k mod N across N GPUs, one host thread + one context per GPU, skies uploaded to
+ * each), --batch B (frames per kernel launch), --stats FILE (per-frame JSON lines).
+ * Backgrounds must be PNG (any colour type / bit depth); no JPEG decoder is linked.
+ */
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/curvis_hip.h"
+#include "png_io.h"
+
+namespace {
+
+/* ------------------------------------------------------------------ tiny TOML subset (key = value) */
+struct TomlValue {
+  enum Kind { STRING, INTEGER, FLOAT, BOOLEAN } kind = STRING;
+  std::string s;
+  long long i = 0;
+  double f = 0.0;
+};
+typedef std::map<std::string, TomlValue> TomlTable;
+
+bool parse_toml(const std::string &text, TomlTable &out, std::string &err) {
+  std::istringstream in(text);
+  std::string line;
+  int ln = 0;
+  while (std::getline(in, line)) {
+    ++ln;
+    /* strip comments outside strings */
+    bool in_str = false;
+    size_t cut = std::string::npos;
+    for (size_t k = 0; k < line.size(); ++k) {
+      if (line[k] == '"' && (k == 0 || line[k - 1] != '\\')) in_str = !in_str;
+      if (line[k] == '#' && !in_str) {
+        cut = k;
+        break;
+      }
+    }
+    if (cut != std::string::npos) line.resize(cut);
+    auto trim = [](std::string &s) {
+      size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+      s = (a == std::string::npos) ? std::string() : s.substr(a, b - a + 1);
+    };
+    trim(line);
+    if (line.empty()) continue;
+    if (line[0] == '[') continue; /* tables are not used by the reference's settings */
+    const size_t eq = line.find('=');
+    if (eq == std::string::npos) {
+      err = "line " + std::to_string(ln) + ": expected key = value";
+      return false;
+    }
+    std::string key = line.substr(0, eq), val = line.substr(eq + 1);
+    trim(key);
+    trim(val);
+    if (key.empty() || val.empty()) {
+      err = "line " + std::to_string(ln) + ": empty key or value";
+      return false;
+    }
+    TomlValue v;
+    if (val[0] == '"' || val[0] == '\'') {
+      const char q = val[0];
+      const size_t end = val.find_last_of(q);
+      if (end == 0) {
+        err = "line " + std::to_string(ln) + ": unterminated string";
+        return false;
+      }
+      v.kind = TomlValue::STRING;
+      v.s = val.substr(1, end - 1);
+    } else if (val == "true" || val == "false") {
+      v.kind = TomlValue::BOOLEAN;
+      v.i = val == "true";
+    } else {
+      std::string num;
+      for (char ch : val)
+        if (ch != '_') num.push_back(ch);
+      const bool is_float = num.find_first_of(".eE") != std::string::npos || num == "inf" || num == "nan" ||
+                            num == "+inf" || num == "-inf";
+      char *endp = nullptr;
+      errno = 0;
+      if (is_float) {
+        v.kind = TomlValue::FLOAT;
+        v.f = std::strtod(num.c_str(), &endp);
+      } else {
+        v.kind = TomlValue::INTEGER;
+        v.i = std::strtoll(num.c_str(), &endp, 10);
+        v.f = (double)v.i;
+      }
+      if (!endp || *endp != 0 || errno == ERANGE) {
+        err = "line " + std::to_string(ln) + ": invalid value `" + val + "`";
+        return false;
+      }
+    }
+    out[key] = v;
+  }
+  return true;
+}
+
+/* serde semantics: missing field = error; an integer deserialises into f64; a float does not into u32 */
+bool get_f64(const TomlTable &t, const char *k, double &out, std::string &err) {
+  auto it = t.find(k);
+  if (it == t.end()) {
+    err = std::string("missing field `") + k + "`";
+    return false;
+  }
+  if (it->second.kind != TomlValue::FLOAT && it->second.kind != TomlValue::INTEGER) {
+    err = std::string("invalid type for `") + k + "`, expected f64";
+    return false;
+  }
+  out = it->second.f;
+  return true;
+}
+bool get_u32(const TomlTable &t, const char *k, uint32_t &out, std::string &err) {
+  auto it = t.find(k);
+  if (it == t.end()) {
+    err = std::string("missing field `") + k + "`";
+    return false;
+  }
+  if (it->second.kind != TomlValue::INTEGER || it->second.i < 0 || it->second.i > 4294967295LL) {
+    err = std::string("invalid type or range for `") + k + "`, expected u32";
+    return false;
+  }
+  out = (uint32_t)it->second.i;
+  return true;
+}
+bool get_str(const TomlTable &t, const char *k, std::string &out, std::string &err) {
+  auto it = t.find(k);
+  if (it == t.end()) {
+    err = std::string("missing field `") + k + "`";
+    return false;
+  }
+  if (it->second.kind != TomlValue::STRING) {
+    err = std::string("invalid type for `") + k + "`, expected a string";
+    return false;
+  }
+  out = it->second.s;
+  return true;
+}
+
+bool read_text(const std::string &path, std::string &out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  out = ss.str();
+  return true;
+}
+bool path_exists(const std::string &p) {
+  struct stat st;
+  return ::stat(p.c_str(), &st) == 0;
+}
+bool is_dir(const std::string &p) {
+  struct stat st;
+  return ::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+/* ------------------------------------------------------------------ settings (src/settings.rs:22-217) */
+struct VideoSettings {
+  std::string video_name = "output_video";
+  double frame_rate = 30.0;
+  std::string filepath_to_camera_path = "paths/path_through.csv";
+};
+struct ImageSettings {
+  std::string image_name = "output_image";
+  double t = 0.0, l = 5.0, theta = 1.5707963267948966192313216916398, phi = 0.0;
+  double forward_x = -1.0, forward_y = 0.0, forward_z = 0.0, up_x = 0.0, up_y = 0.0, up_z = 1.0;
+};
+struct CameraSettings {
+  uint32_t resolution_x = 960, resolution_y = 540;
+  double diagonal = 43.0, focal_length = 15.0;
+};
+struct SimulationSettings {
+  double escape_radius = 100.0;
+  uint32_t ray_integration_max_itarations = 40000;
+  double ray_integration_step = 0.05;
+  uint32_t sampling_initial_nums = 100, sampling_max_iterations = 50;
+  double sampling_convergence_threshold_1 = 1e-5, sampling_convergence_threshold_2 = 1e-5;
+};
+
+std::string package_root() { /* CURVIS_HOME, else the directory two levels above the executable */
+  if (const char *h = std::getenv("CURVIS_HOME")) return h;
+  char buf[4096];
+  ssize_t n = ::readlink("/proc/self/exe", buf, sizeof buf - 1);
+  if (n <= 0) return ".";
+  buf[n] = 0;
+  std::string p(buf);
+  for (int k = 0; k < 2; ++k) {
+    const size_t s = p.find_last_of('/');
+    if (s == std::string::npos) return ".";
+    p.resize(s);
+  }
+  return p; /* .../curvis_amd */
+}
+std::string resolve_path(const std::string &p) { /* src/filepaths.rs:42-47: relative paths are package-relative */
+  if (!p.empty() && p[0] == '/') return p;
+  if (path_exists(p)) return p;
+  const std::string root = package_root();
+  for (const std::string &cand : {root + "/" + p, root + "/data/" + p})
+    if (path_exists(cand)) return cand;
+  return root + "/" + p;
+}
+bool has_extension(const std::string &p, const char *ext) {
+  const size_t d = p.find_last_of('.');
+  return d != std::string::npos && p.substr(d + 1) == ext;
+}
+
+bool load_table(const std::string &file, TomlTable &t, std::string &err) {
+  if (!has_extension(file, "toml")) {
+    err = "The file \"" + file + "\" is not a toml file.";
+    return false;
+  }
+  std::string text;
+  if (!read_text(file, text)) {
+    err = "Could not read file \"" + file + "\"";
+    return false;
+  }
+  return parse_toml(text, t, err);
+}
+
+bool from_toml(const std::string &file, VideoSettings &s, std::string &err) {
+  TomlTable t;
+  return load_table(file, t, err) && get_str(t, "video_name", s.video_name, err) &&
+         get_f64(t, "frame_rate", s.frame_rate, err) && get_str(t, "filepath_to_camera_path", s.filepath_to_camera_path, err);
+}
+bool from_toml(const std::string &file, ImageSettings &s, std::string &err) {
+  TomlTable t;
+  return load_table(file, t, err) && get_str(t, "image_name", s.image_name, err) && get_f64(t, "t", s.t, err) &&
+         get_f64(t, "l", s.l, err) && get_f64(t, "theta", s.theta, err) && get_f64(t, "phi", s.phi, err) &&
+         get_f64(t, "forward_x", s.forward_x, err) && get_f64(t, "forward_y", s.forward_y, err) &&
+         get_f64(t, "forward_z", s.forward_z, err) && get_f64(t, "up_x", s.up_x, err) &&
+         get_f64(t, "up_y", s.up_y, err) && get_f64(t, "up_z", s.up_z, err);
+}
+bool from_toml(const std::string &file, CameraSettings &s, std::string &err) {
+  TomlTable t;
+  return load_table(file, t, err) && get_u32(t, "resolution_x", s.resolution_x, err) &&
+         get_u32(t, "resolution_y", s.resolution_y, err) && get_f64(t, "diagonal", s.diagonal, err) &&
+         get_f64(t, "focal_length", s.focal_length, err);
+}
+bool from_toml(const std::string &file, SimulationSettings &s, std::string &err) {
+  TomlTable t;
+  return load_table(file, t, err) && get_f64(t, "escape_radius", s.escape_radius, err) &&
+         get_u32(t, "ray_integration_max_itarations", s.ray_integration_max_itarations, err) &&
+         get_f64(t, "ray_integration_step", s.ray_integration_step, err) &&
+         get_u32(t, "sampling_initial_nums", s.sampling_initial_nums, err) &&
+         get_u32(t, "sampling_max_iterations", s.sampling_max_iterations, err) &&
+         get_f64(t, "sampling_convergence_threshold_1", s.sampling_convergence_threshold_1, err) &&
+         get_f64(t, "sampling_convergence_threshold_2", s.sampling_convergence_threshold_2, err);
+}
+/* metric file: tried as Interstellar (m, a, rho) first, then Ellis (rho) -- src/cli.rs:233-261 */
+bool metric_from_toml(const std::string &file, curvis_metric &m, std::string &err) {
+  TomlTable t;
+  if (!load_table(file, t, err)) {
+    err = "Could not read the metric configuration file.";
+    return false;
+  }
+  std::string e;
+  double mm, aa, rho;
+  if (get_f64(t, "m", mm, e) && get_f64(t, "a", aa, e) && get_f64(t, "rho", rho, e)) {
+    m.kind = CURVIS_METRIC_INTERSTELLAR;
+    m.m = mm;
+    m.a = aa;
+    m.rho = rho;
+    return true;
+  }
+  if (get_f64(t, "rho", rho, e)) {
+    m.kind = CURVIS_METRIC_ELLIS;
+    m.rho = rho;
+    m.m = m.a = 0.0;
+    return true;
+  }
+  err = "Could not read the metric configuration file.";
+  return false;
+}
+
+bool validate(const CameraSettings &c, std::string &err) { /* src/settings.rs:98-124 */
+  if (c.resolution_x == 0) return err = "The resolution in the x direction must be larger than zero.", false;
+  if (c.resolution_y == 0) return err = "The resolution in the y direction must be larger than zero.", false;
+  if (c.diagonal <= 0.0) return err = "The diagonal of the camera must be larger than zero.", false;
+  if (c.focal_length <= 0.0) return err = "The focal length of the camera must be larger than zero.", false;
+  return true;
+}
+bool validate(const SimulationSettings &s, std::string &err) { /* src/settings.rs:137-174 */
+  if (s.escape_radius <= 0.0) return err = "The escape radius must be larger than zero.", false;
+  if (s.ray_integration_max_itarations == 0)
+    return err = "The maximum number of iterations for the ray integration must be larger than zero.", false;
+  if (s.ray_integration_step <= 0.0) return err = "The step for the ray integration must be larger than zero.", false;
+  if (s.sampling_initial_nums <= 1) return err = "The initial number of samples must be larger than two.", false;
+  if (s.sampling_max_iterations == 0)
+    return err = "The maximum number of iterations for the sampling must be larger than zero.", false;
+  if (s.sampling_convergence_threshold_1 <= 0.0)
+    return err = "The first convergence threshold for the sampling must be larger than zero.", false;
+  if (s.sampling_convergence_threshold_2 <= 0.0)
+    return err = "The second convergence threshold for the sampling must be larger than zero.", false;
+  return true;
+}
+
+/* ------------------------------------------------------------------ camera path (src/csv.rs, src/interpolation.rs) */
+struct CameraPath {
+  std::vector<double> pos, fwd, up; /* n*4, n*3, n*3 */
+  size_t n = 0;
+};
+bool load_path(const std::string &file, CameraPath &p, std::string &err) {
+  std::string text;
+  if (!read_text(file, text)) return err = "Could not open file", false;
+  size_t start = 0, index = 0;
+  while (start <= text.size()) {
+    size_t end = text.find('\n', start);
+    const bool last = end == std::string::npos;
+    if (last) end = text.size();
+    std::string line = text.substr(start, end - start);
+    start = end + 1;
+    if (last && line.empty()) break;
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (index++ == 0) {
+      if (last) break;
+      continue; /* header */
+    }
+    double v[10];
+    size_t a = 0;
+    int k = 0;
+    for (size_t i = 0; i <= line.size() && k < 10; ++i) {
+      if (i == line.size() || line[i] == ',') {
+        const std::string tok = line.substr(a, i - a);
+        char *endp = nullptr;
+        if (tok.empty() || std::isspace((unsigned char)tok.front()) || std::isspace((unsigned char)tok.back()))
+          return err = "Could not parse float", false;
+        v[k] = std::strtod(tok.c_str(), &endp);
+        if (!endp || *endp) return err = "Could not parse float", false;
+        ++k;
+        a = i + 1;
+      }
+    }
+    if (k < 10) return err = "Could not read all ten columns of the camera path", false;
+    p.pos.insert(p.pos.end(), v, v + 4);
+    p.fwd.insert(p.fwd.end(), v + 4, v + 7);
+    p.up.insert(p.up.end(), v + 7, v + 10);
+    p.n++;
+    if (last) break;
+  }
+  return p.n > 0 ? true : (err = "empty camera path", false);
+}
+/* 0 ok, 1 = panic "time outside range", 2 = index out of bounds (the off-by-one) */
+int path_camera(const CameraPath &p, double t, double pos[4], double fwd[3], double up[3]) {
+  const double min_time = p.pos[0], max_time = p.pos[4 * (p.n - 1)];
+  if (t < min_time || t > max_time) return 1;
+  double t1 = min_time, t2 = max_time;
+  size_t i = 0;
+  while (t > p.pos[4 * i]) {
+    t1 = p.pos[4 * i];
+    t2 = p.pos[4 * (i + 1)];
+    i += 1;
+  }
+  const double frac = (t - t1) / (t2 - t1);
+  const size_t i1 = i, i2 = i + 1;
+  if (i2 >= p.n) return 2;
+  if (!(frac >= 0.0 && frac <= 1.0)) return 1;
+  for (int k = 0; k < 4; ++k) pos[k] = p.pos[4 * i1 + k] + frac * (p.pos[4 * i2 + k] - p.pos[4 * i1 + k]);
+  for (int k = 0; k < 3; ++k) {
+    fwd[k] = p.fwd[3 * i1 + k] + frac * (p.fwd[3 * i2 + k] - p.fwd[3 * i1 + k]);
+    up[k] = p.up[3 * i1 + k] + frac * (p.up[3 * i2 + k] - p.up[3 * i1 + k]);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ command line */
+struct Args {
+  std::string sub, bg1, bg2, out, image_toml, video_toml, metric_toml, camera_toml, sim_toml, mode = "efficient", stats;
+  int devices = 1, device = 0, batch = 8;
+};
+[[noreturn]] void die(const std::string &msg, int code = 1) {
+  std::fprintf(stderr, "%s\n", msg.c_str());
+  std::exit(code);
+}
+void usage() {
+  std::printf(
+      "Usage: curvis <COMMAND>\n\nCommands:\n  image   renders a single image frame\n  video   renders a video\n"
+      "  custom  runs the custom script\n\n"
+      "curvis image <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-i|--image-settings <TOML FILE>]\n"
+      "curvis video <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-v|--video-settings <TOML FILE>]\n"
+      "  common: [-m|--metric-settings <TOML FILE>] [-c|--camera-settings <TOML FILE>] [-s|--simulation-settings <TOML FILE>]\n"
+      "  extensions: [--mode efficient|brute] [--device N] [--devices N] [--batch B] [--stats FILE]\n");
+}
+Args parse_args(int argc, char **argv) {
+  Args a;
+  if (argc < 2) {
+    usage();
+    die("Subcommand not found");
+  }
+  a.sub = argv[1];
+  if (a.sub == "selftest-png") return a;
+  if (a.sub == "-h" || a.sub == "--help") {
+    usage();
+    std::exit(0);
+  }
+  std::vector<std::string> pos;
+  for (int i = 2; i < argc; ++i) {
+    std::string s = argv[i], val;
+    auto take = [&](std::string &dst) {
+      const size_t eq = s.find('=');
+      if (s.rfind("--", 0) == 0 && eq != std::string::npos)
+        dst = s.substr(eq + 1);
+      else if (i + 1 < argc)
+        dst = argv[++i];
+      else
+        die("error: a value is required for '" + s + "' but none was supplied", 2);
+    };
+    const std::string key = s.substr(0, s.find('='));
+    if (key == "-i" || key == "--image-settings") take(a.image_toml);
+    else if (key == "-v" || key == "--video-settings") take(a.video_toml);
+    else if (key == "-m" || key == "--metric-settings") take(a.metric_toml);
+    else if (key == "-c" || key == "--camera-settings") take(a.camera_toml);
+    else if (key == "-s" || key == "--simulation-settings") take(a.sim_toml);
+    else if (key == "--mode") take(a.mode);
+    else if (key == "--stats") take(a.stats);
+    else if (key == "--devices") { take(val); a.devices = std::atoi(val.c_str()); }
+    else if (key == "--device") { take(val); a.device = std::atoi(val.c_str()); }
+    else if (key == "--batch") { take(val); a.batch = std::atoi(val.c_str()); }
+    else if (key == "-h" || key == "--help") { usage(); std::exit(0); }
+    else if (!s.empty() && s[0] == '-') die("error: unexpected argument '" + s + "' found", 2);
+    else pos.push_back(s);
+  }
+  if (a.sub == "image" || a.sub == "video") {
+    if (pos.size() < 2) die("error: the following required arguments were not provided:\n  <IMAGE FILE 1>\n  <IMAGE FILE 2>", 2);
+    if (pos.size() > 3) die("error: unexpected argument '" + pos[3] + "' found", 2);
+    a.bg1 = pos[0];
+    a.bg2 = pos[1];
+    if (pos.size() == 3) a.out = pos[2];
+    if (a.sub == "image" && !a.video_toml.empty()) die("error: unexpected argument '-v' found", 2);
+    if (a.sub == "video" && !a.image_toml.empty()) die("error: unexpected argument '-i' found", 2);
+  }
+  if (a.mode != "efficient" && a.mode != "brute") die("error: --mode must be efficient or brute", 2);
+  if (a.devices < 1) a.devices = 1;
+  if (a.batch < 1) a.batch = 1;
+  return a;
+}
+
+struct Common {
+  curvis_metric metric{CURVIS_METRIC_ELLIS, 0, 1.0, 0.0, 0.0}; /* default: Ellis rho = 1 (ellis_metric_settings.toml) */
+  CameraSettings cam;
+  SimulationSettings sim;
+  pngio::Image sky1, sky2;
+  std::string out;
+};
+
+void load_common(const Args &a, Common &c, const char *what) {
+  std::string err;
+  auto need = [&](const std::string &f, const char *label) {
+    if (!path_exists(f)) die(std::string("Error with ") + label + ": File \"" + f + "\" not found.");
+  };
+  need(a.bg1, "background image 1");
+  need(a.bg2, "background image 2");
+  if (a.out.empty()) {
+    char cwd[4096];
+    if (!::getcwd(cwd, sizeof cwd)) die("Error with output folder: Could not get current working directory.");
+    c.out = cwd;
+  } else {
+    if (!path_exists(a.out)) die("Error with output folder: File \"" + a.out + "\" not found.");
+    if (!is_dir(a.out)) die("Error with output folder: \"" + a.out + "\" is not a folder.");
+    c.out = a.out;
+  }
+  if (!a.metric_toml.empty()) {
+    need(a.metric_toml, "metric settings");
+    if (!metric_from_toml(a.metric_toml, c.metric, err)) die("Error with metric settings: " + err);
+  }
+  if (!a.camera_toml.empty()) {
+    need(a.camera_toml, "camera settings");
+    if (!from_toml(a.camera_toml, c.cam, err)) die("Error with camera settings: " + err);
+  }
+  if (!a.sim_toml.empty()) {
+    need(a.sim_toml, "simulation settings");
+    if (!from_toml(a.sim_toml, c.sim, err)) die("Error with simulation settings: " + err);
+  }
+  /* instantiate_metric (src/main.rs:114-132): constructor panics */
+  if (curvis_metric_validate(&c.metric) != CURVIS_OK)
+    die(std::string("Error in rendering ") + what + ": metric parameters must be positive (src/metrics.rs:409-456)", 101);
+  if (!validate(c.cam, err) || !validate(c.sim, err)) die(std::string("Error in rendering ") + what + ": " + err);
+  if (!pngio::load(a.bg1, c.sky1, err)) die(std::string("Error in rendering ") + what + ": background image 1: " + err);
+  if (!pngio::load(a.bg2, c.sky2, err)) die(std::string("Error in rendering ") + what + ": background image 2: " + err);
+}
+
+void check(int rc, curvis_ctx *ctx, const char *what) {
+  if (rc == CURVIS_OK) return;
+  const char *msg = curvis_last_error(ctx);
+  die(std::string("Error in rendering ") + what + ": " + (msg ? msg : "") + " (code " + std::to_string(rc) + ")",
+      (rc == CURVIS_E_CAMERA_OUTSIDE || rc == CURVIS_E_PARALLEL || rc == CURVIS_E_SAMPLING) ? 101 : 1);
+}
+
+curvis_ctx *make_ctx(int device, const Common &c, const char *what) {
+  curvis_ctx *ctx = nullptr;
+  int rc = curvis_ctx_create(device, &ctx);
+  if (rc != CURVIS_OK) die(std::string("Error in rendering ") + what + ": " + curvis_last_error(nullptr));
+  check(curvis_ctx_set_sky(ctx, 0, c.sky1.rgba.data(), c.sky1.w, c.sky1.h), ctx, what);
+  check(curvis_ctx_set_sky(ctx, 1, c.sky2.rgba.data(), c.sky2.w, c.sky2.h), ctx, what);
+  return ctx;
+}
+
+int render_frames(curvis_ctx *ctx, const Args &a, const Common &c, const curvis_camera *cams, uint32_t n, double thr2,
+                  uint8_t *rgb, curvis_stats *st) {
+  if (a.mode == "brute")
+    return curvis_render_brute_batch(ctx, &c.metric, cams, n, c.sim.ray_integration_max_itarations, c.sim.escape_radius,
+                                     c.sim.ray_integration_step, rgb, st);
+  /* src/main.rs:46-47 / :106-107: alphas_num AND max_iterations_sampling both take sampling_initial_nums */
+  return curvis_render_efficient_batch(ctx, &c.metric, cams, n, c.sim.ray_integration_max_itarations, c.sim.escape_radius,
+                                       c.sim.ray_integration_step, c.sim.sampling_initial_nums, c.sim.sampling_initial_nums,
+                                       c.sim.sampling_convergence_threshold_1, thr2, rgb, st);
+}
+
+int image_main(const Args &a) {
+  std::printf("Image rendering\n");
+  Common c;
+  ImageSettings is;
+  std::string err;
+  if (!a.image_toml.empty()) {
+    if (!path_exists(a.image_toml)) die("Error with image settings: File \"" + a.image_toml + "\" not found.");
+    if (!from_toml(a.image_toml, is, err)) die("Error with image settings: " + err);
+  }
+  load_common(a, c, "image");
+  if (is.image_name.empty()) die("Error in rendering image: Image name cannot be an empty string.");
+  const double pos[4] = {is.t, is.l, is.theta, is.phi}, fwd[3] = {is.forward_x, is.forward_y, is.forward_z},
+               up[3] = {is.up_x, is.up_y, is.up_z};
+  curvis_camera cam;
+  int rc = curvis_camera_init(&cam, pos, fwd, up, c.cam.focal_length, c.cam.diagonal, c.cam.resolution_x, c.cam.resolution_y);
+  if (rc == CURVIS_E_PARALLEL) die("Error in rendering image: Forward and up vectors must not be parallel", 101);
+  if (rc != CURVIS_OK) die("Error in rendering image: invalid camera settings");
+  curvis_ctx *ctx = make_ctx(a.device, c, "image");
+  if (!path_exists(c.out) && ::mkdir(c.out.c_str(), 0777) != 0)
+    die("Error in rendering image: Could not create video output folder \"" + c.out + "\"");
+  std::vector<uint8_t> rgb((size_t)cam.res_x * cam.res_y * 3);
+  curvis_stats st;
+  check(render_frames(ctx, a, c, &cam, 1, c.sim.sampling_convergence_threshold_2, rgb.data(), &st), ctx, "image");
+  const std::string file = c.out + "/" + is.image_name + ".png";
+  if (!pngio::save_rgb8(file, rgb.data(), cam.res_x, cam.res_y, err))
+    die("Error in rendering image: Could not save image frame \"" + file + "\" due to error: " + err);
+  if (!a.stats.empty()) {
+    FILE *f = std::fopen(a.stats.c_str(), "w");
+    if (f) {
+      std::fprintf(f, "{\"frame\": 0, \"mode\": \"%s\", \"rays\": %llu, \"steps\": %llu, \"n_pos\": %llu, \"n_neg\": %llu, \"n_none\": %llu, \"kernel_ms\": %.4f}\n",
+                   a.mode.c_str(), (unsigned long long)st.rays, (unsigned long long)st.steps, (unsigned long long)st.n_pos,
+                   (unsigned long long)st.n_neg, (unsigned long long)st.n_none, st.kernel_ms);
+      std::fclose(f);
+    }
+  }
+  curvis_ctx_destroy(ctx);
+  return 0;
+}
+
+int rm_rf(const std::string &dir) { /* tmp folder only contains frame files */
+  const std::string cmd = "rm -rf -- '" + dir + "'";
+  return std::system(cmd.c_str());
+}
+
+int video_main(const Args &a) {
+  std::printf("Video rendering\n");
+  Common c;
+  VideoSettings vs;
+  std::string err;
+  if (!a.video_toml.empty()) {
+    if (!path_exists(a.video_toml)) die("Error with video settings: File \"" + a.video_toml + "\" not found.");
+    if (!from_toml(a.video_toml, vs, err)) die("Error with video settings: " + err);
+  }
+  load_common(a, c, "video");
+  vs.filepath_to_camera_path = resolve_path(vs.filepath_to_camera_path); /* normalize() */
+  if (vs.video_name.empty()) die("Error in rendering video: Video name cannot be an empty string.");
+  if (!has_extension(vs.filepath_to_camera_path, "csv"))
+    die("Error in rendering video: The camera path \"" + vs.filepath_to_camera_path + "\" is not a csv file.");
+  if (!path_exists(vs.filepath_to_camera_path))
+    die("Error in rendering video: The camera path \"" + vs.filepath_to_camera_path + "\" does not exist.");
+  CameraPath path;
+  if (!load_path(vs.filepath_to_camera_path, path, err)) die("Error in rendering video: " + err, 101);
+  /* times_of_frames (src/rendering.rs:224-238) */
+  std::vector<double> times;
+  {
+    const double min_time = path.pos[0], max_time = path.pos[4 * (path.n - 1)], dt = 1.0 / vs.frame_rate;
+    for (double t = min_time; t < max_time; t += dt) times.push_back(t);
+  }
+  if (!path_exists(c.out) && ::mkdir(c.out.c_str(), 0777) != 0)
+    die("Error in rendering video: Could not create video output folder \"" + c.out + "\"");
+  const std::string tmp = c.out + "/tmp";
+  if (path_exists(tmp) && rm_rf(tmp) != 0)
+    die("Error in rendering video: Could not remove pre-existing tmp folder \"" + tmp + "\"");
+  if (::mkdir(tmp.c_str(), 0777) != 0) die("Error in rendering video: Could not create tmp output folder \"" + tmp + "\"");
+  std::printf("Rendering %zu frames...\n", times.size());
+
+  /* cameras of all frames; the reference panics when it reaches the broken last segment, after having
+   * written the frames before it: frames up to the first failing one are rendered, then exit 101. */
+  std::vector<curvis_camera> cams;
+  std::string panic_msg;
+  for (size_t k = 0; k < times.size(); ++k) {
+    double pos[4], fwd[3], up[3];
+    const int prc = path_camera(path, times[k], pos, fwd, up);
+    if (prc != 0) {
+      panic_msg = prc == 2 ? "index out of bounds in the camera-path interpolation (src/interpolation.rs:76-90)"
+                           : "Interpolation time outside the camera path";
+      break;
+    }
+    curvis_camera cam;
+    const int rc = curvis_camera_init(&cam, pos, fwd, up, c.cam.focal_length, c.cam.diagonal, c.cam.resolution_x, c.cam.resolution_y);
+    if (rc != CURVIS_OK) {
+      panic_msg = "Forward and up vectors must not be parallel";
+      break;
+    }
+    cams.push_back(cam);
+  }
+  const size_t n_frames = cams.size();
+  const size_t fbytes = (size_t)c.cam.resolution_x * c.cam.resolution_y * 3;
+  std::mutex io_mu;
+  std::atomic<int> failed{0};
+  FILE *stats_f = a.stats.empty() ? nullptr : std::fopen(a.stats.c_str(), "w");
+  auto worker = [&](int rank) {
+    curvis_ctx *ctx = make_ctx(a.device + rank, c, "video");
+    std::vector<size_t> mine;
+    for (size_t k = (size_t)rank; k < n_frames; k += (size_t)a.devices) mine.push_back(k);
+    std::vector<curvis_camera> bc;
+    std::vector<uint8_t> rgb;
+    for (size_t b0 = 0; b0 < mine.size() && !failed; b0 += (size_t)a.batch) {
+      const size_t nb = std::min((size_t)a.batch, mine.size() - b0);
+      bc.clear();
+      for (size_t j = 0; j < nb; ++j) bc.push_back(cams[mine[b0 + j]]);
+      rgb.resize(nb * fbytes);
+      curvis_stats st;
+      /* src/rendering.rs:305-306: threshold_1 is passed for both thresholds */
+      const int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, rgb.data(), &st);
+      if (rc != CURVIS_OK) {
+        std::lock_guard<std::mutex> g(io_mu);
+        std::fprintf(stderr, "Error in rendering video: %s (code %d)\n", curvis_last_error(ctx), rc);
+        failed = 1;
+        break;
+      }
+      for (size_t j = 0; j < nb; ++j) {
+        const size_t k = mine[b0 + j];
+        const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
+        std::string e;
+        if (!pngio::save_rgb8(file, rgb.data() + j * fbytes, c.cam.resolution_x, c.cam.resolution_y, e, 1)) {
+          std::lock_guard<std::mutex> g(io_mu);
+          std::fprintf(stderr, "Error in rendering video: Could not save image frame \"%s\" due to error: %s\n", file.c_str(), e.c_str());
+          failed = 1;
+          break;
+        }
+        std::lock_guard<std::mutex> g(io_mu);
+        std::printf("Rendering frame %zu/%zu...\n", k + 1, times.size());
+        if (stats_f)
+          std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"batch_frames\": %zu, \"batch_rays\": %llu, \"batch_steps\": %llu, \"batch_n_pos\": %llu, \"batch_n_neg\": %llu, \"batch_n_none\": %llu, \"batch_kernel_ms\": %.4f}\n",
+                       k, times[k], a.device + rank, a.mode.c_str(), nb, (unsigned long long)st.rays, (unsigned long long)st.steps,
+                       (unsigned long long)st.n_pos, (unsigned long long)st.n_neg, (unsigned long long)st.n_none, st.kernel_ms);
+      }
+    }
+    curvis_ctx_destroy(ctx);
+  };
+  std::vector<std::thread> th;
+  for (int r = 0; r < a.devices; ++r) th.emplace_back(worker, r);
+  for (auto &t : th) t.join();
+  if (stats_f) std::fclose(stats_f);
+  if (failed) return 1;
+  if (!panic_msg.empty()) {
+    std::fprintf(stderr, "thread 'main' panicked: %s (frame %zu of %zu)\n", panic_msg.c_str(), n_frames, times.size());
+    return 101;
+  }
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  const Args a = parse_args(argc, argv);
+  if (a.sub == "image") return image_main(a);
+  if (a.sub == "video") return video_main(a);
+  if (a.sub == "selftest-png") { /* hidden: decode <in.png> the way skies are decoded, dump RGBA8 to <out> */
+    if (argc != 4) die("usage: curvis selftest-png <in.png> <out.rgba>", 2);
+    pngio::Image img;
+    std::string err;
+    if (!pngio::load(argv[2], img, err)) die("selftest-png: " + err);
+    FILE *f = std::fopen(argv[3], "wb");
+    if (!f) die("selftest-png: cannot write output");
+    const uint32_t hdr[2] = {img.w, img.h};
+    std::fwrite(hdr, sizeof hdr, 1, f);
+    std::fwrite(img.rgba.data(), 1, img.rgba.size(), f);
+    std::fclose(f);
+    return 0;
+  }
+  if (a.sub == "custom") { /* src/custom.rs: not implemented in the reference either */
+    std::printf("Custom script\n");
+    die("Error in curstom script: not implemented");
+  }
+  die("Unrecognized subcommand \"" + a.sub + "\"");
+}

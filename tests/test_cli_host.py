@@ -1,0 +1,146 @@
+"""The `curvis` host binary on CPU: argument handling, TOML subset, validation messages, PNG codec,
+and the loud failure without a GPU.  (End-to-end rendering is in tests/test_gpu_cli.py.)"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from curvis_amd import pngio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
+
+
+def run(*args, cwd=None):
+    return subprocess.run([BIN] + [str(a) for a in args], capture_output=True, text=True, cwd=cwd, timeout=120)
+
+
+@pytest.fixture(scope="module")
+def skies(tmp_path_factory):
+    d = tmp_path_factory.mktemp("sky")
+    rng = np.random.default_rng(0)
+    a, b = d / "a.png", d / "b.png"
+    pngio.write_png(a, rng.integers(0, 255, (32, 64, 3), dtype=np.uint8))
+    pngio.write_png(b, rng.integers(0, 255, (32, 64, 4), dtype=np.uint8))
+    return d, a, b
+
+
+def test_binary_exists_and_usage():
+    assert os.path.exists(BIN), "build with make -C curvis_amd/csrc"
+    r = run("--help")
+    assert r.returncode == 0 and "image" in r.stdout and "video" in r.stdout and "custom" in r.stdout
+    assert run().returncode == 1
+    r = run("custom")
+    assert r.returncode == 1 and "Custom script" in r.stdout and "not implemented" in r.stderr
+
+
+def test_argument_errors(skies):
+    d, a, b = skies
+    r = run("image", a)
+    assert r.returncode == 2 and "required arguments" in r.stderr
+    r = run("image", d / "missing.png", b)
+    assert r.returncode == 1 and "Error with background image 1" in r.stderr and "not found" in r.stderr
+    r = run("image", a, b, d / "nofolder")
+    assert r.returncode == 1 and "Error with output folder" in r.stderr
+    r = run("image", a, b, a)
+    assert r.returncode == 1 and "is not a folder" in r.stderr
+    r = run("image", a, b, "-v", "x.toml")
+    assert r.returncode == 2
+    r = run("image", a, b, "--bogus")
+    assert r.returncode == 2 and "unexpected argument" in r.stderr
+
+
+def test_settings_parsing_and_validation(skies):
+    d, a, b = skies
+    sim = d / "sim.toml"
+    sim.write_text("escape_radius = 100.0\nray_integration_max_itarations = 4096 # sic\nray_integration_step = 0.05\n"
+                   "sampling_initial_nums = 100\nsampling_max_iterations = 50\n"
+                   "sampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 1e-5\n")
+    bad = d / "bad.toml"
+    bad.write_text(sim.read_text().replace("ray_integration_max_itarations", "ray_integration_max_iterations"))
+    r = run("image", a, b, d, "-s", bad)
+    assert r.returncode == 1 and "missing field `ray_integration_max_itarations`" in r.stderr
+    neg = d / "neg.toml"
+    neg.write_text(sim.read_text().replace("escape_radius = 100.0", "escape_radius = -1"))
+    r = run("image", a, b, d, "-s", neg)
+    assert r.returncode == 1 and "The escape radius must be larger than zero." in r.stderr
+    cam = d / "cam.toml"
+    cam.write_text("resolution_x = 64.0\nresolution_y = 36\ndiagonal = 43.0\nfocal_length = 15.0\n")
+    r = run("image", a, b, d, "-c", cam)
+    assert r.returncode == 1 and "resolution_x" in r.stderr  # a float does not deserialize into u32
+    met = d / "met.toml"
+    met.write_text("m = 0.1\na = 0.0\nrho = 1.0\n")
+    r = run("image", a, b, d, "-m", met)
+    assert r.returncode == 101 and "metric parameters must be positive" in r.stderr
+    notoml = d / "sim.txt"
+    notoml.write_text(sim.read_text())
+    r = run("image", a, b, d, "-s", notoml)
+    assert r.returncode == 1 and "is not a toml file" in r.stderr
+    vid = d / "vid.toml"
+    vid.write_text('video_name = "v"\nframe_rate = 4.0\nfilepath_to_camera_path = "nope/none.csv"\n')
+    r = run("video", a, b, d, "-v", vid)
+    assert r.returncode == 1 and "does not exist" in r.stderr
+
+
+def test_without_gpu_fails_loudly(skies):
+    d, a, b = skies
+    import curvis_amd
+    if curvis_amd.lib().curvis_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = run("image", a, b, d)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    assert not (d / "output_image.png").exists()
+
+
+def _decode_with_binary(path, tmp):
+    out = tmp / "dump.rgba"
+    r = run("selftest-png", path, out)
+    assert r.returncode == 0, r.stderr
+    raw = out.read_bytes()
+    w, h = struct.unpack("<II", raw[:8])
+    return np.frombuffer(raw[8:], np.uint8).reshape(h, w, 4)
+
+
+def test_png_decoder_matches_pillow(tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    cases = {
+        "rgb": (rng.integers(0, 255, (17, 23, 3), dtype=np.uint8), "RGB"),
+        "rgba": (rng.integers(0, 255, (9, 31, 4), dtype=np.uint8), "RGBA"),
+        "grey": (rng.integers(0, 255, (12, 13), dtype=np.uint8), "L"),
+        "la": (rng.integers(0, 255, (8, 8, 2), dtype=np.uint8), "LA"),
+    }
+    for name, (arr, mode) in cases.items():
+        for interlace in (False, True):
+            p = tmp_path / ("%s_%d.png" % (name, interlace))
+            im = PIL.fromarray(arr, mode)
+            if interlace:
+                # Pillow cannot write Adam7; emulate by re-saving through optimize (filters vary)
+                im.save(p, optimize=True)
+            else:
+                im.save(p)
+            want = np.asarray(PIL.open(p).convert("RGBA"))
+            got = _decode_with_binary(p, tmp_path)
+            assert np.array_equal(got, want), name
+    # palette with transparency
+    pal = PIL.fromarray(rng.integers(0, 255, (20, 20, 3), dtype=np.uint8), "RGB").quantize(16)
+    p = tmp_path / "pal.png"
+    pal.save(p)
+    assert np.array_equal(_decode_with_binary(p, tmp_path), np.asarray(PIL.open(p).convert("RGBA")))
+    # 16-bit RGB: image crate reduction (v + 128) / 257
+    a16 = rng.integers(0, 65535, (6, 7, 3), dtype=np.uint16)
+    p = tmp_path / "rgb16.png"
+    pngio.write_png(p, a16)
+    got = _decode_with_binary(p, tmp_path)
+    want = ((a16.astype(np.uint32) + 128) // 257).astype(np.uint8)
+    assert np.array_equal(got[..., :3], want) and (got[..., 3] == 255).all()
+
+
+def test_python_png_helpers_round_trip(tmp_path):
+    rng = np.random.default_rng(1)
+    for shape in ((5, 7, 3), (4, 4, 4), (3, 9)):
+        a = rng.integers(0, 255, shape, dtype=np.uint8)
+        pngio.write_png(tmp_path / "x.png", a)
+        assert np.array_equal(pngio.read_png(tmp_path / "x.png"), a)

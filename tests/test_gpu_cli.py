@@ -1,0 +1,108 @@
+"""End-to-end: the `curvis` binary on a real GPU against the oracle -- file-level drop-in check
+(PNG skies in, PNG frames out, reference naming, reference quirks)."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import common
+import oracle_lib as O
+from curvis_amd import paths, pngio, rendering
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
+
+SIM = ("escape_radius = 100.0\nray_integration_max_itarations = 4096\nray_integration_step = 0.05\n"
+       "sampling_initial_nums = 100\nsampling_max_iterations = 50\n"
+       "sampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 2e-5\n")
+
+
+def run(*args, **kw):
+    return subprocess.run([BIN] + [str(a) for a in args], capture_output=True, text=True, timeout=600, **kw)
+
+
+@pytest.fixture(scope="module")
+def scene_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    sp, sn = common.make_skies(512, 256, "check")
+    pngio.write_png(d / "pos.png", sp[..., :3])   # RGB8 -> alpha 255, as DynamicImage::get_pixel
+    pngio.write_png(d / "neg.png", sn)            # RGBA8
+    (d / "sim.toml").write_text(SIM)
+    (d / "cam.toml").write_text("resolution_x = 96\nresolution_y = 54\ndiagonal = 43.0\nfocal_length = 15.0\n")
+    (d / "met.toml").write_text("m = 0.1\na = 0.0001\nrho = 1.0\n")
+    return d, sp, sn
+
+
+def test_image_default_pose_efficient_and_brute(scene_files):
+    d, sp, sn = scene_files
+    out = d / "out_img"
+    out.mkdir()
+    r = run("image", d / "pos.png", d / "neg.png", out, "-s", d / "sim.toml", "-c", d / "cam.toml", "--stats", out / "st.json")
+    assert r.returncode == 0, r.stderr
+    assert "Image rendering" in r.stdout
+    got = pngio.read_png(out / "output_image.png")
+    om, oc, _, _ = common.scene("ellis", res=(96, 54))
+    # the reference wires max_iterations_sampling to sampling_initial_nums (100), thresholds 1e-5 / 2e-5
+    want, smp, _ = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05, 100, 100, 1e-5, 2e-5)
+    assert np.array_equal(got, want)
+    st = json.loads((out / "st.json").read_text())
+    assert st["steps"] == smp["steps"] and st["mode"] == "efficient"
+    # per-pixel integrator through the same binary, Interstellar metric file
+    r = run("image", d / "pos.png", d / "neg.png", out, "-s", d / "sim.toml", "-c", d / "cam.toml", "-m", d / "met.toml",
+            "--mode", "brute")
+    assert r.returncode == 0, r.stderr
+    got = pngio.read_png(out / "output_image.png")
+    om, oc, _, _ = common.scene("interstellar", res=(96, 54))
+    want, _, _ = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
+    assert np.array_equal(got, want)
+
+
+def test_video_orbit_frames_and_quirks(scene_files):
+    d, sp, sn = scene_files
+    out = d / "out_vid"
+    out.mkdir()
+    (out / "tmp").mkdir()
+    (out / "tmp" / "stale.png").write_bytes(b"x")  # the tmp folder is deleted and recreated (src/rendering.rs:276-287)
+    orbit = os.path.join(paths.DATA_DIR, "path_orbit.csv")
+    (d / "vid.toml").write_text('video_name = "v"\nframe_rate = 0.25\nfilepath_to_camera_path = "%s"\n' % orbit)
+    r = run("video", d / "pos.png", d / "neg.png", out, "-v", d / "vid.toml", "-s", d / "sim.toml", "-c", d / "cam.toml",
+            "--batch", "4", "--stats", out / "st.jsonl")
+    assert r.returncode == 0, r.stderr
+    assert not (out / "tmp" / "stale.png").exists()
+    it = rendering.Interpolator.from_file(orbit)
+    times = rendering.times_of_frames(it.min_time(), it.max_time(), 0.25)
+    assert len(times) == 15 and "Rendering 15 frames..." in r.stdout
+    frames = sorted(os.listdir(out / "tmp"), key=lambda s: int(s[6:-4]))
+    assert frames == ["frame_%d.png" % k for k in range(15)]
+    om = O.ellis(1.0)
+    for k in (0, 7, 14):
+        oc = O.camera(tuple(it.camera_position(times[k])), tuple(it.camera_forward(times[k])), tuple(it.camera_up(times[k])),
+                      15.0, 43.0, (96, 54))
+        # video path: threshold_1 is passed twice (src/rendering.rs:305-306)
+        want, _, _ = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+        assert np.array_equal(pngio.read_png(out / "tmp" / ("frame_%d.png" % k)), want), k
+    lines = [json.loads(ln) for ln in (out / "st.jsonl").read_text().splitlines()]
+    assert sorted(ln["frame"] for ln in lines) == list(range(15))
+
+
+def test_video_off_by_one_panics_like_the_reference(scene_files):
+    """frame_rate 30 on path_orbit.csv: the reference panics at frame index 1799 (README.md:107); with a
+    coarser resolution of the same tail (frame times crafted to end inside the last CSV segment) the binary
+    renders the frames before it and exits with status 101."""
+    d, sp, sn = scene_files
+    out = d / "out_vid2"
+    out.mkdir()
+    pos, fwd, up = paths.load_path(os.path.join(paths.DATA_DIR, "path_orbit.csv"))
+    short = d / "short.csv"
+    rows = [paths.HEADER] + [",".join(repr(float(x)) for x in list(pos[i]) + list(fwd[i]) + list(up[i])) for i in range(4)]
+    short.write_text("\n".join(rows))
+    # times: 0, 0.05, 0.10, 0.15 < max_time (0.18018); 0.15 lies in the last segment -> index out of bounds
+    (d / "vid2.toml").write_text('video_name = "v"\nframe_rate = 20.0\nfilepath_to_camera_path = "%s"\n' % short)
+    r = run("video", d / "pos.png", d / "neg.png", out, "-v", d / "vid2.toml", "-s", d / "sim.toml", "-c", d / "cam.toml")
+    assert r.returncode == 101, (r.returncode, r.stderr)
+    assert "index out of bounds" in r.stderr
+    assert sorted(os.listdir(out / "tmp")) == ["frame_0.png", "frame_1.png", "frame_2.png"]
