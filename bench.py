@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--refill-threshold", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     ap.add_argument("--fast-math", type=int, default=1, help="1 shared-reciprocal step, 0 compiler IEEE div/sqrt")
+    ap.add_argument("--fuse-shade", type=int, default=1, help="1 shade in the integration kernel's epilogue (default)")
     ap.add_argument("--download", action="store_true",
                     help="copy every frame to host memory inside the timed region (PCIe-inclusive rate, "
                          "reported in DESIGN.md; never the headline value)")
@@ -66,20 +67,28 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # test hooks (1-GPU boxes): CURVIS_BENCH_SHARE_DEVICE=1 maps every rank to GPU 0 and
+    # CURVIS_BENCH_BACKEND=gloo replaces RCCL, so the N>1 control flow can be exercised on one GPU.
+    device_index = 0 if os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1" else local_rank
+    backend = os.environ.get("CURVIS_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
-    ctx = curvis_amd.Context(local_rank)
+    ctx = curvis_amd.Context(device_index)
     ctx.set_option("variant", args.variant)
     if args.refill_threshold is not None:
         ctx.set_option("refill_threshold", args.refill_threshold)
     if args.blocks_per_cu is not None:
         ctx.set_option("blocks_per_cu", args.blocks_per_cu)
     ctx.set_option("fast_math", args.fast_math)
+    ctx.set_option("fuse_shade", args.fuse_shade)
 
     # ---- inputs resident in HBM before the timed region: two skies (rank 0 generates, RCCL broadcast)
     sw, sh = args.sky, args.sky // 2
@@ -92,7 +101,12 @@ def main():
             t = torch.empty((sh, sw, 4), dtype=torch.uint8, device="cuda")
             if rank == 0:
                 t.copy_(torch.from_numpy(host_skies[which]))
-            dist.broadcast(t, src=0)  # RCCL over xGMI, w*h*4 bytes
+            if backend == "nccl":
+                dist.broadcast(t, src=0)  # RCCL over xGMI, w*h*4 bytes
+            else:  # test hook: stage through host memory
+                h = t.cpu()
+                dist.broadcast(h, src=0)
+                t.copy_(h)
             torch.cuda.synchronize()
             ctx.set_sky_device(which, t.data_ptr(), sw, sh, copy=False)
             sky_dev.append(t)  # keep alive
@@ -136,11 +150,12 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        red_dev = "cuda" if backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         agg = torch.tensor([float(steps_executed), float(rays), kernel_ms, shade_ms], dtype=torch.float64,
-                           device="cuda")
+                           device=red_dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         total_steps, total_rays, total_kernel_ms, total_shade_ms = [float(v) for v in agg.tolist()]
     else:
@@ -157,6 +172,7 @@ def main():
         value = total_steps / elapsed / 1e6
         nominal = total_rays * args.max_iter / elapsed / 1e6
         info = ctx.device_info()
+        traffic, traffic_note = pmc_traffic(args)
         out = {
             "metric": "Mrays/s (pixels x steps/s) at 1920x1080, 4096 steps",
             "value": round(value, 1),
@@ -170,7 +186,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (procedural 8192x4096 RGBA8 skies, default camera/metric settings)" +
+            "data": ("synthetic (procedural %dx%d RGBA8 skies, default camera/metric settings)" % (sw, sh)) +
                     ("; frames copied to host inside the timed region" if args.download else ""),
             "config": {
                 "workload": "configs[1]: %s wormhole, %dx%d, cap %d Euler steps, R=100, delta=0.05, single image; "
@@ -193,7 +209,8 @@ def main():
                 "kernel": "geodesic_persistent" if args.variant == 0 else "geodesic_static",
                 "kernel_ms_avg": round(kernel_s * 1e3, 4),
                 "shade_kernel_ms_avg": round(total_shade_ms / n_launches, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_detail": traffic_note,
                 "hbm": {"achieved": round(hbm_gbps, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(hbm_gbps / HBM_PEAK_GBPS, 8),
                         "note": "7 B/ray algorithmic; the loop is register-resident, HBM fraction is ~0 by construction"},
@@ -207,6 +224,24 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/make_profiles.py from separate --pmc FETCH_SIZE / WRITE_SIZE
+    runs of this same command).  Returns (bytes, note) or (None, reason): counters cannot be read from
+    inside an un-profiled run."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        key = "%s_%dx%d_cap%d_variant%d" % (args.metric, args.width, args.height, args.max_iter, args.variant)
+        e = t.get(key)
+        if e is None:
+            return None, "no PMC profile committed for " + key
+        return e["integrate_kernel_bytes"], e
+    except (OSError, ValueError, KeyError) as exc:
+        return None, "profiles/traffic.json unavailable: %s" % exc
 
 
 def cpu_baseline(args, host_skies):

@@ -65,6 +65,9 @@ struct IntegrateParams {
   unsigned long long *counters; /* CNT_N */
   int refill_threshold;
   int fast_ok; /* host-side part of the fast-step guard */
+  /* fused shading (static kernel, non-debug): the epilogue looks the sky up and writes RGB8 itself */
+  cvk::SkyParams sky[2];
+  unsigned char *fb;
 };
 
 struct ShadeParams {
@@ -124,6 +127,42 @@ __device__ __forceinline__ void flush_steps(const IntegrateParams &P, unsigned l
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&P.counters[CNT_STEPS], steps);
     atomicAdd(&P.counters[CNT_RAYS], (unsigned long long)rays);
+  }
+}
+
+/* final photon -> tangent direction -> nearest sky texel (rows R9-R10 of SURVEY.md 8a) */
+template <int KIND>
+__device__ __forceinline__ unsigned shade_ray(const cvk::MetricParams &M, const cvk::SkyParams *sky, const cvk::Ray &q,
+                                              int code, unsigned &tx, unsigned &ty, unsigned &oob) {
+  unsigned texel = 0xFF000000u; /* Rgba([0,0,0,255]) */
+  tx = ty = 0;
+  if (code != cvk::CODE_NONE) {
+    double d0, d1, d2;
+    cvk::ray_direction<KIND>(M, q, d0, d1, d2);
+    const cvk::SkyParams &S = sky[code == cvk::CODE_POS ? 0 : 1];
+    cvk::sky_indices(S, d0, d1, d2, tx, ty);
+    unsigned cx = tx, cy = ty;
+    if (cx >= S.w || cy >= S.h) oob = 1; /* reference: image::get_pixel panics; defined here: clamp + count */
+    if (cx >= S.w) cx = S.w - 1;
+    if (cy >= S.h) cy = S.h - 1;
+    texel = S.texels[(size_t)cy * S.w + cx];
+  }
+  return texel;
+}
+
+__device__ __forceinline__ void flush_escape_counts(unsigned long long *counters, unsigned pos, unsigned neg, unsigned none,
+                                                    unsigned oob) {
+  for (int off = 32; off > 0; off >>= 1) {
+    pos += __shfl_xor(pos, off);
+    neg += __shfl_xor(neg, off);
+    none += __shfl_xor(none, off);
+    oob += __shfl_xor(oob, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (pos) atomicAdd(&counters[CNT_POS], (unsigned long long)pos);
+    if (neg) atomicAdd(&counters[CNT_NEG], (unsigned long long)neg);
+    if (none) atomicAdd(&counters[CNT_NONE], (unsigned long long)none);
+    if (oob) atomicAdd(&counters[CNT_OOB], (unsigned long long)oob);
   }
 }
 
@@ -204,8 +243,11 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
   flush_steps(P, st_steps, st_rays);
 }
 
-/* K1, static form: one ray per thread, hardware block scheduling does the load balancing. */
-template <int KIND, bool PHI, bool FAST>
+/* K1, static form: one ray per thread, hardware block scheduling does the load balancing.
+ * FUSED: the epilogue shades the pixel itself (direction, sky lookup, RGB8 store) instead of staging the
+ * final state in HBM for shade_kernel -- the epilogue needs fewer registers than the loop, so the fusion is
+ * free in occupancy and removes ~200 MB of HBM traffic and one launch per frame. */
+template <int KIND, bool PHI, bool FAST, bool FUSED>
 __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) {
   const unsigned long long id = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long st_steps = 0;
@@ -240,12 +282,26 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
     if (k >= P.max_iter) break;
   }
   if (active) steps = k; /* == max_iter, code stays CODE_NONE */
+  unsigned pos = 0, neg = 0, none = 0, oob = 0;
   if (valid) {
-    store_ray<PHI>(P.store, slot, q, steps, code);
+    if (FUSED) {
+      unsigned tx, ty;
+      const unsigned texel = shade_ray<KIND>(P.metric, P.sky, q, code, tx, ty, oob);
+      unsigned char *dst = P.fb + slot * 3;
+      dst[0] = (unsigned char)(texel & 0xFF);
+      dst[1] = (unsigned char)((texel >> 8) & 0xFF);
+      dst[2] = (unsigned char)((texel >> 16) & 0xFF);
+      pos = (code == cvk::CODE_POS);
+      neg = (code == cvk::CODE_NEG);
+      none = (code == cvk::CODE_NONE);
+    } else {
+      store_ray<PHI>(P.store, slot, q, steps, code);
+    }
     st_steps = steps;
     st_rays = 1;
   }
   flush_steps(P, st_steps, st_rays);
+  if (FUSED) flush_escape_counts(P.counters, pos, neg, none, oob);
 }
 
 /* K2: final photon -> tangent direction -> nearest sky texel -> RGB8 (rows R9-R10 of SURVEY.md 8a).
@@ -265,19 +321,8 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams P) {
     q.p3sq = 0.0;
     const int code = P.store.code[o];
     const unsigned steps = P.store.steps[o];
-    unsigned texel = 0xFF000000u; /* Rgba([0,0,0,255]) */
-    unsigned tx = 0, ty = 0;
-    if (code != cvk::CODE_NONE) {
-      double d0, d1, d2;
-      cvk::ray_direction<KIND>(P.metric, q, d0, d1, d2);
-      const cvk::SkyParams &S = P.sky[code == cvk::CODE_POS ? 0 : 1];
-      cvk::sky_indices(S, d0, d1, d2, tx, ty);
-      unsigned cx = tx, cy = ty;
-      if (cx >= S.w || cy >= S.h) oob = 1; /* reference: image::get_pixel panics; defined here: clamp + count */
-      if (cx >= S.w) cx = S.w - 1;
-      if (cy >= S.h) cy = S.h - 1;
-      texel = S.texels[(size_t)cy * S.w + cx];
-    }
+    unsigned tx, ty;
+    const unsigned texel = shade_ray<KIND>(P.metric, P.sky, q, code, tx, ty, oob);
     unsigned char *dst = P.fb + o * 3;
     dst[0] = (unsigned char)(texel & 0xFF);
     dst[1] = (unsigned char)((texel >> 8) & 0xFF);
@@ -301,18 +346,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams P) {
       d->ty = ty;
     }
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    pos += __shfl_xor(pos, off);
-    neg += __shfl_xor(neg, off);
-    none += __shfl_xor(none, off);
-    oob += __shfl_xor(oob, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (pos) atomicAdd(&P.counters[CNT_POS], (unsigned long long)pos);
-    if (neg) atomicAdd(&P.counters[CNT_NEG], (unsigned long long)neg);
-    if (none) atomicAdd(&P.counters[CNT_NONE], (unsigned long long)none);
-    if (oob) atomicAdd(&P.counters[CNT_OOB], (unsigned long long)oob);
-  }
+  flush_escape_counts(P.counters, pos, neg, none, oob);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -466,6 +500,12 @@ __global__ void selftest_math_kernel(int op, const double *a, const double *b, d
     case 7:
       r = CV_SQRT(x);
       break;
+    case 9:
+      r = __builtin_amdgcn_rcp(x); /* raw v_rcp_f64 seed */
+      break;
+    case 10:
+      r = __builtin_amdgcn_rsq(x); /* raw v_rsq_f64 seed */
+      break;
     default:
       r = CV_FMA(x, y, x);
       break;
@@ -515,6 +555,7 @@ struct curvis_ctx {
   int refill_threshold = 16;
   int blocks_per_cu = 0;    /* 0 = occupancy query */
   int fast_math = 1;        /* 1 shared-reciprocal step (ray_step_fast), 0 compiler IEEE div/sqrt */
+  int fuse_shade = 1;       /* static kernel shades in its epilogue (no ray store, no shade launch) */
   size_t max_store_bytes = (size_t)8 << 30; /* frames of a batch are rendered in chunks below this */
   double last_integrate_ms = 0.0, last_shade_ms = 0.0;
 };
@@ -571,10 +612,13 @@ cvk::CameraParams make_camera(const curvis_camera &c) {
 }
 
 template <int KIND, bool PHI, bool FAST>
-int launch_integrate(curvis_ctx *ctx, const IntegrateParams &P) {
+int launch_integrate(curvis_ctx *ctx, const IntegrateParams &P, bool fused) {
   if (ctx->variant == 1) {
     const unsigned long long blocks = (P.total_rays + 255ull) / 256ull;
-    hipLaunchKernelGGL((geodesic_static<KIND, PHI, FAST>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+    if (fused)
+      hipLaunchKernelGGL((geodesic_static<KIND, false, FAST, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+    else
+      hipLaunchKernelGGL((geodesic_static<KIND, PHI, FAST, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
   } else {
     int per_cu = ctx->blocks_per_cu;
     if (per_cu <= 0) {
@@ -592,9 +636,9 @@ int launch_integrate(curvis_ctx *ctx, const IntegrateParams &P) {
 }
 
 template <int KIND>
-int launch_integrate_kind(curvis_ctx *ctx, bool phi, bool fast, const IntegrateParams &P) {
-  if (phi) return fast ? launch_integrate<KIND, true, true>(ctx, P) : launch_integrate<KIND, true, false>(ctx, P);
-  return fast ? launch_integrate<KIND, false, true>(ctx, P) : launch_integrate<KIND, false, false>(ctx, P);
+int launch_integrate_kind(curvis_ctx *ctx, bool phi, bool fast, bool fused, const IntegrateParams &P) {
+  if (phi) return fast ? launch_integrate<KIND, true, true>(ctx, P, false) : launch_integrate<KIND, true, false>(ctx, P, false);
+  return fast ? launch_integrate<KIND, false, true>(ctx, P, fused) : launch_integrate<KIND, false, false>(ctx, P, fused);
 }
 
 template <int KIND>
@@ -652,11 +696,16 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     rc = ensure_device(ctx, ctx->d_dbg, ctx->dbg_cap, npix * n_frames);
     if (rc) return rc;
   }
-  /* frames per chunk: the ray store of a chunk stays below max_store_bytes */
-  uint32_t chunk = (uint32_t)std::max<size_t>(1, ctx->max_store_bytes / (npix * kStoreBytesPerPixel));
-  if (chunk > n_frames) chunk = n_frames;
-  rc = ensure_device(ctx, ctx->d_store, ctx->store_cap, (size_t)chunk * npix * kStoreBytesPerPixel);
-  if (rc) return rc;
+  /* fused shading: static kernel, no debug dump (option "fuse_shade", default on) -- no ray store at all.
+   * Otherwise frames are rendered in chunks whose ray store stays below max_store_bytes. */
+  const bool fused = ctx->variant == 1 && ctx->fuse_shade != 0 && dbg_out == nullptr;
+  uint32_t chunk = n_frames;
+  if (!fused) {
+    chunk = (uint32_t)std::max<size_t>(1, ctx->max_store_bytes / (npix * kStoreBytesPerPixel));
+    if (chunk > n_frames) chunk = n_frames;
+    rc = ensure_device(ctx, ctx->d_store, ctx->store_cap, (size_t)chunk * npix * kStoreBytesPerPixel);
+    if (rc) return rc;
+  }
   rc = ensure_device(ctx, ctx->d_cams, ctx->cams_cap, (size_t)n_frames);
   if (rc) return rc;
   if (ctx->h_cams_cap < n_frames) {
@@ -693,8 +742,15 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     P.max_iter = max_iterations;
     P.max_radius = max_radius;
     P.delta = delta;
-    P.store = carve_store(ctx->d_store, (size_t)nf * npix);
+    P.store = fused ? RayStore{} : carve_store(ctx->d_store, (size_t)nf * npix);
     P.counters = ctx->d_counters;
+    for (int k = 0; k < 2; ++k) {
+      P.sky[k].texels = (const unsigned *)ctx->d_sky[k];
+      P.sky[k].w = ctx->sky_w[k];
+      P.sky[k].h = ctx->sky_h[k];
+      for (int i = 0; i < 9; ++i) P.sky[k].inv_rot[i] = ctx->sky_inv_rot[k][i];
+    }
+    P.fb = ctx->d_fb + (size_t)f0 * npix * 3;
     P.refill_threshold = ctx->refill_threshold < 1 ? 1 : (ctx->refill_threshold > 64 ? 64 : ctx->refill_threshold);
     P.fast_ok = cvk::metric_fast_ok(metric->kind, MP, max_radius) ? 1 : 0;
 
@@ -715,29 +771,31 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     switch (metric->kind) {
       case CURVIS_METRIC_ELLIS:
-        rc = launch_integrate_kind<cvk::METRIC_ELLIS>(ctx, phi, fast, P);
+        rc = launch_integrate_kind<cvk::METRIC_ELLIS>(ctx, phi, fast, fused, P);
         break;
       case CURVIS_METRIC_INTERSTELLAR:
-        rc = launch_integrate_kind<cvk::METRIC_INTERSTELLAR>(ctx, phi, fast, P);
+        rc = launch_integrate_kind<cvk::METRIC_INTERSTELLAR>(ctx, phi, fast, fused, P);
         break;
       default:
-        rc = launch_integrate_kind<cvk::METRIC_FLAT>(ctx, phi, fast, P);
+        rc = launch_integrate_kind<cvk::METRIC_FLAT>(ctx, phi, fast, fused, P);
         break;
     }
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    switch (metric->kind) {
-      case CURVIS_METRIC_ELLIS:
-        rc = launch_shade_kind<cvk::METRIC_ELLIS>(ctx, dbg_out != nullptr, Q);
-        break;
-      case CURVIS_METRIC_INTERSTELLAR:
-        rc = launch_shade_kind<cvk::METRIC_INTERSTELLAR>(ctx, dbg_out != nullptr, Q);
-        break;
-      default:
-        rc = launch_shade_kind<cvk::METRIC_FLAT>(ctx, dbg_out != nullptr, Q);
-        break;
+    if (!fused) {
+      switch (metric->kind) {
+        case CURVIS_METRIC_ELLIS:
+          rc = launch_shade_kind<cvk::METRIC_ELLIS>(ctx, dbg_out != nullptr, Q);
+          break;
+        case CURVIS_METRIC_INTERSTELLAR:
+          rc = launch_shade_kind<cvk::METRIC_INTERSTELLAR>(ctx, dbg_out != nullptr, Q);
+          break;
+        default:
+          rc = launch_shade_kind<cvk::METRIC_FLAT>(ctx, dbg_out != nullptr, Q);
+          break;
+      }
+      if (rc) return rc;
     }
-    if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N,
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -1377,6 +1435,8 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->blocks_per_cu = (int)value;
   else if (k == "fast_math")
     ctx->fast_math = (int)value;
+  else if (k == "fuse_shade")
+    ctx->fuse_shade = (int)value;
   else if (k == "max_store_bytes")
     ctx->max_store_bytes = (size_t)value;
   else
@@ -1395,6 +1455,8 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->blocks_per_cu;
   else if (k == "fast_math")
     *value = ctx->fast_math;
+  else if (k == "fuse_shade")
+    *value = ctx->fuse_shade;
   else if (k == "max_store_bytes")
     *value = (int64_t)ctx->max_store_bytes;
   else

@@ -180,13 +180,15 @@ int curvis_ctx_synchronize(curvis_ctx *ctx);
 
 /* tuning knobs (not part of the reference surface): "variant" (0 = persistent lane-refill kernel,
  * 1 = static one-ray-per-thread kernel), "refill_threshold", "blocks_per_cu", "fast_math"
- * (1 = shared-reciprocal Euler step, 0 = compiler IEEE division/sqrt; identical results),
+ * (1 = shared-reciprocal Euler step, 0 = compiler IEEE division/sqrt; identical results), "fuse_shade"
+ * (1 = the static kernel shades in its epilogue, 0 = final states staged in HBM + separate shade kernel),
  * "max_store_bytes" (ray-store budget that bounds the frames per launch of a batch). */
 int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value);
 int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value);
 
 /* self-test hooks used by tests/ (device vs host bit-equality of cv_math.h and of IEEE div/sqrt):
- * op: 0 sin, 1 cos, 2 atan, 3 acos, 4 log, 5 atan2(a,b), 6 a/b, 7 sqrt(a), 8 fma(a,b,a) */
+ * op: 0 sin, 1 cos, 2 atan, 3 acos, 4 log, 5 atan2(a,b), 6 a/b, 7 sqrt(a), 8 fma(a,b,a),
+ * 9 raw v_rcp_f64(a), 10 raw v_rsq_f64(a) (hardware seeds, for accuracy measurements) */
 int curvis_selftest_math(curvis_ctx *ctx, int op, const double *a, const double *b, double *out, size_t n);
 
 #ifdef __cplusplus

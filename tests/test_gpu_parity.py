@@ -108,6 +108,13 @@ def test_full_size_frame_bit_exact(gpu_ctx, metric, res, cap):
         common.assert_debug_equal(got_dbg, want_dbg, check_t=True)
         assert np.array_equal(got_rgb, want_rgb)
         assert sys_.last_stats.steps == steps
+        # the production (non-debug) kernels: fused epilogue shading and the staged two-kernel form
+        for fuse in (1, 0):
+            gpu_ctx.set_option("fuse_shade", fuse)
+            assert np.array_equal(sys_.render_image(cap, 100.0, 0.05), want_rgb)
+            s = sys_.last_stats
+            assert (s.steps, s.n_pos + s.n_neg + s.n_none) == (steps, res[0] * res[1])
+        gpu_ctx.set_option("fuse_shade", 1)
     gpu_ctx.set_option("variant", 0)
     gpu_ctx.set_option("fast_math", 1)
 

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round profile collection (run on the GPU box): default bench line, kernel-trace stats, PMC passes
+# (SQ set, FETCH_SIZE, WRITE_SIZE in SEPARATE runs), all-configs table, FP64 micro-benchmarks.
+set -x
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/final
+rm -rf $OUT; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+python -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
+python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py --variant 0 --no-cpu-baseline > $OUT/bench_persistent.json 2>/dev/null
+python bench.py --fast-math 0 --no-cpu-baseline > $OUT/bench_strict.json 2>/dev/null
+python bench.py --download --no-cpu-baseline > $OUT/bench_download.json 2>/dev/null
+python bench.py --metric interstellar --width 3840 --height 2160 --max-iter 8192 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_config3.json 2>/dev/null
+python tools/bench_configs.py > $OUT/configs.md 2> $OUT/configs.err
+./build/ubench_fp64 > $OUT/ubench.log 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+ls -R $OUT | head -60
