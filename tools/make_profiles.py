@@ -34,8 +34,8 @@ kern = "geodesic_static" if ("geodesic_static", "SQ_INSTS_VALU") in sq else "geo
 KIB = 1024.0
 fetch_i = fe[(kern, "FETCH_SIZE")] * KIB * 2   # gfx950: FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md)
 write_i = wr[(kern, "WRITE_SIZE")] * KIB
-fetch_s = fe[("shade_kernel", "FETCH_SIZE")] * KIB * 2
-write_s = wr[("shade_kernel", "WRITE_SIZE")] * KIB
+fetch_s = fe.get(("shade_kernel", "FETCH_SIZE"), 0.0) * KIB * 2   # absent when shading is fused into the epilogue
+write_s = wr.get(("shade_kernel", "WRITE_SIZE"), 0.0) * KIB
 traffic = {
     "ellis_1920x1080_cap4096_variant1": {
         "integrate_kernel_bytes": int(fetch_i + write_i), "integrate_fetch_bytes": int(fetch_i),
