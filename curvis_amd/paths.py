@@ -62,7 +62,25 @@ def load_path(path):
     return a[:, 0:4].copy(), a[:, 4:7].copy(), a[:, 7:10].copy()
 
 
-if __name__ == "__main__":
+def ensure_paths():
+    """Generate the two camera paths into DATA_DIR if they are not there yet (they are build products of
+    this module, not checked in) and return their file names."""
     os.makedirs(DATA_DIR, exist_ok=True)
-    write_orbit(os.path.join(DATA_DIR, "path_orbit.csv"))
-    write_through(os.path.join(DATA_DIR, "path_through.csv"))
+    out = {}
+    for name, writer in (("path_orbit.csv", write_orbit), ("path_through.csv", write_through)):
+        dst = os.path.join(DATA_DIR, name)
+        if not os.path.exists(dst):
+            tmp = dst + ".tmp.%d" % os.getpid()
+            writer(tmp)
+            os.replace(tmp, dst)
+        out[name] = dst
+    return out
+
+
+def path_file(name):
+    """absolute file name of a generated camera path ("path_orbit.csv" / "path_through.csv")."""
+    return ensure_paths()[name]
+
+
+if __name__ == "__main__":
+    print(ensure_paths())

@@ -67,7 +67,7 @@ def test_video_orbit_frames_and_quirks(scene_files):
     out.mkdir()
     (out / "tmp").mkdir()
     (out / "tmp" / "stale.png").write_bytes(b"x")  # the tmp folder is deleted and recreated (src/rendering.rs:276-287)
-    orbit = os.path.join(paths.DATA_DIR, "path_orbit.csv")
+    orbit = paths.path_file("path_orbit.csv")
     (d / "vid.toml").write_text('video_name = "v"\nframe_rate = 0.25\nfilepath_to_camera_path = "%s"\n' % orbit)
     r = run("video", d / "pos.png", d / "neg.png", out, "-v", d / "vid.toml", "-s", d / "sim.toml", "-c", d / "cam.toml",
             "--batch", "4", "--stats", out / "st.jsonl")
@@ -96,7 +96,7 @@ def test_video_off_by_one_panics_like_the_reference(scene_files):
     d, sp, sn = scene_files
     out = d / "out_vid2"
     out.mkdir()
-    pos, fwd, up = paths.load_path(os.path.join(paths.DATA_DIR, "path_orbit.csv"))
+    pos, fwd, up = paths.load_path(paths.path_file("path_orbit.csv"))
     short = d / "short.csv"
     rows = [paths.HEADER] + [",".join(repr(float(x)) for x in list(pos[i]) + list(fwd[i]) + list(up[i])) for i in range(4)]
     short.write_text("\n".join(rows))

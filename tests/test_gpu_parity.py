@@ -241,3 +241,48 @@ def test_efficient_default_960x540_vs_oracle(gpu_ctx):
     d = np.abs(got.astype(int) - libm_rgb.astype(int)).max(axis=2)
     print("efficient 960x540 vs libm oracle: exact %.5f, <=1 LSB %.5f, max %d" % ((d == 0).mean(), (d <= 1).mean(), d.max()))
     assert (d <= 1).mean() > 0.999
+
+
+def test_config3_full_size_4k_interstellar(gpu_ctx):
+    """BASELINE configs[2] at full size: Interstellar (m=0.1, a=1e-4, rho=1), 3840x2160, cap 8192 --
+    8 294 400 rays, 1.6e10 Euler steps -- pixels, step total and escape counts bit-exact against the oracle
+    (rows striped over the host cores)."""
+    import os
+    if (os.cpu_count() or 1) < 16:
+        pytest.skip("needs a many-core host for the 1.6e10-step oracle run")
+    sp, sn = common.make_skies(2048, 1024, "check")
+    om, oc, pm, pc = common.scene("interstellar", res=(3840, 2160))
+    want_rgb, want_dbg, steps = oracle_full_frame(O.CV, om, oc, sp, sn, 8192, threads=min(128, os.cpu_count()))
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
+                                         context=gpu_ctx)
+    got = sys_.render_image(8192, 100.0, 0.05)
+    s = sys_.last_stats
+    assert np.array_equal(got, want_rgb)
+    assert s.steps == steps
+    assert (s.n_pos, s.n_neg, s.n_none) == (int((want_dbg["code"] == 1).sum()), int((want_dbg["code"] == -1).sum()),
+                                           int((want_dbg["code"] == 0).sum()))
+
+
+def test_rotated_skies_and_random_cameras(gpu_ctx):
+    """SphericalImage orientation (src/images.rs:71-90, :132-142) and arbitrary camera poses: pixels and texel
+    indices bit-exact against the oracle."""
+    import ctypes as C
+    rng = np.random.default_rng(42)
+    sp, sn = common.make_skies(256, 128, "check")
+    for trial in range(4):
+        fwd_s, up_s = rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3)
+        rot, inv, upo = np.zeros(9), np.zeros(9), np.zeros(3)
+        assert O.lib().cvo_orientation_new(O._dp(fwd_s), O._dp(up_s), O._dp(rot), O._dp(inv), O._dp(upo)) == 0
+        pos = (0.0, float(rng.uniform(-6, 6)), float(rng.uniform(0.4, 2.7)), float(rng.uniform(0, 6.2)))
+        fwd, up = tuple(rng.uniform(-1, 1, 3)), tuple(rng.uniform(-1, 1, 3))
+        metric = ["ellis", "interstellar", "flat", "ellis"][trial]
+        if metric == "flat":
+            pos = (0.0, abs(pos[1]) + 1.0, pos[2], pos[3])
+        om, oc, pm, pc = common.scene(metric, res=(37, 21), pos=pos, fwd=fwd, up=up, focal=float(rng.uniform(8, 40)))
+        want_rgb, want_dbg, st = O.render_image(O.CV, om, oc, O.sky(sp, inv), O.sky(sn, inv), 3000, 100.0, 0.05, debug=True)
+        sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp, fwd_s, up_s),
+                                             curvis_amd.SphericalImage(sn, fwd_s, up_s), pc, context=gpu_ctx)
+        got_rgb, got_dbg = sys_.render_image_debug(3000, 100.0, 0.05)
+        common.assert_debug_equal(got_dbg, want_dbg)
+        assert np.array_equal(got_rgb, want_rgb)
+        assert np.array_equal(sys_.render_image(3000, 100.0, 0.05), want_rgb)

@@ -31,7 +31,7 @@ def test_shipped_paths_match_generators(tmp_path):
     o, t = tmp_path / "o.csv", tmp_path / "t.csv"
     paths.write_orbit(o)
     paths.write_through(t)
-    assert o.read_bytes() == open(os.path.join(paths.DATA_DIR, "path_orbit.csv"), "rb").read()
-    assert t.read_bytes() == open(os.path.join(paths.DATA_DIR, "path_through.csv"), "rb").read()
-    pos, fwd, up = paths.load_path(os.path.join(paths.DATA_DIR, "path_orbit.csv"))
+    assert o.read_bytes() == open(paths.path_file("path_orbit.csv"), "rb").read()
+    assert t.read_bytes() == open(paths.path_file("path_through.csv"), "rb").read()
+    pos, fwd, up = paths.load_path(paths.path_file("path_orbit.csv"))
     assert pos.shape == (1000, 4) and fwd.shape == (1000, 3) and up.shape == (1000, 3)

@@ -15,8 +15,8 @@ import oracle_lib as O
 from curvis_amd import paths, rendering
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORBIT = os.path.join(paths.DATA_DIR, "path_orbit.csv")
-THROUGH = os.path.join(paths.DATA_DIR, "path_through.csv")
+ORBIT = paths.path_file("path_orbit.csv")
+THROUGH = paths.path_file("path_through.csv")
 
 
 def test_interpolator_matches_oracle_including_off_by_one():
@@ -72,7 +72,7 @@ WORKER = textwrap.dedent("""
 
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    it = rendering.Interpolator.from_file(os.path.join(paths.DATA_DIR, "path_orbit.csv"))
+    it = rendering.Interpolator.from_file(paths.path_file("path_orbit.csv"))
     ctx = StubContext()
     v = rendering.VideoRenderingSystem(None, ctx, it, 4.0, (8, 8), 43.0, 15.0, 100.0, 64, 0.05, rank=rank, world_size=world, batch=7)
     local = v.render(download=False)

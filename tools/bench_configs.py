@@ -46,7 +46,7 @@ def main():
     single("config 3 (Interstellar 4K)", inter, (3840, 2160), 8192, reps=3)
 
     def video(name, metric, csv, fps, res, cap, batch, max_frames=None):
-        it = rendering.Interpolator.from_file(os.path.join(paths.DATA_DIR, csv))
+        it = rendering.Interpolator.from_file(paths.path_file(csv))
         v = rendering.VideoRenderingSystem(metric, ctx, it, fps, res, 43.0, 15.0, 100.0, cap, 0.05, rank=0,
                                            world_size=args.world, batch=batch)
         n_total = len(v.times_of_frames())
