@@ -286,3 +286,65 @@ def test_rotated_skies_and_random_cameras(gpu_ctx):
         common.assert_debug_equal(got_dbg, want_dbg)
         assert np.array_equal(got_rgb, want_rgb)
         assert np.array_equal(sys_.render_image(3000, 100.0, 0.05), want_rgb)
+
+
+def _assert_debug_equal_nan_tolerant(got, want):
+    """bit-exact except that NaN == NaN regardless of payload (x86 and gfx950 propagate payloads differently)."""
+    for f in ("steps", "code", "tx", "ty"):
+        assert np.array_equal(got[f], want[f]), f
+    for f in ("x", "p"):
+        g, w = got[f][..., 1:], want[f][..., 1:]
+        both_nan = np.isnan(g) & np.isnan(w)
+        same = (common.bits(g) == common.bits(w)) | both_nan
+        bad = np.argwhere(~same)
+        assert bad.size == 0, "%s differs at %s: %r vs %r" % (f, bad[0], g[tuple(bad[0])], w[tuple(bad[0])])
+
+
+ADVERSARIAL = [
+    # name, metric ctor args, camera pos, fwd, up, delta, cap, R, res
+    ("near_pole_camera", ("ellis", 1.0), (0.0, 4.0, 0.02, 0.3), (-1.0, 0.05, 0.02), (0.0, 0.0, 1.0), 0.05, 3000, 100.0, (24, 16)),
+    ("pole_crossing_rows", ("ellis", 1.0), (0.0, 3.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 0.05, 4096, 100.0, (64, 9)),
+    ("camera_in_throat", ("ellis", 1.0), (0.0, 0.0, common.HALF_PI, 1.0), (1.0, 0.2, 0.1), (0.0, 0.0, 1.0), 0.05, 3000, 100.0, (24, 16)),
+    ("negative_zero_l", ("ellis", 1.0), (0.0, -0.0, 1.0, 1.0), (-1.0, 0.2, 0.1), (0.0, 0.0, 1.0), 0.05, 3000, 100.0, (16, 12)),
+    ("huge_delta", ("ellis", 1.0), (0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 7.5, 400, 100.0, (24, 16)),
+    ("cap_bound", ("ellis", 1.0), (0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 1e-3, 300, 100.0, (24, 16)),
+    ("tiny_rho", ("ellis", 1e-3), (0.0, 0.5, 1.2, 0.0), (-1.0, 0.01, 0.0), (0.0, 0.0, 1.0), 0.01, 6000, 20.0, (24, 16)),
+    ("huge_rho", ("ellis", 1e3), (0.0, 500.0, 1.2, 0.0), (-1.0, 0.3, 0.1), (0.0, 0.0, 1.0), 10.0, 5000, 1e4, (24, 16)),
+    ("interstellar_long_throat", ("interstellar", 0.5, 2.0, 1.0), (0.0, 4.0, common.HALF_PI, 0.0), (-1.0, 0.02, 0.01), (0.0, 0.0, 1.0), 0.05, 6000, 60.0, (24, 16)),
+    ("interstellar_inside_throat", ("interstellar", 0.1, 1.0, 1.0), (0.0, 0.5, 1.0, 0.0), (1.0, 0.3, 0.2), (0.0, 0.0, 1.0), 0.05, 4000, 60.0, (24, 16)),
+    ("strict_fallback_radius", ("ellis", 1.0), (0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 1e93, 50, 1e95, (16, 12)),
+    ("flat_space", ("flat",), (0.0, 5.0, 1.0, 0.5), (-1.0, 0.2, 0.1), (0.0, 0.0, 1.0), 0.05, 4096, 100.0, (24, 16)),
+    ("flat_through_origin", ("flat",), (0.0, 2.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 0.25, 2000, 50.0, (17, 11)),
+]
+
+
+@pytest.mark.parametrize("case", ADVERSARIAL, ids=[c[0] for c in ADVERSARIAL])
+def test_adversarial_fast_equals_strict_equals_oracle(gpu_ctx, case):
+    """Guards of the shared-reciprocal step: poles, throat, zero / negative-zero l, huge and tiny parameters,
+    cap-bound rays, ranges where the host-side guard disables the shortcut.  Fast == strict == oracle."""
+    name, margs, pos, fwd, up, delta, cap, R, res = case
+    sp, sn = common.make_skies(128, 64, "check")
+    if margs[0] == "ellis":
+        om, pm = O.ellis(margs[1]), curvis_amd.EllisMetric(margs[1])
+    elif margs[0] == "interstellar":
+        om, pm = O.interstellar(*margs[1:]), curvis_amd.InterstellarMetric(*margs[1:])
+    else:
+        om, pm = O.flat(), curvis_amd.FlatSphericalMetric()
+    oc = O.camera(pos, fwd, up, 15.0, 43.0, res)
+    pc = curvis_amd.Camera(pos, fwd, up, 15.0, 43.0, res[0], res[1])
+    with np.errstate(all="ignore"):
+        want_rgb, want_dbg, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, R, delta, debug=True)
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
+                                         context=gpu_ctx)
+    try:
+        for variant in (1, 0):
+            for fast in (1, 0):
+                gpu_ctx.set_option("variant", variant)
+                gpu_ctx.set_option("fast_math", fast)
+                got_rgb, got_dbg = sys_.render_image_debug(cap, R, delta)
+                _assert_debug_equal_nan_tolerant(got_dbg, want_dbg)
+                assert np.array_equal(got_rgb, want_rgb), (variant, fast)
+                assert np.array_equal(sys_.render_image(cap, R, delta), want_rgb), (variant, fast)
+    finally:
+        gpu_ctx.set_option("variant", 1)
+        gpu_ctx.set_option("fast_math", 1)
