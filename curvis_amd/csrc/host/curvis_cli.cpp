@@ -16,13 +16,17 @@
  * Extensions (do not exist in the reference): --mode efficient|brute (default efficient = what the
  * reference renders; brute = RelativisticSystem::render_image, the per-pixel integrator),
  * --devices N (frames k mod N across N GPUs, one host thread + one context per GPU, skies uploaded to
- * each), --batch B (frames per kernel launch), --stats FILE (per-frame JSON lines).
+ * each), --batch B (frames per kernel launch), --writers T (PNG encoder threads), --stats FILE (per-frame
+ * JSON lines).
  * Backgrounds must be PNG (any colour type / bit depth); no JPEG decoder is linked.
  */
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -30,6 +34,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -394,7 +399,7 @@ int path_camera(const CameraPath &p, double t, double pos[4], double fwd[3], dou
 /* ------------------------------------------------------------------ command line */
 struct Args {
   std::string sub, bg1, bg2, out, image_toml, video_toml, metric_toml, camera_toml, sim_toml, mode = "efficient", stats;
-  int devices = 1, device = 0, batch = 8;
+  int devices = 1, device = 0, batch = 8, writers = 8;
 };
 [[noreturn]] void die(const std::string &msg, int code = 1) {
   std::fprintf(stderr, "%s\n", msg.c_str());
@@ -444,6 +449,7 @@ Args parse_args(int argc, char **argv) {
     else if (key == "--devices") { take(val); a.devices = std::atoi(val.c_str()); }
     else if (key == "--device") { take(val); a.device = std::atoi(val.c_str()); }
     else if (key == "--batch") { take(val); a.batch = std::atoi(val.c_str()); }
+    else if (key == "--writers") { take(val); a.writers = std::atoi(val.c_str()); }
     else if (key == "-h" || key == "--help") { usage(); std::exit(0); }
     else if (!s.empty() && s[0] == '-') die("error: unexpected argument '" + s + "' found", 2);
     else pos.push_back(s);
@@ -460,6 +466,7 @@ Args parse_args(int argc, char **argv) {
   if (a.mode != "efficient" && a.mode != "brute") die("error: --mode must be efficient or brute", 2);
   if (a.devices < 1) a.devices = 1;
   if (a.batch < 1) a.batch = 1;
+  if (a.writers < 1) a.writers = 1;
   return a;
 }
 
@@ -578,6 +585,52 @@ int rm_rf(const std::string &dir) { /* tmp folder only contains frame files */
   return std::system(cmd.c_str());
 }
 
+/* frame writers: PNG encoding (zlib) costs more host time per frame than the GPU needs to render it, so
+ * frames are compressed and written by a small pool of host threads while the GPU renders the next batch. */
+class WriterPool {
+ public:
+  explicit WriterPool(int n) {
+    for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
+  }
+  ~WriterPool() { finish(); }
+  void submit(std::function<void()> job) {
+    std::unique_lock<std::mutex> g(mu_);
+    cv_space_.wait(g, [this] { return q_.size() < 64; }); /* bound the frames held in host memory */
+    q_.push_back(std::move(job));
+    cv_work_.notify_one();
+  }
+  void finish() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (done_) return;
+      done_ = true;
+    }
+    cv_work_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+
+ private:
+  void run() {
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_work_.wait(g, [this] { return done_ || !q_.empty(); });
+        if (q_.empty()) return;
+        job = std::move(q_.front());
+        q_.pop_front();
+        cv_space_.notify_one();
+      }
+      job();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_space_;
+  std::deque<std::function<void()>> q_;
+  std::vector<std::thread> th_;
+  bool done_ = false;
+};
+
 int video_main(const Args &a) {
   std::printf("Video rendering\n");
   Common c;
@@ -635,6 +688,7 @@ int video_main(const Args &a) {
   std::mutex io_mu;
   std::atomic<int> failed{0};
   FILE *stats_f = a.stats.empty() ? nullptr : std::fopen(a.stats.c_str(), "w");
+  WriterPool writers(a.writers);
   auto worker = [&](int rank) {
     curvis_ctx *ctx = make_ctx(a.device + rank, c, "video");
     std::vector<size_t> mine;
@@ -655,22 +709,27 @@ int video_main(const Args &a) {
         failed = 1;
         break;
       }
+      /* hand the frames of this batch to the writer pool (each job owns a copy of its frame) */
       for (size_t j = 0; j < nb; ++j) {
         const size_t k = mine[b0 + j];
-        const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
-        std::string e;
-        if (!pngio::save_rgb8(file, rgb.data() + j * fbytes, c.cam.resolution_x, c.cam.resolution_y, e, 1)) {
+        auto frame = std::make_shared<std::vector<uint8_t>>(rgb.begin() + j * fbytes, rgb.begin() + (j + 1) * fbytes);
+        const curvis_stats stc = st;
+        writers.submit([&, k, frame, stc, nb, rank] {
+          const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
+          std::string e;
+          const bool ok = pngio::save_rgb8(file, frame->data(), c.cam.resolution_x, c.cam.resolution_y, e, 1);
           std::lock_guard<std::mutex> g(io_mu);
-          std::fprintf(stderr, "Error in rendering video: Could not save image frame \"%s\" due to error: %s\n", file.c_str(), e.c_str());
-          failed = 1;
-          break;
-        }
-        std::lock_guard<std::mutex> g(io_mu);
-        std::printf("Rendering frame %zu/%zu...\n", k + 1, times.size());
-        if (stats_f)
-          std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"batch_frames\": %zu, \"batch_rays\": %llu, \"batch_steps\": %llu, \"batch_n_pos\": %llu, \"batch_n_neg\": %llu, \"batch_n_none\": %llu, \"batch_kernel_ms\": %.4f}\n",
-                       k, times[k], a.device + rank, a.mode.c_str(), nb, (unsigned long long)st.rays, (unsigned long long)st.steps,
-                       (unsigned long long)st.n_pos, (unsigned long long)st.n_neg, (unsigned long long)st.n_none, st.kernel_ms);
+          if (!ok) {
+            std::fprintf(stderr, "Error in rendering video: Could not save image frame \"%s\" due to error: %s\n", file.c_str(), e.c_str());
+            failed = 1;
+            return;
+          }
+          std::printf("Rendering frame %zu/%zu...\n", k + 1, times.size());
+          if (stats_f)
+            std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"batch_frames\": %zu, \"batch_rays\": %llu, \"batch_steps\": %llu, \"batch_n_pos\": %llu, \"batch_n_neg\": %llu, \"batch_n_none\": %llu, \"batch_kernel_ms\": %.4f}\n",
+                         k, times[k], a.device + rank, a.mode.c_str(), nb, (unsigned long long)stc.rays, (unsigned long long)stc.steps,
+                         (unsigned long long)stc.n_pos, (unsigned long long)stc.n_neg, (unsigned long long)stc.n_none, stc.kernel_ms);
+        });
       }
     }
     curvis_ctx_destroy(ctx);
@@ -678,6 +737,7 @@ int video_main(const Args &a) {
   std::vector<std::thread> th;
   for (int r = 0; r < a.devices; ++r) th.emplace_back(worker, r);
   for (auto &t : th) t.join();
+  writers.finish();
   if (stats_f) std::fclose(stats_f);
   if (failed) return 1;
   if (!panic_msg.empty()) {
