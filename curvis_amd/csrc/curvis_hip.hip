@@ -595,6 +595,7 @@ cvk::MetricParams make_metric(const curvis_metric &m) {
   M.m = m.m;
   M.a = m.a;
   M.pim = CV_PI * m.m;
+  M.inv_pim = 1.0 / M.pim;
   M.two_o_pi = 2.0 / CV_PI;
   return M;
 }

@@ -37,11 +37,14 @@ struct MetricParams {
   double rho2;     /* rho*rho (rho.powi(2)) */
   double m, a;     /* Interstellar mass / half-length */
   double pim;      /* PI*m: denominator of scaled_distance (src/metrics.rs:461) */
+  double inv_pim;  /* RN(1/(PI*m)) computed on the host: lets the fast step divide by the constant with the
+                      three-instruction Markstein sequence (exact for a correctly rounded reciprocal) */
   double two_o_pi; /* 2.0/PI (src/metrics.rs:481) */
 };
 
-/* r(l), r^2(l), r'(l): src/metrics.rs:417-421 / 467-485 / 501-505 */
-template <int KIND>
+/* r(l), r^2(l), r'(l): src/metrics.rs:417-421 / 467-485 / 501-505.
+ * FASTDIV (fast step only): the division by the constant PI*m uses M.inv_pim. */
+template <int KIND, bool FASTDIV = false>
 CV_HD void metric_eval(const MetricParams &M, double l, double &r, double &r2, double &rd) {
   if (KIND == METRIC_ELLIS) {
     r2 = M.rho2 + l * l;
@@ -50,7 +53,14 @@ CV_HD void metric_eval(const MetricParams &M, double l, double &r, double &r2, d
   } else if (KIND == METRIC_INTERSTELLAR) {
     double al = CV_FABS(l);
     if (al > M.a) {
-      double x = 2.0 * (al - M.a) / M.pim;
+      const double xn = 2.0 * (al - M.a);
+      double x;
+      if (FASTDIV) {
+        const double q0 = xn * M.inv_pim;
+        x = CV_FMA(CV_FMA(-M.pim, q0, xn), M.inv_pim, q0);
+      } else {
+        x = xn / M.pim;
+      }
       double at = cv_atan(x);
       r = M.rho + M.m * (x * at - cv_log(1.0 + x * x) / 2.0);
       double sg = (cv_bits(l) >> 63) ? -1.0 : 1.0; /* l.signum(), l != NaN-safe below */
@@ -212,7 +222,7 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
     sqrt_and_rsqrt(r2, r, y_r);
     rd = div_with_recip(q.l, r, y_r);
   } else {
-    metric_eval<KIND>(M, q.l, r, r2, rd);
+    metric_eval<KIND, true>(M, q.l, r, r2, rd);
     y_r = recip_nr2(r);
   }
   const double y_s = recip_nr2(s);

@@ -97,6 +97,25 @@ CV_HD double cv_fma_c(double a, double b, double c) {
 #endif
 }
 
+/* n/d for operands and quotient well inside the normal range (as inside atan/log below).  Host: the IEEE
+ * operator.  Device: the AMDGPU fdiv expansion (v_rcp_f64, two Newton steps, quotient, exact remainder,
+ * final fma) without its div_scale/div_fixup range handling -- the same instructions the compiler emits
+ * for `/` when no scaling is needed, hence the same correctly rounded result. */
+CV_HD double cv_div_nr(double n, double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(d);
+  double e = CV_FMA(-d, y, 1.0);
+  y = CV_FMA(y, e, y);
+  e = CV_FMA(-d, y, 1.0);
+  y = CV_FMA(y, e, y);
+  const double q = n * y;
+  const double r = CV_FMA(-d, q, n);
+  return CV_FMA(r, y, q);
+#else
+  return n / d;
+#endif
+}
+
 /* ------------------------------------------------------------------------- */
 /* sin / cos                                                                  */
 /* ------------------------------------------------------------------------- */
@@ -414,12 +433,12 @@ CV_HD double cv_atan(double x) {
         lo = 6.12323399573676603587e-17;
       }
     }
-    t = num / den;
+    t = cv_div_nr(num, den); /* |num| <= den, 1 <= den < 2^67 */
   }
   double z = t * t;
   double w = z * z;
-  double s1 = z * CV_FMA(w, CV_FMA(w, CV_FMA(w, CV_FMA(w, CV_FMA(w, aT10, aT8), aT6), aT4), aT2), aT0);
-  double s2 = w * CV_FMA(w, CV_FMA(w, CV_FMA(w, CV_FMA(w, aT9, aT7), aT5), aT3), aT1);
+  double s1 = z * cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, aT10, aT8), aT6), aT4), aT2), aT0);
+  double s2 = w * cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, aT9, aT7), aT5), aT3), aT1);
   if (id < 0) return t - t * (s1 + s2);
   double r = hi - ((t * (s1 + s2) - lo) - t);
   return neg ? -r : r;
@@ -583,11 +602,11 @@ CV_HD double cv_log(double x) {
   x = cv_from_bits(((uint64_t)hx << 32) | (ux & 0xffffffffULL));
   double f = x - 1.0;
   double hfsq = 0.5 * f * f;
-  double s = f / (2.0 + f);
+  double s = cv_div_nr(f, 2.0 + f); /* |f| < 0.42, 1.7 < 2+f < 2.42 */
   double z = s * s;
   double w = z * z;
-  double t1 = w * CV_FMA(w, CV_FMA(w, Lg6, Lg4), Lg2);
-  double t2 = z * CV_FMA(w, CV_FMA(w, CV_FMA(w, Lg7, Lg5), Lg3), Lg1);
+  double t1 = w * cv_fma_c(w, cv_fma_c(w, Lg6, Lg4), Lg2);
+  double t2 = z * cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, Lg7, Lg5), Lg3), Lg1);
   double R = t2 + t1;
   double dk = (double)k;
   /* s*(hfsq+R) + dk*ln2_lo - hfsq + f + dk*ln2_hi */
