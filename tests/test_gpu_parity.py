@@ -348,3 +348,36 @@ def test_adversarial_fast_equals_strict_equals_oracle(gpu_ctx, case):
     finally:
         gpu_ctx.set_option("variant", 1)
         gpu_ctx.set_option("fast_math", 1)
+
+
+def test_rccl_sky_broadcast_entry_point(gpu_ctx):
+    """curvis_ctx_bcast_skies on a single-rank RCCL communicator (the 1-GPU box cannot host more ranks):
+    shapes and both textures go through ncclBroadcast and the context renders the same frame afterwards."""
+    import ctypes as C
+    from curvis_amd import _abi
+    try:
+        rccl = C.CDLL("librccl.so")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        sp, sn = common.make_skies(256, 128, "check")
+        om, oc, pm, pc = common.scene("ellis", res=(32, 18))
+        gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+        gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+        before, _ = gpu_ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+        _abi.check(_abi.lib().curvis_ctx_bcast_skies(gpu_ctx._h, comm, 0), gpu_ctx._h)
+        after, _ = gpu_ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+        want, _, _ = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
+        assert np.array_equal(before, want) and np.array_equal(after, want)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
