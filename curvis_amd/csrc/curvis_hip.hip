@@ -1,23 +1,28 @@
 /* curvis_hip.hip -- gfx950 kernels and C ABI of libcurvis_hip.so (see include/curvis_hip.h).
  *
- * Kernels
- *   geodesic_persistent<KIND,DEBUG>  K1, the hot kernel.  Persistent waves: every lane owns one ray
- *       (pixel -> photon -> forward-Euler loop -> tangent direction -> nearest sky texel -> RGB8
- *       store, i.e. rows R1-R10 of SURVEY.md section 8a fused).  When at least `refill_threshold`
- *       lanes of a wave have terminated (escaped or hit the cap) the wave retires them together and
- *       refills the free lanes from a global ray queue with ONE wave-aggregated atomic
- *       (ballot + popcount + mbcnt rank), so lanes never idle behind a slow neighbour (rays orbiting
- *       the throat run to the cap while their neighbours finish in ~2000 steps) and the grid has
- *       no tail of half-empty waves until the queue is dry.
- *   geodesic_static<KIND,DEBUG>      one ray per thread, no refill: A/B baseline for the above.
- *   selftest_math                    cv_math.h / IEEE div / sqrt on device for bit-equality tests.
+ * Kernels (per-ray arithmetic lives in cv_device.h / cv_efficient.h / cv_math.h)
+ *   geodesic_static<KIND,PHI,FAST,FUSED>   the default hot kernel of RelativisticSystem::render_image
+ *       (src/systems.rs:307-330): one ray per lane -- pixel -> photon -> forward-Euler loop to escape or
+ *       cap with a wave-uniform step counter -> (FUSED) tangent direction, nearest sky texel, RGB8 store in
+ *       the epilogue, i.e. rows R1-R10 of SURVEY.md 8a in ONE launch per batch of frames and no
+ *       intermediate HBM traffic.  Hardware block scheduling balances the grid.
+ *   geodesic_persistent<KIND,PHI,FAST>     persistent waves: when `refill_threshold` lanes of a wave have
+ *       terminated they are stored together and the free lanes are refilled from a global ray queue with
+ *       ONE wave-aggregated atomic (ballot + popcount + mbcnt rank), so lanes never idle behind a slow
+ *       neighbour.  Final states are staged in the ray store and shaded by shade_kernel.  Selectable
+ *       ("variant" = 0); measured 3-8 % slower than the static kernel on every workload tried.
+ *   shade_kernel<KIND,DEBUG>               staged shading (persistent kernel, debug dump of every ray).
+ *   escape_angle_kernel<KIND,FAST>, efficient_pixel_kernel   render_image_efficient (src/systems.rs:333-527).
+ *   selftest_math_kernel                   cv_math.h / IEEE div / sqrt / hardware seeds for the tests.
+ *   FAST = shared-reciprocal Euler step (cv_device.h ray_step_fast), !FAST = compiler IEEE div/sqrt;
+ *   PHI = integrate phi as well (debug dump, escape angles).
  *
- * Ray order: rays are numbered by 8x8 pixel tiles (tile-major, then row-major inside the tile) so
- * the 64 rays a wave draws together are spatial neighbours: similar step counts, neighbouring sky
- * texels, and a 3-byte store pattern that covers whole 24-byte row segments.
+ * Ray order: rays are numbered by 8x8 pixel tiles (tile-major, then row-major inside the tile) so the 64
+ * rays of a wave are spatial neighbours: similar step counts, neighbouring sky texels, and 3-byte stores
+ * that cover whole 24-byte row segments.
  *
- * No MFMA: the loop is a latency/issue-bound chain of FP64 VALU ops (div, sqrt, sincos) on five
- * registers of state; HBM traffic is 3 B out + 4 B in per ~2000 steps.
+ * No MFMA, no LDS: the loop is an issue-bound chain of FP64 VALU ops (5 divisions, sqrt, sincos per step)
+ * on five registers of state; HBM traffic is 3 B out + 4 B in per ~2000 steps (DESIGN.md sections 5-6).
  */
 #include <hip/hip_runtime.h>
 

@@ -61,12 +61,6 @@ CV_HD double cv_from_bits(uint64_t u) {
 }
 CV_HD uint32_t cv_hi(double x) { return (uint32_t)(cv_bits(x) >> 32); }
 CV_HD uint32_t cv_lo(double x) { return (uint32_t)cv_bits(x); }
-CV_HD double cv_with_hi(double x, uint32_t hi) {
-  return cv_from_bits(((uint64_t)hi << 32) | (cv_bits(x) & 0xffffffffULL));
-}
-CV_HD double cv_copysign(double mag, double sgn) {
-  return cv_from_bits((cv_bits(mag) & 0x7fffffffffffffffULL) | (cv_bits(sgn) & 0x8000000000000000ULL));
-}
 
 /* 64x64 -> 128 multiply pieces */
 CV_HD uint64_t cv_mulhi64(uint64_t a, uint64_t b) {
