@@ -76,6 +76,12 @@ SYMBOLS = {
                                                 C.c_double, _vp, C.POINTER(Stats)]),
     "curvis_ctx_sampling_info": (C.c_int, [_vp, C.c_uint32, C.POINTER(SamplingInfo)]),
     "curvis_ctx_samples": (C.c_int, [_vp, C.c_uint32, _dp, _dp, _dp, C.c_size_t]),
+    "curvis_compute_escape_angles": (C.c_int, [_vp, C.POINTER(Metric), C.c_double, _dp, C.c_uint32, C.c_double,
+                                               C.c_uint32, C.c_double, _dp, C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_uint32)]),
+    "curvis_new_photon": (C.c_int, [C.POINTER(Metric), _dp, _dp, _dp, _dp]),
+    "curvis_photon_trajectories": (C.c_int, [_vp, C.POINTER(Metric), C.c_uint32, _dp, _dp, C.c_uint32, C.c_double,
+                                             _dp]),
     "curvis_ctx_framebuffer": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "curvis_ctx_download": (C.c_int, [_vp, _vp, C.c_size_t]),
     "curvis_ctx_synchronize": (C.c_int, [_vp]),

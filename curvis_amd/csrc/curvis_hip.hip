@@ -475,6 +475,49 @@ __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPix
   }
 }
 
+/* compute_photon_trajectory (src/systems.rs:77-92): the state BEFORE each of `iterations` Euler steps,
+ * all eight components (t and p_t included: x_t += (p_t * -1) * delta, p_t += 0 * delta), one thread per
+ * photon.  Momentum is covariant on entry (what new_photon produces). */
+struct TrajectoryParams {
+  cvk::MetricParams metric;
+  const double *x0, *p0; /* n*4 each */
+  double *out;           /* n * iterations * 8: [photon][iteration][x0..x3, p0..p3] */
+  unsigned n, iterations;
+  double delta;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(64) void trajectory_kernel(const TrajectoryParams P) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  double t = P.x0[4 * i], pt = P.p0[4 * i];
+  cvk::Ray q;
+  q.l = P.x0[4 * i + 1];
+  q.th = P.x0[4 * i + 2];
+  q.ph = P.x0[4 * i + 3];
+  q.p1 = P.p0[4 * i + 1];
+  q.p2 = P.p0[4 * i + 2];
+  q.p3 = P.p0[4 * i + 3];
+  q.p3sq = q.p3 * q.p3;
+  double p3 = q.p3;
+  double *o = P.out + (size_t)i * P.iterations * 8;
+  for (unsigned k = 0; k < P.iterations; ++k) {
+    o[0] = t;
+    o[1] = q.l;
+    o[2] = q.th;
+    o[3] = q.ph;
+    o[4] = pt;
+    o[5] = q.p1;
+    o[6] = q.p2;
+    o[7] = p3;
+    o += 8;
+    cvk::ray_step<KIND, true>(P.metric, q, P.delta);
+    t = t + (pt * (1.0 / -1.0)) * P.delta; /* dx0 = p0 * g00.powi(-1) */
+    pt = pt + 0.0 * P.delta;
+    p3 = p3 + 0.0 * P.delta;
+  }
+}
+
 __global__ void selftest_math_kernel(int op, const double *a, const double *b, double *out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1405,6 +1448,98 @@ int curvis_ctx_samples(const curvis_ctx *ctx, uint32_t frame, double *alpha, dou
     if (escape_angle) escape_angle[i] = pts[i].e;
     if (escape_space) escape_space[i] = pts[i].s;
   }
+  return CURVIS_OK;
+}
+
+int curvis_new_photon(const curvis_metric *metric, const double position[4], const double direction[3], double x[4],
+                      double p_cov[4]) {
+  if (!metric || !position || !direction || !x || !p_cov) return CURVIS_E_INVALID;
+  if (curvis_metric_validate(metric) != CURVIS_OK) return CURVIS_E_METRIC;
+  const cvk::MetricParams MP = make_metric(*metric);
+  cvk::Ray q;
+  switch (metric->kind) {
+    case CURVIS_METRIC_ELLIS:
+      cvk::ray_init_dir<cvk::METRIC_ELLIS>(MP, position, direction[0], direction[1], direction[2], q);
+      break;
+    case CURVIS_METRIC_INTERSTELLAR:
+      cvk::ray_init_dir<cvk::METRIC_INTERSTELLAR>(MP, position, direction[0], direction[1], direction[2], q);
+      break;
+    default:
+      cvk::ray_init_dir<cvk::METRIC_FLAT>(MP, position, direction[0], direction[1], direction[2], q);
+      break;
+  }
+  for (int i = 0; i < 4; ++i) x[i] = position[i];
+  p_cov[0] = 1.0;
+  p_cov[1] = q.p1;
+  p_cov[2] = q.p2;
+  p_cov[3] = q.p3;
+  return CURVIS_OK;
+}
+
+int curvis_photon_trajectories(curvis_ctx *ctx, const curvis_metric *metric, uint32_t n_photons, const double *x0,
+                               const double *p0_cov, uint32_t iterations, double delta, double *out) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (!metric || !x0 || !p0_cov || !out) return fail(ctx, CURVIS_E_INVALID, "null argument");
+  if (curvis_metric_validate(metric) != CURVIS_OK) return fail(ctx, CURVIS_E_METRIC, "invalid metric parameters");
+  if (n_photons == 0 || iterations == 0) return CURVIS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t in_bytes = (size_t)n_photons * 4 * sizeof(double);
+  const size_t out_bytes = (size_t)n_photons * iterations * 8 * sizeof(double);
+  int rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, 2 * in_bytes + out_bytes);
+  if (rc) return rc;
+  double *d_x = (double *)ctx->d_eff, *d_p = d_x + (size_t)n_photons * 4, *d_out = d_p + (size_t)n_photons * 4;
+  HIP_TRY(ctx, hipMemcpyAsync(d_x, x0, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_p, p0_cov, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  TrajectoryParams P;
+  P.metric = make_metric(*metric);
+  P.x0 = d_x;
+  P.p0 = d_p;
+  P.out = d_out;
+  P.n = n_photons;
+  P.iterations = iterations;
+  P.delta = delta;
+  const unsigned blocks = (n_photons + 63u) / 64u;
+  switch (metric->kind) {
+    case CURVIS_METRIC_ELLIS:
+      hipLaunchKernelGGL((trajectory_kernel<cvk::METRIC_ELLIS>), dim3(blocks), dim3(64), 0, ctx->stream, P);
+      break;
+    case CURVIS_METRIC_INTERSTELLAR:
+      hipLaunchKernelGGL((trajectory_kernel<cvk::METRIC_INTERSTELLAR>), dim3(blocks), dim3(64), 0, ctx->stream, P);
+      break;
+    default:
+      hipLaunchKernelGGL((trajectory_kernel<cvk::METRIC_FLAT>), dim3(blocks), dim3(64), 0, ctx->stream, P);
+      break;
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CURVIS_OK;
+}
+
+int curvis_compute_escape_angles(curvis_ctx *ctx, const curvis_metric *metric, double l, const double *alphas,
+                                 uint32_t n, double delta, uint32_t max_iterations, double max_radius,
+                                 double *angle, int32_t *space, uint32_t *steps) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (!metric || !alphas || !angle || !space) return fail(ctx, CURVIS_E_INVALID, "null argument");
+  if (curvis_metric_validate(metric) != CURVIS_OK) return fail(ctx, CURVIS_E_METRIC, "invalid metric parameters");
+  if (std::fabs(l) > max_radius)
+    return fail(ctx, CURVIS_E_CAMERA_OUTSIDE,
+                "Photon already beyond the maximum radius. Cannot evaluate escape. (src/systems.rs:122-124)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const cvk::MetricParams MP = make_metric(*metric);
+  std::vector<double> a(alphas, alphas + n), ls(n, l), ang, spc;
+  std::vector<uint32_t> st;
+  std::vector<int> status;
+  int rc = eval_escape_batch(ctx, metric, MP, a, ls, max_iterations, max_radius, delta, ang, spc, st, status, nullptr);
+  if (rc) return rc;
+  bool panic = false;
+  for (uint32_t i = 0; i < n; ++i) {
+    angle[i] = ang[i];
+    space[i] = status[i] == cvk::ESC_PANIC ? 0 : status[i];
+    if (steps) steps[i] = st[i];
+    if (status[i] == cvk::ESC_PANIC) panic = true;
+  }
+  if (panic) return fail(ctx, CURVIS_E_PARALLEL, "v1 and v2 must not be parallel (src/algebra.rs:95-97) for at least one sample");
   return CURVIS_OK;
 }
 

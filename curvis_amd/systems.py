@@ -215,6 +215,34 @@ class Context:
         check(lib().curvis_ctx_samples(self._h, frame, dptr(a), dptr(e), dptr(s), n), self._h)
         return a, e, s
 
+    def compute_escape_angles_range(self, metric, l, alphas, delta, max_iterations, max_radius):
+        """src/systems.rs:265-281: returns (angle[n], space[n] in {+1,-1,0}, steps[n])."""
+        alphas = np.ascontiguousarray(alphas, dtype=np.float64)
+        n = alphas.size
+        angle = np.zeros(n)
+        space = np.zeros(n, dtype=np.int32)
+        steps = np.zeros(n, dtype=np.uint32)
+        m = metric._c()
+        check(lib().curvis_compute_escape_angles(self._h, C.byref(m), float(l), dptr(alphas), n, delta, max_iterations,
+                                                 max_radius, dptr(angle), space.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                 steps.ctypes.data_as(C.POINTER(C.c_uint32))), self._h)
+        return angle, space, steps
+
+    def compute_photon_trajectory(self, metric, positions, directions, iterations, delta):
+        """src/systems.rs:77-92 for a batch of photons built with new_photon(position, direction):
+        returns an array [n, iterations, 8] = (x[4], p_cov[4]) before each step."""
+        positions = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 4)
+        directions = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+        n = positions.shape[0]
+        m = metric._c()
+        x0, p0 = np.zeros((n, 4)), np.zeros((n, 4))
+        for i in range(n):
+            check(lib().curvis_new_photon(C.byref(m), dptr(positions[i]), dptr(directions[i]), dptr(x0[i]), dptr(p0[i])))
+        out = np.zeros((n, iterations, 8))
+        check(lib().curvis_photon_trajectories(self._h, C.byref(m), n, dptr(x0), dptr(p0), iterations, delta, dptr(out)),
+              self._h)
+        return out
+
     def selftest_math(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float64)
         out = np.empty_like(a)

@@ -173,6 +173,22 @@ int curvis_ctx_sampling_info(const curvis_ctx *ctx, uint32_t frame, curvis_sampl
 int curvis_ctx_samples(const curvis_ctx *ctx, uint32_t frame, double *alpha, double *escape_angle,
                        double *escape_space, size_t cap);
 
+/* compute_escape_angles_range / compute_escape_angle (src/systems.rs:203-281, re-exported by src/lib.rs:37):
+ * photons at (0, l, pi/2, 0) with tangent direction (cos a, 0, sin a); angle[i] = escape angle in [0, 2 pi)
+ * (NaN when not escaped), space[i] = +1 / -1 / 0 (EscapeAngle::{PositiveSpace, NegativeSpace, NotEscaped}). */
+int curvis_compute_escape_angles(curvis_ctx *ctx, const curvis_metric *metric, double l, const double *alphas,
+                                 uint32_t n, double delta, uint32_t max_iterations, double max_radius,
+                                 double *angle, int32_t *space, uint32_t *steps /* nullable */);
+/* DiagonalSphericalMetric::new_photon (src/metrics.rs:301-334), host-side: position (t,l,theta,phi) and a
+ * tangent-space direction -> contravariant position x and covariant momentum p. */
+int curvis_new_photon(const curvis_metric *metric, const double position[4], const double direction[3], double x[4],
+                      double p_cov[4]);
+/* compute_photon_trajectory (src/systems.rs:77-92, re-exported by src/lib.rs:37) for n photons:
+ * out[photon][iteration][0..7] = (x_t, x_l, x_theta, x_phi, p_t, p_l, p_theta, p_phi) BEFORE that iteration's
+ * Euler step; momentum covariant. */
+int curvis_photon_trajectories(curvis_ctx *ctx, const curvis_metric *metric, uint32_t n_photons, const double *x0,
+                               const double *p0_cov, uint32_t iterations, double delta, double *out);
+
 /* device framebuffer of the last render (RGB8, frames back to back) */
 int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes);
 int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);

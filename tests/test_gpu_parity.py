@@ -381,3 +381,30 @@ def test_rccl_sky_broadcast_entry_point(gpu_ctx):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_library_api_escape_angles_and_trajectories(gpu_ctx):
+    """src/lib.rs:37 re-exports compute_escape_angle and compute_photon_trajectory: both through the ABI,
+    bit-exact against the oracle (trajectories including the t and p_t lanes)."""
+    import ctypes as C
+    alphas = np.concatenate([np.linspace(-0.3, 3.45, 41), [0.0, np.pi / 2, 2.9, 3.0, np.pi]])
+    for name, om, pm in (("ellis", O.ellis(), curvis_amd.EllisMetric(1.0)),
+                         ("interstellar", O.interstellar(), curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0))):
+        ang, spc, st = gpu_ctx.compute_escape_angles_range(pm, 5.0, alphas, 0.05, 4096, 100.0)
+        for i, a in enumerate(alphas):
+            code, want, steps = O.compute_escape_angle(O.CV, om, 5.0, float(a), 0.05, 4096, 100.0)
+            assert spc[i] == code and st[i] == steps, (name, a)
+            if code != 0:
+                assert np.float64(ang[i]).view(np.uint64) == np.float64(want).view(np.uint64), (name, a)
+            else:
+                assert np.isnan(ang[i])
+        pos = np.array([[0.0, 5.0, np.pi / 2, 0.0], [2.5, -3.0, 1.0, 4.0], [0.0, 0.5, 2.0, 1.0]])
+        dirs = np.array([[np.cos(np.pi / 4), 0.0, np.sin(np.pi / 4)], [-1.0, 0.2, 0.3], [0.1, -0.9, 0.2]])
+        traj = gpu_ctx.compute_photon_trajectory(pm, pos, dirs, 300, 0.01)
+        for i in range(3):
+            x, p = np.zeros(4), np.zeros(4)
+            O.lib().cvo_new_photon(O.CV, C.byref(om), O._dp(pos[i].copy()), O._dp(dirs[i].copy()), O._dp(x), O._dp(p))
+            for k in range(300):
+                want = np.concatenate([x, p])
+                assert np.array_equal(traj[i, k].view(np.uint64), want.view(np.uint64)), (name, i, k)
+                O.lib().cvo_update(O.CV, C.byref(om), O._dp(x), O._dp(p), 0.01)
