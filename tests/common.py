@@ -111,3 +111,32 @@ def twin_render_efficient(pm, pc, sky_pos, sky_neg, max_iter, max_radius, delta,
         raise RuntimeError("twin efficient render failed: %d" % rc)
     k = n.value
     return rgb, dict(a=a[:k].copy(), e=e[:k].copy(), s=s[:k].copy(), calls=calls.value, steps=steps.value)
+
+
+def random_scene(rng, res=(16, 9)):
+    """a random but valid scene: (oracle metric, oracle camera, product metric, product camera, delta, cap, R)"""
+    kind = rng.choice(["ellis", "interstellar", "flat"], p=[0.5, 0.4, 0.1])
+    if kind == "ellis":
+        rho = float(10 ** rng.uniform(-1, 1))
+        om, pm = O.ellis(rho), curvis_amd.EllisMetric(rho)
+        scale = rho
+    elif kind == "interstellar":
+        m, a, rho = float(10 ** rng.uniform(-2, 0)), float(10 ** rng.uniform(-4, 0.3)), float(10 ** rng.uniform(-0.5, 0.7))
+        om, pm = O.interstellar(m, a, rho), curvis_amd.InterstellarMetric(m, a, rho)
+        scale = rho
+    else:
+        om, pm = O.flat(), curvis_amd.FlatSphericalMetric()
+        scale = 1.0
+    R = float(scale * rng.uniform(20, 120))
+    l = float(rng.uniform(-0.5, 0.5) * R * 0.2)
+    if kind == "flat":
+        l = abs(l) + 0.5
+    pos = (float(rng.uniform(-3, 3)), l, float(rng.uniform(0.15, 3.0)), float(rng.uniform(-7, 7)))
+    fwd = tuple(rng.uniform(-1, 1, 3))
+    up = tuple(rng.uniform(-1, 1, 3))
+    focal, diag = float(rng.uniform(8, 60)), float(rng.uniform(15, 60))
+    delta = float(scale * 10 ** rng.uniform(-2, -0.7))
+    cap = int(rng.integers(200, 3000))
+    oc = O.camera(pos, fwd, up, focal, diag, res)
+    pc = curvis_amd.Camera(pos, fwd, up, focal, diag, res[0], res[1])
+    return om, oc, pm, pc, delta, cap, R

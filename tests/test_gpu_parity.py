@@ -408,3 +408,51 @@ def test_library_api_escape_angles_and_trajectories(gpu_ctx):
                 want = np.concatenate([x, p])
                 assert np.array_equal(traj[i, k].view(np.uint64), want.view(np.uint64)), (name, i, k)
                 O.lib().cvo_update(O.CV, C.byref(om), O._dp(x), O._dp(p), 0.01)
+
+
+def test_fuzz_gpu_vs_oracle(gpu_ctx):
+    """60 random scenes through the ABI (brute, all four kernel flavours on a subset) and 12 through the
+    efficient renderer, against the oracle."""
+    rng = np.random.default_rng(777)
+    sp, sn = common.make_skies(64, 32, "check")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    try:
+        for trial in range(60):
+            om, oc, pm, pc, delta, cap, R = common.random_scene(rng, res=(16, 9))
+            with np.errstate(all="ignore"):
+                want_rgb, want_dbg, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, R, delta, debug=True)
+            flavours = [(1, 1), (1, 0), (0, 1), (0, 0)] if trial % 6 == 0 else [(1, 1)]
+            for variant, fast in flavours:
+                gpu_ctx.set_option("variant", variant)
+                gpu_ctx.set_option("fast_math", fast)
+                rgb, s, dbg = gpu_ctx.render_brute(pm, pc, cap, R, delta, debug=True)
+                _assert_debug_equal_nan_tolerant(dbg, want_dbg)
+                assert np.array_equal(rgb, want_rgb), (trial, variant, fast)
+                rgb2, s2 = gpu_ctx.render_brute(pm, pc, cap, R, delta)
+                assert np.array_equal(rgb2, want_rgb) and s2.steps == st.steps
+    finally:
+        gpu_ctx.set_option("variant", 1)
+        gpu_ctx.set_option("fast_math", 1)
+    done = 0
+    for trial in range(40):
+        om, oc, pm, pc, delta, cap, R = common.random_scene(rng, res=(16, 9))
+        if om.kind == O.FLAT:
+            continue
+        try:
+            with np.errstate(all="ignore"):
+                want_rgb, want, _ = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, R, delta, 40, 40,
+                                                             1e-4, 1e-4)
+        except RuntimeError:
+            # the reference panics (fewer than 3 finite samples / undefined rotation): the ABI must report it too
+            with pytest.raises(curvis_amd.CurvisError):
+                gpu_ctx.render_efficient(pm, pc, cap, R, delta, 40, 40, 1e-4, 1e-4)
+            continue
+        rgb, _ = gpu_ctx.render_efficient(pm, pc, cap, R, delta, 40, 40, 1e-4, 1e-4)
+        a, e, s = gpu_ctx.samples(0)
+        assert np.array_equal(common.bits(a), common.bits(want["a"])) and np.array_equal(common.bits(e), common.bits(want["e"]))
+        assert np.array_equal(rgb, want_rgb), trial
+        done += 1
+        if done >= 12:
+            break
+    assert done >= 6

@@ -38,3 +38,18 @@ def test_flavours_agree_to_rounding():
     d = np.abs(a["x"][same][:, 1:3] - b["x"][same][:, 1:3])
     assert np.median(d) < 1e-11
     assert np.abs(a_rgb.astype(int) - b_rgb.astype(int)).max() <= 1 or (a_rgb != b_rgb).any(axis=2).mean() < 0.03
+
+
+def test_fuzz_twin_vs_oracle():
+    """30 random scenes (metric parameters, pose, step, radius, cap): the kernel source on x86, strict and
+    fast step, against the oracle -- full ray state."""
+    rng = np.random.default_rng(2024)
+    sp, sn = common.make_skies(64, 32, "check")
+    for trial in range(30):
+        om, oc, pm, pc, delta, cap, R = common.random_scene(rng, res=(12, 8))
+        with np.errstate(all="ignore"):
+            want_rgb, want_dbg, _ = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, R, delta, debug=True)
+        for fast in (0, 1):
+            got_rgb, got_dbg = common.twin_render(pm, pc, sp, sn, cap, R, delta, fast=fast)
+            common.assert_debug_equal(got_dbg, want_dbg, check_t=False)
+            assert np.array_equal(got_rgb, want_rgb), (trial, fast)
