@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -604,6 +605,10 @@ struct curvis_ctx {
   int blocks_per_cu = 0;    /* 0 = occupancy query */
   int fast_math = 1;        /* 1 shared-reciprocal step (ray_step_fast), 0 compiler IEEE div/sqrt */
   int fuse_shade = 1;       /* static kernel shades in its epilogue (no ray store, no shade launch) */
+  int sampling_speculation = 4; /* efficient renderer: depth of the speculative subtree evaluated below every
+                                   refined interval (0 = one launch per refinement round, no speculation) */
+  uint32_t last_sampling_launches = 0;
+  uint64_t last_sampling_evaluated = 0;
   size_t max_store_bytes = (size_t)8 << 30; /* frames of a batch are rendered in chunks below this */
   double last_integrate_ms = 0.0, last_shade_ms = 0.0;
 };
@@ -1007,37 +1012,122 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
     smp[f].thr1 = thr1;
     smp[f].thr2 = thr2;
   }
+  /* Evaluation cache + speculation.  Every point the sampler will ever ask for is the midpoint of two
+   * samples that are adjacent at that time, i.e. a node of the dyadic tree below an interval of the current
+   * table, computed by the same (lo + hi) / 2.0.  So whenever some requested alpha is not cached yet, the
+   * launch also evaluates the whole subtree of depth `spec` below the interval it comes from (and, on the
+   * first launch, below every interval of the uniform grid): the GPU is idle anyway -- a round is a single
+   * wave's 2000-step dependency chain -- and the following rounds are then served from the cache without
+   * a launch.  The sampler consumes exactly the values the sequential algorithm would compute; calls and
+   * steps are counted at consumption, so the bookkeeping equals the reference's. */
+  struct Cached {
+    double e, s;
+    uint32_t steps;
+    int status;
+  };
+  auto key_of = [](double a) {
+    uint64_t u;
+    std::memcpy(&u, &a, sizeof u);
+    return u;
+  };
+  const int spec = ctx->sampling_speculation < 0 ? 0 : (ctx->sampling_speculation > 8 ? 8 : ctx->sampling_speculation);
+  std::vector<std::unordered_map<uint64_t, Cached>> cache(n_frames);
+  std::vector<char> planned(n_frames, 0);
   double sample_ms = 0.0;
-  std::vector<double> b_alpha, b_l, r_angle, r_space;
-  std::vector<uint32_t> r_steps;
+  uint64_t evaluated = 0;
+  uint32_t launches = 0;
+  std::vector<double> b_alpha, b_l, r_angle, r_space, ce, cs;
+  std::vector<uint32_t> r_steps, cst;
   std::vector<int> r_status;
-  std::vector<size_t> b_off(n_frames + 1);
+  std::vector<uint32_t> b_frame;
   bool panic = false;
   for (;;) {
-    b_alpha.clear();
-    b_l.clear();
-    bool any = false;
+    /* advance every sampler as far as the cache allows */
+    bool any_waiting = false;
     for (uint32_t f = 0; f < n_frames; ++f) {
-      b_off[f] = b_alpha.size();
-      if (smp[f].plan()) {
-        any = true;
-        b_alpha.insert(b_alpha.end(), smp[f].pending.begin(), smp[f].pending.end());
-        b_l.insert(b_l.end(), smp[f].pending.size(), cams[f].pos[1]);
+      for (;;) {
+        if (!planned[f]) {
+          if (!smp[f].plan()) break; /* finished */
+          planned[f] = 1;
+        }
+        bool all_cached = true;
+        for (double a : smp[f].pending)
+          if (!cache[f].count(key_of(a))) {
+            all_cached = false;
+            break;
+          }
+        if (!all_cached) {
+          any_waiting = true;
+          break;
+        }
+        const size_t n = smp[f].pending.size();
+        ce.resize(n);
+        cs.resize(n);
+        cst.resize(n);
+        for (size_t k = 0; k < n; ++k) {
+          const Cached &c = cache[f][key_of(smp[f].pending[k])];
+          ce[k] = c.e;
+          cs[k] = c.s;
+          cst[k] = c.steps;
+          if (c.status == cvk::ESC_PANIC) panic = true;
+        }
+        smp[f].consume(ce.data(), cs.data(), cst.data());
+        planned[f] = 0;
       }
     }
-    b_off[n_frames] = b_alpha.size();
-    if (!any) break;
+    if (!any_waiting) break;
+    /* one launch: the missing points of every waiting frame plus their speculative subtrees */
+    b_alpha.clear();
+    b_l.clear();
+    b_frame.clear();
+    for (uint32_t f = 0; f < n_frames; ++f) {
+      if (!planned[f]) continue;
+      std::unordered_map<uint64_t, char> queued;
+      auto want = [&](double a) {
+        const uint64_t k = key_of(a);
+        if (cache[f].count(k) || queued.count(k)) return;
+        queued[k] = 1;
+        b_alpha.push_back(a);
+        b_l.push_back(cams[f].pos[1]);
+        b_frame.push_back(f);
+      };
+      struct Node {
+        double lo, hi;
+        int depth;
+      };
+      std::vector<Node> stack;
+      const cvs::Sampler &S = smp[f];
+      for (size_t k = 0; k < S.pending.size(); ++k) {
+        want(S.pending[k]);
+        if (spec <= 0) continue;
+        if (S.pend_lo[k] == S.pend_lo[k]) {
+          stack.push_back(Node{S.pend_lo[k], S.pend_hi[k], spec});
+        } else if (k + 1 < S.pending.size()) { /* uniform grid: subtree below [x_k, x_{k+1}] */
+          stack.push_back(Node{S.pending[k], S.pending[k + 1], spec > 3 ? 3 : spec});
+        }
+        while (!stack.empty()) {
+          const Node nd = stack.back();
+          stack.pop_back();
+          const double mid = (nd.lo + nd.hi) / 2.0;
+          if (!(mid > nd.lo && mid < nd.hi)) continue; /* interval exhausted in double precision */
+          want(mid);
+          if (nd.depth > 1) {
+            stack.push_back(Node{nd.lo, mid, nd.depth - 1});
+            stack.push_back(Node{mid, nd.hi, nd.depth - 1});
+          }
+        }
+      }
+    }
     rc = eval_escape_batch(ctx, metric, MP, b_alpha, b_l, max_iter, max_radius, delta, r_angle, r_space, r_steps,
                            r_status, &sample_ms);
     if (rc) return rc;
-    for (size_t k = 0; k < r_status.size(); ++k)
-      if (r_status[k] == cvk::ESC_PANIC) panic = true;
-    for (uint32_t f = 0; f < n_frames; ++f) {
-      if (smp[f].finished) continue;
-      const size_t o = b_off[f];
-      smp[f].consume(r_angle.data() + o, r_space.data() + o, r_steps.data() + o);
-    }
+    ++launches;
+    evaluated += b_alpha.size();
+    for (size_t k = 0; k < b_alpha.size(); ++k)
+      cache[b_frame[k]][key_of(b_alpha[k])] = Cached{r_angle[k], r_space[k], r_steps[k], r_status[k]};
   }
+  ctx->last_sampling_launches = launches;
+  ctx->last_sampling_evaluated = evaluated;
   ctx->last_samples.assign(n_frames, {});
   ctx->last_sampling_info.assign(n_frames, curvis_sampling_info{});
   uint64_t total_steps = 0;
@@ -1578,6 +1668,8 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->fast_math = (int)value;
   else if (k == "fuse_shade")
     ctx->fuse_shade = (int)value;
+  else if (k == "sampling_speculation")
+    ctx->sampling_speculation = (int)value;
   else if (k == "max_store_bytes")
     ctx->max_store_bytes = (size_t)value;
   else
@@ -1598,6 +1690,12 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->fast_math;
   else if (k == "fuse_shade")
     *value = ctx->fuse_shade;
+  else if (k == "sampling_speculation")
+    *value = ctx->sampling_speculation;
+  else if (k == "last_sampling_launches")
+    *value = ctx->last_sampling_launches;
+  else if (k == "last_sampling_evaluated")
+    *value = (int64_t)ctx->last_sampling_evaluated;
   else if (k == "max_store_bytes")
     *value = (int64_t)ctx->max_store_bytes;
   else

@@ -144,7 +144,7 @@ struct EfficientFrame {
 /* interp 1.0.3 interp_slice for one query against precomputed slopes m / intercepts c:
  * i = min(prev_index(x, xp), n-2), prev_index = (number of leading x < xp) - 1, saturating.
  * x is strictly increasing here, so a binary search gives the same count as the crate's linear scan. */
-CV_HD double interp_query(const double *x, const double *m, const double *c, unsigned n, double xp) {
+CV_HD unsigned interp_index(const double *x, unsigned n, double xp) {
   unsigned lo = 0, hi = n; /* first index with !(x[i] < xp); NaN xp -> 0 */
   while (lo < hi) {
     const unsigned mid = (lo + hi) >> 1;
@@ -155,7 +155,7 @@ CV_HD double interp_query(const double *x, const double *m, const double *c, uns
   }
   unsigned i = lo ? lo - 1 : 0;
   if (i > n - 2) i = n - 2;
-  return m[i] * xp + c[i];
+  return i;
 }
 
 /* steps 2 + 4 + 5 of render_image_efficient for one pixel: returns the final direction on the background
@@ -185,8 +185,9 @@ CV_HD void efficient_pixel(const CameraParams &C, const EfficientFrame &F, unsig
     esc = c_e[0]; /* y[0] */
     space = c_s[0];
   } else {
-    esc = interp_query(sx, m_e, c_e, n_samples, alpha);
-    space = interp_query(sx, m_s, c_s, n_samples, alpha);
+    const unsigned i = interp_index(sx, n_samples, alpha); /* both tables share the abscissae */
+    esc = m_e[i] * alpha + c_e[i];
+    space = m_s[i] * alpha + c_s[i];
   }
   const double an = norm3(axis); /* Unit::new_normalize: 0/0 -> NaN for the centre pixel */
   const double u[3] = {axis[0] / an, axis[1] / an, axis[2] / an};

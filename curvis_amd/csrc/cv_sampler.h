@@ -40,16 +40,24 @@ struct Sampler {
   uint32_t rounds = 0;
   /* plan of the current round */
   std::vector<double> pending;  /* alphas to evaluate, in the reference's evaluation order */
+  std::vector<double> pend_lo, pend_hi; /* the adjacent samples each pending alpha is the midpoint of
+                                           (NaN for the initial uniform grid) -- used for speculation */
   std::vector<uint8_t> refined; /* per visited triple start: 1 = refined (consumes two evaluations) */
   std::vector<size_t> visit;    /* triple start indices in visiting order */
 
   /* plan the next batch; returns false when the sampler has finished (or panicked) */
   bool plan() {
     pending.clear();
+    pend_lo.clear();
+    pend_hi.clear();
     if (finished) return false;
     if (!started) { /* compute_uniform_range */
       const double step = (a_max - a_min) / (double)(n0 - 1);
-      for (size_t i = 0; i < n0; ++i) pending.push_back(a_min + (double)i * step);
+      for (size_t i = 0; i < n0; ++i) {
+        pending.push_back(a_min + (double)i * step);
+        pend_lo.push_back(std::nan(""));
+        pend_hi.push_back(std::nan(""));
+      }
       return true;
     }
     if (!(iteration < max_iterations)) {
@@ -80,7 +88,11 @@ struct Sampler {
       } else {
         refined.push_back(1);
         pending.push_back((b1.a + b2.a) / 2.0);
+        pend_lo.push_back(b1.a);
+        pend_hi.push_back(b2.a);
         pending.push_back((b2.a + b3.a) / 2.0);
+        pend_lo.push_back(b2.a);
+        pend_hi.push_back(b3.a);
         i += 2;
       }
     }

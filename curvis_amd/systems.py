@@ -157,6 +157,11 @@ class Context:
     def set_option(self, key, value):
         check(lib().curvis_ctx_set_option(self._h, key.encode(), int(value)), self._h)
 
+    def get_option(self, key):
+        v = C.c_int64(0)
+        check(lib().curvis_ctx_get_option(self._h, key.encode(), C.byref(v)), self._h)
+        return v.value
+
     def framebuffer(self):
         p, n = C.c_void_p(), C.c_size_t(0)
         check(lib().curvis_ctx_framebuffer(self._h, C.byref(p), C.byref(n)), self._h)

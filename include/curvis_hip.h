@@ -198,7 +198,10 @@ int curvis_ctx_synchronize(curvis_ctx *ctx);
  * 1 = static one-ray-per-thread kernel), "refill_threshold", "blocks_per_cu", "fast_math"
  * (1 = shared-reciprocal Euler step, 0 = compiler IEEE division/sqrt; identical results), "fuse_shade"
  * (1 = the static kernel shades in its epilogue, 0 = final states staged in HBM + separate shade kernel),
- * "max_store_bytes" (ray-store budget that bounds the frames per launch of a batch). */
+ * "max_store_bytes" (ray-store budget that bounds the frames per launch of a batch),
+ * "sampling_speculation" (efficient renderer: depth of the speculative dyadic subtree evaluated below every
+ * refined interval, default 4, 0 = one launch per refinement round); read-only after an efficient render:
+ * "last_sampling_launches", "last_sampling_evaluated". */
 int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value);
 int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value);
 

@@ -456,3 +456,30 @@ def test_fuzz_gpu_vs_oracle(gpu_ctx):
         if done >= 12:
             break
     assert done >= 6
+
+
+def test_efficient_speculation_is_transparent(gpu_ctx):
+    """speculative subtree evaluation changes the number of launches, never the result or the bookkeeping."""
+    sp, sn = common.make_skies(256, 128, "check")
+    om, oc, pm, pc = common.scene("ellis", res=(64, 36))
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    out = {}
+    try:
+        for depth in (0, 2, 4, 6):
+            gpu_ctx.set_option("sampling_speculation", depth)
+            rgb, st = gpu_ctx.render_efficient(pm, pc, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+            info = gpu_ctx.sampling_info(0)
+            out[depth] = (rgb, gpu_ctx.samples(0), (info.n_samples, info.calls, info.steps, info.rounds),
+                          gpu_ctx.get_option("last_sampling_launches"), gpu_ctx.get_option("last_sampling_evaluated"))
+    finally:
+        gpu_ctx.set_option("sampling_speculation", 4)
+    base = out[0]
+    assert base[2][:3] == (678, 712, 1496307) and base[3] == base[2][3] + 1 and base[4] == 712
+    for depth in (2, 4, 6):
+        o = out[depth]
+        assert np.array_equal(o[0], base[0]) and o[2] == base[2]
+        for a, b in zip(o[1], base[1]):
+            assert np.array_equal(common.bits(a), common.bits(b))
+        assert o[3] < base[3] and o[4] > base[4]
+    assert out[6][3] <= 5
