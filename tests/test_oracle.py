@@ -232,3 +232,40 @@ def test_path_frames_and_off_by_one(tmp_path):
     assert L.cvo_times_of_frames(tmin, tmax, 24.0, None, 0) == 480
     assert L.cvo_times_of_frames(tmin, tmax, 30.0, None, 0) == 600
     L.cvo_path_free(C.byref(p))
+
+
+def test_nalgebra_restatements_against_independent_formulas():
+    """The third-party arithmetic (nalgebra, interp) is restated from the crates' published behaviour; this
+    checks the restatements numerically (1e-14) against independent implementations: scipy rotations,
+    numpy.interp (inside the table), orthonormality of face_towards."""
+    scipy_rot = pytest.importorskip("scipy.spatial.transform").Rotation
+    rng = np.random.default_rng(9)
+    m = np.zeros(9)
+    for _ in range(200):
+        axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+        ang = float(rng.uniform(-6, 6))
+        for fl in FLS:
+            L.cvo_from_axis_angle(fl, O._dp(axis.copy()), ang, O._dp(m))
+            np.testing.assert_allclose(m.reshape(3, 3), scipy_rot.from_rotvec(axis * ang).as_matrix(), atol=1e-14)
+        a, b = rng.normal(size=3), rng.normal(size=3)
+        for fl in FLS:
+            assert L.cvo_rotation_between(fl, O._dp(a.copy()), O._dp(b.copy()), O._dp(m)) == 0
+            R = m.reshape(3, 3)
+            np.testing.assert_allclose(R @ (a / np.linalg.norm(a)), b / np.linalg.norm(b), atol=1e-13)
+            np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-13)
+            assert abs(np.linalg.det(R) - 1) < 1e-13
+        d, u = rng.normal(size=3), rng.normal(size=3)
+        L.cvo_face_towards(O._dp(d.copy()), O._dp(u.copy()), O._dp(m))
+        F = m.reshape(3, 3)
+        np.testing.assert_allclose(F.T @ F, np.eye(3), atol=1e-13)
+        np.testing.assert_allclose(F[:, 2], d / np.linalg.norm(d), atol=1e-14)   # z column = dir
+        assert abs(F[:, 1] @ u) > 0 and (F[:, 1] @ u) > 0                         # y column on the up side
+    # antiparallel -> None; parallel -> identity
+    assert L.cvo_rotation_between(O.LIBM, O._dp(O.vec(1, 0, 0)), O._dp(O.vec(-2, 0, 0)), O._dp(m)) == -1
+    assert L.cvo_rotation_between(O.LIBM, O._dp(O.vec(1, 0, 0)), O._dp(O.vec(3, 0, 0)), O._dp(m)) == 0
+    assert np.array_equal(m.reshape(3, 3), np.eye(3))
+    x = np.sort(rng.uniform(0, 10, 50)); y = rng.normal(size=50)
+    xp = rng.uniform(x[0], x[-1], 500)
+    out = np.zeros_like(xp)
+    L.cvo_interp_slice(O._dp(x), O._dp(y), 50, O._dp(xp), xp.size, O._dp(out))
+    np.testing.assert_allclose(out, np.interp(xp, x, y), atol=1e-12)
