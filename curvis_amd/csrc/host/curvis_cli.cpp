@@ -16,8 +16,8 @@
  * Extensions (do not exist in the reference): --mode efficient|brute (default efficient = what the
  * reference renders; brute = RelativisticSystem::render_image, the per-pixel integrator),
  * --devices N (frames k mod N across N GPUs, one host thread + one context per GPU, skies uploaded to
- * each), --batch B (frames per kernel launch), --writers T (PNG encoder threads), --stats FILE (per-frame
- * JSON lines).
+ * each or broadcast from GPU 0 with RCCL: --sky-broadcast rccl|upload), --batch B (frames per kernel launch),
+ * --writers T (PNG encoder threads), --stats FILE (per-frame JSON lines).
  * Backgrounds must be PNG (any colour type / bit depth); no JPEG decoder is linked.
  */
 #include <sys/stat.h>
@@ -40,6 +40,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <rccl/rccl.h>
 
 #include "../../../include/curvis_hip.h"
 #include "png_io.h"
@@ -398,7 +400,8 @@ int path_camera(const CameraPath &p, double t, double pos[4], double fwd[3], dou
 
 /* ------------------------------------------------------------------ command line */
 struct Args {
-  std::string sub, bg1, bg2, out, image_toml, video_toml, metric_toml, camera_toml, sim_toml, mode = "efficient", stats;
+  std::string sub, bg1, bg2, out, image_toml, video_toml, metric_toml, camera_toml, sim_toml, mode = "efficient", stats,
+      sky_broadcast = "rccl";
   int devices = 1, device = 0, batch = 8, writers = 8;
 };
 [[noreturn]] void die(const std::string &msg, int code = 1) {
@@ -446,6 +449,7 @@ Args parse_args(int argc, char **argv) {
     else if (key == "-s" || key == "--simulation-settings") take(a.sim_toml);
     else if (key == "--mode") take(a.mode);
     else if (key == "--stats") take(a.stats);
+    else if (key == "--sky-broadcast") take(a.sky_broadcast);
     else if (key == "--devices") { take(val); a.devices = std::atoi(val.c_str()); }
     else if (key == "--device") { take(val); a.device = std::atoi(val.c_str()); }
     else if (key == "--batch") { take(val); a.batch = std::atoi(val.c_str()); }
@@ -464,6 +468,7 @@ Args parse_args(int argc, char **argv) {
     if (a.sub == "video" && !a.image_toml.empty()) die("error: unexpected argument '-i' found", 2);
   }
   if (a.mode != "efficient" && a.mode != "brute") die("error: --mode must be efficient or brute", 2);
+  if (a.sky_broadcast != "rccl" && a.sky_broadcast != "upload") die("error: --sky-broadcast must be rccl or upload", 2);
   if (a.devices < 1) a.devices = 1;
   if (a.batch < 1) a.batch = 1;
   if (a.writers < 1) a.writers = 1;
@@ -521,12 +526,19 @@ void check(int rc, curvis_ctx *ctx, const char *what) {
       (rc == CURVIS_E_CAMERA_OUTSIDE || rc == CURVIS_E_PARALLEL || rc == CURVIS_E_SAMPLING) ? 101 : 1);
 }
 
-curvis_ctx *make_ctx(int device, const Common &c, const char *what) {
+curvis_ctx *make_ctx_bare(int device, const char *what) {
   curvis_ctx *ctx = nullptr;
   int rc = curvis_ctx_create(device, &ctx);
   if (rc != CURVIS_OK) die(std::string("Error in rendering ") + what + ": " + curvis_last_error(nullptr));
+  return ctx;
+}
+void upload_skies(curvis_ctx *ctx, const Common &c, const char *what) {
   check(curvis_ctx_set_sky(ctx, 0, c.sky1.rgba.data(), c.sky1.w, c.sky1.h), ctx, what);
   check(curvis_ctx_set_sky(ctx, 1, c.sky2.rgba.data(), c.sky2.w, c.sky2.h), ctx, what);
+}
+curvis_ctx *make_ctx(int device, const Common &c, const char *what) {
+  curvis_ctx *ctx = make_ctx_bare(device, what);
+  upload_skies(ctx, c, what);
   return ctx;
 }
 
@@ -689,8 +701,29 @@ int video_main(const Args &a) {
   std::atomic<int> failed{0};
   FILE *stats_f = a.stats.empty() ? nullptr : std::fopen(a.stats.c_str(), "w");
   WriterPool writers(a.writers);
+  /* sky distribution: rank 0 uploads the two textures once; with --sky-broadcast rccl (default for
+   * --devices > 1) the other GPUs receive them with ncclBroadcast over xGMI (curvis_ctx_bcast_skies),
+   * otherwise every GPU uploads from host memory. */
+  std::vector<ncclComm_t> comms;
+  bool use_rccl = a.sky_broadcast == "rccl" && (a.devices > 1 || std::getenv("CURVIS_FORCE_RCCL"));
+  if (use_rccl) {
+    std::vector<int> devs;
+    for (int r = 0; r < a.devices; ++r) devs.push_back(a.device + r);
+    comms.resize(a.devices);
+    if (ncclCommInitAll(comms.data(), a.devices, devs.data()) != ncclSuccess) {
+      std::fprintf(stderr, "warning: ncclCommInitAll failed, uploading the skies to every device instead\n");
+      comms.clear();
+      use_rccl = false;
+    }
+  }
   auto worker = [&](int rank) {
-    curvis_ctx *ctx = make_ctx(a.device + rank, c, "video");
+    curvis_ctx *ctx = make_ctx_bare(a.device + rank, "video");
+    if (use_rccl) {
+      if (rank == 0) upload_skies(ctx, c, "video");
+      check(curvis_ctx_bcast_skies(ctx, comms[rank], 0), ctx, "video");
+    } else {
+      upload_skies(ctx, c, "video");
+    }
     std::vector<size_t> mine;
     for (size_t k = (size_t)rank; k < n_frames; k += (size_t)a.devices) mine.push_back(k);
     std::vector<curvis_camera> bc;
@@ -737,6 +770,7 @@ int video_main(const Args &a) {
   std::vector<std::thread> th;
   for (int r = 0; r < a.devices; ++r) th.emplace_back(worker, r);
   for (auto &t : th) t.join();
+  for (ncclComm_t cm : comms) ncclCommDestroy(cm);
   writers.finish();
   if (stats_f) std::fclose(stats_f);
   if (failed) return 1;

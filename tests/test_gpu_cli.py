@@ -106,3 +106,23 @@ def test_video_off_by_one_panics_like_the_reference(scene_files):
     assert r.returncode == 101, (r.returncode, r.stderr)
     assert "index out of bounds" in r.stderr
     assert sorted(os.listdir(out / "tmp")) == ["frame_0.png", "frame_1.png", "frame_2.png"]
+
+
+def test_video_rccl_sky_broadcast_path(scene_files):
+    """--sky-broadcast rccl (the multi-GPU default) forced on the single GPU: rank 0 uploads, the textures
+    go through ncclBroadcast (curvis_ctx_bcast_skies); frames must equal those of the upload path."""
+    d, sp, sn = scene_files
+    orbit = paths.path_file("path_orbit.csv")
+    (d / "vid3.toml").write_text('video_name = "v"\nframe_rate = 0.1\nfilepath_to_camera_path = "%s"\n' % orbit)
+    outs = []
+    for tag, env_extra, flag in (("rccl", {"CURVIS_FORCE_RCCL": "1"}, "rccl"), ("upload", {}, "upload")):
+        out = d / ("out_vid_" + tag)
+        out.mkdir()
+        r = run("video", d / "pos.png", d / "neg.png", out, "-v", d / "vid3.toml", "-s", d / "sim.toml", "-c", d / "cam.toml",
+                "--sky-broadcast", flag, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, r.stderr
+        outs.append(out)
+    names = sorted(os.listdir(outs[0] / "tmp"))
+    assert names == sorted(os.listdir(outs[1] / "tmp")) and len(names) == 6
+    for n in names:
+        assert np.array_equal(pngio.read_png(outs[0] / "tmp" / n), pngio.read_png(outs[1] / "tmp" / n))
