@@ -11,7 +11,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # test infrastructure (oracle + host twin) is (re)built on demand; both are plain gcc builds
+    # product (HIP library + curvis binary; hipcc cross-compiles without a GPU) and test infrastructure
+    # (oracle + host twin, plain gcc) are (re)built on demand -- no-ops when up to date
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "curvis_amd", "csrc")], check=True)
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "host_twin")], check=True)
 
