@@ -211,6 +211,8 @@ def main():
                 "shade_kernel_ms_avg": round(total_shade_ms / n_launches, 4),
                 "traffic": traffic,
                 "traffic_detail": traffic_note,
+                "valu_busy_pmc": traffic_note.get("valu_busy") if isinstance(traffic_note, dict) else None,
+                "valu_instr_per_wave_step_pmc": traffic_note.get("valu_instr_per_wave_step") if isinstance(traffic_note, dict) else None,
                 "hbm": {"achieved": round(hbm_gbps, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(hbm_gbps / HBM_PEAK_GBPS, 8),
                         "note": "7 B/ray algorithmic; the loop is register-resident, HBM fraction is ~0 by construction"},

@@ -45,6 +45,13 @@ traffic = {
                   "gfx950 note in MI355X_MICROARCH.md), profiles/%s_pmc_*.csv" % rnd,
     }
 }
+_gui = sq[(kern, "GRBM_GUI_ACTIVE")] / 8.0
+traffic["ellis_1920x1080_cap4096_variant1"].update({
+    "valu_busy": round(4 * sq[(kern, "SQ_ACTIVE_INST_VALU")] / (1024 * _gui), 4),
+    "valu_instr_per_wave_step": round(sq[(kern, "SQ_INSTS_VALU")] / ws, 1),
+    "salu_instr_per_wave_step": round(sq[(kern, "SQ_INSTS_SALU")] / ws, 1),
+    "shader_cycles_per_frame": int(_gui),
+})
 json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 
 for kind in ("sq", "fetch", "write"):
