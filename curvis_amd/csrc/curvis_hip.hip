@@ -86,6 +86,16 @@ struct ShadeParams {
   unsigned long long *counters;
 };
 
+/* Per-workgroup LDS copy of the sin/cos table (4 KiB): the Euler loop evaluates sincos once per step per
+ * lane with a data-dependent index; two ds_read_b128 from LDS instead of divergent __constant__ loads. */
+__device__ __forceinline__ cv_sc_tab_t load_sincos_table(double (*lds)[4]) {
+  const double *src = &cv_sc_table_dev[0][0];
+  double *dst = &lds[0][0];
+  for (unsigned i = threadIdx.x; i < 512u; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  return lds;
+}
+
 /* ray id -> (frame, pixel).  Rays are numbered by 8x8 pixel tiles so the 64 rays a wave draws
  * together are spatial neighbours (similar step counts, neighbouring texels). */
 __device__ __forceinline__ bool decode_ray(const IntegrateParams &P, unsigned long long id, unsigned &frame,
@@ -118,11 +128,11 @@ __device__ __forceinline__ bool ray_escaped(double l, double R) { return __built
 __device__ __forceinline__ int escape_code(double l) { return l > 0.0 ? cvk::CODE_POS : cvk::CODE_NEG; }
 
 template <int KIND, bool PHI, bool FAST>
-__device__ __forceinline__ void one_step(const IntegrateParams &P, cvk::Ray &q, bool lane_ok) {
+__device__ __forceinline__ void one_step(const cvk::MetricParams &M, double delta, cvk::Ray &q, bool lane_ok) {
   if (FAST)
-    cvk::ray_step_fast<KIND, PHI>(P.metric, q, P.delta, lane_ok);
+    cvk::ray_step_fast<KIND, PHI>(M, q, delta, lane_ok);
   else
-    cvk::ray_step<KIND, PHI>(P.metric, q, P.delta);
+    cvk::ray_step<KIND, PHI>(M, q, delta);
 }
 
 __device__ __forceinline__ void flush_steps(const IntegrateParams &P, unsigned long long steps, unsigned rays) {
@@ -176,6 +186,9 @@ __device__ __forceinline__ void flush_escape_counts(unsigned long long *counters
  * `refill_threshold` lanes are free; terminated rays are stored together at that point. */
 template <int KIND, bool PHI, bool FAST>
 __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams P) {
+  __shared__ double s_sc[128][4];
+  cvk::MetricParams M = P.metric;
+  M.T = load_sincos_table(s_sc);
   const unsigned lane = threadIdx.x & 63u;
   cvk::Ray q;
   q.l = q.th = q.ph = q.p1 = q.p2 = q.p3 = q.p3sq = 0.0;
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
         if (need && mine < P.total_rays) {
           unsigned frame, px, py;
           if (decode_ray(P, mine, frame, px, py)) {
-            cvk::ray_init<KIND>(P.metric, P.cams[frame], px, py, q);
+            cvk::ray_init<KIND>(M, P.cams[frame], px, py, q);
             slot = (size_t)frame * P.W * P.H + (size_t)py * P.W + px;
             steps = 0;
             lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
     const int thr = dry ? 64 : P.refill_threshold;
     for (;;) { /* integrate until `thr` lanes are free */
       if (active) {
-        one_step<KIND, PHI, FAST>(P, q, lane_ok);
+        one_step<KIND, PHI, FAST>(M, P.delta, q, lane_ok);
         ++steps;
         const bool esc = ray_escaped(q.l, P.max_radius);
         if (esc | (steps >= P.max_iter)) { /* loop bound of src/systems.rs:126 */
@@ -255,6 +268,9 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
  * free in occupancy and removes ~200 MB of HBM traffic and one launch per frame. */
 template <int KIND, bool PHI, bool FAST, bool FUSED>
 __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) {
+  __shared__ double s_sc[128][4];
+  cvk::MetricParams M = P.metric;
+  M.T = load_sincos_table(s_sc);
   const unsigned long long id = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long st_steps = 0;
   unsigned st_rays = 0;
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
   unsigned steps = 0;
   int code = cvk::CODE_NONE;
   if (id < P.total_rays && decode_ray(P, id, frame, px, py)) {
-    cvk::ray_init<KIND>(P.metric, P.cams[frame], px, py, q);
+    cvk::ray_init<KIND>(M, P.cams[frame], px, py, q);
     lane_ok_w = FAST && P.fast_ok && cvk::ray_fast_ok(q);
     valid = true;
     active = P.max_iter != 0;
@@ -278,7 +294,7 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
   while (__any(active)) {
     ++k;
     if (active) {
-      one_step<KIND, PHI, FAST>(P, q, lane_ok_w);
+      one_step<KIND, PHI, FAST>(M, P.delta, q, lane_ok_w);
       if (ray_escaped(q.l, P.max_radius)) {
         active = false;
         steps = k;
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
   if (valid) {
     if (FUSED) {
       unsigned tx, ty;
-      const unsigned texel = shade_ray<KIND>(P.metric, P.sky, q, code, tx, ty, oob);
+      const unsigned texel = shade_ray<KIND>(M, P.sky, q, code, tx, ty, oob);
       unsigned char *dst = P.fb + slot * 3;
       dst[0] = (unsigned char)(texel & 0xFF);
       dst[1] = (unsigned char)((texel >> 8) & 0xFF);
@@ -328,7 +344,9 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams P) {
     const int code = P.store.code[o];
     const unsigned steps = P.store.steps[o];
     unsigned tx, ty;
-    const unsigned texel = shade_ray<KIND>(P.metric, P.sky, q, code, tx, ty, oob);
+    cvk::MetricParams M = P.metric;
+    M.T = cv_sc_table();
+    const unsigned texel = shade_ray<KIND>(M, P.sky, q, code, tx, ty, oob);
     unsigned char *dst = P.fb + o * 3;
     dst[0] = (unsigned char)(texel & 0xFF);
     dst[1] = (unsigned char)((texel >> 8) & 0xFF);
@@ -376,6 +394,9 @@ struct EscapeAngleParams {
  * with tangent direction (cos a, 0, sin a), Euler loop WITH phi, world direction, angle. */
 template <int KIND, bool FAST>
 __global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParams P) {
+  __shared__ double s_sc[128][4];
+  cvk::MetricParams M = P.metric;
+  M.T = load_sincos_table(s_sc);
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   const double alpha = P.alpha[i];
@@ -383,15 +404,15 @@ __global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParam
   cv_sincos(alpha, &sa, &ca);
   const double pos[4] = {0.0, P.l_cam[i], CV_PI / 2.0, 0.0};
   cvk::Ray q;
-  cvk::ray_init_dir<KIND>(P.metric, pos, ca, 0.0, sa, q);
+  cvk::ray_init_dir<KIND>(M, pos, ca, 0.0, sa, q);
   const bool lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
   unsigned steps = 0;
   int code = cvk::CODE_NONE;
   while (steps < P.max_iter) {
     if (FAST)
-      cvk::ray_step_fast<KIND, true>(P.metric, q, P.delta, lane_ok);
+      cvk::ray_step_fast<KIND, true>(M, q, P.delta, lane_ok);
     else
-      cvk::ray_step<KIND, true>(P.metric, q, P.delta);
+      cvk::ray_step<KIND, true>(M, q, P.delta);
     ++steps;
     if (q.l > P.max_radius) {
       code = cvk::CODE_POS;
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParam
   double angle = nan, space = nan;
   int status = code;
   if (code != cvk::CODE_NONE) {
-    if (cvk::escape_angle_of<KIND>(P.metric, q, angle)) {
+    if (cvk::escape_angle_of<KIND>(M, q, angle)) {
       space = (code == cvk::CODE_POS) ? 1.0 : -1.0;
     } else {
       angle = nan;
@@ -491,6 +512,8 @@ template <int KIND>
 __global__ __launch_bounds__(64) void trajectory_kernel(const TrajectoryParams P) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
+  cvk::MetricParams M = P.metric;
+  M.T = cv_sc_table();
   double t = P.x0[4 * i], pt = P.p0[4 * i];
   cvk::Ray q;
   q.l = P.x0[4 * i + 1];
@@ -512,7 +535,7 @@ __global__ __launch_bounds__(64) void trajectory_kernel(const TrajectoryParams P
     o[6] = q.p2;
     o[7] = p3;
     o += 8;
-    cvk::ray_step<KIND, true>(P.metric, q, P.delta);
+    cvk::ray_step<KIND, true>(M, q, P.delta);
     t = t + (pt * (1.0 / -1.0)) * P.delta; /* dx0 = p0 * g00.powi(-1) */
     pt = pt + 0.0 * P.delta;
     p3 = p3 + 0.0 * P.delta;
@@ -650,6 +673,7 @@ cvk::MetricParams make_metric(const curvis_metric &m) {
   M.pim = CV_PI * m.m;
   M.inv_pim = 1.0 / M.pim;
   M.two_o_pi = 2.0 / CV_PI;
+  M.T = cv_sc_table(); /* host table; kernels substitute their own copy (LDS or __constant__) */
   return M;
 }
 

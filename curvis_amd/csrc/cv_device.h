@@ -40,6 +40,8 @@ struct MetricParams {
   double inv_pim;  /* RN(1/(PI*m)) computed on the host: lets the fast step divide by the constant with the
                       three-instruction Markstein sequence (exact for a correctly rounded reciprocal) */
   double two_o_pi; /* 2.0/PI (src/metrics.rs:481) */
+  cv_sc_tab_t T;   /* sin/cos table the per-ray functions read: LDS copy in the hot kernels, cv_sc_table()
+                      (host static / device __constant__) everywhere else */
 };
 
 /* r(l), r^2(l), r'(l): src/metrics.rs:417-421 / 467-485 / 501-505.
@@ -118,7 +120,7 @@ CV_HD void ray_step_core(const MetricParams &M, Ray &q, double delta, double s, 
 template <int KIND, bool PHI>
 CV_HD void ray_step(const MetricParams &M, Ray &q, double delta) {
   double s, c;
-  cv_sincos(q.th, &s, &c);
+  cv_sincos_t(q.th, M.T, &s, &c);
   ray_step_core<KIND, PHI>(M, q, delta, s, c);
 }
 
@@ -206,7 +208,7 @@ CV_HD bool metric_fast_ok(int kind, const MetricParams &M, double max_radius) {
 template <int KIND, bool PHI>
 CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_ok) {
   double s, c;
-  cv_sincos(q.th, &s, &c);
+  cv_sincos_t(q.th, M.T, &s, &c);
   /* guard (branch-free): sin(theta) and l finite, non-zero, far from the exponent limits.  cos(theta)
    * needs no test of its own: it is finite iff sin(theta) is, and the cosine of a double is never
    * zero or subnormal. */
@@ -290,7 +292,7 @@ CV_HD void ray_init(const MetricParams &M, const CameraParams &C, unsigned px, u
   q.ph = C.pos[3];
   q.p1 = d0;
   q.p2 = d1 * r;
-  q.p3 = d2 * r * cv_sin(C.pos[2]);
+  q.p3 = d2 * r * cv_sin_t(C.pos[2], M.T);
   q.p3sq = q.p3 * q.p3;
 }
 
@@ -305,7 +307,7 @@ CV_HD void ray_init_dir(const MetricParams &M, const double pos[4], double dx, d
   q.ph = pos[3];
   q.p1 = d0;
   q.p2 = d1 * r;
-  q.p3 = d2 * r * cv_sin(pos[2]);
+  q.p3 = d2 * r * cv_sin_t(pos[2], M.T);
   q.p3sq = q.p3 * q.p3;
 }
 
@@ -315,7 +317,7 @@ template <int KIND>
 CV_HD void ray_direction(const MetricParams &M, const Ray &q, double &d0, double &d1, double &d2) {
   double r, r2, rd;
   metric_eval<KIND>(M, q.l, r, r2, rd);
-  const double s = cv_sin(q.th);
+  const double s = cv_sin_t(q.th, M.T);
   const double g22c = 1.0 / r2;
   const double g33c = 1.0 / (r2 * (s * s));
   const double v1 = q.p1; /* * 1.0 */

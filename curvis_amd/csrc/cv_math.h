@@ -17,11 +17,11 @@
  * results; tests/test_cv_math.py checks that on the GPU and checks the accuracy
  * (< 1 ulp) against mpmath.
  *
- * Algorithms: argument reduction and polynomial/rational kernels follow the
- * classical Sun fdlibm / FreeBSD msun designs (Cody-Waite pi/2 split in 33-bit
- * pieces, K.C. Ng's kernels; coefficients are the published minimax values),
- * evaluated here with fma-Horner; huge-argument reduction is a 192-bit integer
- * Payne-Hanek written for 64-bit multiplies (v_mul_hi_u32 pairs on gfx950).
+ * Algorithms: sin/cos are table-driven (pi/64 grid of double-double values +
+ * degree-3 Taylor kernels, three-piece Cody-Waite reduction); atan/acos/log and the
+ * pi/2 reduction of unusual arguments follow the classical Sun fdlibm / FreeBSD msun
+ * designs (published minimax coefficients) evaluated with fma-Horner; huge-argument
+ * reduction is a 192-bit integer Payne-Hanek written for 64-bit multiplies.
  *
  * The header is C99 / C++ / HIP clean.  All functions are `static inline`.
  */
@@ -29,6 +29,8 @@
 #define CURVIS_CV_MATH_H
 
 #include <stdint.h>
+
+#include "cv_sincos_table.h"
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define CV_HD __host__ __device__ static inline
@@ -113,40 +115,6 @@ CV_HD double cv_div_nr(double n, double d) {
 /* ------------------------------------------------------------------------- */
 /* sin / cos                                                                  */
 /* ------------------------------------------------------------------------- */
-
-/* sin on [-pi/4, pi/4] of the head/tail pair x+y  (|y| <= ulp(x)/2). */
-CV_HD double cv_ksin(double x, double y) {
-  const double S1 = -1.66666666666666324348e-01, /* 0xBFC5555555555549 */
-      S2 = 8.33333333332248946124e-03,           /* 0x3F8111111110F8A6 */
-      S3 = -1.98412698298579493134e-04,          /* 0xBF2A01A019C161D5 */
-      S4 = 2.75573137070700676789e-06,           /* 0x3EC71DE357B1FE7D */
-      S5 = -2.50507602534068634195e-08,          /* 0xBE5AE5E68A2B9CEB */
-      S6 = 1.58969099521155010221e-10;           /* 0x3DE5D93A5ACFD57C */
-  double z = x * x;
-  double v = z * x;
-  double r = cv_fma_c(z, cv_fma_c(z, cv_fma_c(z, cv_fma_c(z, S6, S5), S4), S3), S2);
-  /* x - ((z*(y/2 - v*r) - y) - v*S1) */
-  double t = CV_FMA(-v, r, 0.5 * y);
-  double u = CV_FMA(z, t, -y);
-  return x - CV_FMA(-v, S1, u);
-}
-
-/* cos on [-pi/4, pi/4] of the head/tail pair x+y. */
-CV_HD double cv_kcos(double x, double y) {
-  const double C1 = 4.16666666666666019037e-02, /* 0x3FA555555555554C */
-      C2 = -1.38888888888741095749e-03,         /* 0xBF56C16C16C15177 */
-      C3 = 2.48015872894767294178e-05,          /* 0x3EFA01A019CB1590 */
-      C4 = -2.75573143513906633035e-07,         /* 0xBE927E4F809C52AD */
-      C5 = 2.08757232129817482790e-09,          /* 0x3E21EE9EBDB4B1C4 */
-      C6 = -1.13596475577881948265e-11;         /* 0xBDA8FAE9BE8838D4 */
-  double z = x * x;
-  double r = z * cv_fma_c(z, cv_fma_c(z, cv_fma_c(z, cv_fma_c(z, cv_fma_c(z, C6, C5), C4), C3), C2), C1);
-  double hz = 0.5 * z;
-  double w = 1.0 - hz;
-  /* w + (((1-w)-hz) + (z*r - x*y)) */
-  double e = CV_FMA(z, r, -(x * y));
-  return w + (((1.0 - w) - hz) + e);
-}
 
 /* 2/pi: 64 zero bits, then 1216 fractional bits (tools/gen_math_tables.py). */
 #if defined(__HIPCC__) || defined(__HIP__)
@@ -305,56 +273,105 @@ CV_HD int cv_rem_pio2(double x, double *y0, double *y1) {
   return ((int)fn) & 3;
 }
 
-/* sin and cos of x together.
+/* sin(K*pi/64), cos(K*pi/64), K = 0..127, as double-double {S_hi, S_lo, C_hi, C_lo} (cv_sincos_table.h).
+ * Host code reads the static copy; device code reads the __constant__ copy unless the caller passes its
+ * own pointer (the hot kernels keep a copy in LDS: 4 KiB per workgroup, two ds_read_b128 per evaluation). */
+typedef const double (*cv_sc_tab_t)[4];
+#if defined(__HIPCC__) || defined(__HIP__)
+__device__ __constant__ static const double cv_sc_table_dev[128][4] = {CV_SC_TABLE_ROWS};
+#endif
+static const double cv_sc_table_host[128][4] = {CV_SC_TABLE_ROWS};
+CV_HD cv_sc_tab_t cv_sc_table(void) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return cv_sc_table_dev;
+#else
+  return cv_sc_table_host;
+#endif
+}
+
+/* sin/cos of K*pi/64 + (y + yl), |y| <= pi/128:
+ *   sin = S + [ C*y + ( S_lo + S*(cos y - 1) + C*(sin y - y) ) ],   cos = C + [ -S*y + ( C_lo + C*(cos y - 1) - S*(sin y - y) ) ]
+ * with sin y - y = y^3 (s1 + s2 z + s3 z^2) + yl and cos y - 1 = z (c1 + c2 z + c3 z^2) - y*yl, z = y^2 (Taylor
+ * coefficients: truncation < 2^-61 on this interval).  The bracket is evaluated with one fma, so each
+ * result carries two roundings; the error is < 0.6 ulp except where the result is much smaller than pi/64
+ * times its partner (next to the zeros of sin resp. cos), where it stays below 1 ulp. */
+CV_HD void cv_sincos_core(int K, double y, double yl, cv_sc_tab_t T, double *sn, double *cs) {
+  const double Sh = T[K][0], Sl = T[K][1], Ch = T[K][2], Cl = T[K][3];
+  const double z = y * y;
+  const double ps = cv_fma_c(z, cv_fma_c(z, -1.98412698412698412698e-04, 8.33333333333333321769e-03), -1.66666666666666657415e-01);
+  const double pc = cv_fma_c(z, cv_fma_c(z, -1.38888888888888894189e-03, 4.16666666666666643537e-02), -0.5);
+  const double yz = y * z;
+  const double sl = CV_FMA(yz, ps, yl);
+  const double cm = CV_FMA(-y, yl, z * pc);
+  double e = CV_FMA(Sh, cm, Sl);
+  e = CV_FMA(Ch, sl, e);
+  *sn = Sh + CV_FMA(Ch, y, e);
+  double f = CV_FMA(Ch, cm, Cl);
+  f = CV_FMA(-Sh, sl, f);
+  *cs = Ch + CV_FMA(-Sh, y, f);
+}
+
+/* sin and cos of x together, table-driven.
  *
- * Main path (|x| < 1024 and x not within 2^-20 of a multiple of pi/2), branch-free:
- *   k  = rint(x * 2/pi)
- *   r1 = fma(-k, P1, x)     exact: x - k*P1 is a multiple of 2^-53 below 1 in magnitude
- *   t  = fma(-k, P2, r1)    head of the reduced argument
- *   u  = r1 - t             exact (|u| <= 2^-44, a multiple of ulp(t) >= 2^-72)
- *   lo = fma(-k, P3, fma(-k, P2, u))    tail: rounding error of t, plus the third piece of pi/2
- * with pi/2 = P1 + P2 + P3 to 2^-161.  Everything else (tiny, huge, non-finite, or deeply
- * cancelling arguments such as theta == fl(pi/2), which the equatorial rays hold for ever) takes
- * cv_rem_pio2, the fdlibm-style iterative / Payne-Hanek reduction.  Both paths feed the same
- * kernels; which path an argument takes is a function of the argument alone, so host and device
- * agree bit for bit. */
-CV_HD void cv_sincos(double x, double *sn, double *cs) {
-  const double INVPIO2 = 6.36619772367581382433e-01; /* 0x3FE45F306DC9C883 */
-  const double P1 = 1.57079632679489655800e+00;      /* 0x3FF921FB54442D18 */
-  const double P2 = 6.12323399573676603587e-17;      /* 0x3C91A62633145C07 */
-  const double P3 = -1.4973849048591698e-33;         /* 0xB91F1976B7ED8FBC */
-  const double k = CV_RINT(x * INVPIO2);
-  const double r1 = CV_FMA(-k, P1, x);
-  const double t = CV_FMA(-k, P2, r1);
-  double y0, y1;
-  int n;
+ * Main path (|x| < 1024 and x not within 2^-20 of a multiple of pi/64), branch-free:
+ *   k  = rint(x * 64/pi)                     |k| < 2^15
+ *   r1 = fma(-k, Q1, x)                      exact: Q1 has 38 bits, the difference fits 53 bits
+ *   t  = fma(-k, Q2, r1)                     head of the reduced argument, |t| <= pi/128
+ *   u  = r1 - t                              exact (|u| < 2^-27, a multiple of ulp(t) >= 2^-72)
+ *   tl = fma(-k, Q3, fma(-k, Q2, u))         tail: rounding error of t plus the third piece of pi/64
+ * with pi/64 = Q1 + Q2 + Q3 to 2^-134.  Every other argument (tiny, huge, non-finite, or deeply cancelling
+ * such as theta == fl(pi/2), which the equatorial rays hold for ever) is first reduced modulo pi/2 by
+ * cv_rem_pio2 (fdlibm-style iterations / 192-bit Payne-Hanek) and then by the same three-piece step with
+ * |k| <= 17.  Which path an argument takes is a function of the argument alone, and both paths end in
+ * cv_sincos_core, so host and device agree bit for bit. */
+CV_HD void cv_sincos_t(double x, cv_sc_tab_t T, double *sn, double *cs) {
+  const double k = CV_RINT(x * CV_64OPI);
+  const double r1 = CV_FMA(-k, CV_PIO64_1, x);
+  const double t = CV_FMA(-k, CV_PIO64_2, r1);
+  double y, yl;
+  int K;
   if (CV_FABS(x) < 1024.0 && CV_FABS(t) >= 9.5367431640625e-07 /* 2^-20 */) {
     const double u = r1 - t;
-    y0 = t;
-    y1 = CV_FMA(-k, P3, CV_FMA(-k, P2, u));
-    n = (int)k;
+    y = t;
+    yl = CV_FMA(-k, CV_PIO64_3, CV_FMA(-k, CV_PIO64_2, u));
+    K = (int)k;
   } else {
     const uint32_t ix = cv_hi(x) & 0x7fffffffu;
     if (ix >= 0x7ff00000u) { /* inf / nan */
       *sn = *cs = x - x;
       return;
     }
+    if (ix < 0x3e400000u) { /* |x| < 2^-27: sin x = x (keeps the sign of zero), cos x = 1 */
+      *sn = x;
+      *cs = 1.0;
+      return;
+    }
+    double y0, y1;
+    int n = 0;
     if (ix <= 0x3fe921fbu) { /* |x| <= ~pi/4 */
       y0 = x;
       y1 = 0.0;
-      n = 0;
     } else {
       n = cv_rem_pio2(x, &y0, &y1);
     }
+    const double k2 = CV_RINT(y0 * CV_64OPI);
+    const double a1 = CV_FMA(-k2, CV_PIO64_1, y0);
+    const double t2 = CV_FMA(-k2, CV_PIO64_2, a1);
+    const double u2 = a1 - t2;
+    y = t2;
+    yl = CV_FMA(-k2, CV_PIO64_3, CV_FMA(-k2, CV_PIO64_2, u2)) + y1;
+    K = n * 32 + (int)k2;
   }
-  const double s = cv_ksin(y0, y1);
-  const double c = cv_kcos(y0, y1);
-  const double so = (n & 1) ? c : s;
-  const double co = (n & 1) ? s : c;
-  *sn = cv_from_bits(cv_bits(so) ^ ((uint64_t)(n & 2) << 62));
-  *cs = cv_from_bits(cv_bits(co) ^ ((uint64_t)((n + 1) & 2) << 62));
+  cv_sincos_core(K & 127, y, yl, T, sn, cs);
 }
 
+CV_HD void cv_sincos(double x, double *sn, double *cs) { cv_sincos_t(x, cv_sc_table(), sn, cs); }
+
+CV_HD double cv_sin_t(double x, cv_sc_tab_t T) {
+  double s, c;
+  cv_sincos_t(x, T, &s, &c);
+  return s;
+}
 CV_HD double cv_sin(double x) {
   double s, c;
   cv_sincos(x, &s, &c);

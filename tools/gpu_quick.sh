@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error|assert" | tail -15 > $OUT/pytest_gpu.log
 for v in 1 0; do python bench.py --steps 10 --warmup 2 --variant $v --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/q_bench_v${v}.json; done
 python bench.py --steps 5 --warmup 2 --metric interstellar --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/q_bench_interstellar.json
 python bench.py --steps 10 --warmup 2 --download --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/q_bench_download.json
