@@ -88,12 +88,36 @@ struct ShadeParams {
 
 /* Per-workgroup LDS copy of the sin/cos table (4 KiB): the Euler loop evaluates sincos once per step per
  * lane with a data-dependent index; two ds_read_b128 from LDS instead of divergent __constant__ loads. */
-__device__ __forceinline__ cv_sc_tab_t load_sincos_table(double (*lds)[4]) {
+template <int KIND>
+struct MathTablesLds {
+  static constexpr unsigned LOG_ROWS = (KIND == cvk::METRIC_INTERSTELLAR) ? 256u : 1u;
+  double sc[128][4];
+  static constexpr unsigned ATAN_ROWS = (KIND == cvk::METRIC_INTERSTELLAR) ? (unsigned)CV_ATAN_TABLE_N : 1u;
+  double lg[LOG_ROWS][3]; /* only the Interstellar metric evaluates a logarithm and an arc tangent per step */
+  double at[ATAN_ROWS][8];
+};
+
+/* copy the elementary-function tables of cv_math.h into LDS and point the metric at them */
+template <int KIND>
+__device__ __forceinline__ void load_math_tables(MathTablesLds<KIND> &L, cvk::MetricParams &M) {
   const double *src = &cv_sc_table_dev[0][0];
-  double *dst = &lds[0][0];
+  double *dst = &L.sc[0][0];
   for (unsigned i = threadIdx.x; i < 512u; i += blockDim.x) dst[i] = src[i];
+  M.T = L.sc;
+  if (KIND == cvk::METRIC_INTERSTELLAR) {
+    const double *lsrc = &cv_log_table_dev[0][0];
+    double *ldst = &L.lg[0][0];
+    for (unsigned i = threadIdx.x; i < 768u; i += blockDim.x) ldst[i] = lsrc[i];
+    M.LT = L.lg;
+    const double *asrc = &cv_atan_table_dev[0][0];
+    double *adst = &L.at[0][0];
+    for (unsigned i = threadIdx.x; i < 8u * CV_ATAN_TABLE_N; i += blockDim.x) adst[i] = asrc[i];
+    M.AT = L.at;
+  } else {
+    M.LT = cv_log_table();
+    M.AT = cv_atan_table();
+  }
   __syncthreads();
-  return lds;
 }
 
 /* ray id -> (frame, pixel).  Rays are numbered by 8x8 pixel tiles so the 64 rays a wave draws
@@ -186,9 +210,9 @@ __device__ __forceinline__ void flush_escape_counts(unsigned long long *counters
  * `refill_threshold` lanes are free; terminated rays are stored together at that point. */
 template <int KIND, bool PHI, bool FAST>
 __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams P) {
-  __shared__ double s_sc[128][4];
+  __shared__ MathTablesLds<KIND> s_tab;
   cvk::MetricParams M = P.metric;
-  M.T = load_sincos_table(s_sc);
+  load_math_tables<KIND>(s_tab, M);
   const unsigned lane = threadIdx.x & 63u;
   cvk::Ray q;
   q.l = q.th = q.ph = q.p1 = q.p2 = q.p3 = q.p3sq = 0.0;
@@ -268,9 +292,9 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
  * free in occupancy and removes ~200 MB of HBM traffic and one launch per frame. */
 template <int KIND, bool PHI, bool FAST, bool FUSED>
 __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) {
-  __shared__ double s_sc[128][4];
+  __shared__ MathTablesLds<KIND> s_tab;
   cvk::MetricParams M = P.metric;
-  M.T = load_sincos_table(s_sc);
+  load_math_tables<KIND>(s_tab, M);
   const unsigned long long id = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long st_steps = 0;
   unsigned st_rays = 0;
@@ -346,6 +370,8 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams P) {
     unsigned tx, ty;
     cvk::MetricParams M = P.metric;
     M.T = cv_sc_table();
+    M.LT = cv_log_table();
+    M.AT = cv_atan_table();
     const unsigned texel = shade_ray<KIND>(M, P.sky, q, code, tx, ty, oob);
     unsigned char *dst = P.fb + o * 3;
     dst[0] = (unsigned char)(texel & 0xFF);
@@ -394,9 +420,9 @@ struct EscapeAngleParams {
  * with tangent direction (cos a, 0, sin a), Euler loop WITH phi, world direction, angle. */
 template <int KIND, bool FAST>
 __global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParams P) {
-  __shared__ double s_sc[128][4];
+  __shared__ MathTablesLds<KIND> s_tab;
   cvk::MetricParams M = P.metric;
-  M.T = load_sincos_table(s_sc);
+  load_math_tables<KIND>(s_tab, M);
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
   const double alpha = P.alpha[i];
@@ -514,6 +540,8 @@ __global__ __launch_bounds__(64) void trajectory_kernel(const TrajectoryParams P
   if (i >= P.n) return;
   cvk::MetricParams M = P.metric;
   M.T = cv_sc_table();
+  M.LT = cv_log_table();
+  M.AT = cv_atan_table();
   double t = P.x0[4 * i], pt = P.p0[4 * i];
   cvk::Ray q;
   q.l = P.x0[4 * i + 1];
@@ -673,7 +701,9 @@ cvk::MetricParams make_metric(const curvis_metric &m) {
   M.pim = CV_PI * m.m;
   M.inv_pim = 1.0 / M.pim;
   M.two_o_pi = 2.0 / CV_PI;
-  M.T = cv_sc_table(); /* host table; kernels substitute their own copy (LDS or __constant__) */
+  M.T = cv_sc_table(); /* host tables; kernels substitute their own copies (LDS or __constant__) */
+  M.LT = cv_log_table();
+  M.AT = cv_atan_table();
   return M;
 }
 

@@ -42,6 +42,8 @@ struct MetricParams {
   double two_o_pi; /* 2.0/PI (src/metrics.rs:481) */
   cv_sc_tab_t T;   /* sin/cos table the per-ray functions read: LDS copy in the hot kernels, cv_sc_table()
                       (host static / device __constant__) everywhere else */
+  cv_log_tab_t LT; /* same for cv_log_t and cv_atan_t (Interstellar only) */
+  cv_atan_tab_t AT;
 };
 
 /* r(l), r^2(l), r'(l): src/metrics.rs:417-421 / 467-485 / 501-505.
@@ -63,8 +65,8 @@ CV_HD void metric_eval(const MetricParams &M, double l, double &r, double &r2, d
       } else {
         x = xn / M.pim;
       }
-      double at = cv_atan(x);
-      r = M.rho + M.m * (x * at - cv_log(1.0 + x * x) / 2.0);
+      double at = cv_atan_t(x, M.AT);
+      r = M.rho + M.m * (x * at - cv_log_t(1.0 + x * x, M.LT) / 2.0);
       double sg = (cv_bits(l) >> 63) ? -1.0 : 1.0; /* l.signum(), l != NaN-safe below */
       if (l != l) sg = l;
       rd = M.two_o_pi * sg * at;

@@ -31,6 +31,8 @@
 #include <stdint.h>
 
 #include "cv_sincos_table.h"
+#include "cv_log_table.h"
+#include "cv_atan_table.h"
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define CV_HD __host__ __device__ static inline
@@ -387,7 +389,23 @@ CV_HD double cv_cos(double x) {
 /* atan / atan2                                                               */
 /* ------------------------------------------------------------------------- */
 
-CV_HD double cv_atan(double x) {
+/* rows j = -64..256 of cv_atan_table.h: {X_hi, X_lo, q1..q6} (20.1 KiB).  Host: static copy; device:
+ * __constant__ copy unless the caller passes its own (the Interstellar kernels keep one in LDS). */
+typedef const double (*cv_atan_tab_t)[8];
+#if defined(__HIPCC__) || defined(__HIP__)
+__device__ __constant__ static const double cv_atan_table_dev[CV_ATAN_TABLE_N][8] = {CV_ATAN_TABLE_ROWS};
+#endif
+static const double cv_atan_table_host[CV_ATAN_TABLE_N][8] = {CV_ATAN_TABLE_ROWS};
+CV_HD cv_atan_tab_t cv_atan_table(void) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return cv_atan_table_dev;
+#else
+  return cv_atan_table_host;
+#endif
+}
+
+/* |x| < 0.4375 (odd minimax polynomial, fdlibm coefficients), |x| >= 2^66, NaN */
+CV_HD double cv_atan_edge(double x) {
   const double aT0 = 3.33333333333329318027e-01, /* 0x3FD555555555550D */
       aT1 = -1.99999999998764832476e-01,         /* 0xBFC999999998EBC4 */
       aT2 = 1.42857142725034663711e-01,          /* 0x3FC24924920083FF */
@@ -401,59 +419,42 @@ CV_HD double cv_atan(double x) {
       aT10 = 1.62858201153657823623e-02;         /* 0x3F90AD3AE322DA11 */
   const uint32_t hx = cv_hi(x);
   const uint32_t ix = hx & 0x7fffffffu;
-  const int neg = (int)(hx >> 31);
   if (ix >= 0x44100000u) { /* |x| >= 2^66 */
     if (ix > 0x7ff00000u || (ix == 0x7ff00000u && cv_lo(x) != 0)) return x + x; /* nan */
-    double z = 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
-    return neg ? -z : z;
+    const double z = 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
+    return (hx >> 31) ? -z : z;
   }
-  double hi = 0.0, lo = 0.0, t;
-  int id = -1;
-  if (ix < 0x3fdc0000u) { /* |x| < 0.4375 */
-    if (ix < 0x3e400000u) return x; /* |x| < 2^-27 */
-    t = x;
-  } else {
-    double ax = CV_FABS(x);
-    double num, den;
-    if (ix < 0x3ff30000u) {   /* |x| < 1.1875 */
-      if (ix < 0x3fe60000u) { /* 7/16 <= |x| < 11/16 */
-        id = 0;
-        num = CV_FMA(2.0, ax, -1.0);
-        den = 2.0 + ax;
-        hi = 4.63647609000806093515e-01;
-        lo = 2.26987774529616870924e-17;
-      } else { /* 11/16 <= |x| < 19/16 */
-        id = 1;
-        num = ax - 1.0;
-        den = ax + 1.0;
-        hi = 7.85398163397448278999e-01;
-        lo = 3.06161699786838301793e-17;
-      }
-    } else {
-      if (ix < 0x40038000u) { /* |x| < 2.4375 */
-        id = 2;
-        num = ax - 1.5;
-        den = CV_FMA(1.5, ax, 1.0);
-        hi = 9.82793723247329054082e-01;
-        lo = 1.39033110312309984516e-17;
-      } else { /* 2.4375 <= |x| < 2^66 */
-        id = 3;
-        num = -1.0;
-        den = ax;
-        hi = 1.57079632679489655800e+00;
-        lo = 6.12323399573676603587e-17;
-      }
-    }
-    t = cv_div_nr(num, den); /* |num| <= den, 1 <= den < 2^67 */
-  }
-  double z = t * t;
-  double w = z * z;
-  double s1 = z * cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, aT10, aT8), aT6), aT4), aT2), aT0);
-  double s2 = w * cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, aT9, aT7), aT5), aT3), aT1);
-  if (id < 0) return t - t * (s1 + s2);
-  double r = hi - ((t * (s1 + s2) - lo) - t);
-  return neg ? -r : r;
+  if (ix < 0x3e400000u) return x; /* |x| < 2^-27 */
+  const double z = x * x;
+  const double w = z * z;
+  const double s1 = z * cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, aT10, aT8), aT6), aT4), aT2), aT0);
+  const double s2 = w * cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, aT9, aT7), aT5), aT3), aT1);
+  return x - x * (s1 + s2);
 }
+
+/* atan x, table-driven for 0.4375 <= |x| < 2^66 (branch-free):
+ *   u = |x| < 2 ? |x| : -1/|x|        (correctly rounded reciprocal; u in [-1/2, 0) or [0.4375, 2))
+ *   j = rint(128 u), h = u - j/128    exact, |h| <= 2^-8
+ *   atan|x| = X_j + h (q1 + q2 h + ... + q6 h^2..h^5),   X_j = atan(j/128) (+ pi/2 on the reciprocal branch)
+ * evaluated as X_hi + fma(h, Q, X_lo).  Error: 0.5 ulp of the last addition + the rounding of the reciprocal
+ * (<= 2^-53 u/(1+u^2) <= 0.2 ulp of a result >= atan 2) + Taylor truncation h^7/7 (< 0.03 ulp): < 0.75 ulp. */
+CV_HD double cv_atan_t(double x, cv_atan_tab_t T) {
+  const uint64_t ux = cv_bits(x);
+  const uint32_t hx = (uint32_t)(ux >> 32);
+  const uint32_t ix = hx & 0x7fffffffu;
+  if (ix - 0x3fdc0000u >= 0x44100000u - 0x3fdc0000u) return cv_atan_edge(x);
+  const double ax = cv_from_bits(ux & 0x7fffffffffffffffULL);
+  const double inv = cv_div_nr(-1.0, ax);
+  const double u = (ix >= 0x40000000u) ? inv : ax;
+  const double jf = CV_RINT(u * 128.0);
+  const double h = CV_FMA(jf, -0.0078125, u);
+  const double *R = T[(int)jf + 64];
+  const double Q = cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, R[7], R[6]), R[5]), R[4]), R[3]), R[2]);
+  const double r = R[0] + CV_FMA(h, Q, R[1]);
+  return cv_from_bits(cv_bits(r) | (ux & 0x8000000000000000ULL));
+}
+
+CV_HD double cv_atan(double x) { return cv_atan_t(x, cv_atan_table()); }
 
 CV_HD double cv_atan2(double y, double x) {
   const double PI_LO = 1.2246467991473531772E-16; /* 0x3CA1A62633145C07 */
@@ -581,16 +582,32 @@ CV_HD double cv_acos(double x) {
 /* natural logarithm                                                          */
 /* ------------------------------------------------------------------------- */
 
-CV_HD double cv_log(double x) {
+/* {invc, logc_hi, logc_lo} per 1/256-wide slice of [1, 2) (cv_log_table.h).  Host code reads the static
+ * copy, device code the __constant__ copy unless the caller passes its own (the Interstellar kernels keep
+ * one in LDS: 6 KiB per workgroup). */
+typedef const double (*cv_log_tab_t)[3];
+#if defined(__HIPCC__) || defined(__HIP__)
+__device__ __constant__ static const double cv_log_table_dev[256][3] = {CV_LOG_TABLE_ROWS};
+#endif
+static const double cv_log_table_host[256][3] = {CV_LOG_TABLE_ROWS};
+CV_HD cv_log_tab_t cv_log_table(void) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return cv_log_table_dev;
+#else
+  return cv_log_table_host;
+#endif
+}
+
+/* log x, table-driven.  x = 2^k z, z in [1, 2); i = top 8 mantissa bits; c = 1/invc_i is close to z:
+ *   r  = fma(z, invc, -1)             exact (invc is a multiple of 2^-9 and |r| <= 2^-8)
+ *   w  = k*LN2_HI + logc_hi           exact (both multiples of 2^-32)
+ *   hi + lo = w + r                   Fast2Sum (w == 0 or |w| >= |r|, checked by the table generator)
+ *   log x = hi + (lo + k*LN2_LO + logc_lo + r^2 (-1/2 + r/3 - ... + r^5/7))
+ * Taylor truncation < 2^-59 relative even on the slice next to 1 (invc = 1, w = 0, log x = r + ...), so the
+ * error is 0.5 ulp of the final addition plus ~0.02 ulp. */
+CV_HD double cv_log_t(double x, cv_log_tab_t T) {
   const double LN2_HI = 6.93147180369123816490e-01, /* 0x3FE62E42FEE00000 */
-      LN2_LO = 1.90821492927058770002e-10,          /* 0x3DEA39EF35793C76 */
-      Lg1 = 6.666666666666735130e-01,               /* 0x3FE5555555555593 */
-      Lg2 = 3.999999999940941908e-01,               /* 0x3FD999999997FA04 */
-      Lg3 = 2.857142874366239149e-01,               /* 0x3FD2492494229359 */
-      Lg4 = 2.222219843214978396e-01,               /* 0x3FCC71C51D8E78AF */
-      Lg5 = 1.818357216161805012e-01,               /* 0x3FC7466496CB03DE */
-      Lg6 = 1.531383769920937332e-01,               /* 0x3FC39A09D078C69F */
-      Lg7 = 1.479819860511658591e-01;               /* 0x3FC2F112DF3E5244 */
+      LN2_LO = 1.90821492927058770002e-10;          /* 0x3DEA39EF35793C76 */
   uint64_t ux = cv_bits(x);
   uint32_t hx = (uint32_t)(ux >> 32);
   int k = 0;
@@ -603,25 +620,24 @@ CV_HD double cv_log(double x) {
     hx = (uint32_t)(ux >> 32);
   } else if (hx >= 0x7ff00000u) {
     return x + x; /* inf or nan */
-  } else if (hx == 0x3ff00000u && (uint32_t)ux == 0) {
-    return 0.0; /* log(1) = +0 */
   }
-  /* reduce x into [sqrt(2)/2, sqrt(2)) */
-  hx += 0x3ff00000u - 0x3fe6a09eu;
   k += (int)(hx >> 20) - 0x3ff;
-  hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
-  x = cv_from_bits(((uint64_t)hx << 32) | (ux & 0xffffffffULL));
-  double f = x - 1.0;
-  double hfsq = 0.5 * f * f;
-  double s = cv_div_nr(f, 2.0 + f); /* |f| < 0.42, 1.7 < 2+f < 2.42 */
-  double z = s * s;
-  double w = z * z;
-  double t1 = w * cv_fma_c(w, cv_fma_c(w, Lg6, Lg4), Lg2);
-  double t2 = z * cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, Lg7, Lg5), Lg3), Lg1);
-  double R = t2 + t1;
-  double dk = (double)k;
-  /* s*(hfsq+R) + dk*ln2_lo - hfsq + f + dk*ln2_hi */
-  return CV_FMA(s, hfsq + R, dk * LN2_LO) - hfsq + f + dk * LN2_HI;
+  const unsigned i = (hx >> 12) & 0xffu;
+  const double z = cv_from_bits(((uint64_t)((hx & 0x000fffffu) | 0x3ff00000u) << 32) | (ux & 0xffffffffULL));
+  const double invc = T[i][0], lch = T[i][1], lcl = T[i][2];
+  const double r = CV_FMA(z, invc, -1.0);
+  const double kd = (double)k;
+  const double w = CV_FMA(kd, LN2_HI, lch);
+  const double hi = w + r;
+  const double lo = ((w - hi) + r) + CV_FMA(kd, LN2_LO, lcl);
+  const double r2 = r * r;
+  const double p = cv_fma_c(
+      r, cv_fma_c(r, cv_fma_c(r, cv_fma_c(r, cv_fma_c(r, 1.42857142857142849213e-01, -1.66666666666666657415e-01), 0.2), -0.25),
+                  3.33333333333333314830e-01),
+      -0.5);
+  return hi + CV_FMA(r2, p, lo);
 }
+
+CV_HD double cv_log(double x) { return cv_log_t(x, cv_log_table()); }
 
 #endif /* CURVIS_CV_MATH_H */

@@ -78,7 +78,7 @@ void twin_render(const curvis_metric *m, const curvis_camera *c, const uint8_t *
                  const uint8_t *sky_neg, unsigned wn, unsigned hn, unsigned max_iter, double R, double delta,
                  uint8_t *rgb, curvis_ray_debug *dbg, int fast) {
   cvk::MetricParams M;
-  M.rho = m->rho; M.rho2 = m->rho * m->rho; M.m = m->m; M.a = m->a; M.pim = CV_PI * m->m; M.inv_pim = 1.0 / M.pim; M.two_o_pi = 2.0 / CV_PI; M.T = cv_sc_table();
+  M.rho = m->rho; M.rho2 = m->rho * m->rho; M.m = m->m; M.a = m->a; M.pim = CV_PI * m->m; M.inv_pim = 1.0 / M.pim; M.two_o_pi = 2.0 / CV_PI; M.T = cv_sc_table(); M.LT = cv_log_table(); M.AT = cv_atan_table();
   cvk::CameraParams C;
   for (int i = 0; i < 4; ++i) C.pos[i] = c->pos[i];
   for (int i = 0; i < 9; ++i) C.rot[i] = c->rot[i];
@@ -138,7 +138,7 @@ extern "C" int twin_render_efficient(const curvis_metric *m, const curvis_camera
                                      double thr2, uint8_t *rgb, double *sa, double *se, double *ss, size_t cap,
                                      size_t *n_out, uint64_t *calls, uint64_t *steps_out, int fast) {
   cvk::MetricParams M;
-  M.rho = m->rho; M.rho2 = m->rho * m->rho; M.m = m->m; M.a = m->a; M.pim = CV_PI * m->m; M.inv_pim = 1.0 / M.pim; M.two_o_pi = 2.0 / CV_PI; M.T = cv_sc_table();
+  M.rho = m->rho; M.rho2 = m->rho * m->rho; M.m = m->m; M.a = m->a; M.pim = CV_PI * m->m; M.inv_pim = 1.0 / M.pim; M.two_o_pi = 2.0 / CV_PI; M.T = cv_sc_table(); M.LT = cv_log_table(); M.AT = cv_atan_table();
   cvk::CameraParams C;
   for (int i = 0; i < 4; ++i) C.pos[i] = c->pos[i];
   for (int i = 0; i < 9; ++i) C.rot[i] = c->rot[i];

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Interstellar loop: gpu tests + Interstellar bench (+ Ellis for reference)
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT; cd $GRAFT_REPO_ROOT
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error|assert" | tail -15 > $OUT/pytest_gpu.log
+python bench.py --steps 5 --warmup 2 --metric interstellar --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/q_bench_interstellar.json
+python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/q_bench_v1.json
+cd /tmp
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/q_pmc_inter -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --metric interstellar --no-cpu-baseline > $OUT/q_pmc_inter.log 2>&1
