@@ -20,4 +20,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- p
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-ls -R $OUT | head -60
+INTER="--metric interstellar --steps 2 --warmup 1 --no-cpu-baseline"
+python $GRAFT_REPO_ROOT/bench.py --metric interstellar --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_interstellar_1080p.json 2>/dev/null
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq_inter -o pmc -- python $GRAFT_REPO_ROOT/bench.py $INTER > $OUT/pmc_sq_inter.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_inter -o pmc -- python $GRAFT_REPO_ROOT/bench.py $INTER > $OUT/pmc_fetch_inter.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_inter -o pmc -- python $GRAFT_REPO_ROOT/bench.py $INTER > $OUT/pmc_write_inter.log 2>&1
+ls -R $OUT | head -80

@@ -52,6 +52,28 @@ traffic["ellis_1920x1080_cap4096_variant1"].update({
     "salu_instr_per_wave_step": round(sq[(kern, "SQ_INSTS_SALU")] / ws, 1),
     "shader_cycles_per_frame": int(_gui),
 })
+# second entry: the Interstellar metric at the same frame size (configs[2]/[4] use this kernel instantiation)
+inter_path = os.path.join(G, "bench_interstellar_1080p.json")
+inter = None
+if os.path.exists(inter_path) and os.path.exists(os.path.join(G, "pmc_sq_inter", "pmc_counter_collection.csv")):
+    inter = json.loads(open(inter_path).read().strip().splitlines()[-1])
+    isq, ife, iwr = pmc("sq_inter"), pmc("fetch_inter"), pmc("write_inter")
+    iws = inter["config"]["executed_steps_per_frame"] / 64.0
+    igui = isq[(kern, "GRBM_GUI_ACTIVE")] / 8.0
+    ifetch, iwrite = ife[(kern, "FETCH_SIZE")] * KIB * 2, iwr[(kern, "WRITE_SIZE")] * KIB
+    traffic["interstellar_1920x1080_cap4096_variant1"] = {
+        "integrate_kernel_bytes": int(ifetch + iwrite), "integrate_fetch_bytes": int(ifetch),
+        "integrate_write_bytes": int(iwrite), "shade_kernel_bytes": 0, "algorithmic_bytes": 7 * rays,
+        "source": "as above, profiles/%s_pmc_*_interstellar.csv" % rnd,
+        "valu_busy": round(4 * isq[(kern, "SQ_ACTIVE_INST_VALU")] / (1024 * igui), 4),
+        "valu_instr_per_wave_step": round(isq[(kern, "SQ_INSTS_VALU")] / iws, 1),
+        "salu_instr_per_wave_step": round(isq[(kern, "SQ_INSTS_SALU")] / iws, 1),
+        "shader_cycles_per_frame": int(igui),
+    }
+    for kind in ("sq", "fetch", "write"):
+        shutil.copy(os.path.join(G, "pmc_%s_inter" % kind, "pmc_counter_collection.csv"),
+                    os.path.join(P, "%s_pmc_%s_interstellar.csv" % (rnd, kind)))
+    shutil.copy(inter_path, os.path.join(P, "%s_bench_interstellar_1080p.json" % rnd))
 json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 
 for kind in ("sq", "fetch", "write"):
@@ -91,6 +113,17 @@ lines.append("| HBM traffic, integration kernel | read %.2f MB + write %.2f MB |
 lines.append("| HBM traffic, shade kernel | read %.2f MB + write %.2f MB |" % (fetch_s / 1e6, write_s / 1e6))
 lines.append("| algorithmic HBM bytes (7 B/ray) | %.2f MB |" % (7 * rays / 1e6))
 lines.append("")
+if inter is not None:
+    t = traffic["interstellar_1920x1080_cap4096_variant1"]
+    lines.append("## Interstellar metric, same frame (`bench.py --metric interstellar`)\n")
+    lines.append("| quantity | value |\n|---|---|")
+    lines.append("| throughput | %.1f %s, %.3f ms per frame |" % (inter["value"], inter["unit"], inter["ms_per_step"]))
+    lines.append("| VALU / SALU instructions per wave-step | %.1f / %.1f |" % (t["valu_instr_per_wave_step"], t["salu_instr_per_wave_step"]))
+    lines.append("| VALU busy | %.3f |" % t["valu_busy"])
+    lines.append("| shader cycles per wave-step per SIMD | %.0f |" % (t["shader_cycles_per_frame"] * 1024 / iws))
+    lines.append("| algorithmic FP64 rate (46 flop/step) | %.2f TFLOP/s = %.3f of 78.6 |" % (inter["roofline"]["achieved"], inter["roofline"]["frac"]))
+    lines.append("| HBM traffic | read %.2f MB + write %.2f MB |" % (t["integrate_fetch_bytes"] / 1e6, t["integrate_write_bytes"] / 1e6))
+    lines.append("")
 lines.append("## All BASELINE configurations on one GPU\n")
 lines.append(open(os.path.join(G, "configs.md")).read())
 open(os.path.join(P, "%s_summary.md" % rnd), "w").write("\n".join(lines))
