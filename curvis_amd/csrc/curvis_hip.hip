@@ -312,22 +312,26 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
     active = P.max_iter != 0;
     slot = (size_t)frame * P.W * P.H + (size_t)py * P.W + px;
   }
-  /* All lanes of a wave start together, so the step counter is wave-uniform (an SGPR): a lane records
-   * it when it escapes; lanes still active when the counter reaches max_iterations are NotEscaped. */
-  unsigned k = 0;
-  while (__any(active)) {
-    ++k;
-    if (active) {
+  /* All lanes of a wave start together, so the step counter is wave-uniform (an SGPR).  The loop is a plain
+   * divergent loop: a lane leaves it (drops out of EXEC) when it escapes and records the counter; the
+   * back-edge is "EXEC still non-empty", so activity costs no VALU instruction at all.  Lanes still inside
+   * when the counter reaches max_iterations are NotEscaped (code stays CODE_NONE). */
+  if (active) {
+    unsigned k = 0;
+    for (;;) {
+      ++k;
       one_step<KIND, PHI, FAST>(M, P.delta, q, lane_ok_w);
       if (ray_escaped(q.l, P.max_radius)) {
-        active = false;
         steps = k;
         code = escape_code(q.l);
+        break;
+      }
+      if (k >= P.max_iter) {
+        steps = P.max_iter;
+        break;
       }
     }
-    if (k >= P.max_iter) break;
   }
-  if (active) steps = k; /* == max_iter, code stays CODE_NONE */
   unsigned pos = 0, neg = 0, none = 0, oob = 0;
   if (valid) {
     if (FUSED) {

@@ -211,11 +211,12 @@ template <int KIND, bool PHI>
 CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_ok) {
   double s, c;
   cv_sincos_t(q.th, M.T, &s, &c);
-  /* guard (branch-free): sin(theta) and l finite, non-zero, far from the exponent limits.  cos(theta)
-   * needs no test of its own: it is finite iff sin(theta) is, and the cosine of a double is never
+  /* guard (branch-free, one compare each): sin(theta) and l non-zero, not NaN and far from the underflow
+   * limit.  Upper bounds are implied: |sin| <= 1, and a step is only executed for a ray that has not
+   * escaped, |l| <= max_radius < 2^90 (metric_fast_ok; an infinite l has escaped, a NaN fails the compare).
+   * cos(theta) needs no test of its own: it is finite iff sin(theta) is, and the cosine of a double is never
    * zero or subnormal. */
-  const bool ok = (int)lane_ok & (int)hi_word_in(s, CV_HI_2POW(-60), CV_HI_2POW(1)) &
-                  (int)hi_word_in(q.l, CV_HI_2POW(-100), CV_HI_2POW(100));
+  const bool ok = (int)lane_ok & (int)(CV_FABS(s) > 0x1p-60) & (int)(CV_FABS(q.l) > 0x1p-100);
   if (!ok) {
     ray_step_core<KIND, PHI>(M, q, delta, s, c);
     return;
@@ -240,7 +241,8 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
   const double num = b2 * rd;
   const double r3 = r * (r * r);
   double dp1;
-  if (hi_word_in(num, CV_HI_2POW(-300), CV_HI_2POW(300))) {
+  const double anum = CV_FABS(num);
+  if ((int)(anum > 0x1p-300) & (int)(anum < 0x1p300)) {
     dp1 = div_with_recip(num, r3, y_r2 * y_r);
   } else { /* zero (r' == 0 inside the Interstellar throat), huge (|p_theta| exploding at a pole) or NaN */
     dp1 = num / r3;
