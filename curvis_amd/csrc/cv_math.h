@@ -95,6 +95,18 @@ CV_HD double cv_fma_c(double a, double b, double c) {
 #endif
 }
 
+/* same with the addend in a scalar register pair: for a loop-invariant constant this frees the VGPR pair the
+ * "v" form pins it in (one constant-bus operand per VOP3 instruction is allowed on gfx9) */
+CV_HD double cv_fma_ks(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CV_NO_ASM_FMA)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+#else
+  return CV_FMA(a, b, c);
+#endif
+}
+
 /* n/d for operands and quotient well inside the normal range (as inside atan/log below).  Host: the IEEE
  * operator.  Device: the AMDGPU fdiv expansion (v_rcp_f64, two Newton steps, quotient, exact remainder,
  * final fma) without its div_scale/div_fixup range handling -- the same instructions the compiler emits
@@ -300,8 +312,8 @@ CV_HD cv_sc_tab_t cv_sc_table(void) {
 CV_HD void cv_sincos_core(int K, double y, double yl, cv_sc_tab_t T, double *sn, double *cs) {
   const double Sh = T[K][0], Sl = T[K][1], Ch = T[K][2], Cl = T[K][3];
   const double z = y * y;
-  const double ps = cv_fma_c(z, cv_fma_c(z, -1.98412698412698412698e-04, 8.33333333333333321769e-03), -1.66666666666666657415e-01);
-  const double pc = cv_fma_c(z, cv_fma_c(z, -1.38888888888888894189e-03, 4.16666666666666643537e-02), -0.5);
+  const double ps = cv_fma_ks(z, cv_fma_ks(z, -1.98412698412698412698e-04, 8.33333333333333321769e-03), -1.66666666666666657415e-01);
+  const double pc = cv_fma_ks(z, cv_fma_ks(z, -1.38888888888888894189e-03, 4.16666666666666643537e-02), -0.5);
   const double yz = y * z;
   const double sl = CV_FMA(yz, ps, yl);
   const double cm = CV_FMA(-y, yl, z * pc);
@@ -631,9 +643,9 @@ CV_HD double cv_log_t(double x, cv_log_tab_t T) {
   const double hi = w + r;
   const double lo = ((w - hi) + r) + CV_FMA(kd, LN2_LO, lcl);
   const double r2 = r * r;
-  const double p = cv_fma_c(
-      r, cv_fma_c(r, cv_fma_c(r, cv_fma_c(r, cv_fma_c(r, 1.42857142857142849213e-01, -1.66666666666666657415e-01), 0.2), -0.25),
-                  3.33333333333333314830e-01),
+  const double p = cv_fma_ks(
+      r, cv_fma_ks(r, cv_fma_ks(r, cv_fma_ks(r, cv_fma_ks(r, 1.42857142857142849213e-01, -1.66666666666666657415e-01), 0.2), -0.25),
+                   3.33333333333333314830e-01),
       -0.5);
   return hi + CV_FMA(r2, p, lo);
 }
