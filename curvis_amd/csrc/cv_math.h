@@ -50,6 +50,9 @@
 #define CV_FABS(a) __builtin_fabs((a))
 #define CV_SQRT(a) __builtin_sqrt((a))
 #define CV_RINT(a) __builtin_rint((a))
+/* 1.5 * 2^52: fma(x, c, MAGIC) - MAGIC is the integer nearest to the exact product x*c (|x*c| < 2^31), and the
+ * low word of the biased sum is that integer in two's complement -- rounding and int conversion in two ops */
+#define CV_RND_MAGIC 6755399441055744.0
 
 #define CV_PI 3.14159265358979311600e+00 /* 0x400921FB54442D18 = Rust std::f64::consts::PI */
 
@@ -328,7 +331,7 @@ CV_HD void cv_sincos_core(int K, double y, double yl, cv_sc_tab_t T, double *sn,
 /* sin and cos of x together, table-driven.
  *
  * Main path (|x| < 1024 and x not within 2^-20 of a multiple of pi/64), branch-free:
- *   k  = rint(x * 64/pi)                     |k| < 2^15
+ *   k  = nearest integer to x * 64/pi        |k| < 2^15 (magic-number rounding, see CV_RND_MAGIC)
  *   r1 = fma(-k, Q1, x)                      exact: Q1 has 38 bits, the difference fits 53 bits
  *   t  = fma(-k, Q2, r1)                     head of the reduced argument, |t| <= pi/128
  *   u  = r1 - t                              exact (|u| < 2^-27, a multiple of ulp(t) >= 2^-72)
@@ -339,7 +342,8 @@ CV_HD void cv_sincos_core(int K, double y, double yl, cv_sc_tab_t T, double *sn,
  * |k| <= 17.  Which path an argument takes is a function of the argument alone, and both paths end in
  * cv_sincos_core, so host and device agree bit for bit. */
 CV_HD void cv_sincos_t(double x, cv_sc_tab_t T, double *sn, double *cs) {
-  const double k = CV_RINT(x * CV_64OPI);
+  const double kb = CV_FMA(x, CV_64OPI, CV_RND_MAGIC);
+  const double k = kb - CV_RND_MAGIC;
   const double r1 = CV_FMA(-k, CV_PIO64_1, x);
   const double t = CV_FMA(-k, CV_PIO64_2, r1);
   double y, yl;
@@ -348,7 +352,7 @@ CV_HD void cv_sincos_t(double x, cv_sc_tab_t T, double *sn, double *cs) {
     const double u = r1 - t;
     y = t;
     yl = CV_FMA(-k, CV_PIO64_3, CV_FMA(-k, CV_PIO64_2, u));
-    K = (int)k;
+    K = (int)cv_lo(kb);
   } else {
     const uint32_t ix = cv_hi(x) & 0x7fffffffu;
     if (ix >= 0x7ff00000u) { /* inf / nan */
@@ -458,9 +462,10 @@ CV_HD double cv_atan_t(double x, cv_atan_tab_t T) {
   const double ax = cv_from_bits(ux & 0x7fffffffffffffffULL);
   const double inv = cv_div_nr(-1.0, ax);
   const double u = (ix >= 0x40000000u) ? inv : ax;
-  const double jf = CV_RINT(u * 128.0);
+  const double jb = CV_FMA(u, 128.0, CV_RND_MAGIC);
+  const double jf = jb - CV_RND_MAGIC;
   const double h = CV_FMA(jf, -0.0078125, u);
-  const double *R = T[(int)jf + 64];
+  const double *R = T[(int)cv_lo(jb) + 64];
   const double Q = cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, R[7], R[6]), R[5]), R[4]), R[3]), R[2]);
   const double r = R[0] + CV_FMA(h, Q, R[1]);
   return cv_from_bits(cv_bits(r) | (ux & 0x8000000000000000ULL));
