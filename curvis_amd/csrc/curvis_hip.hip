@@ -313,24 +313,30 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
     slot = (size_t)frame * P.W * P.H + (size_t)py * P.W + px;
   }
   /* All lanes of a wave start together, so the step counter is wave-uniform (an SGPR).  The loop is a plain
-   * divergent loop: a lane leaves it (drops out of EXEC) when it escapes and records the counter; the
-   * back-edge is "EXEC still non-empty", so activity costs no VALU instruction at all.  Lanes still inside
-   * when the counter reaches max_iterations are NotEscaped (code stays CODE_NONE). */
+   * divergent loop: a lane leaves it (drops out of EXEC) when it escapes; the back-edge is "EXEC still
+   * non-empty", so activity costs no VALU instruction.  The counter is recorded per lane only in the
+   * iterations in which some lane escapes (a scalar branch on the ballot; the per-lane test goes through the
+   * ballot mask so that the compiler keeps the block inside the loop instead of sinking it behind the exit,
+   * which would cost a counter copy to a VGPR in every iteration).  Lanes still inside when the counter
+   * reaches max_iterations are NotEscaped (code stays CODE_NONE). */
   if (active) {
+    const unsigned lane = threadIdx.x & 63u;
     unsigned k = 0;
+    steps = P.max_iter;
     for (;;) {
       ++k;
       one_step<KIND, PHI, FAST>(M, P.delta, q, lane_ok_w);
-      if (ray_escaped(q.l, P.max_radius)) {
-        steps = k;
-        code = escape_code(q.l);
-        break;
+      const bool esc = ray_escaped(q.l, P.max_radius);
+      const unsigned long long em = __builtin_amdgcn_ballot_w64(esc);
+      if (em) { /* rare: at most 64 times per wave.  The volatile asm keeps this a real (scalar) branch. */
+        unsigned kv;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kv) : "s"(k));
+        if ((em >> lane) & 1ull) steps = kv;
       }
-      if (k >= P.max_iter) {
-        steps = P.max_iter;
-        break;
-      }
+      if (esc) break;
+      if (k >= P.max_iter) break;
     }
+    if (ray_escaped(q.l, P.max_radius)) code = escape_code(q.l); /* the state is final: same test as in the loop */
   }
   unsigned pos = 0, neg = 0, none = 0, oob = 0;
   if (valid) {
