@@ -74,6 +74,9 @@ struct IntegrateParams {
   /* fused shading (static kernel, non-debug): the epilogue looks the sky up and writes RGB8 itself */
   cvk::SkyParams sky[2];
   unsigned char *fb;
+  /* diagnostics (CURVIS_TRACE_FILE): per wave of the static kernel {start, end (wall_clock64 ticks), HW_ID,
+   * XCC_ID}; null in normal operation */
+  unsigned long long *trace;
 };
 
 struct ShadeParams {
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
   cvk::MetricParams M = P.metric;
   load_math_tables<KIND>(s_tab, M);
   const unsigned long long id = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long t_start = P.trace ? wall_clock64() : 0ull;
   unsigned long long st_steps = 0;
   unsigned st_rays = 0;
   unsigned frame, px, py;
@@ -358,6 +362,16 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
   }
   flush_steps(P, st_steps, st_rays);
   if (FUSED) flush_escape_counts(P.counters, pos, neg, none, oob);
+  if (P.trace && (threadIdx.x & 63u) == 0) {
+    unsigned hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    unsigned long long *rec = P.trace + 4ull * (id >> 6);
+    rec[0] = t_start;
+    rec[1] = wall_clock64();
+    rec[2] = hw_id;
+    rec[3] = xcc_id;
+  }
 }
 
 /* K2: final photon -> tangent direction -> nearest sky texel -> RGB8 (rows R9-R10 of SURVEY.md 8a).
@@ -871,6 +885,11 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     P.fb = ctx->d_fb + (size_t)f0 * npix * 3;
     P.refill_threshold = ctx->refill_threshold < 1 ? 1 : (ctx->refill_threshold > 64 ? 64 : ctx->refill_threshold);
     P.fast_ok = cvk::metric_fast_ok(metric->kind, MP, max_radius) ? 1 : 0;
+    P.trace = nullptr;
+    const char *trace_file = getenv("CURVIS_TRACE_FILE");
+    const size_t trace_words = (size_t)(P.total_rays / 64ull) * 4u;
+    if (trace_file && *trace_file && ctx->variant == 1)
+      HIP_TRY(ctx, hipMalloc((void **)&P.trace, trace_words * sizeof(unsigned long long)));
 
     ShadeParams Q;
     Q.metric = MP;
@@ -900,6 +919,16 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     }
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    if (P.trace) { /* diagnostics only: dump the per-wave records of this launch (binary u64 x 4 per wave) */
+      std::vector<unsigned long long> tr(trace_words);
+      HIP_TRY(ctx, hipMemcpyAsync(tr.data(), P.trace, trace_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      HIP_TRY(ctx, hipFree(P.trace));
+      if (FILE *fp = fopen(trace_file, "wb")) {
+        fwrite(tr.data(), sizeof(unsigned long long), tr.size(), fp);
+        fclose(fp);
+      }
+    }
     if (!fused) {
       switch (metric->kind) {
         case CURVIS_METRIC_ELLIS:
@@ -1728,6 +1757,7 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->refill_threshold = (int)value;
   else if (k == "blocks_per_cu")
     ctx->blocks_per_cu = (int)value;
+
   else if (k == "fast_math")
     ctx->fast_math = (int)value;
   else if (k == "fuse_shade")
@@ -1750,6 +1780,7 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->refill_threshold;
   else if (k == "blocks_per_cu")
     *value = ctx->blocks_per_cu;
+
   else if (k == "fast_math")
     *value = ctx->fast_math;
   else if (k == "fuse_shade")
