@@ -680,8 +680,9 @@ struct curvis_ctx {
   int blocks_per_cu = 0;    /* 0 = occupancy query */
   int fast_math = 1;        /* 1 shared-reciprocal step (ray_step_fast), 0 compiler IEEE div/sqrt */
   int fuse_shade = 1;       /* static kernel shades in its epilogue (no ray store, no shade launch) */
-  int sampling_speculation = 4; /* efficient renderer: depth of the speculative subtree evaluated below every
-                                   refined interval (0 = one launch per refinement round, no speculation) */
+  int sampling_speculation = -1; /* efficient renderer: depth of the speculative subtree evaluated below every
+                                    refined interval (0 = one launch per refinement round, no speculation;
+                                    -1 = automatic: 6 for one or two frames, 4 for larger batches) */
   uint32_t last_sampling_launches = 0;
   uint64_t last_sampling_evaluated = 0;
   size_t max_store_bytes = (size_t)8 << 30; /* frames of a batch are rendered in chunks below this */
@@ -1123,7 +1124,11 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
     std::memcpy(&u, &a, sizeof u);
     return u;
   };
-  const int spec = ctx->sampling_speculation < 0 ? 0 : (ctx->sampling_speculation > 8 ? 8 : ctx->sampling_speculation);
+  /* automatic depth: a launch costs one wave's dependency chain whatever it evaluates, until the batch holds
+   * enough rays to load the chip -- single images gain from depth 6 (4 launches instead of 5-6), batches of
+   * frames already fill the launches at depth 4 (tools/gpu_efficient_sweep.py) */
+  const int spec = ctx->sampling_speculation < 0 ? (n_frames <= 2 ? 6 : 4)
+                                                 : (ctx->sampling_speculation > 8 ? 8 : ctx->sampling_speculation);
   std::vector<std::unordered_map<uint64_t, Cached>> cache(n_frames);
   std::vector<char> planned(n_frames, 0);
   double sample_ms = 0.0;

@@ -200,7 +200,8 @@ int curvis_ctx_synchronize(curvis_ctx *ctx);
  * (1 = the static kernel shades in its epilogue, 0 = final states staged in HBM + separate shade kernel),
  * "max_store_bytes" (ray-store budget that bounds the frames per launch of a batch),
  * "sampling_speculation" (efficient renderer: depth of the speculative dyadic subtree evaluated below every
- * refined interval, default 4, 0 = one launch per refinement round); read-only after an efficient render:
+ * refined interval; 0 = one launch per refinement round; default -1 = automatic, 6 for one or two frames and 4
+ * for larger batches); read-only after an efficient render:
  * "last_sampling_launches", "last_sampling_evaluated". */
 int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value);
 int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value);

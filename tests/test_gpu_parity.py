@@ -473,7 +473,7 @@ def test_efficient_speculation_is_transparent(gpu_ctx):
             out[depth] = (rgb, gpu_ctx.samples(0), (info.n_samples, info.calls, info.steps, info.rounds),
                           gpu_ctx.get_option("last_sampling_launches"), gpu_ctx.get_option("last_sampling_evaluated"))
     finally:
-        gpu_ctx.set_option("sampling_speculation", 4)
+        gpu_ctx.set_option("sampling_speculation", -1)
     base = out[0]
     assert base[2][:3] == (678, 712, 1496307) and base[3] == base[2][3] + 1 and base[4] == 712
     for depth in (2, 4, 6):
