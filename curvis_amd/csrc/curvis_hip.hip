@@ -49,6 +49,14 @@
 namespace {
 
 enum { CNT_NEXT = 0, CNT_STEPS, CNT_POS, CNT_NEG, CNT_NONE, CNT_OOB, CNT_RAYS, CNT_N };
+/* The statistics counters are replicated CNT_SLOTS times, one 128-byte line each, and a workgroup adds to the
+ * replica blockIdx.x mod CNT_SLOTS: tens of thousands of waves adding to ONE address serialise in a single
+ * L2 channel (it made the 0.06 ms per-pixel kernel of the efficient renderer take 0.40 ms).  The host sums
+ * the replicas.  CNT_NEXT (the persistent kernel's queue head) lives in replica 0 only. */
+enum { CNT_SLOTS = 64, CNT_STRIDE = 16, CNT_WORDS = CNT_SLOTS * CNT_STRIDE };
+__device__ __forceinline__ unsigned long long *counter_replica(unsigned long long *base) {
+  return base + (size_t)(blockIdx.x & (CNT_SLOTS - 1)) * CNT_STRIDE;
+}
 
 /* Final ray states, structure-of-arrays in HBM, indexed by pixel id = frame*W*H + py*W + px.
  * Written by the integration kernel, read once by the shading kernel (48-56 B per ray against
@@ -168,8 +176,9 @@ __device__ __forceinline__ void flush_steps(const IntegrateParams &P, unsigned l
     rays += __shfl_xor(rays, off);
   }
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&P.counters[CNT_STEPS], steps);
-    atomicAdd(&P.counters[CNT_RAYS], (unsigned long long)rays);
+    unsigned long long *c = counter_replica(P.counters);
+    atomicAdd(&c[CNT_STEPS], steps);
+    atomicAdd(&c[CNT_RAYS], (unsigned long long)rays);
   }
 }
 
@@ -202,10 +211,11 @@ __device__ __forceinline__ void flush_escape_counts(unsigned long long *counters
     oob += __shfl_xor(oob, off);
   }
   if ((threadIdx.x & 63) == 0) {
-    if (pos) atomicAdd(&counters[CNT_POS], (unsigned long long)pos);
-    if (neg) atomicAdd(&counters[CNT_NEG], (unsigned long long)neg);
-    if (none) atomicAdd(&counters[CNT_NONE], (unsigned long long)none);
-    if (oob) atomicAdd(&counters[CNT_OOB], (unsigned long long)oob);
+    unsigned long long *c = counter_replica(counters);
+    if (pos) atomicAdd(&c[CNT_POS], (unsigned long long)pos);
+    if (neg) atomicAdd(&c[CNT_NEG], (unsigned long long)neg);
+    if (none) atomicAdd(&c[CNT_NONE], (unsigned long long)none);
+    if (oob) atomicAdd(&c[CNT_OOB], (unsigned long long)oob);
   }
 }
 
@@ -540,10 +550,11 @@ __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPix
     oob += __shfl_xor(oob, off);
   }
   if ((threadIdx.x & 63) == 0) {
-    if (pos) atomicAdd(&P.counters[CNT_POS], (unsigned long long)pos);
-    if (neg) atomicAdd(&P.counters[CNT_NEG], (unsigned long long)neg);
-    if (none) atomicAdd(&P.counters[CNT_NONE], (unsigned long long)none);
-    if (oob) atomicAdd(&P.counters[CNT_OOB], (unsigned long long)oob);
+    unsigned long long *c = counter_replica(P.counters);
+    if (pos) atomicAdd(&c[CNT_POS], (unsigned long long)pos);
+    if (neg) atomicAdd(&c[CNT_NEG], (unsigned long long)neg);
+    if (none) atomicAdd(&c[CNT_NONE], (unsigned long long)none);
+    if (oob) atomicAdd(&c[CNT_OOB], (unsigned long long)oob);
   }
 }
 
@@ -859,7 +870,7 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
 
   for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
     const uint32_t nf = std::min(chunk, n_frames - f0);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_WORDS, ctx->stream));
     IntegrateParams P;
     P.metric = MP;
     P.cams = ctx->d_cams + f0;
@@ -945,10 +956,11 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
       if (rc) return rc;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N,
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_WORDS,
                                 hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < CNT_N; ++k) tot[k] += ctx->h_counters[k];
+    for (int r = 0; r < CNT_SLOTS; ++r)
+      for (int k = 0; k < CNT_N; ++k) tot[k] += ctx->h_counters[r * CNT_STRIDE + k];
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     integrate_ms += ms;
@@ -1307,7 +1319,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   std::memcpy(stage.data() + o_ms, m_s.data(), sizeof(double) * T);
   std::memcpy(stage.data() + o_cs, c_s.data(), sizeof(double) * T);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eff, stage.data(), off, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_WORDS, ctx->stream));
   EfficientPixelParams Q;
   for (int k = 0; k < 2; ++k) {
     Q.sky[k].texels = (const unsigned *)ctx->d_sky[k];
@@ -1334,7 +1346,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, Q);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_N,
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_WORDS,
                               hipMemcpyDeviceToHost, ctx->stream));
   if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1343,10 +1355,13 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   if (stats) {
     stats->rays = (uint64_t)npix * n_frames;
     stats->steps = total_steps;
-    stats->n_pos = ctx->h_counters[CNT_POS];
-    stats->n_neg = ctx->h_counters[CNT_NEG];
-    stats->n_none = ctx->h_counters[CNT_NONE];
-    stats->n_oob = ctx->h_counters[CNT_OOB];
+    uint64_t tot[CNT_N] = {0};
+    for (int r = 0; r < CNT_SLOTS; ++r)
+      for (int k = 0; k < CNT_N; ++k) tot[k] += ctx->h_counters[r * CNT_STRIDE + k];
+    stats->n_pos = tot[CNT_POS];
+    stats->n_neg = tot[CNT_NEG];
+    stats->n_none = tot[CNT_NONE];
+    stats->n_oob = tot[CNT_OOB];
     stats->integrate_ms = sample_ms;
     stats->shade_ms = ms;
     stats->kernel_ms = sample_ms + ms;
@@ -1402,9 +1417,9 @@ int curvis_ctx_create(int device, curvis_ctx **out) {
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev2)) != hipSuccess)
     return bail(std::string("hipEventCreate: ") + hipGetErrorString(e));
-  if ((e = hipMalloc((void **)&ctx->d_counters, sizeof(unsigned long long) * CNT_N)) != hipSuccess)
+  if ((e = hipMalloc((void **)&ctx->d_counters, sizeof(unsigned long long) * CNT_WORDS)) != hipSuccess)
     return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
-  if ((e = hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned long long) * CNT_N)) != hipSuccess)
+  if ((e = hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned long long) * CNT_WORDS)) != hipSuccess)
     return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   *out = ctx;
   return CURVIS_OK;
