@@ -140,3 +140,34 @@ def random_scene(rng, res=(16, 9)):
     oc = O.camera(pos, fwd, up, focal, diag, res)
     pc = curvis_amd.Camera(pos, fwd, up, focal, diag, res[0], res[1])
     return om, oc, pm, pc, delta, cap, R
+
+
+def table_edge_inputs():
+    """Arguments on and next to every row boundary of the cv_math.h tables: atan rows (u = j/128 +- 1/256 for the
+    direct branch, x = -1/u for the reciprocal branch, the 0.4375 / 2 / 2^66 switches) and log slices
+    (z = 1 + i/256, all exponents incl. subnormal scaling)."""
+    import math
+    at, lg = [], []
+    for j in range(-64, 257):
+        for d in (-1.0 / 256, 0.0, 1.0 / 256):
+            for e in (-1, 0, 1):
+                c = j / 128.0 + d
+                c = math.nextafter(c, math.inf) if e > 0 else math.nextafter(c, -math.inf) if e < 0 else c
+                if 0.4375 <= c < 2.0:
+                    at += [c, -c]
+                if -0.5 <= c < 0.0:
+                    at += [-1.0 / c, 1.0 / c]
+    for x in (0.4375, 2.0, 2.0 ** 66, 128.0, 256.0):
+        at += [x, math.nextafter(x, 0.0), math.nextafter(x, math.inf), -x]
+    for i in range(257):
+        z = 1.0 + i / 256.0
+        for zz in (math.nextafter(z, 0.0), z, math.nextafter(z, math.inf)):
+            for k in (-1070, -1022, -60, -1, 0, 1, 2, 10, 1023):
+                try:
+                    v = math.ldexp(zz, k)
+                except OverflowError:
+                    continue
+                if 0.0 < v < math.inf:
+                    lg.append(v)
+    lg += [5e-324, 2.2250738585072014e-308, math.nextafter(2.2250738585072014e-308, 0.0), 1.7976931348623157e308]
+    return np.array(at, dtype=np.float64), np.array(lg, dtype=np.float64)

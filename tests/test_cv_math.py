@@ -94,3 +94,10 @@ def test_special_values_match_ieee_semantics():
     assert np.isnan(t(3, np.array([1.0000000000000002, -1.5, np.nan]))).all()
     assert list(t(4, np.array([1.0, 0.0, np.inf]))) == [0.0, -np.inf, np.inf] and np.isnan(t(4, np.array([-1.0])))[0]
     assert list(t(2, np.array([np.inf, -np.inf, 0.0]))) == [math.pi / 2, -math.pi / 2, 0.0]
+
+
+def test_table_row_boundaries():
+    """atan / log on and next to every row boundary of their tables (and the branch switches)."""
+    at, lg = common.table_edge_inputs()
+    assert max_ulp_error("atan", [float(v) for v in at]) < 0.8
+    assert max_ulp_error("log", [float(v) for v in lg]) < 0.6

@@ -25,6 +25,9 @@ def test_device_math_bit_identical_to_host(gpu_ctx):
         4: np.concatenate([u(1, 1e6, n), 10.0 ** u(-300, 300, n // 4), np.array([0.0, -1.0, 1.0, np.inf, 5e-324])]),
     }
     cases[1] = cases[0]
+    at_edges, lg_edges = common.table_edge_inputs()   # row boundaries of the atan / log tables
+    cases[2] = np.concatenate([cases[2], at_edges])
+    cases[4] = np.concatenate([cases[4], lg_edges])
     for op, a in cases.items():
         got = gpu_ctx.selftest_math(op, a)
         want = common.twin_math(op, a)

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > $OUT/pytest_gpu.log
 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --variant 0 --no-cpu-baseline > $OUT/bench_persistent.json 2>/dev/null
@@ -25,4 +25,9 @@ python $GRAFT_REPO_ROOT/bench.py --metric interstellar --steps 5 --warmup 2 --no
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq_inter -o pmc -- python $GRAFT_REPO_ROOT/bench.py $INTER > $OUT/pmc_sq_inter.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_inter -o pmc -- python $GRAFT_REPO_ROOT/bench.py $INTER > $OUT/pmc_fetch_inter.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_inter -o pmc -- python $GRAFT_REPO_ROOT/bench.py $INTER > $OUT/pmc_write_inter.log 2>&1
+cd $GRAFT_REPO_ROOT
+(python tools/gpu_cli_video.py; python tools/gpu_cli_image.py) > $OUT/cli_video.txt 2>&1
+SPECS=0,4,6 BATCHES=8,30 python tools/gpu_efficient_sweep.py 2>&1 | grep spec > $OUT/efficient_sweep.txt
+python tools/gpu_tail.py 2>&1 | grep frames > $OUT/tail.txt
+python tools/gpu_trace.py > /dev/null 2>&1 && python tools/analyze_trace.py gpurun_out/trace_config2.bin > $OUT/wave_trace_config2.txt
 ls -R $OUT | head -80
