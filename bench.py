@@ -49,7 +49,7 @@ def parse():
                     help="copy every frame to host memory inside the timed region (PCIe-inclusive rate, "
                          "reported in DESIGN.md; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-row-step", type=int, default=16)
+    ap.add_argument("--cpu-row-step", type=int, default=8)
     return ap.parse_args()
 
 

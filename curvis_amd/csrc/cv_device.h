@@ -65,8 +65,11 @@ CV_HD void metric_eval(const MetricParams &M, double l, double &r, double &r2, d
       } else {
         x = xn / M.pim;
       }
-      double at = cv_atan_t(x, M.AT);
-      r = M.rho + M.m * (x * at - cv_log_t(1.0 + x * x, M.LT) / 2.0);
+      /* x >= +0 here; on the fast step l is finite and |l| <= max_radius < 2^90 (guard), so 1 + x^2 is a finite
+       * normal number >= 1: the entry points without sign / special-case handling return the same values */
+      const double at = FASTDIV ? cv_atan_nonneg_t(x, M.AT) : cv_atan_t(x, M.AT);
+      const double lg = FASTDIV ? cv_log_ge1_t(1.0 + x * x, M.LT) : cv_log_t(1.0 + x * x, M.LT);
+      r = M.rho + M.m * (x * at - lg / 2.0);
       double sg = (cv_bits(l) >> 63) ? -1.0 : 1.0; /* l.signum(), l != NaN-safe below */
       if (l != l) sg = l;
       rd = M.two_o_pi * sg * at;

@@ -454,12 +454,8 @@ CV_HD double cv_atan_edge(double x) {
  *   atan|x| = X_j + h (q1 + q2 h + ... + q6 h^2..h^5),   X_j = atan(j/128) (+ pi/2 on the reciprocal branch)
  * evaluated as X_hi + fma(h, Q, X_lo).  Error: 0.5 ulp of the last addition + the rounding of the reciprocal
  * (<= 2^-53 u/(1+u^2) <= 0.2 ulp of a result >= atan 2) + Taylor truncation h^7/7 (< 0.03 ulp): < 0.75 ulp. */
-CV_HD double cv_atan_t(double x, cv_atan_tab_t T) {
-  const uint64_t ux = cv_bits(x);
-  const uint32_t hx = (uint32_t)(ux >> 32);
-  const uint32_t ix = hx & 0x7fffffffu;
-  if (ix - 0x3fdc0000u >= 0x44100000u - 0x3fdc0000u) return cv_atan_edge(x);
-  const double ax = cv_from_bits(ux & 0x7fffffffffffffffULL);
+/* table path for 0.4375 <= ax < 2^66 (ix = high word of ax): atan(ax) */
+CV_HD double cv_atan_main(double ax, uint32_t ix, cv_atan_tab_t T) {
   const double inv = cv_div_nr(-1.0, ax);
   const double u = (ix >= 0x40000000u) ? inv : ax;
   const double jb = CV_FMA(u, 128.0, CV_RND_MAGIC);
@@ -467,8 +463,23 @@ CV_HD double cv_atan_t(double x, cv_atan_tab_t T) {
   const double h = CV_FMA(jf, -0.0078125, u);
   const double *R = T[(int)cv_lo(jb) + 64];
   const double Q = cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, R[7], R[6]), R[5]), R[4]), R[3]), R[2]);
-  const double r = R[0] + CV_FMA(h, Q, R[1]);
+  return R[0] + CV_FMA(h, Q, R[1]);
+}
+
+CV_HD double cv_atan_t(double x, cv_atan_tab_t T) {
+  const uint64_t ux = cv_bits(x);
+  const uint32_t hx = (uint32_t)(ux >> 32);
+  const uint32_t ix = hx & 0x7fffffffu;
+  if (ix - 0x3fdc0000u >= 0x44100000u - 0x3fdc0000u) return cv_atan_edge(x);
+  const double r = cv_atan_main(cv_from_bits(ux & 0x7fffffffffffffffULL), ix, T);
   return cv_from_bits(cv_bits(r) | (ux & 0x8000000000000000ULL));
+}
+
+/* the same value for an argument known to be >= +0 (the Interstellar radial coordinate): no sign handling */
+CV_HD double cv_atan_nonneg_t(double x, cv_atan_tab_t T) {
+  const uint32_t ix = cv_hi(x);
+  if (ix - 0x3fdc0000u >= 0x44100000u - 0x3fdc0000u) return cv_atan_edge(x);
+  return cv_atan_main(x, ix, T);
 }
 
 CV_HD double cv_atan(double x) { return cv_atan_t(x, cv_atan_table()); }
@@ -622,23 +633,11 @@ CV_HD cv_log_tab_t cv_log_table(void) {
  *   log x = hi + (lo + k*LN2_LO + logc_lo + r^2 (-1/2 + r/3 - ... + r^5/7))
  * Taylor truncation < 2^-59 relative even on the slice next to 1 (invc = 1, w = 0, log x = r + ...), so the
  * error is 0.5 ulp of the final addition plus ~0.02 ulp. */
-CV_HD double cv_log_t(double x, cv_log_tab_t T) {
+/* log of the normal positive double with bits ux (hx = high word), plus k0 * ln 2 */
+CV_HD double cv_log_main(uint64_t ux, uint32_t hx, int k0, cv_log_tab_t T) {
   const double LN2_HI = 6.93147180369123816490e-01, /* 0x3FE62E42FEE00000 */
       LN2_LO = 1.90821492927058770002e-10;          /* 0x3DEA39EF35793C76 */
-  uint64_t ux = cv_bits(x);
-  uint32_t hx = (uint32_t)(ux >> 32);
-  int k = 0;
-  if (hx < 0x00100000u || (hx >> 31)) {          /* x < 2^-1022, zero, or negative */
-    if ((ux << 1) == 0) return -1.0 / (x * x);   /* log(+-0) = -inf */
-    if (hx >> 31) return (x - x) / 0.0;          /* log(-#) = NaN */
-    k -= 54;
-    x *= 1.80143985094819840000e+16; /* 2^54: scale up subnormal */
-    ux = cv_bits(x);
-    hx = (uint32_t)(ux >> 32);
-  } else if (hx >= 0x7ff00000u) {
-    return x + x; /* inf or nan */
-  }
-  k += (int)(hx >> 20) - 0x3ff;
+  const int k = k0 + (int)(hx >> 20) - 0x3ff;
   const unsigned i = (hx >> 12) & 0xffu;
   const double z = cv_from_bits(((uint64_t)((hx & 0x000fffffu) | 0x3ff00000u) << 32) | (ux & 0xffffffffULL));
   const double invc = T[i][0], lch = T[i][1], lcl = T[i][2];
@@ -653,6 +652,29 @@ CV_HD double cv_log_t(double x, cv_log_tab_t T) {
                    3.33333333333333314830e-01),
       -0.5);
   return hi + CV_FMA(r2, p, lo);
+}
+
+CV_HD double cv_log_t(double x, cv_log_tab_t T) {
+  uint64_t ux = cv_bits(x);
+  uint32_t hx = (uint32_t)(ux >> 32);
+  int k = 0;
+  if (hx < 0x00100000u || (hx >> 31)) {          /* x < 2^-1022, zero, or negative */
+    if ((ux << 1) == 0) return -1.0 / (x * x);   /* log(+-0) = -inf */
+    if (hx >> 31) return (x - x) / 0.0;          /* log(-#) = NaN */
+    k -= 54;
+    x *= 1.80143985094819840000e+16; /* 2^54: scale up subnormal */
+    ux = cv_bits(x);
+    hx = (uint32_t)(ux >> 32);
+  } else if (hx >= 0x7ff00000u) {
+    return x + x; /* inf or nan */
+  }
+  return cv_log_main(ux, hx, k, T);
+}
+
+/* the same value for a finite argument >= 1 (1 + x^2 of the Interstellar metric): none of the special cases */
+CV_HD double cv_log_ge1_t(double x, cv_log_tab_t T) {
+  const uint64_t ux = cv_bits(x);
+  return cv_log_main(ux, (uint32_t)(ux >> 32), 0, T);
 }
 
 CV_HD double cv_log(double x) { return cv_log_t(x, cv_log_table()); }
