@@ -33,7 +33,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -1126,22 +1125,47 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
    * wave's 2000-step dependency chain -- and the following rounds are then served from the cache without
    * a launch.  The sampler consumes exactly the values the sequential algorithm would compute; calls and
    * steps are counted at consumption, so the bookkeeping equals the reference's. */
+  /* open-addressing table keyed by the bit pattern of alpha; state 0 = empty, 1 = queued for the next launch,
+   * 2 = evaluated (a node-based std::unordered_map cost more host time per batch than the kernels) */
   struct Cached {
+    uint64_t key;
     double e, s;
     uint32_t steps;
     int status;
+    uint32_t state;
+  };
+  struct EvalCache {
+    std::vector<Cached> slots;
+    size_t used = 0;
+    EvalCache() : slots(4096, Cached{0, 0.0, 0.0, 0, 0, 0}) {}
+    static size_t hash(uint64_t k) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20); }
+    Cached *find(uint64_t k) { /* the slot holding k, or the empty slot where it would go */
+      const size_t mask = slots.size() - 1;
+      size_t i = hash(k) & mask;
+      while (slots[i].state != 0 && slots[i].key != k) i = (i + 1) & mask;
+      return &slots[i];
+    }
+    Cached *claim(uint64_t k) { /* find, inserting an empty (state 0) entry for a new key */
+      if (2 * (used + 1) > slots.size()) {
+        std::vector<Cached> old;
+        old.swap(slots);
+        slots.assign(old.size() * 2, Cached{0, 0.0, 0.0, 0, 0, 0});
+        for (const Cached &c : old)
+          if (c.state != 0) *find(c.key) = c;
+      }
+      Cached *c = find(k);
+      if (c->state == 0) c->key = k;
+      return c;
+    }
   };
   auto key_of = [](double a) {
     uint64_t u;
     std::memcpy(&u, &a, sizeof u);
     return u;
   };
-  /* automatic depth: a launch costs one wave's dependency chain whatever it evaluates, until the batch holds
-   * enough rays to load the chip -- single images gain from depth 6 (4 launches instead of 5-6), batches of
-   * frames already fill the launches at depth 4 (tools/gpu_efficient_sweep.py) */
   const int spec = ctx->sampling_speculation < 0 ? (n_frames <= 2 ? 6 : 4)
                                                  : (ctx->sampling_speculation > 8 ? 8 : ctx->sampling_speculation);
-  std::vector<std::unordered_map<uint64_t, Cached>> cache(n_frames);
+  std::vector<EvalCache> cache(n_frames);
   std::vector<char> planned(n_frames, 0);
   double sample_ms = 0.0;
   uint64_t evaluated = 0;
@@ -1151,7 +1175,14 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   std::vector<int> r_status;
   std::vector<uint32_t> b_frame;
   bool panic = false;
+  const bool dbg_timing = getenv("CURVIS_DEBUG_TIMING") != nullptr;
+  double t_adv = 0.0, t_build = 0.0, t_eval = 0.0, t_ins = 0.0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
   for (;;) {
+    const auto tp0 = now();
     /* advance every sampler as far as the cache allows */
     bool any_waiting = false;
     for (uint32_t f = 0; f < n_frames; ++f) {
@@ -1162,7 +1193,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
         }
         bool all_cached = true;
         for (double a : smp[f].pending)
-          if (!cache[f].count(key_of(a))) {
+          if (cache[f].find(key_of(a))->state != 2) {
             all_cached = false;
             break;
           }
@@ -1175,7 +1206,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
         cs.resize(n);
         cst.resize(n);
         for (size_t k = 0; k < n; ++k) {
-          const Cached &c = cache[f][key_of(smp[f].pending[k])];
+          const Cached &c = *cache[f].find(key_of(smp[f].pending[k]));
           ce[k] = c.e;
           cs[k] = c.s;
           cst[k] = c.steps;
@@ -1185,6 +1216,8 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
         planned[f] = 0;
       }
     }
+    const auto tp1 = now();
+    t_adv += secs(tp0, tp1);
     if (!any_waiting) break;
     /* one launch: the missing points of every waiting frame plus their speculative subtrees */
     b_alpha.clear();
@@ -1192,11 +1225,11 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
     b_frame.clear();
     for (uint32_t f = 0; f < n_frames; ++f) {
       if (!planned[f]) continue;
-      std::unordered_map<uint64_t, char> queued;
       auto want = [&](double a) {
-        const uint64_t k = key_of(a);
-        if (cache[f].count(k) || queued.count(k)) return;
-        queued[k] = 1;
+        Cached *c = cache[f].claim(key_of(a));
+        if (c->state != 0) return; /* evaluated, or already queued for this launch */
+        c->state = 1;
+        cache[f].used++;
         b_alpha.push_back(a);
         b_l.push_back(cams[f].pos[1]);
         b_frame.push_back(f);
@@ -1228,14 +1261,28 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
         }
       }
     }
+    const auto tp2 = now();
+    t_build += secs(tp1, tp2);
     rc = eval_escape_batch(ctx, metric, MP, b_alpha, b_l, max_iter, max_radius, delta, r_angle, r_space, r_steps,
                            r_status, &sample_ms);
     if (rc) return rc;
+    const auto tp3 = now();
+    t_eval += secs(tp2, tp3);
     ++launches;
     evaluated += b_alpha.size();
-    for (size_t k = 0; k < b_alpha.size(); ++k)
-      cache[b_frame[k]][key_of(b_alpha[k])] = Cached{r_angle[k], r_space[k], r_steps[k], r_status[k]};
+    for (size_t k = 0; k < b_alpha.size(); ++k) {
+      Cached *c = cache[b_frame[k]].find(key_of(b_alpha[k]));
+      c->e = r_angle[k];
+      c->s = r_space[k];
+      c->steps = r_steps[k];
+      c->status = r_status[k];
+      c->state = 2;
+    }
+    t_ins += secs(tp3, now());
   }
+  if (dbg_timing)
+    fprintf(stderr, "[curvis] sampling host phases (ms): advance %.3f, build %.3f, evaluate (copies+kernel+sync) %.3f of which kernels %.3f, cache insert %.3f; launches %u, points %llu\n",
+            t_adv, t_build, t_eval, sample_ms, t_ins, launches, (unsigned long long)evaluated);
   ctx->last_sampling_launches = launches;
   ctx->last_sampling_evaluated = evaluated;
   ctx->last_samples.assign(n_frames, {});
