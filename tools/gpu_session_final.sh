@@ -14,7 +14,7 @@ python bench.py --fast-math 0 --no-cpu-baseline > $OUT/bench_strict.json 2>/dev/
 python bench.py --download --no-cpu-baseline > $OUT/bench_download.json 2>/dev/null
 python bench.py --metric interstellar --width 3840 --height 2160 --max-iter 8192 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_config3.json 2>/dev/null
 python tools/bench_configs.py > $OUT/configs.md 2> $OUT/configs.err
-./build/ubench_fp64 > $OUT/ubench.log 2>&1
+make -s -C curvis_amd/csrc ubench > /dev/null 2>&1; ./build/ubench_fp64 > $OUT/ubench.log 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
