@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--max-iter", type=int, default=4096)
     ap.add_argument("--metric", default="ellis", choices=["ellis", "interstellar"])
     ap.add_argument("--sky", type=int, default=8192, help="sky width (height = width/2)")
-    ap.add_argument("--variant", type=int, default=1, help="1 static kernel (default), 0 persistent lane-refill kernel")
+    ap.add_argument("--variant", type=int, default=1, help="1 static kernel (default), 0 persistent lane-refill kernel, 2 static + end-game relay")
     ap.add_argument("--refill-threshold", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     ap.add_argument("--fast-math", type=int, default=1, help="1 shared-reciprocal step, 0 compiler IEEE div/sqrt")
@@ -191,7 +191,7 @@ def main():
             "config": {
                 "workload": "configs[1]: %s wormhole, %dx%d, cap %d Euler steps, R=100, delta=0.05, single image; "
                             "%d frame(s)/GPU/step" % (args.metric, args.width, args.height, args.max_iter, 1),
-                "kernel": ("geodesic_persistent" if args.variant == 0 else "geodesic_static") +
+                "kernel": ({0: "geodesic_persistent", 2: "geodesic_relay"}.get(args.variant, "geodesic_static")) +
                           ("<fast>" if args.fast_math else "<strict>"),
                 "frames_per_gpu": args.steps,
                 "rays_per_frame": int(per_launch_rays),
@@ -206,7 +206,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / FP64_VECTOR_PEAK_TFLOPS, 4),
                 "flop_per_step": flop,
-                "kernel": "geodesic_persistent" if args.variant == 0 else "geodesic_static",
+                "kernel": {0: "geodesic_persistent", 2: "geodesic_relay"}.get(args.variant, "geodesic_static"),
                 "kernel_ms_avg": round(kernel_s * 1e3, 4),
                 "shade_kernel_ms_avg": round(total_shade_ms / n_launches, 4),
                 "traffic": traffic,

@@ -383,6 +383,209 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
   }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * K1, relay form ("variant" = 2, launches of one or two frames): the static kernel plus a hand-over of
+ * unfinished tiles in the END-GAME of the launch, with the hardware workgroup dispatcher as load balancer.
+ *
+ * A single-frame launch ends with ~2 ms in which no fresh workgroup is left and every SIMD finishes the 5-6
+ * waves it happens to hold; the SIMDs finish between 10.8 and 12.0 ms (wave trace): ~1 ms of a
+ * 12 ms frame is imbalance that cannot be repaired because a wave, once placed, stays where it is.
+ *
+ * Here the grid is [fresh workgroups | relay workgroups].  A fresh wave runs the static kernel's loop in
+ * segments of `seg` steps.  Once every fresh workgroup has started (a counter), a wave that reaches a segment
+ * boundary with unfinished rays PARKS its tile -- state of the 64 rays to HBM (56 B per ray), tile id into a
+ * ticket ring -- and exits.  Its slot goes to the next relay workgroup, which the dispatcher places on
+ * whichever CU has room: a relay wave takes the oldest parked tile, integrates one more segment, and parks
+ * it again or shades it.  Tiles therefore drift, `seg` steps at a time, from CUs with a backlog to CUs that
+ * ran dry.  There is no persistent loop (inside one it costs 86-155 VGPRs instead of 61): every
+ * wave does one piece of work and exits.  Results are bit-identical: same per-ray arithmetic, state
+ * round-trips through HBM as doubles.
+ *
+ * Ring protocol: `tail` / `head` hand out tickets; a parker writes tile+1 into slot ticket%CAP (release), a
+ * relay wave waits for its slot to become non-zero (acquire) and clears it.  At most one tile per resident
+ * wave is parked, CAP = 32768.  `remaining` counts unfinished tiles; waiting relay waves leave when it
+ * reaches zero (their tickets are then never filled).  If the relay workgroups of a launch run out while
+ * tiles are still parked, the host launches more (relay-only grid) until `remaining` is zero; a wave that has
+ * waited absurdly long sets `error` and leaves, so a logic error shows up as CURVIS_E_HIP, not as a hang. */
+struct RelayQueue { /* all zero before the first launch of a frame (one hipMemsetAsync) */
+  unsigned long long started;  /* fresh workgroups that have begun */
+  unsigned long long head, tail;
+  unsigned long long finished; /* tiles shaded so far */
+  unsigned long long error;
+  unsigned long long pad[3];
+  unsigned ring[1];            /* kRelayRing entries follow */
+};
+constexpr unsigned kRelayRing = 32768; /* >= resident waves (256 CUs x 32) with margin */
+struct RelayArgs {
+  RelayQueue *q;
+  unsigned long long n_tiles;
+  unsigned fresh_blocks; /* workgroups [0, fresh_blocks) start tiles, the rest relay parked ones */
+  unsigned seg;          /* steps per segment */
+};
+
+/* Hand-over traffic of the relay kernel goes around the caches: system-scope relaxed atomics compile to
+ * write-through stores / cache-bypassing loads (sc0 sc1), so publishing a tile needs only "my stores have
+ * been acknowledged" (a workgroup-scope release = s_waitcnt) instead of an agent-scope release fence, which on
+ * this multi-XCD part writes back the whole L2 (buffer_wbl2) -- measured ~80 us per hand-over. */
+template <typename T>
+__device__ __forceinline__ void st_sys(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+template <typename T>
+__device__ __forceinline__ T ld_sys(const T *p) { return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+template <int KIND, bool FAST>
+__global__ __launch_bounds__(256) void geodesic_relay(const IntegrateParams P, const RelayArgs A) {
+  __shared__ MathTablesLds<KIND> s_tab;
+  RelayQueue *const Q = A.q;
+  const unsigned long long t_start = P.trace ? wall_clock64() : 0ull;
+  unsigned long long t_work = 0ull; /* diagnostics: when the wave had its tile */
+  const bool fresh = blockIdx.x < A.fresh_blocks;
+  /* a relay workgroup that starts when every tile is finished leaves at once (workgroup-uniform branch, taken
+   * before the table load and its barrier): the grid holds many more relay workgroups than are usually needed */
+  if (!fresh && __hip_atomic_load(&Q->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.n_tiles) return;
+  cvk::MetricParams M = P.metric;
+  load_math_tables<KIND>(s_tab, M);
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned long long tile;
+  if (fresh) {
+    if (threadIdx.x == 0) atomicAdd(&Q->started, 1ull);
+    tile = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  } else {
+    /* relay wave: take the oldest parked tile, or leave when every tile is finished */
+    unsigned long long tk = 0;
+    if (lane == 0) tk = atomicAdd(&Q->head, 1ull);
+    unsigned *slot_p = Q->ring + (__builtin_amdgcn_readfirstlane((unsigned)tk) & (kRelayRing - 1u));
+    unsigned v = 0, spins = 0;
+    for (;;) {
+      v = ld_sys(slot_p);
+      if (v) break;
+      /* the own ring slot is polled every ~1 us, the shared `remaining` word only every 8th time */
+      if ((spins & 7u) == 0u && __hip_atomic_load(&Q->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.n_tiles) break;
+      if (++spins > 500000u) { /* ~1 s */
+        if (lane == 0) atomicAdd(&Q->error, 1ull);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    if (!v) return;
+    if (lane == 0) st_sys(slot_p, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* order the state loads below after the ticket load */
+    tile = (unsigned long long)(v - 1u);
+  }
+  if (P.trace) t_work = wall_clock64();
+  const unsigned long long id = tile * 64ull + lane;
+  unsigned frame, px, py;
+  cvk::Ray q;
+  q.l = q.th = q.ph = q.p1 = q.p2 = q.p3 = q.p3sq = 0.0;
+  const bool valid = id < P.total_rays && decode_ray(P, id, frame, px, py);
+  bool active = false;
+  unsigned steps = 0, k0 = 0;
+  int code = cvk::CODE_NONE;
+  if (fresh) {
+    if (valid) {
+      cvk::ray_init<KIND>(M, P.cams[frame], px, py, q);
+      active = P.max_iter != 0;
+      steps = P.max_iter;
+    }
+  } else {
+    q.l = ld_sys(&P.store.l[id]);
+    q.th = ld_sys(&P.store.th[id]);
+    q.p1 = ld_sys(&P.store.p1[id]);
+    q.p2 = ld_sys(&P.store.p2[id]);
+    q.p3 = ld_sys(&P.store.p3[id]);
+    q.p3sq = q.p3 * q.p3;
+    steps = ld_sys(&P.store.steps[id]);
+    const int c = ld_sys(&P.store.code[id]);
+    active = (c & 4) != 0;
+    code = (c & 3) == 1 ? cvk::CODE_POS : (c & 3) == 2 ? cvk::CODE_NEG : cvk::CODE_NONE;
+    /* the step counter is wave-uniform: every active lane parked it in `steps` (a parked tile has one) */
+    const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
+    k0 = __builtin_amdgcn_readlane(steps, am ? (int)__builtin_ctzll(am) : 0);
+    if (active) steps = P.max_iter;
+  }
+  const bool lane_ok_w = FAST && P.fast_ok && cvk::ray_fast_ok(q);
+  const unsigned SEG = A.seg;
+  bool parked = false;
+  for (;;) {
+    const unsigned seg_end = (P.max_iter - k0 > SEG) ? k0 + SEG : P.max_iter;
+    if (active) {
+      unsigned k = k0;
+      for (;;) {
+        ++k;
+        one_step<KIND, false, FAST>(M, P.delta, q, lane_ok_w);
+        const bool esc = ray_escaped(q.l, P.max_radius);
+        const unsigned long long em = __builtin_amdgcn_ballot_w64(esc);
+        if (em) { /* rare; the volatile asm keeps this a real (scalar) branch */
+          unsigned kv;
+          asm volatile("v_mov_b32 %0, %1" : "=v"(kv) : "s"(k));
+          if ((em >> lane) & 1ull) steps = kv;
+        }
+        if (esc) break;
+        if (k >= seg_end) break;
+      }
+      if (ray_escaped(q.l, P.max_radius)) {
+        code = escape_code(q.l);
+        active = false;
+      }
+    }
+    k0 = seg_end;
+    if (!__builtin_amdgcn_ballot_w64(active) || k0 >= P.max_iter) break; /* tile finished */
+    /* keep the tile while fresh workgroups are still being started, and afterwards unless a relay wave is
+     * waiting for a ticket right now (head > tail): a hand-over then costs the tile ~1 us, whereas a tile parked
+     * with nobody waiting would sit idle until the dispatcher has placed another relay workgroup */
+    if (fresh && __hip_atomic_load(&Q->started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)A.fresh_blocks)
+      continue;
+    if (__hip_atomic_load(&Q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <=
+        __hip_atomic_load(&Q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      continue;
+    parked = true;
+    break;
+  }
+  unsigned long long st_steps = 0;
+  unsigned st_rays = 0, pos = 0, neg = 0, none = 0, oob = 0;
+  if (parked) {
+    st_sys(&P.store.l[id], q.l);
+    st_sys(&P.store.th[id], q.th);
+    st_sys(&P.store.p1[id], q.p1);
+    st_sys(&P.store.p2[id], q.p2);
+    st_sys(&P.store.p3[id], q.p3);
+    st_sys(&P.store.steps[id], active ? k0 : steps);
+    st_sys(&P.store.code[id], (code == cvk::CODE_POS ? 1 : code == cvk::CODE_NEG ? 2 : 0) | (active ? 4 : 0));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* every lane's write-through stores acknowledged */
+    if (lane == 0) {
+      const unsigned long long tk = atomicAdd(&Q->tail, 1ull);
+      st_sys(Q->ring + ((unsigned)tk & (kRelayRing - 1u)), (unsigned)tile + 1u);
+    }
+  } else {
+    if (valid) {
+      unsigned tx, ty;
+      const unsigned texel = shade_ray<KIND>(M, P.sky, q, code, tx, ty, oob);
+      unsigned char *dst = P.fb + ((size_t)frame * P.W * P.H + (size_t)py * P.W + px) * 3;
+      dst[0] = (unsigned char)(texel & 0xFF);
+      dst[1] = (unsigned char)((texel >> 8) & 0xFF);
+      dst[2] = (unsigned char)((texel >> 16) & 0xFF);
+      pos = (code == cvk::CODE_POS);
+      neg = (code == cvk::CODE_NEG);
+      none = (code == cvk::CODE_NONE);
+      st_steps = steps;
+      st_rays = 1;
+    }
+    if (lane == 0 && tile < A.n_tiles) atomicAdd(&Q->finished, 1ull);
+  }
+  flush_steps(P, st_steps, st_rays);
+  flush_escape_counts(P.counters, pos, neg, none, oob);
+  if (P.trace && lane == 0) { /* CURVIS_TRACE_FILE: {start, end, HW_ID, XCC_ID | flags, got-tile time, tile} per wave */
+    unsigned hw_id, xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    unsigned long long *rec = P.trace + 4ull * ((unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6));
+    rec[0] = t_start;
+    rec[1] = wall_clock64();
+    rec[2] = (unsigned long long)hw_id | ((unsigned long long)(xcc_id & 0xf) << 32) | ((unsigned long long)(fresh ? 1 : 0) << 40) |
+             ((unsigned long long)(parked ? 1 : 0) << 41) | ((unsigned long long)(k0 & 0xffff) << 44);
+    rec[3] = t_work;
+  }
+}
+
 /* K2: final photon -> tangent direction -> nearest sky texel -> RGB8 (rows R9-R10 of SURVEY.md 8a).
  * One thread per pixel, coalesced reads of the ray store, 3-byte stores of consecutive pixels. */
 template <int KIND, bool DEBUG>
@@ -670,6 +873,14 @@ struct curvis_ctx {
   curvis_ray_debug *d_dbg = nullptr;
   size_t dbg_cap = 0;
   unsigned char *d_store = nullptr; /* RayStore arrays, carved from one allocation */
+  unsigned char *d_rq = nullptr;    /* RelayQueue + ticket ring of the relay kernel */
+  int relay_segment = 0;            /* steps between two hand-over points; 0 = automatic */
+  long long relay_min_blocks = -1;  /* smallest grid (fresh workgroups) the relay kernel is used for; -1 = automatic
+                                       (three times the ~6 resident workgroups per CU: below that there is hardly
+                                       a dispatch phase and the static kernel is as good) */
+  uint32_t last_relay_launches = 0;
+  uint64_t last_relay_parks = 0, last_relay_waiters = 0;
+  unsigned relay_resident_blocks = 0; /* cached occupancy query (per metric kinds it differs little; first use wins) */
   size_t store_cap = 0;
   hipEvent_t ev2 = nullptr;
   /* efficient mode scratch (device) */
@@ -754,9 +965,47 @@ cvk::CameraParams make_camera(const curvis_camera &c) {
   return C;
 }
 
+/* grid = fresh workgroups + relay workgroups; see geodesic_relay */
+template <int KIND, bool FAST>
+int launch_relay(curvis_ctx *ctx, const IntegrateParams &P, bool relay_only) {
+  const size_t bytes = sizeof(RelayQueue) + sizeof(unsigned) * kRelayRing;
+  if (!ctx->d_rq) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_rq, bytes));
+  RelayArgs A;
+  A.q = (RelayQueue *)ctx->d_rq;
+  A.n_tiles = P.total_rays / 64ull;
+  const unsigned long long fresh_blocks = relay_only ? 0ull : (P.total_rays + 255ull) / 256ull;
+  A.fresh_blocks = (unsigned)fresh_blocks;
+  /* segment = about half the length of an ordinary ray, (R / delta) / 2 steps: one or two hand-over points per
+   * tile in flight (measured optimum 512-1024 for ~2000-step rays; shorter segments cost more in boundary
+   * checks and workgroup launches than the finer balance returns) */
+  {
+    const double half = 0.5 * P.max_radius / P.delta;
+    unsigned seg = (half >= 256.0 && half <= 65536.0) ? (unsigned)half : 1024u;
+    A.seg = ctx->relay_segment > 0 ? (unsigned)ctx->relay_segment : seg;
+  }
+  if (ctx->relay_resident_blocks == 0) {
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, geodesic_relay<KIND, FAST>, 256, 0));
+    if (per_cu <= 0) per_cu = 1;
+    ctx->relay_resident_blocks = (unsigned)per_cu * (unsigned)ctx->prop.multiProcessorCount;
+  }
+  const unsigned long long resident_blocks = ctx->relay_resident_blocks;
+  if (!relay_only) HIP_TRY(ctx, hipMemsetAsync(ctx->d_rq, 0, bytes, ctx->stream));
+  /* every tile in flight when the fresh workgroups run out (at most the resident waves) is passed on once per
+   * segment of its remaining steps: (max_iter / seg) <= 16 hand-overs each, usually ~2; surplus relay
+   * workgroups leave at once */
+  unsigned long long relay_blocks = resident_blocks * 24ull;
+  if (relay_blocks > fresh_blocks * 2ull + resident_blocks) relay_blocks = fresh_blocks * 2ull + resident_blocks;
+  hipLaunchKernelGGL((geodesic_relay<KIND, FAST>), dim3((unsigned)(fresh_blocks + relay_blocks)), dim3(256), 0, ctx->stream,
+                     P, A);
+  HIP_TRY(ctx, hipGetLastError());
+  return CURVIS_OK;
+}
+
 template <int KIND, bool PHI, bool FAST>
-int launch_integrate(curvis_ctx *ctx, const IntegrateParams &P, bool fused) {
-  if (ctx->variant == 1) {
+int launch_integrate(curvis_ctx *ctx, const IntegrateParams &P, bool fused, int relay) {
+  if (relay && fused) return launch_relay<KIND, FAST>(ctx, P, relay == 2);
+  if (ctx->variant == 1 || ctx->variant == 2) {
     const unsigned long long blocks = (P.total_rays + 255ull) / 256ull;
     if (fused)
       hipLaunchKernelGGL((geodesic_static<KIND, false, FAST, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
@@ -779,9 +1028,17 @@ int launch_integrate(curvis_ctx *ctx, const IntegrateParams &P, bool fused) {
 }
 
 template <int KIND>
-int launch_integrate_kind(curvis_ctx *ctx, bool phi, bool fast, bool fused, const IntegrateParams &P) {
-  if (phi) return fast ? launch_integrate<KIND, true, true>(ctx, P, false) : launch_integrate<KIND, true, false>(ctx, P, false);
-  return fast ? launch_integrate<KIND, false, true>(ctx, P, fused) : launch_integrate<KIND, false, false>(ctx, P, fused);
+int launch_integrate_kind(curvis_ctx *ctx, bool phi, bool fast, bool fused, int relay, const IntegrateParams &P) {
+  if (phi)
+    return fast ? launch_integrate<KIND, true, true>(ctx, P, false, 0) : launch_integrate<KIND, true, false>(ctx, P, false, 0);
+  return fast ? launch_integrate<KIND, false, true>(ctx, P, fused, relay) : launch_integrate<KIND, false, false>(ctx, P, fused, relay);
+}
+int launch_integrate_any(curvis_ctx *ctx, int kind, bool phi, bool fast, bool fused, int relay, const IntegrateParams &P) {
+  switch (kind) {
+    case CURVIS_METRIC_ELLIS: return launch_integrate_kind<cvk::METRIC_ELLIS>(ctx, phi, fast, fused, relay, P);
+    case CURVIS_METRIC_INTERSTELLAR: return launch_integrate_kind<cvk::METRIC_INTERSTELLAR>(ctx, phi, fast, fused, relay, P);
+    default: return launch_integrate_kind<cvk::METRIC_FLAT>(ctx, phi, fast, fused, relay, P);
+  }
 }
 
 template <int KIND>
@@ -841,8 +1098,19 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   }
   /* fused shading: static kernel, no debug dump (option "fuse_shade", default on) -- no ray store at all.
    * Otherwise frames are rendered in chunks whose ray store stays below max_store_bytes. */
-  const bool fused = ctx->variant == 1 && ctx->fuse_shade != 0 && dbg_out == nullptr;
+  const bool fused = (ctx->variant == 1 || ctx->variant == 2) && ctx->fuse_shade != 0 && dbg_out == nullptr;
+  /* relay kernel ("variant" = 2): end-game hand-over of tiles; only launches of one or two frames have a tail
+   * worth its staging area (56 B per ray) -- larger batches use the static kernel */
+  const unsigned long long relay_fresh_blocks = ((unsigned long long)((W + 7) / 8) * ((H + 7) / 8) * n_frames + 3ull) / 4ull;
+  const unsigned long long relay_min = ctx->relay_min_blocks >= 0 ? (unsigned long long)ctx->relay_min_blocks
+                                                                   : 18ull * (unsigned long long)ctx->prop.multiProcessorCount;
+  const bool relay = ctx->variant == 2 && fused && n_frames <= 2 && relay_fresh_blocks >= relay_min;
   uint32_t chunk = n_frames;
+  if (relay) {
+    const size_t rays = (size_t)((W + 7) / 8) * ((H + 7) / 8) * 64u * n_frames;
+    rc = ensure_device(ctx, ctx->d_store, ctx->store_cap, rays * kStoreBytesPerPixel);
+    if (rc) return rc;
+  }
   if (!fused) {
     chunk = (uint32_t)std::max<size_t>(1, ctx->max_store_bytes / (npix * kStoreBytesPerPixel));
     if (chunk > n_frames) chunk = n_frames;
@@ -885,7 +1153,8 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     P.max_iter = max_iterations;
     P.max_radius = max_radius;
     P.delta = delta;
-    P.store = fused ? RayStore{} : carve_store(ctx->d_store, (size_t)nf * npix);
+    P.store = relay ? carve_store(ctx->d_store, (size_t)P.total_rays)
+                    : fused ? RayStore{} : carve_store(ctx->d_store, (size_t)nf * npix);
     P.counters = ctx->d_counters;
     for (int k = 0; k < 2; ++k) {
       P.sky[k].texels = (const unsigned *)ctx->d_sky[k];
@@ -899,8 +1168,12 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     P.trace = nullptr;
     const char *trace_file = getenv("CURVIS_TRACE_FILE");
     const size_t trace_words = (size_t)(P.total_rays / 64ull) * 4u;
-    if (trace_file && *trace_file && ctx->variant == 1)
-      HIP_TRY(ctx, hipMalloc((void **)&P.trace, trace_words * sizeof(unsigned long long)));
+    size_t trace_alloc_words = trace_words;
+    if (relay) trace_alloc_words = (size_t)((P.total_rays + 255ull) / 256ull) * 3u * 16u + 65536u * 16u; /* all workgroups x 4 waves */
+    if (trace_file && *trace_file && (ctx->variant == 1 || relay)) {
+      HIP_TRY(ctx, hipMalloc((void **)&P.trace, trace_alloc_words * sizeof(unsigned long long)));
+      HIP_TRY(ctx, hipMemsetAsync(P.trace, 0, trace_alloc_words * sizeof(unsigned long long), ctx->stream));
+    }
 
     ShadeParams Q;
     Q.metric = MP;
@@ -917,22 +1190,12 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     Q.counters = ctx->d_counters;
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    switch (metric->kind) {
-      case CURVIS_METRIC_ELLIS:
-        rc = launch_integrate_kind<cvk::METRIC_ELLIS>(ctx, phi, fast, fused, P);
-        break;
-      case CURVIS_METRIC_INTERSTELLAR:
-        rc = launch_integrate_kind<cvk::METRIC_INTERSTELLAR>(ctx, phi, fast, fused, P);
-        break;
-      default:
-        rc = launch_integrate_kind<cvk::METRIC_FLAT>(ctx, phi, fast, fused, P);
-        break;
-    }
+    rc = launch_integrate_any(ctx, metric->kind, phi, fast, fused, relay ? 1 : 0, P);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     if (P.trace) { /* diagnostics only: dump the per-wave records of this launch (binary u64 x 4 per wave) */
-      std::vector<unsigned long long> tr(trace_words);
-      HIP_TRY(ctx, hipMemcpyAsync(tr.data(), P.trace, trace_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      std::vector<unsigned long long> tr(trace_alloc_words);
+      HIP_TRY(ctx, hipMemcpyAsync(tr.data(), P.trace, trace_alloc_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       HIP_TRY(ctx, hipFree(P.trace));
       if (FILE *fp = fopen(trace_file, "wb")) {
@@ -955,9 +1218,32 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
       if (rc) return rc;
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_WORDS,
-                                hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last_relay_launches = relay ? 1 : 0;
+    for (;;) {
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_WORDS,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+      if (relay) /* queue header rides along with the counters: finished / error */
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + CNT_WORDS, ctx->d_rq, sizeof(unsigned long long) * 8,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if (!relay) break;
+      /* normally the one launch finished every tile; more relay workgroups only if the grid ran out of them
+       * with tiles still parked */
+      const RelayQueue *hq = (const RelayQueue *)(ctx->h_counters + CNT_WORDS);
+      const unsigned long long n_tiles = P.total_rays / 64ull;
+      if (hq->error != 0)
+        return fail(ctx, CURVIS_E_HIP, "relay kernel: " + std::to_string(hq->error) + " waves gave up waiting, " +
+                                           std::to_string(n_tiles - hq->finished) + " tiles unfinished");
+      ctx->last_relay_parks = hq->tail;
+      ctx->last_relay_waiters = hq->head;
+      if (hq->finished >= n_tiles) break;
+      if (ctx->last_relay_launches++ > 64)
+        return fail(ctx, CURVIS_E_HIP, "relay kernel: tiles still unfinished after 64 relay launches");
+      rc = launch_integrate_any(ctx, metric->kind, phi, fast, fused, 2, P);
+      if (rc) return rc;
+      HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+      HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+    }
     for (int r = 0; r < CNT_SLOTS; ++r)
       for (int k = 0; k < CNT_N; ++k) tot[k] += ctx->h_counters[r * CNT_STRIDE + k];
     float ms = 0.f;
@@ -1466,7 +1752,7 @@ int curvis_ctx_create(int device, curvis_ctx **out) {
     return bail(std::string("hipEventCreate: ") + hipGetErrorString(e));
   if ((e = hipMalloc((void **)&ctx->d_counters, sizeof(unsigned long long) * CNT_WORDS)) != hipSuccess)
     return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
-  if ((e = hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned long long) * CNT_WORDS)) != hipSuccess)
+  if ((e = hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned long long) * (CNT_WORDS + 8))) != hipSuccess)
     return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   *out = ctx;
   return CURVIS_OK;
@@ -1481,6 +1767,7 @@ void curvis_ctx_destroy(curvis_ctx *ctx) {
   if (ctx->d_fb) (void)hipFree(ctx->d_fb);
   if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
   if (ctx->d_store) (void)hipFree(ctx->d_store);
+  if (ctx->d_rq) (void)hipFree(ctx->d_rq);
   if (ctx->d_eff) (void)hipFree(ctx->d_eff);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->d_cams) (void)hipFree(ctx->d_cams);
@@ -1824,6 +2111,10 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->refill_threshold = (int)value;
   else if (k == "blocks_per_cu")
     ctx->blocks_per_cu = (int)value;
+  else if (k == "relay_segment")
+    ctx->relay_segment = (int)value;
+  else if (k == "relay_min_blocks")
+    ctx->relay_min_blocks = (long long)value;
 
   else if (k == "fast_math")
     ctx->fast_math = (int)value;
@@ -1847,6 +2138,16 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->refill_threshold;
   else if (k == "blocks_per_cu")
     *value = ctx->blocks_per_cu;
+  else if (k == "relay_segment")
+    *value = ctx->relay_segment;
+  else if (k == "relay_min_blocks")
+    *value = ctx->relay_min_blocks;
+  else if (k == "last_relay_launches")
+    *value = ctx->last_relay_launches;
+  else if (k == "last_relay_parks")
+    *value = (int64_t)ctx->last_relay_parks;
+  else if (k == "last_relay_waiters")
+    *value = (int64_t)ctx->last_relay_waiters;
 
   else if (k == "fast_math")
     *value = ctx->fast_math;

@@ -195,14 +195,19 @@ int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);
 int curvis_ctx_synchronize(curvis_ctx *ctx);
 
 /* tuning knobs (not part of the reference surface): "variant" (0 = persistent lane-refill kernel,
- * 1 = static one-ray-per-thread kernel), "refill_threshold", "blocks_per_cu", "fast_math"
+ * 1 = static one-ray-per-thread kernel, 2 = the static kernel with end-game hand-over of unfinished tiles
+ * between waves ("relay"; used for launches of one or two frames of at least "relay_min_blocks" workgroups,
+ * default automatic; "relay_segment" = steps between hand-over points, 0 = automatic; identical results; a
+ * few per cent faster on 540p-900p single frames, no gain at 1080p and above), "refill_threshold",
+ * "blocks_per_cu", "fast_math"
  * (1 = shared-reciprocal Euler step, 0 = compiler IEEE division/sqrt; identical results), "fuse_shade"
  * (1 = the static kernel shades in its epilogue, 0 = final states staged in HBM + separate shade kernel),
  * "max_store_bytes" (ray-store budget that bounds the frames per launch of a batch),
  * "sampling_speculation" (efficient renderer: depth of the speculative dyadic subtree evaluated below every
  * refined interval; 0 = one launch per refinement round; default -1 = automatic, 6 for one or two frames and 4
  * for larger batches); read-only after an efficient render:
- * "last_sampling_launches", "last_sampling_evaluated". */
+ * "last_sampling_launches", "last_sampling_evaluated"; after a relay render: "last_relay_launches",
+ * "last_relay_parks". */
 int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value);
 int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value);
 

@@ -70,8 +70,38 @@ def test_full_ray_state_bit_exact_vs_oracle(gpu_ctx, variant, fast, metric, res,
     assert (s.rays, s.steps, s.n_pos, s.n_neg, s.n_none) == (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none)
     # the non-debug kernel (phi not integrated) must give the same pixels
     assert np.array_equal(sys_.render_image(cap, 100.0, 0.05), want_rgb)
-    gpu_ctx.set_option("variant", 0)
+    gpu_ctx.set_option("variant", 1)
     gpu_ctx.set_option("fast_math", 1)
+
+
+@pytest.mark.parametrize("metric,res,pos,fwd,cap", CASES)
+def test_relay_kernel_bit_exact(gpu_ctx, metric, res, pos, fwd, cap):
+    """"variant" 2 (end-game hand-over of tiles between waves through HBM and a ticket ring): forced onto small
+    frames with short segments so that tiles are parked and relayed many times (and the host has to launch extra
+    relay workgroups); pixels and statistics must equal the oracle's."""
+    sp, sn = common.make_skies(256, 128, "check")
+    om, oc, pm, pc = common.scene(metric, res=res, pos=pos, fwd=fwd)
+    want_rgb, _, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, debug=True)
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    try:
+        gpu_ctx.set_option("variant", 2)
+        gpu_ctx.set_option("relay_min_blocks", 0)
+        parks = 0
+        for seg in (16, 100, 0):
+            gpu_ctx.set_option("relay_segment", seg)
+            for _ in range(2):
+                rgb, s = gpu_ctx.render_brute(pm, pc, cap, 100.0, 0.05)
+                assert np.array_equal(rgb, want_rgb), seg
+                assert (s.rays, s.steps, s.n_pos, s.n_neg, s.n_none) == (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none)
+                assert gpu_ctx.get_option("last_relay_launches") >= 1
+                parks += gpu_ctx.get_option("last_relay_parks")
+        if cap >= 1000 and metric != "flat":
+            assert parks > 0   # the hand-over path was really exercised
+    finally:
+        gpu_ctx.set_option("variant", 1)
+        gpu_ctx.set_option("relay_min_blocks", -1)
+        gpu_ctx.set_option("relay_segment", 0)
 
 
 def oracle_full_frame(fl, om, oc, sky_pos, sky_neg, cap, threads=None):
@@ -118,7 +148,7 @@ def test_full_size_frame_bit_exact(gpu_ctx, metric, res, cap):
             s = sys_.last_stats
             assert (s.steps, s.n_pos + s.n_neg + s.n_none) == (steps, res[0] * res[1])
         gpu_ctx.set_option("fuse_shade", 1)
-    gpu_ctx.set_option("variant", 0)
+    gpu_ctx.set_option("variant", 1)
     gpu_ctx.set_option("fast_math", 1)
 
 
