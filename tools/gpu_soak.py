@@ -26,7 +26,8 @@ def worker(tag, n):
             res = [(320, 180), (641, 359), (1280, 720), (96, 54)][it % 4]
             metric = m_e if it % 3 else m_i
             cam = curvis_amd.Camera((0, 4.0 + (it % 5), np.pi / 2, 0.1 * (it % 7)), (-1, 0, 0), (0, 0, 1), 15, 43, *res)
-            ctx.set_option("variant", it % 2)
+            ctx.set_option("variant", it % 3)
+            ctx.set_option("relay_min_blocks", 0 if it % 2 else -1)
             ctx.set_option("fast_math", (it // 2) % 2)
             key = (res, it % 3 != 0, it % 5, it % 7)
             if it % 4 == 3:
