@@ -405,8 +405,9 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
  * relay wave waits for its slot to become non-zero (acquire) and clears it.  At most one tile per resident
  * wave is parked, CAP = 32768.  `remaining` counts unfinished tiles; waiting relay waves leave when it
  * reaches zero (their tickets are then never filled).  If the relay workgroups of a launch run out while
- * tiles are still parked, the host launches more (relay-only grid) until `remaining` is zero; a wave that has
- * waited absurdly long sets `error` and leaves, so a logic error shows up as CURVIS_E_HIP, not as a hang. */
+ * tiles are still parked, the host launches more (relay-only grid) until every tile is finished; a wave that has
+ * waited ~20 s sets `error` and leaves, so a logic error shows up as CURVIS_E_HIP, not as a hang (a relay wave
+ * legitimately waits at most for the rest of the launch: the kernel is meant for launches of milliseconds). */
 struct RelayQueue { /* all zero before the first launch of a frame (one hipMemsetAsync) */
   unsigned long long started;  /* fresh workgroups that have begun */
   unsigned long long head, tail;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void geodesic_relay(const IntegrateParams P, c
       if (v) break;
       /* the own ring slot is polled every ~1 us, the shared `remaining` word only every 8th time */
       if ((spins & 7u) == 0u && __hip_atomic_load(&Q->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.n_tiles) break;
-      if (++spins > 500000u) { /* ~1 s */
+      if (++spins > 20000000u) { /* ~20 s of waiting: longer than any launch this kernel is chosen for */
         if (lane == 0) atomicAdd(&Q->error, 1ull);
         break;
       }
