@@ -905,6 +905,7 @@ struct curvis_ctx {
   int sampling_speculation = -1; /* efficient renderer: depth of the speculative subtree evaluated below every
                                     refined interval (0 = one launch per refinement round, no speculation;
                                     -1 = automatic: 6 for one or two frames, 4 for larger batches) */
+  int sampling_speculation_first = -1; /* the same for the first launch (below the uniform grid); -1 = automatic: 7 / 3 */
   uint32_t last_sampling_launches = 0;
   uint64_t last_sampling_evaluated = 0;
   size_t max_store_bytes = (size_t)8 << 30; /* frames of a batch are rendered in chunks below this */
@@ -1450,9 +1451,12 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
     std::memcpy(&u, &a, sizeof u);
     return u;
   };
-  const int spec = ctx->sampling_speculation < 0 ? (n_frames <= 2 ? 6 : 4)
+  const int spec = ctx->sampling_speculation < 0 ? (n_frames <= 2 ? 8 : 4)
                                                  : (ctx->sampling_speculation > 8 ? 8 : ctx->sampling_speculation);
   std::vector<EvalCache> cache(n_frames);
+  /* depth of the subtrees evaluated below the intervals of the initial uniform grid (first launch) */
+  const int first_cap = ctx->sampling_speculation_first < 0 ? (n_frames <= 2 ? 7 : 3)
+                                                            : (ctx->sampling_speculation_first > 8 ? 8 : ctx->sampling_speculation_first);
   std::vector<char> planned(n_frames, 0);
   double sample_ms = 0.0;
   uint64_t evaluated = 0;
@@ -1533,7 +1537,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
         if (S.pend_lo[k] == S.pend_lo[k]) {
           stack.push_back(Node{S.pend_lo[k], S.pend_hi[k], spec});
         } else if (k + 1 < S.pending.size()) { /* uniform grid: subtree below [x_k, x_{k+1}] */
-          stack.push_back(Node{S.pending[k], S.pending[k + 1], spec > 3 ? 3 : spec});
+          stack.push_back(Node{S.pending[k], S.pending[k + 1], spec > first_cap ? first_cap : spec});
         }
         while (!stack.empty()) {
           const Node nd = stack.back();
@@ -2123,6 +2127,8 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->fuse_shade = (int)value;
   else if (k == "sampling_speculation")
     ctx->sampling_speculation = (int)value;
+  else if (k == "sampling_speculation_first")
+    ctx->sampling_speculation_first = (int)value;
   else if (k == "max_store_bytes")
     ctx->max_store_bytes = (size_t)value;
   else
@@ -2156,6 +2162,8 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->fuse_shade;
   else if (k == "sampling_speculation")
     *value = ctx->sampling_speculation;
+  else if (k == "sampling_speculation_first")
+    *value = ctx->sampling_speculation_first;
   else if (k == "last_sampling_launches")
     *value = ctx->last_sampling_launches;
   else if (k == "last_sampling_evaluated")
