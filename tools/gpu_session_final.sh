@@ -27,7 +27,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_inter -o pmc --
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_inter -o pmc -- python $GRAFT_REPO_ROOT/bench.py $INTER > $OUT/pmc_write_inter.log 2>&1
 cd $GRAFT_REPO_ROOT
 (python tools/gpu_cli_video.py; python tools/gpu_cli_image.py) > $OUT/cli_video.txt 2>&1
-SPECS=0,4,6 BATCHES=8,30 python tools/gpu_efficient_sweep.py 2>&1 | grep spec > $OUT/efficient_sweep.txt
+SPECS=0,4,6,8 BATCHES=8,30 python tools/gpu_efficient_sweep.py 2>&1 | grep spec > $OUT/efficient_sweep.txt
 python tools/gpu_tail.py 2>&1 | grep frames > $OUT/tail.txt
 python tools/gpu_trace.py > /dev/null 2>&1 && python tools/analyze_trace.py gpurun_out/trace_config2.bin > $OUT/wave_trace_config2.txt
 timeout 900 python tools/gpu_deep_fuzz.py 2000 7 2>&1 | grep -E "MISMATCH|scenes" | tail -5 > $OUT/deep_fuzz.txt
