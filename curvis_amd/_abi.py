@@ -64,6 +64,8 @@ SYMBOLS = {
     "curvis_metric_validate": (C.c_int, [C.POINTER(Metric)]),
     "curvis_render_brute": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_double, C.c_double,
                                       _vp, C.POINTER(Stats)]),
+    "curvis_render_brute_rows": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.c_double, C.c_double, _vp, C.POINTER(Stats)]),
     "curvis_render_brute_debug": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_double,
                                             C.c_double, _vp, _vp, C.POINTER(Stats)]),
     "curvis_render_brute_batch": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_uint32,

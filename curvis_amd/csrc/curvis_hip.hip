@@ -69,7 +69,8 @@ struct RayStore {
 struct IntegrateParams {
   cvk::MetricParams metric;
   const cvk::CameraParams *cams; /* device, n_frames entries */
-  unsigned n_frames, W, H, tiles_x, tiles_y;
+  unsigned n_frames, W, H, tiles_x, tiles_y; /* H = rows rendered by this launch (a band of the frame or all of it) */
+  unsigned row0;                 /* first image row of the band: pixel (px, py) of the launch is image row row0 + py */
   unsigned rays_per_frame;       /* tiles_x*tiles_y*64 (padded to whole 8x8 tiles) */
   unsigned long long total_rays; /* n_frames * rays_per_frame */
   unsigned max_iter;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
         if (need && mine < P.total_rays) {
           unsigned frame, px, py;
           if (decode_ray(P, mine, frame, px, py)) {
-            cvk::ray_init<KIND>(M, P.cams[frame], px, py, q);
+            cvk::ray_init<KIND>(M, P.cams[frame], px, py + P.row0, q);
             slot = (size_t)frame * P.W * P.H + (size_t)py * P.W + px;
             steps = 0;
             lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
   unsigned steps = 0;
   int code = cvk::CODE_NONE;
   if (id < P.total_rays && decode_ray(P, id, frame, px, py)) {
-    cvk::ray_init<KIND>(M, P.cams[frame], px, py, q);
+    cvk::ray_init<KIND>(M, P.cams[frame], px, py + P.row0, q);
     lane_ok_w = FAST && P.fast_ok && cvk::ray_fast_ok(q);
     valid = true;
     active = P.max_iter != 0;
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256) void geodesic_relay(const IntegrateParams P, c
   int code = cvk::CODE_NONE;
   if (fresh) {
     if (valid) {
-      cvk::ray_init<KIND>(M, P.cams[frame], px, py, q);
+      cvk::ray_init<KIND>(M, P.cams[frame], px, py + P.row0, q);
       active = P.max_iter != 0;
       steps = P.max_iter;
     }
@@ -1071,16 +1072,22 @@ constexpr size_t kStoreBytesPerPixel = 6 * sizeof(double) + sizeof(unsigned) + s
 
 int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cams, uint32_t n_frames,
                 uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
-                curvis_ray_debug *dbg_out, curvis_stats *stats) {
+                curvis_ray_debug *dbg_out, curvis_stats *stats, uint32_t row_begin = 0, uint32_t row_count = 0) {
   if (!ctx) return CURVIS_E_INVALID;
   if (!metric || !cams || n_frames == 0) return fail(ctx, CURVIS_E_INVALID, "null metric/camera or zero frames");
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = curvis_metric_validate(metric);
   if (rc != CURVIS_OK) return fail(ctx, rc, "invalid metric parameters (src/metrics.rs:409-456)");
-  const uint32_t W = cams[0].res_x, H = cams[0].res_y;
-  if (W == 0 || H == 0) return fail(ctx, CURVIS_E_INVALID, "resolution must be greater than 0 (src/cameras.rs:98)");
+  const uint32_t W = cams[0].res_x, H_full = cams[0].res_y;
+  if (W == 0 || H_full == 0) return fail(ctx, CURVIS_E_INVALID, "resolution must be greater than 0 (src/cameras.rs:98)");
+  /* row band (curvis_render_brute_rows): the launch covers image rows [row_begin, row_begin + row_count); the
+   * cameras keep the full resolution, which is what pixel -> direction uses */
+  const bool band = row_count != 0;
+  if (band && ((uint64_t)row_begin + row_count > H_full || n_frames != 1 || dbg_out))
+    return fail(ctx, CURVIS_E_INVALID, "row band outside the frame (or used with a batch / the debug dump)");
+  const uint32_t H = band ? row_count : H_full;
   for (uint32_t f = 0; f < n_frames; ++f) {
-    if (cams[f].res_x != W || cams[f].res_y != H)
+    if (cams[f].res_x != W || cams[f].res_y != H_full)
       return fail(ctx, CURVIS_E_INVALID, "all cameras of a batch must share one resolution");
     if (std::fabs(cams[f].pos[1]) > max_radius)
       return fail(ctx, CURVIS_E_CAMERA_OUTSIDE,
@@ -1146,6 +1153,7 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     P.n_frames = nf;
     P.W = W;
     P.H = H;
+    P.row0 = band ? row_begin : 0u;
     P.tiles_x = (W + 7) / 8;
     P.tiles_y = (H + 7) / 8;
     const unsigned long long rpf = (unsigned long long)P.tiles_x * P.tiles_y * 64ull;
@@ -1940,6 +1948,14 @@ int curvis_render_brute(curvis_ctx *ctx, const curvis_metric *metric, const curv
                         uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
                         curvis_stats *stats) {
   return render_impl(ctx, metric, camera, 1, max_iterations, max_radius, delta, rgb_out, nullptr, stats);
+}
+
+int curvis_render_brute_rows(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
+                             uint32_t row_begin, uint32_t row_count, uint32_t max_iterations, double max_radius,
+                             double delta, uint8_t *rgb_out, curvis_stats *stats) {
+  if (row_count == 0) return fail(ctx, CURVIS_E_INVALID, "row_count must be greater than 0");
+  return render_impl(ctx, metric, camera, 1, max_iterations, max_radius, delta, rgb_out, nullptr, stats, row_begin,
+                     row_count);
 }
 
 int curvis_render_brute_debug(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,

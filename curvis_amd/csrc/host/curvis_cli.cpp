@@ -15,7 +15,7 @@
  *
  * Extensions (do not exist in the reference): --mode efficient|brute (default efficient = what the
  * reference renders; brute = RelativisticSystem::render_image, the per-pixel integrator),
- * --devices N (frames k mod N across N GPUs, one host thread + one context per GPU, skies uploaded to
+ * --devices N (image --mode brute: rows of the frame split over N GPUs; video: frames k mod N across N GPUs, one host thread + one context per GPU, skies uploaded to
  * each or broadcast from GPU 0 with RCCL: --sky-broadcast rccl|upload), --batch B (frames per kernel launch),
  * --writers T (PNG encoder threads), --stats FILE (per-frame JSON lines).
  * Backgrounds must be PNG (any colour type / bit depth); no JPEG decoder is linked.
@@ -575,7 +575,43 @@ int image_main(const Args &a) {
     die("Error in rendering image: Could not create video output folder \"" + c.out + "\"");
   std::vector<uint8_t> rgb((size_t)cam.res_x * cam.res_y * 3);
   curvis_stats st;
-  check(render_frames(ctx, a, c, &cam, 1, c.sim.sampling_convergence_threshold_2, rgb.data(), &st), ctx, "image");
+  std::memset(&st, 0, sizeof st);
+  if (a.mode == "brute" && a.devices > 1) {
+    /* --mode brute --devices N: the rows of the ONE frame are split over N GPUs (rays are independent,
+     * src/systems.rs:316-326); one host thread + one context per GPU, the bands land in place in `rgb` */
+    std::vector<curvis_ctx *> ctxs((size_t)a.devices, nullptr);
+    std::vector<curvis_stats> sts((size_t)a.devices);
+    std::vector<int> rcs((size_t)a.devices, CURVIS_OK);
+    ctxs[0] = ctx;
+    const bool share = std::getenv("CURVIS_TEST_SHARE_DEVICE") != nullptr; /* test hook: all bands on one GPU */
+    for (int r = 1; r < a.devices; ++r) ctxs[(size_t)r] = make_ctx(share ? a.device : a.device + r, c, "image");
+    const uint32_t H = cam.res_y, base = H / (uint32_t)a.devices, extra = H % (uint32_t)a.devices;
+    std::vector<std::thread> th;
+    for (int r = 0; r < a.devices; ++r)
+      th.emplace_back([&, r] {
+        const uint32_t begin = (uint32_t)r * base + std::min<uint32_t>((uint32_t)r, extra);
+        const uint32_t count = base + ((uint32_t)r < extra ? 1u : 0u);
+        std::memset(&sts[(size_t)r], 0, sizeof(curvis_stats));
+        if (count == 0) return;
+        rcs[(size_t)r] = curvis_render_brute_rows(ctxs[(size_t)r], &c.metric, &cam, begin, count,
+                                                  c.sim.ray_integration_max_itarations, c.sim.escape_radius,
+                                                  c.sim.ray_integration_step, rgb.data() + (size_t)begin * cam.res_x * 3,
+                                                  &sts[(size_t)r]);
+      });
+    for (auto &t : th) t.join();
+    for (int r = 0; r < a.devices; ++r) {
+      check(rcs[(size_t)r], ctxs[(size_t)r], "image");
+      st.rays += sts[(size_t)r].rays;
+      st.steps += sts[(size_t)r].steps;
+      st.n_pos += sts[(size_t)r].n_pos;
+      st.n_neg += sts[(size_t)r].n_neg;
+      st.n_none += sts[(size_t)r].n_none;
+      st.kernel_ms = std::max(st.kernel_ms, sts[(size_t)r].kernel_ms);
+      if (r > 0) curvis_ctx_destroy(ctxs[(size_t)r]);
+    }
+  } else {
+    check(render_frames(ctx, a, c, &cam, 1, c.sim.sampling_convergence_threshold_2, rgb.data(), &st), ctx, "image");
+  }
   const std::string file = c.out + "/" + is.image_name + ".png";
   if (!pngio::save_rgb8(file, rgb.data(), cam.res_x, cam.res_y, err))
     die("Error in rendering image: Could not save image frame \"" + file + "\" due to error: " + err);

@@ -88,6 +88,33 @@ def frames_of_rank(n_frames, rank, world_size):
     return list(range(rank, n_frames, world_size))
 
 
+def rows_of_rank(height, rank, world_size):
+    """single image split by rows: rank r renders rows [begin, begin + count), bands differ by at
+    most one row and cover [0, height) exactly; ranks beyond the height get an empty band."""
+    base, extra = divmod(height, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, base + (1 if rank < extra else 0)
+
+
+def render_image_sharded(context, metric, camera, max_iterations, max_radius, delta, rank=0, world_size=1, dist=None):
+    """RelativisticSystem::render_image with the rows of ONE frame split over the ranks; every rank renders its band
+    on its own GPU, rank 0 returns the assembled H x W x 3 image (others None) plus the list of per-band stats."""
+    H, W = camera.resolution_height, camera.resolution_width
+    begin, count = rows_of_rank(H, rank, world_size)
+    band, st = (context.render_brute_rows(metric, camera, begin, count, max_iterations, max_radius, delta)
+                if count else (np.zeros((0, W, 3), np.uint8), None))
+    info = {"rank": rank, "row_begin": begin, "rows": count, "steps": int(st.steps) if st else 0,
+            "rays": int(st.rays) if st else 0}
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return band, [info]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, (info, band))
+    if rank != 0:
+        return None, [p[0] for p in parts]
+    parts.sort(key=lambda p: p[0]["row_begin"])
+    return np.concatenate([p[1] for p in parts], axis=0), [p[0] for p in parts]
+
+
 class VideoRenderingSystem:
     """VideoRenderingSystem<M> (src/rendering.rs:178-327) over one curvis Context per rank."""
 

@@ -191,6 +191,17 @@ class Context:
             rgb = rgb[0]
         return rgb, st
 
+    def render_brute_rows(self, metric, camera, row_begin, row_count, max_iterations, max_radius, delta, download=True):
+        """rows [row_begin, row_begin + row_count) of render_image: (row_count x W x 3 uint8 or None, stats)."""
+        W = camera.resolution_width
+        m = metric._c()
+        st = Stats()
+        rgb = np.empty((row_count, W, 3), dtype=np.uint8) if download else None
+        check(lib().curvis_render_brute_rows(self._h, C.byref(m), C.byref(camera._c), row_begin, row_count, max_iterations,
+                                             max_radius, delta, rgb.ctypes.data if download else None, C.byref(st)),
+              self._h)
+        return rgb, st
+
     def render_efficient(self, metric, cameras, max_iterations_propagation, max_radius, delta, alpha_nums,
                          max_iterations_sampling, thr1, thr2, download=True):
         """render_image_efficient for one Camera or a list (samplers advance in lock step)."""

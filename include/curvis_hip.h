@@ -133,7 +133,13 @@ int curvis_metric_validate(const curvis_metric *m);
 int curvis_render_brute(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
                         uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
                         curvis_stats *stats);
-/* same, plus the final state of every ray (dbg_out: res_y*res_x entries, row-major). */
+/* A band of image rows [row_begin, row_begin + row_count) of the same frame: rays are independent
+ * (src/systems.rs:316-326), so a single image can be split across GPUs by rows and assembled on the host
+ * (SURVEY 8e).  rgb_out: row_count*res_x*3 or NULL; stats cover the band. */
+int curvis_render_brute_rows(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
+                             uint32_t row_begin, uint32_t row_count, uint32_t max_iterations, double max_radius,
+                             double delta, uint8_t *rgb_out, curvis_stats *stats);
+/* same as curvis_render_brute, plus the final state of every ray (dbg_out: res_y*res_x entries, row-major). */
 int curvis_render_brute_debug(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
                               uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
                               curvis_ray_debug *dbg_out, curvis_stats *stats);

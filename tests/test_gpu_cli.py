@@ -61,6 +61,26 @@ def test_image_default_pose_efficient_and_brute(scene_files):
     assert np.array_equal(got, want)
 
 
+def test_image_rows_split_over_devices(scene_files):
+    """image --mode brute --devices 3: three contexts render row bands of the one frame (all on this GPU through
+    the CURVIS_TEST_SHARE_DEVICE hook; on a multi-GPU node one band per GPU); file and statistics equal the
+    single-device run."""
+    d, sp, sn = scene_files
+    outs = []
+    for n in (1, 3):
+        out = d / ("out_rows%d" % n)
+        out.mkdir()
+        r = run("image", d / "pos.png", d / "neg.png", out, "-s", d / "sim.toml", "-c", d / "cam.toml", "--mode", "brute",
+                "--devices", n, "--stats", out / "st.json", env=dict(os.environ, CURVIS_TEST_SHARE_DEVICE="1"))
+        assert r.returncode == 0, r.stderr
+        st = json.loads((out / "st.json").read_text())
+        outs.append((pngio.read_png(out / "output_image.png"), st["rays"], st["steps"], st["n_pos"], st["n_neg"], st["n_none"]))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+    om, oc, _, _ = common.scene("ellis", res=(96, 54))
+    want, _, _ = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
+    assert np.array_equal(outs[1][0], want)
+
+
 def test_video_orbit_frames_and_quirks(scene_files):
     d, sp, sn = scene_files
     out = d / "out_vid"

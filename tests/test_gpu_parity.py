@@ -104,6 +104,34 @@ def test_relay_kernel_bit_exact(gpu_ctx, metric, res, pos, fwd, cap):
         gpu_ctx.set_option("relay_segment", 0)
 
 
+@pytest.mark.parametrize("metric,res,pos,fwd,cap", CASES[:3])
+def test_row_bands_equal_the_full_frame(gpu_ctx, metric, res, pos, fwd, cap):
+    """curvis_render_brute_rows: any split of the rows reproduces the full frame and its statistics (all kernel
+    variants; ragged bands that cut 8x8 tiles)."""
+    sp, sn = common.make_skies(256, 128, "check")
+    om, oc, pm, pc = common.scene(metric, res=res, pos=pos, fwd=fwd)
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    full, st = gpu_ctx.render_brute(pm, pc, cap, 100.0, 0.05)
+    H = res[1]
+    try:
+        for variant in (1, 0, 2):
+            gpu_ctx.set_option("variant", variant)
+            gpu_ctx.set_option("relay_min_blocks", 0)
+            for cuts in ([0, H], [0, 1, H], [0, 5, 13, H - 1, H], [0, H // 2, H]):
+                parts, steps, rays = [], 0, 0
+                for b, e in zip(cuts, cuts[1:]):
+                    rgb, s = gpu_ctx.render_brute_rows(pm, pc, b, e - b, cap, 100.0, 0.05)
+                    parts.append(rgb); steps += s.steps; rays += s.rays
+                assert np.array_equal(np.concatenate(parts, axis=0), full), (variant, cuts)
+                assert (steps, rays) == (st.steps, st.rays)
+        with pytest.raises(curvis_amd.CurvisError):
+            gpu_ctx.render_brute_rows(pm, pc, H - 1, 2, cap, 100.0, 0.05)
+    finally:
+        gpu_ctx.set_option("variant", 1)
+        gpu_ctx.set_option("relay_min_blocks", -1)
+
+
 def oracle_full_frame(fl, om, oc, sky_pos, sky_neg, cap, threads=None):
     """whole-frame oracle render with the rows striped over host threads (ctypes drops the GIL)."""
     import os

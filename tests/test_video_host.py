@@ -106,3 +106,57 @@ def test_two_rank_gloo_video_sharding(tmp_path):
     assert out["ranks"] == [k % 2 for k in range(240)]
     assert out["steps"] == 240 * 1000
     assert out["launches0"] == 18  # 120 frames of rank 0 in batches of 7
+
+
+def test_row_bands_are_a_partition():
+    for h, w in [(1080, 8), (2160, 8), (7, 2), (3, 8), (1, 1), (1081, 4)]:
+        bands = [rendering.rows_of_rank(h, r, w) for r in range(w)]
+        assert bands[0][0] == 0 and sum(c for _, c in bands) == h
+        for (b0, c0), (b1, _) in zip(bands, bands[1:]):
+            assert b1 == b0 + c0
+        assert max(c for _, c in bands) - min(c for _, c in bands) <= 1
+
+
+ROW_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch.distributed as dist
+    from curvis_amd import rendering, systems
+
+    class StubStats:
+        def __init__(self, rows, w): self.rays = rows * w; self.steps = 10 * rows * w
+    class StubContext:   # the product has no CPU renderer: a band is filled with its absolute row numbers
+        def render_brute_rows(self, metric, cam, row_begin, row_count, max_it, R, delta, download=True):
+            rgb = np.zeros((row_count, cam.resolution_width, 3), np.uint8)
+            rgb[:, :, 0] = (np.arange(row_begin, row_begin + row_count) %% 256)[:, None]
+            rgb[:, :, 1] = dist.get_rank() + 1
+            return rgb, StubStats(row_count, cam.resolution_width)
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cam = systems.Camera((0.0, 5.0, 1.5707963267948966, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 15.0, 43.0, 16, 37)
+    img, info = rendering.render_image_sharded(StubContext(), None, cam, 64, 100.0, 0.05, rank, world, dist)
+    if rank == 0:
+        ok = img.shape == (37, 16, 3) and bool(np.all(img[:, 0, 0] == np.arange(37) %% 256))
+        print(json.dumps({"ok": ok, "owners": [int(v) for v in img[:, 0, 1]], "steps": sum(d["steps"] for d in info),
+                          "bands": [[d["row_begin"], d["rows"]] for d in sorted(info, key=lambda d: d["rank"])]}))
+    else:
+        assert img is None
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_gloo_row_band_image(tmp_path):
+    """single image split by rows over two ranks and assembled on rank 0 (optional split)"""
+    script = tmp_path / "row_worker.py"
+    script.write_text(ROW_WORKER % {"root": ROOT})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["ok"] and out["bands"] == [[0, 19], [19, 18]]
+    assert out["owners"] == [1] * 19 + [2] * 18 and out["steps"] == 10 * 37 * 16
