@@ -258,6 +258,14 @@ def cpu_baseline(args, host_skies):
     _, _, st = O.render_image(O.LIBM, om, oc, sp, sn, args.max_iter, 100.0, 0.05, row_begin=0,
                               row_step=args.cpu_row_step)
     dt = time.perf_counter() - t0
+    # "C1 in full" -- the reference's default image (256x144, cap 40 000) end to end on the same core
+    c1 = None
+    if args.metric == "ellis":
+        t1 = time.perf_counter()
+        _, _, st1 = O.render_image(O.LIBM, O.ellis(1.0), O.camera(res=(256, 144)), sp, sn, 40000, 100.0, 0.05)
+        d1 = time.perf_counter() - t1
+        c1 = {"workload": "config 1 in full: 256x144, cap 40000", "rays": int(st1.rays), "steps": int(st1.steps),
+              "seconds": round(d1, 2), "value": round(st1.steps / d1 / 1e6, 2)}
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -276,6 +284,7 @@ def cpu_baseline(args, host_skies):
             args.cpu_row_step, args.width, args.height, st.rays, st.steps, dt),
         "host_cpu": model,
         "host_logical_cpus": os.cpu_count(),
+        "config1_full": c1,
     }
 
 
