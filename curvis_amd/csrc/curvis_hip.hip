@@ -888,6 +888,8 @@ struct curvis_ctx {
   /* efficient mode scratch (device) */
   unsigned char *d_eff = nullptr;
   size_t eff_cap = 0;
+  unsigned char *h_eff = nullptr; /* pinned staging mirror of d_eff for the sampling launches */
+  size_t h_eff_cap = 0;
   /* sample tables of the last efficient render, per frame (for tests / statistics) */
   std::vector<std::vector<cvs::BiPoint>> last_samples;
   std::vector<curvis_sampling_info> last_sampling_info;
@@ -1330,8 +1332,21 @@ int eval_escape_batch(curvis_ctx *ctx, const curvis_metric *metric, const cvk::M
   double *d_alpha = (double *)ctx->d_eff, *d_l = d_alpha + n, *d_angle = d_l + n, *d_space = d_angle + n;
   unsigned *d_steps = (unsigned *)(d_space + n);
   int *d_status = (int *)(d_steps + n);
-  HIP_TRY(ctx, hipMemcpyAsync(d_alpha, alpha.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d_l, lcam.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  /* one pinned staging buffer, one copy in and one copy out per launch: pageable hipMemcpyAsync of more than
+   * 1 MiB takes a path that costs ~10 ms per array on this stack (a 262 144-point launch took 20-30 ms instead of
+   * 3), and six small pageable copies per launch cost more host time than the kernel of a small launch */
+  if (ctx->h_eff_cap < bytes) {
+    if (ctx->h_eff) HIP_TRY(ctx, hipHostFree(ctx->h_eff));
+    ctx->h_eff = nullptr;
+    ctx->h_eff_cap = 0;
+    const size_t cap = bytes + bytes / 2;
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_eff, cap));
+    ctx->h_eff_cap = cap;
+  }
+  double *h_alpha = (double *)ctx->h_eff, *h_l = h_alpha + n;
+  std::memcpy(h_alpha, alpha.data(), n * sizeof(double));
+  std::memcpy(h_l, lcam.data(), n * sizeof(double));
+  HIP_TRY(ctx, hipMemcpyAsync(d_alpha, h_alpha, 2 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   EscapeAngleParams P;
   P.metric = MP;
   P.alpha = d_alpha;
@@ -1360,11 +1375,14 @@ int eval_escape_batch(curvis_ctx *ctx, const curvis_metric *metric, const cvk::M
   }
   if (rc) return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(angle.data(), d_angle, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(space.data(), d_space, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(steps.data(), d_steps, n * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(status.data(), d_status, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  const size_t out_bytes = n * (2 * sizeof(double) + sizeof(unsigned) + sizeof(int));
+  unsigned char *h_out = ctx->h_eff + 2 * n * sizeof(double);
+  HIP_TRY(ctx, hipMemcpyAsync(h_out, d_angle, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(angle.data(), h_out, n * sizeof(double));
+  std::memcpy(space.data(), h_out + n * sizeof(double), n * sizeof(double));
+  std::memcpy(steps.data(), h_out + 2 * n * sizeof(double), n * sizeof(unsigned));
+  std::memcpy(status.data(), h_out + 2 * n * sizeof(double) + n * sizeof(unsigned), n * sizeof(int));
   float ms = 0.f;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   if (ms_acc) *ms_acc += ms;
@@ -1782,6 +1800,7 @@ void curvis_ctx_destroy(curvis_ctx *ctx) {
   if (ctx->d_store) (void)hipFree(ctx->d_store);
   if (ctx->d_rq) (void)hipFree(ctx->d_rq);
   if (ctx->d_eff) (void)hipFree(ctx->d_eff);
+  if (ctx->h_eff) (void)hipHostFree(ctx->h_eff);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->d_cams) (void)hipFree(ctx->d_cams);
   if (ctx->h_cams) (void)hipHostFree(ctx->h_cams);
