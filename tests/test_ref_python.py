@@ -64,3 +64,20 @@ def test_camera_matrix_equals_the_oracle():
         oc = O.camera((0.0, 5.0, 1.0, 0.0), tuple(fwd), tuple(up), 15.0, 43.0, (16, 9))
         got = np.array(oc.rot, dtype=np.float64).reshape(3, 3)
         assert np.array_equal(np.array(rot).view(np.uint64), got.view(np.uint64))
+
+
+@pytest.mark.parametrize("name,pos,n0", [("ellis", (0.0, 5.0, HALF_PI, 0.0), 24), ("interstellar", (0.0, 4.0, 1.3, 0.7), 20)])
+def test_efficient_renderer_equals_independent_python_restatement(name, pos, n0):
+    """render_image_efficient (what `curvis image|video` run): sample table, call/step counts and pixels"""
+    sp, sn = common.make_skies(64, 32, "check")
+    om = {"ellis": lambda: O.ellis(1.0), "interstellar": lambda: O.interstellar(0.1, 1e-4, 1.0)}[name]()
+    res, fwd, up = (10, 6), (-1.0, 0.1, 0.05), (0.0, 0.0, 1.0)
+    oc = O.camera(pos, fwd, up, 15.0, 43.0, res)
+    want_rgb, want, _ = O.render_image_efficient(O.LIBM, om, oc, O.sky(sp), O.sky(sn), 3000, 100.0, 0.05, n0, 12, 1e-3, 1e-3)
+    cam = R.Camera(pos, fwd, up, 15.0, 43.0, res[0], res[1])
+    rgb, (sa, se, ss), steps, calls = R.render_image_efficient(_metric(name), cam, sp, sn, 3000, 100.0, 0.05, n0, 12, 1e-3, 1e-3)
+    assert np.array_equal(np.array(sa).view(np.uint64), np.asarray(want["a"]).view(np.uint64))
+    assert np.array_equal(np.array(se).view(np.uint64), np.asarray(want["e"]).view(np.uint64))
+    assert np.array_equal(np.array(ss), np.asarray(want["s"]))
+    assert (steps, calls) == (want["steps"], want["calls"])
+    assert np.array_equal(np.array(rgb, dtype=np.uint8), want_rgb)
