@@ -13,6 +13,10 @@
  * (tests/test_oracle.py).  Third-party arithmetic (nalgebra 0.33.0, interp 1.0.3,
  * image 0.25.2 -- pinned in Cargo.lock, not under /root/reference) is restated
  * from the published behaviour of those crates; see DESIGN.md section 3.
+ * An independent second restatement (tests/ref_python.py, plain Python, written
+ * from the reference text) agrees with the libm flavour of this one bit for bit
+ * on whole small frames of both renderers (tests/test_ref_python.py); the libm
+ * flavour must be built with -fno-builtin-sin/cos (see the Makefile).
  *
  * Two math flavours, selected by the `fl` argument of every entry point:
  *   CVO_LIBM (0): glibc libm sin/cos/acos/atan/atan2/log -- what a Linux build of
