@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--max-iter", type=int, default=4096)
     ap.add_argument("--metric", default="ellis", choices=["ellis", "interstellar"])
     ap.add_argument("--sky", type=int, default=8192, help="sky width (height = width/2)")
-    ap.add_argument("--variant", type=int, default=1, help="1 static kernel (default), 0 persistent lane-refill kernel, 2 static + end-game relay")
+    ap.add_argument("--variant", type=int, default=-1,
+                    help="-1 library default (static kernel; relay kernel for big single frames), 1 static, 2 relay, 0 persistent lane-refill")
     ap.add_argument("--refill-threshold", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     ap.add_argument("--fast-math", type=int, default=1, help="1 shared-reciprocal step, 0 compiler IEEE div/sqrt")
@@ -172,7 +173,10 @@ def main():
         value = total_steps / elapsed / 1e6
         nominal = total_rays * args.max_iter / elapsed / 1e6
         info = ctx.device_info()
-        traffic, traffic_note = pmc_traffic(args)
+        # which integration kernel the library chose (automatic: relay for big single frames, else static)
+        kernel_name = ("geodesic_persistent" if args.variant == 0 else
+                       "geodesic_relay" if ctx.get_option("last_relay_launches") > 0 else "geodesic_static")
+        traffic, traffic_note = pmc_traffic(args, kernel_name)
         out = {
             "metric": "Mrays/s (pixels x steps/s) at 1920x1080, 4096 steps",
             "value": round(value, 1),
@@ -191,8 +195,7 @@ def main():
             "config": {
                 "workload": "configs[1]: %s wormhole, %dx%d, cap %d Euler steps, R=100, delta=0.05, single image; "
                             "%d frame(s)/GPU/step" % (args.metric, args.width, args.height, args.max_iter, 1),
-                "kernel": ({0: "geodesic_persistent", 2: "geodesic_relay"}.get(args.variant, "geodesic_static")) +
-                          ("<fast>" if args.fast_math else "<strict>"),
+                "kernel": kernel_name + ("<fast>" if args.fast_math else "<strict>"),
                 "frames_per_gpu": args.steps,
                 "rays_per_frame": int(per_launch_rays),
                 "executed_steps_per_frame": int(per_launch_steps),
@@ -206,7 +209,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / FP64_VECTOR_PEAK_TFLOPS, 4),
                 "flop_per_step": flop,
-                "kernel": {0: "geodesic_persistent", 2: "geodesic_relay"}.get(args.variant, "geodesic_static"),
+                "kernel": kernel_name,
                 "kernel_ms_avg": round(kernel_s * 1e3, 4),
                 "shade_kernel_ms_avg": round(total_shade_ms / n_launches, 4),
                 "traffic": traffic,
@@ -228,7 +231,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args):
+def pmc_traffic(args, kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/traffic.json, written by tools/make_profiles.py from separate --pmc FETCH_SIZE / WRITE_SIZE
     runs of this same command).  Returns (bytes, note) or (None, reason): counters cannot be read from
@@ -237,7 +240,7 @@ def pmc_traffic(args):
     try:
         with open(path) as f:
             t = json.load(f)
-        key = "%s_%dx%d_cap%d_variant%d" % (args.metric, args.width, args.height, args.max_iter, args.variant)
+        key = "%s_%dx%d_cap%d_%s" % (args.metric, args.width, args.height, args.max_iter, kernel_name)
         e = t.get(key)
         if e is None:
             return None, "no PMC profile committed for " + key

@@ -878,8 +878,8 @@ struct curvis_ctx {
   unsigned char *d_rq = nullptr;    /* RelayQueue + ticket ring of the relay kernel */
   int relay_segment = 0;            /* steps between two hand-over points; 0 = automatic */
   long long relay_min_blocks = -1;  /* smallest grid (fresh workgroups) the relay kernel is used for; -1 = automatic
-                                       (three times the ~6 resident workgroups per CU: below that there is hardly
-                                       a dispatch phase and the static kernel is as good) */
+                                       (7 per CU, a little more than the ~6 resident ones: below that there is no
+                                       dispatch phase and the static kernel is better) */
   uint32_t last_relay_launches = 0;
   uint64_t last_relay_parks = 0, last_relay_waiters = 0;
   unsigned relay_resident_blocks = 0; /* cached occupancy query (per metric kinds it differs little; first use wins) */
@@ -900,7 +900,8 @@ struct curvis_ctx {
   unsigned long long *d_counters = nullptr;
   unsigned long long *h_counters = nullptr; /* pinned */
   /* options */
-  int variant = 1;          /* 1 static one-ray-per-thread (default: fastest on the BASELINE configs), 0 persistent lane-refill */
+  int variant = -1;         /* -1 automatic (default): static kernel, relay kernel for single images of >= ~1800 workgroups;
+                               1 static one-ray-per-thread, 2 relay (subject to relay_min_blocks), 0 persistent lane-refill */
   int refill_threshold = 16;
   int blocks_per_cu = 0;    /* 0 = occupancy query */
   int fast_math = 1;        /* 1 shared-reciprocal step (ray_step_fast), 0 compiler IEEE div/sqrt */
@@ -1010,7 +1011,7 @@ int launch_relay(curvis_ctx *ctx, const IntegrateParams &P, bool relay_only) {
 template <int KIND, bool PHI, bool FAST>
 int launch_integrate(curvis_ctx *ctx, const IntegrateParams &P, bool fused, int relay) {
   if (relay && fused) return launch_relay<KIND, FAST>(ctx, P, relay == 2);
-  if (ctx->variant == 1 || ctx->variant == 2) {
+  if (ctx->variant != 0) {
     const unsigned long long blocks = (P.total_rays + 255ull) / 256ull;
     if (fused)
       hipLaunchKernelGGL((geodesic_static<KIND, false, FAST, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
@@ -1109,13 +1110,15 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   }
   /* fused shading: static kernel, no debug dump (option "fuse_shade", default on) -- no ray store at all.
    * Otherwise frames are rendered in chunks whose ray store stays below max_store_bytes. */
-  const bool fused = (ctx->variant == 1 || ctx->variant == 2) && ctx->fuse_shade != 0 && dbg_out == nullptr;
-  /* relay kernel ("variant" = 2): end-game hand-over of tiles; only launches of one or two frames have a tail
-   * worth its staging area (56 B per ray) -- larger batches use the static kernel */
+  const bool fused = ctx->variant != 0 && ctx->fuse_shade != 0 && dbg_out == nullptr;
+  /* relay kernel ("variant" = 2, and the automatic choice for big enough single images): end-game hand-over of
+   * tiles; only launches of one or two frames have a tail worth its staging area (56 B per ray) -- larger batches
+   * use the static kernel, and so do frames too small to have a dispatch phase (measured: 640x360 +9 %,
+   * 960x540 -11 %, 1280x720 -6 %, 1920x1080 -1..-4 %, 4K -0.5 %; tools/gpu_relay_sizes.py) */
   const unsigned long long relay_fresh_blocks = ((unsigned long long)((W + 7) / 8) * ((H + 7) / 8) * n_frames + 3ull) / 4ull;
   const unsigned long long relay_min = ctx->relay_min_blocks >= 0 ? (unsigned long long)ctx->relay_min_blocks
-                                                                   : 18ull * (unsigned long long)ctx->prop.multiProcessorCount;
-  const bool relay = ctx->variant == 2 && fused && n_frames <= 2 && relay_fresh_blocks >= relay_min;
+                                                                   : 7ull * (unsigned long long)ctx->prop.multiProcessorCount;
+  const bool relay = (ctx->variant == 2 || ctx->variant < 0) && fused && n_frames <= 2 && relay_fresh_blocks >= relay_min;
   uint32_t chunk = n_frames;
   if (relay) {
     const size_t rays = (size_t)((W + 7) / 8) * ((H + 7) / 8) * 64u * n_frames;
@@ -1182,7 +1185,7 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     const size_t trace_words = (size_t)(P.total_rays / 64ull) * 4u;
     size_t trace_alloc_words = trace_words;
     if (relay) trace_alloc_words = (size_t)((P.total_rays + 255ull) / 256ull) * 3u * 16u + 65536u * 16u; /* all workgroups x 4 waves */
-    if (trace_file && *trace_file && (ctx->variant == 1 || relay)) {
+    if (trace_file && *trace_file && (ctx->variant != 0 || relay)) {
       HIP_TRY(ctx, hipMalloc((void **)&P.trace, trace_alloc_words * sizeof(unsigned long long)));
       HIP_TRY(ctx, hipMemsetAsync(P.trace, 0, trace_alloc_words * sizeof(unsigned long long), ctx->stream));
     }

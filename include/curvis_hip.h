@@ -200,11 +200,12 @@ int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes);
 int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);
 int curvis_ctx_synchronize(curvis_ctx *ctx);
 
-/* tuning knobs (not part of the reference surface): "variant" (0 = persistent lane-refill kernel,
- * 1 = static one-ray-per-thread kernel, 2 = the static kernel with end-game hand-over of unfinished tiles
- * between waves ("relay"; used for launches of one or two frames of at least "relay_min_blocks" workgroups,
- * default automatic; "relay_segment" = steps between hand-over points, 0 = automatic; identical results; a
- * few per cent faster on 540p-900p single frames, no gain at 1080p and above), "refill_threshold",
+/* tuning knobs (not part of the reference surface): "variant" (-1 = automatic, the default: the static
+ * one-ray-per-thread kernel, and for launches of one or two frames with at least "relay_min_blocks" workgroups
+ * -- default 7 per CU, i.e. from about 960x540 -- the relay kernel; 0 = persistent lane-refill kernel;
+ * 1 = static kernel always; 2 = relay kernel = the static kernel with end-game hand-over of unfinished tiles
+ * between waves, still subject to "relay_min_blocks"; "relay_segment" = steps between hand-over points,
+ * 0 = automatic; all variants give identical results), "refill_threshold",
  * "blocks_per_cu", "fast_math"
  * (1 = shared-reciprocal Euler step, 0 = compiler IEEE division/sqrt; identical results), "fuse_shade"
  * (1 = the static kernel shades in its epilogue, 0 = final states staged in HBM + separate shade kernel),

@@ -70,7 +70,7 @@ def test_full_ray_state_bit_exact_vs_oracle(gpu_ctx, variant, fast, metric, res,
     assert (s.rays, s.steps, s.n_pos, s.n_neg, s.n_none) == (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none)
     # the non-debug kernel (phi not integrated) must give the same pixels
     assert np.array_equal(sys_.render_image(cap, 100.0, 0.05), want_rgb)
-    gpu_ctx.set_option("variant", 1)
+    gpu_ctx.set_option("variant", -1)
     gpu_ctx.set_option("fast_math", 1)
 
 
@@ -99,7 +99,7 @@ def test_relay_kernel_bit_exact(gpu_ctx, metric, res, pos, fwd, cap):
         if cap >= 1000 and metric != "flat":
             assert parks > 0   # the hand-over path was really exercised
     finally:
-        gpu_ctx.set_option("variant", 1)
+        gpu_ctx.set_option("variant", -1)
         gpu_ctx.set_option("relay_min_blocks", -1)
         gpu_ctx.set_option("relay_segment", 0)
 
@@ -128,7 +128,7 @@ def test_row_bands_equal_the_full_frame(gpu_ctx, metric, res, pos, fwd, cap):
         with pytest.raises(curvis_amd.CurvisError):
             gpu_ctx.render_brute_rows(pm, pc, H - 1, 2, cap, 100.0, 0.05)
     finally:
-        gpu_ctx.set_option("variant", 1)
+        gpu_ctx.set_option("variant", -1)
         gpu_ctx.set_option("relay_min_blocks", -1)
 
 
@@ -176,7 +176,7 @@ def test_full_size_frame_bit_exact(gpu_ctx, metric, res, cap):
             s = sys_.last_stats
             assert (s.steps, s.n_pos + s.n_neg + s.n_none) == (steps, res[0] * res[1])
         gpu_ctx.set_option("fuse_shade", 1)
-    gpu_ctx.set_option("variant", 1)
+    gpu_ctx.set_option("variant", -1)
     gpu_ctx.set_option("fast_math", 1)
 
 
@@ -407,7 +407,7 @@ def test_adversarial_fast_equals_strict_equals_oracle(gpu_ctx, case):
                 assert np.array_equal(got_rgb, want_rgb), (variant, fast)
                 assert np.array_equal(sys_.render_image(cap, R, delta), want_rgb), (variant, fast)
     finally:
-        gpu_ctx.set_option("variant", 1)
+        gpu_ctx.set_option("variant", -1)
         gpu_ctx.set_option("fast_math", 1)
 
 
@@ -493,7 +493,7 @@ def test_fuzz_gpu_vs_oracle(gpu_ctx):
                 rgb2, s2 = gpu_ctx.render_brute(pm, pc, cap, R, delta)
                 assert np.array_equal(rgb2, want_rgb) and s2.steps == st.steps
     finally:
-        gpu_ctx.set_option("variant", 1)
+        gpu_ctx.set_option("variant", -1)
         gpu_ctx.set_option("fast_math", 1)
     done = 0
     for trial in range(40):

@@ -19,7 +19,7 @@ def pmc(kind):
     for r in rows:
         name = r["Kernel_Name"]
         short = "geodesic_static" if "geodesic_static" in name else "geodesic_persistent" if "geodesic_persistent" in name \
-            else "shade_kernel" if "shade_kernel" in name else None
+            else "geodesic_relay" if "geodesic_relay" in name else "shade_kernel" if "shade_kernel" in name else None
         if short:
             agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
@@ -30,14 +30,15 @@ steps = bench["config"]["executed_steps_per_frame"]
 rays = bench["config"]["rays_per_frame"]
 ws = steps / 64.0
 sq, fe, wr = pmc("sq"), pmc("fetch"), pmc("write")
-kern = "geodesic_static" if ("geodesic_static", "SQ_INSTS_VALU") in sq else "geodesic_persistent"
+kern = ("geodesic_relay" if ("geodesic_relay", "SQ_INSTS_VALU") in sq else
+        "geodesic_static" if ("geodesic_static", "SQ_INSTS_VALU") in sq else "geodesic_persistent")
 KIB = 1024.0
 fetch_i = fe[(kern, "FETCH_SIZE")] * KIB * 2   # gfx950: FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md)
 write_i = wr[(kern, "WRITE_SIZE")] * KIB
 fetch_s = fe.get(("shade_kernel", "FETCH_SIZE"), 0.0) * KIB * 2   # absent when shading is fused into the epilogue
 write_s = wr.get(("shade_kernel", "WRITE_SIZE"), 0.0) * KIB
 traffic = {
-    "ellis_1920x1080_cap4096_variant1": {
+    "ellis_1920x1080_cap4096_%s" % kern: {
         "integrate_kernel_bytes": int(fetch_i + write_i), "integrate_fetch_bytes": int(fetch_i),
         "integrate_write_bytes": int(write_i), "shade_kernel_bytes": int(fetch_s + write_s),
         "algorithmic_bytes": 7 * rays,
@@ -46,7 +47,7 @@ traffic = {
     }
 }
 _gui = sq[(kern, "GRBM_GUI_ACTIVE")] / 8.0
-traffic["ellis_1920x1080_cap4096_variant1"].update({
+traffic["ellis_1920x1080_cap4096_%s" % kern].update({
     "valu_busy": round(4 * sq[(kern, "SQ_ACTIVE_INST_VALU")] / (1024 * _gui), 4),
     "valu_instr_per_wave_step": round(sq[(kern, "SQ_INSTS_VALU")] / ws, 1),
     "salu_instr_per_wave_step": round(sq[(kern, "SQ_INSTS_SALU")] / ws, 1),
@@ -61,7 +62,7 @@ if os.path.exists(inter_path) and os.path.exists(os.path.join(G, "pmc_sq_inter",
     iws = inter["config"]["executed_steps_per_frame"] / 64.0
     igui = isq[(kern, "GRBM_GUI_ACTIVE")] / 8.0
     ifetch, iwrite = ife[(kern, "FETCH_SIZE")] * KIB * 2, iwr[(kern, "WRITE_SIZE")] * KIB
-    traffic["interstellar_1920x1080_cap4096_variant1"] = {
+    traffic["interstellar_1920x1080_cap4096_%s" % kern] = {
         "integrate_kernel_bytes": int(ifetch + iwrite), "integrate_fetch_bytes": int(ifetch),
         "integrate_write_bytes": int(iwrite), "shade_kernel_bytes": 0, "algorithmic_bytes": 7 * rays,
         "source": "as above, profiles/%s_pmc_*_interstellar.csv" % rnd,
@@ -118,7 +119,7 @@ lines.append("| HBM traffic, shade kernel | read %.2f MB + write %.2f MB |" % (f
 lines.append("| algorithmic HBM bytes (7 B/ray) | %.2f MB |" % (7 * rays / 1e6))
 lines.append("")
 if inter is not None:
-    t = traffic["interstellar_1920x1080_cap4096_variant1"]
+    t = traffic["interstellar_1920x1080_cap4096_%s" % kern]
     lines.append("## Interstellar metric, same frame (`bench.py --metric interstellar`)\n")
     lines.append("| quantity | value |\n|---|---|")
     lines.append("| throughput | %.1f %s, %.3f ms per frame |" % (inter["value"], inter["unit"], inter["ms_per_step"]))
