@@ -162,7 +162,9 @@ def test_full_size_frame_bit_exact(gpu_ctx, metric, res, cap):
     want_rgb, want_dbg, steps = oracle_full_frame(O.CV, om, oc, sp, sn, cap)
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
                                          context=gpu_ctx)
-    for variant, fast in [(0, 1), (1, 1), (0, 0)]:
+    # -1 = the library's automatic choice: at these sizes the relay kernel for the production render (checked below
+    # through last_relay_launches), the static kernel for the debug dump
+    for variant, fast in [(0, 1), (1, 1), (0, 0), (-1, 1), (2, 0)]:
         gpu_ctx.set_option("variant", variant)
         gpu_ctx.set_option("fast_math", fast)
         got_rgb, got_dbg = sys_.render_image_debug(cap, 100.0, 0.05)
@@ -175,6 +177,8 @@ def test_full_size_frame_bit_exact(gpu_ctx, metric, res, cap):
             assert np.array_equal(sys_.render_image(cap, 100.0, 0.05), want_rgb)
             s = sys_.last_stats
             assert (s.steps, s.n_pos + s.n_neg + s.n_none) == (steps, res[0] * res[1])
+            if fuse and variant in (-1, 2):
+                assert gpu_ctx.get_option("last_relay_launches") >= 1 and gpu_ctx.get_option("last_relay_parks") > 0
         gpu_ctx.set_option("fuse_shade", 1)
     gpu_ctx.set_option("variant", -1)
     gpu_ctx.set_option("fast_math", 1)
