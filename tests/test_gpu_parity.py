@@ -98,6 +98,11 @@ def test_relay_kernel_bit_exact(gpu_ctx, metric, res, pos, fwd, cap):
                 parks += gpu_ctx.get_option("last_relay_parks")
         if cap >= 1000 and metric != "flat":
             assert parks > 0   # the hand-over path was really exercised
+        # two frames in one relay launch (the largest batch the relay kernel is used for)
+        gpu_ctx.set_option("relay_segment", 50)
+        rgb2, s2 = gpu_ctx.render_brute(pm, [pc, pc], cap, 100.0, 0.05)
+        assert np.array_equal(rgb2[0], want_rgb) and np.array_equal(rgb2[1], want_rgb)
+        assert (s2.rays, s2.steps) == (2 * st.rays, 2 * st.steps) and gpu_ctx.get_option("last_relay_launches") >= 1
     finally:
         gpu_ctx.set_option("variant", -1)
         gpu_ctx.set_option("relay_min_blocks", -1)
