@@ -18,7 +18,7 @@ from curvis_amd import paths, rendering, skies  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=8, help="simulated world size for the video shards")
-    ap.add_argument("--variant", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--c5-frames", type=int, default=12, help="frames of the config-5 shard to render")
     args = ap.parse_args()
     ctx = curvis_amd.Context(0)
