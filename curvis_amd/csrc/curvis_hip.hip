@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void geodesic_relay(const IntegrateParams P, c
     unsigned hw_id, xcc_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-    unsigned long long *rec = P.trace + 4ull * ((unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6));
+    unsigned long long *rec = P.trace + 4ull * ((unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     rec[0] = t_start;
     rec[1] = wall_clock64();
     rec[2] = (unsigned long long)hw_id | ((unsigned long long)(xcc_id & 0xf) << 32) | ((unsigned long long)(fresh ? 1 : 0) << 40) |
@@ -882,7 +882,9 @@ struct curvis_ctx {
                                        dispatch phase and the static kernel is better) */
   uint32_t last_relay_launches = 0;
   uint64_t last_relay_parks = 0, last_relay_waiters = 0;
-  unsigned relay_resident_blocks = 0; /* cached occupancy query (per metric kinds it differs little; first use wins) */
+  unsigned relay_resident_blocks[3][2] = {{0, 0}, {0, 0}, {0, 0}}; /* cached occupancy query per kernel instantiation */
+  int relay_resident_threads = 0;                                  /* ... valid for this workgroup size */
+  int block_threads = 0; /* workgroup size of the static / relay kernels: 64, 128 or 256; 0 = automatic */
   size_t store_cap = 0;
   hipEvent_t ev2 = nullptr;
   /* efficient mode scratch (device) */
@@ -971,6 +973,13 @@ cvk::CameraParams make_camera(const curvis_camera &c) {
   return C;
 }
 
+/* workgroup size of the static and relay kernels ("block_threads"; total_rays is a multiple of 64) */
+unsigned integrate_block_threads(const curvis_ctx *ctx, int kind) {
+  (void)kind;
+  const int bt = ctx->block_threads;
+  return (bt == 64 || bt == 128 || bt == 256) ? (unsigned)bt : 256u;
+}
+
 /* grid = fresh workgroups + relay workgroups; see geodesic_relay */
 template <int KIND, bool FAST>
 int launch_relay(curvis_ctx *ctx, const IntegrateParams &P, bool relay_only) {
@@ -979,7 +988,8 @@ int launch_relay(curvis_ctx *ctx, const IntegrateParams &P, bool relay_only) {
   RelayArgs A;
   A.q = (RelayQueue *)ctx->d_rq;
   A.n_tiles = P.total_rays / 64ull;
-  const unsigned long long fresh_blocks = relay_only ? 0ull : (P.total_rays + 255ull) / 256ull;
+  const unsigned bt = integrate_block_threads(ctx, KIND);
+  const unsigned long long fresh_blocks = relay_only ? 0ull : (P.total_rays + bt - 1ull) / bt;
   A.fresh_blocks = (unsigned)fresh_blocks;
   /* segment = about half the length of an ordinary ray, (R / delta) / 2 steps: one or two hand-over points per
    * tile in flight (measured optimum 512-1024 for ~2000-step rays; shorter segments cost more in boundary
@@ -989,20 +999,25 @@ int launch_relay(curvis_ctx *ctx, const IntegrateParams &P, bool relay_only) {
     unsigned seg = (half >= 256.0 && half <= 65536.0) ? (unsigned)half : 1024u;
     A.seg = ctx->relay_segment > 0 ? (unsigned)ctx->relay_segment : seg;
   }
-  if (ctx->relay_resident_blocks == 0) {
-    int per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, geodesic_relay<KIND, FAST>, 256, 0));
-    if (per_cu <= 0) per_cu = 1;
-    ctx->relay_resident_blocks = (unsigned)per_cu * (unsigned)ctx->prop.multiProcessorCount;
+  if (ctx->relay_resident_threads != (int)bt) {
+    for (auto &row : ctx->relay_resident_blocks) row[0] = row[1] = 0;
+    ctx->relay_resident_threads = (int)bt;
   }
-  const unsigned long long resident_blocks = ctx->relay_resident_blocks;
+  unsigned &cached = ctx->relay_resident_blocks[KIND][FAST ? 1 : 0];
+  if (cached == 0) {
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, geodesic_relay<KIND, FAST>, (int)bt, 0));
+    if (per_cu <= 0) per_cu = 1;
+    cached = (unsigned)per_cu * (unsigned)ctx->prop.multiProcessorCount;
+  }
+  const unsigned long long resident_blocks = cached;
   if (!relay_only) HIP_TRY(ctx, hipMemsetAsync(ctx->d_rq, 0, bytes, ctx->stream));
   /* every tile in flight when the fresh workgroups run out (at most the resident waves) is passed on once per
    * segment of its remaining steps: (max_iter / seg) <= 16 hand-overs each, usually ~2; surplus relay
    * workgroups leave at once */
   unsigned long long relay_blocks = resident_blocks * 24ull;
   if (relay_blocks > fresh_blocks * 2ull + resident_blocks) relay_blocks = fresh_blocks * 2ull + resident_blocks;
-  hipLaunchKernelGGL((geodesic_relay<KIND, FAST>), dim3((unsigned)(fresh_blocks + relay_blocks)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL((geodesic_relay<KIND, FAST>), dim3((unsigned)(fresh_blocks + relay_blocks)), dim3(bt), 0, ctx->stream,
                      P, A);
   HIP_TRY(ctx, hipGetLastError());
   return CURVIS_OK;
@@ -1012,11 +1027,12 @@ template <int KIND, bool PHI, bool FAST>
 int launch_integrate(curvis_ctx *ctx, const IntegrateParams &P, bool fused, int relay) {
   if (relay && fused) return launch_relay<KIND, FAST>(ctx, P, relay == 2);
   if (ctx->variant != 0) {
-    const unsigned long long blocks = (P.total_rays + 255ull) / 256ull;
+    const unsigned bt = integrate_block_threads(ctx, KIND);
+    const unsigned long long blocks = (P.total_rays + bt - 1ull) / bt;
     if (fused)
-      hipLaunchKernelGGL((geodesic_static<KIND, false, FAST, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+      hipLaunchKernelGGL((geodesic_static<KIND, false, FAST, true>), dim3((unsigned)blocks), dim3(bt), 0, ctx->stream, P);
     else
-      hipLaunchKernelGGL((geodesic_static<KIND, PHI, FAST, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, P);
+      hipLaunchKernelGGL((geodesic_static<KIND, PHI, FAST, false>), dim3((unsigned)blocks), dim3(bt), 0, ctx->stream, P);
   } else {
     int per_cu = ctx->blocks_per_cu;
     if (per_cu <= 0) {
@@ -1184,7 +1200,7 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     const char *trace_file = getenv("CURVIS_TRACE_FILE");
     const size_t trace_words = (size_t)(P.total_rays / 64ull) * 4u;
     size_t trace_alloc_words = trace_words;
-    if (relay) trace_alloc_words = (size_t)((P.total_rays + 255ull) / 256ull) * 3u * 16u + 65536u * 16u; /* all workgroups x 4 waves */
+    if (relay) trace_alloc_words = (size_t)(P.total_rays / 64ull) * 3u * 4u + 65536u * 16u; /* every wave of the grid */
     if (trace_file && *trace_file && (ctx->variant != 0 || relay)) {
       HIP_TRY(ctx, hipMalloc((void **)&P.trace, trace_alloc_words * sizeof(unsigned long long)));
       HIP_TRY(ctx, hipMemsetAsync(P.trace, 0, trace_alloc_words * sizeof(unsigned long long), ctx->stream));
@@ -2154,6 +2170,8 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->refill_threshold = (int)value;
   else if (k == "blocks_per_cu")
     ctx->blocks_per_cu = (int)value;
+  else if (k == "block_threads")
+    ctx->block_threads = (int)value;
   else if (k == "relay_segment")
     ctx->relay_segment = (int)value;
   else if (k == "relay_min_blocks")
@@ -2183,6 +2201,8 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->refill_threshold;
   else if (k == "blocks_per_cu")
     *value = ctx->blocks_per_cu;
+  else if (k == "block_threads")
+    *value = ctx->block_threads;
   else if (k == "relay_segment")
     *value = ctx->relay_segment;
   else if (k == "relay_min_blocks")

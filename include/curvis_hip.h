@@ -205,7 +205,8 @@ int curvis_ctx_synchronize(curvis_ctx *ctx);
  * -- default 7 per CU, i.e. from about 960x540 -- the relay kernel; 0 = persistent lane-refill kernel;
  * 1 = static kernel always; 2 = relay kernel = the static kernel with end-game hand-over of unfinished tiles
  * between waves, still subject to "relay_min_blocks"; "relay_segment" = steps between hand-over points,
- * 0 = automatic; all variants give identical results), "refill_threshold",
+ * 0 = automatic; all variants give identical results), "block_threads" (workgroup size of the static / relay
+ * kernels: 64, 128 or 256; 0 = automatic = 256), "refill_threshold",
  * "blocks_per_cu", "fast_math"
  * (1 = shared-reciprocal Euler step, 0 = compiler IEEE division/sqrt; identical results), "fuse_shade"
  * (1 = the static kernel shades in its epilogue, 0 = final states staged in HBM + separate shade kernel),

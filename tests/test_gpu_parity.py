@@ -103,7 +103,16 @@ def test_relay_kernel_bit_exact(gpu_ctx, metric, res, pos, fwd, cap):
         rgb2, s2 = gpu_ctx.render_brute(pm, [pc, pc], cap, 100.0, 0.05)
         assert np.array_equal(rgb2[0], want_rgb) and np.array_equal(rgb2[1], want_rgb)
         assert (s2.rays, s2.steps) == (2 * st.rays, 2 * st.steps) and gpu_ctx.get_option("last_relay_launches") >= 1
+        # other workgroup sizes ("block_threads"): one and two waves per workgroup, relay and static kernels
+        for bt in (64, 128):
+            gpu_ctx.set_option("block_threads", bt)
+            for variant in (2, 1):
+                gpu_ctx.set_option("variant", variant)
+                rgb, s = gpu_ctx.render_brute(pm, pc, cap, 100.0, 0.05)
+                assert np.array_equal(rgb, want_rgb), (bt, variant)
+                assert (s.rays, s.steps, s.n_pos, s.n_neg, s.n_none) == (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none)
     finally:
+        gpu_ctx.set_option("block_threads", 0)
         gpu_ctx.set_option("variant", -1)
         gpu_ctx.set_option("relay_min_blocks", -1)
         gpu_ctx.set_option("relay_segment", 0)

@@ -83,7 +83,7 @@ shutil.copy(os.path.join(G, "stats", "bench_kernel_stats.csv"), os.path.join(P, 
 shutil.copy(os.path.join(G, "ubench.log"), os.path.join(P, "%s_ubench_fp64.txt" % rnd))
 shutil.copy(os.path.join(G, "configs.md"), os.path.join(P, "%s_configs.md" % rnd))
 for src_name, dst_name in (("cli_video.txt", "cli_video.txt"), ("efficient_sweep.txt", "efficient_sweep.txt"),
-                           ("tail.txt", "frames_per_launch.txt"), ("deep_fuzz.txt", "deep_fuzz.txt"), ("efficient_phases.txt", "efficient_phases.txt"), ("wave_trace_config2.txt", "wave_trace_config2.txt")):
+                           ("tail.txt", "frames_per_launch.txt"), ("deep_fuzz.txt", "deep_fuzz.txt"), ("efficient_phases.txt", "efficient_phases.txt"), ("wave_trace_config2.txt", "wave_trace_config2.txt"), ("wave_trace_config2_relay.txt", "wave_trace_config2_relay.txt")):
     if os.path.exists(os.path.join(G, src_name)):
         shutil.copy(os.path.join(G, src_name), os.path.join(P, "%s_%s" % (rnd, dst_name)))
 for n in ("bench_default", "bench_persistent", "bench_strict", "bench_download", "bench_config3"):
