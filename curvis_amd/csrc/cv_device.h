@@ -168,13 +168,13 @@ CV_HD double rsq_seed(double x) {
   return 1.0 / CV_SQRT(x);
 #endif
 }
-/* y ~ 1/d: hardware seed + two Newton steps (identical to the fdiv expansion's reciprocal) */
+/* y ~ 1/d to about an ulp: hardware seed (2^-23) + ONE third-order step, y0 (1 + e + e^2) with e = 1 - d y0,
+ * i.e. 1/d (1 - e^3): 2^-69 before the final rounding, in three fmas (two Newton steps take four) */
 CV_HD double recip_nr2(double d) {
-  double y = rcp_seed(d);
-  double e = CV_FMA(-d, y, 1.0);
-  y = CV_FMA(y, e, y);
-  e = CV_FMA(-d, y, 1.0);
-  return CV_FMA(y, e, y);
+  const double y0 = rcp_seed(d);
+  const double e = CV_FMA(-d, y0, 1.0);
+  const double p = CV_FMA(e, e, e);
+  return CV_FMA(y0, p, y0);
 }
 /* correctly rounded n/d given y ~ 1/d */
 CV_HD double div_with_recip(double n, double d, double y) {
@@ -182,22 +182,24 @@ CV_HD double div_with_recip(double n, double d, double y) {
   const double rem = CV_FMA(-d, q0, n);
   return CV_FMA(rem, y, q0);
 }
-/* root = sqrt(x) correctly rounded (the AMDGPU Goldschmidt sequence without scaling), y ~ 1/sqrt(x) */
+/* root = sqrt(x) correctly rounded, y ~ 1/sqrt(x) to about an ulp (Goldschmidt on the hardware seed, no
+ * scaling).  With g0 = x y0, h0 = y0 / 2 and e = 1/2 - h0 g0:  sqrt(x) = g0 (1 - 2e)^(-1/2) = g0 (1 + e + 3/2 e^2
+ * + 5/2 e^3 ...), and the same factor takes h0 to 1/(2 sqrt(x)).  One third-order step p = e + 3/2 e^2 brings
+ * BOTH to rounding accuracy (seed 2^-23 -> 2^-70 before rounding); the final residual step g + (x - g^2) h then
+ * sees the exact residual (fma) and an h good to 2^-53, i.e. a value within ~2^-53 ulp of sqrt(x) before its
+ * single rounding, and 1/sqrt(x) = h + h needs no Newton step of its own.  11 instructions; the compiler's
+ * expansion (second-order step, two residual steps with a 2^-45 h) plus a reciprocal refinement took 13. */
 CV_HD void sqrt_and_rsqrt(double x, double &root, double &y) {
   const double y0 = rsq_seed(x);
   double g = x * y0;
   double h = 0.5 * y0;
   const double e = CV_FMA(-h, g, 0.5);
-  g = CV_FMA(g, e, g);
-  h = CV_FMA(h, e, h);
-  double d = CV_FMA(-g, g, x);
-  g = CV_FMA(d, h, g);
-  d = CV_FMA(-g, g, x);
-  g = CV_FMA(d, h, g);
-  root = g;
-  const double yy = h + h;
-  const double e2 = CV_FMA(-yy, g, 1.0);
-  y = CV_FMA(yy, e2, yy);
+  const double p = e * CV_FMA(1.5, e, 1.0);
+  g = CV_FMA(g, p, g);
+  h = CV_FMA(h, p, h);
+  const double d = CV_FMA(-g, g, x);
+  root = CV_FMA(d, h, g);
+  y = h + h;
 }
 /* lo_hi <= (high word of |v|) < hi_hi : exponent-range test with two integer ops */
 CV_HD bool hi_word_in(double v, uint32_t lo_hi, uint32_t hi_hi) {

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""A/B two builds of libcurvis_hip.so on the same box, interleaved: build/ab/old.so vs build/ab/new.so.
+Each measurement runs in a child process (the library path is fixed at import)."""
+import os, subprocess, sys
+import numpy as np
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import curvis_amd._abi as A
+A.LIB_PATH = sys.argv[1]
+import curvis_amd
+from curvis_amd import skies
+ctx = curvis_amd.Context(0)
+ctx.set_sky(0, curvis_amd.SphericalImage(skies.smooth(512, 256, 0))); ctx.set_sky(1, curvis_amd.SphericalImage(skies.smooth(512, 256, 1)))
+cam = curvis_amd.Camera((0.0, 5.0, np.pi / 2, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 15.0, 43.0, 1920, 1080)
+out = []
+for m, nf in ((curvis_amd.EllisMetric(1.0), 1), (curvis_amd.EllisMetric(1.0), 6), (curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0), 1)):
+    ts = []
+    for _ in range(12):
+        _, st = ctx.render_brute(m, cam if nf == 1 else [cam] * nf, 4096, 100.0, 0.05, download=False)
+        ts.append(st.integrate_ms / nf)
+    out.append(float(np.median(ts[2:])))
+print(" ".join("%%.4f" %% v for v in out))
+''' % root
+res = {"old": [], "new": []}
+for rnd in range(int(os.environ.get("ROUNDS", "4"))):
+    for name in ("old", "new"):
+        r = subprocess.run([sys.executable, "-c", CHILD, os.path.join(root, "build", "ab", name + ".so")], capture_output=True, text=True)
+        vals = [float(v) for v in r.stdout.split()] if r.returncode == 0 else None
+        print(name, r.stdout.strip() if vals else r.stderr[-400:], flush=True)
+        if vals: res[name].append(vals)
+for name in res:
+    print(name, "median over rounds [ellis x1, ellis x6 per frame, interstellar x1] ms:", np.median(np.array(res[name]), axis=0))
