@@ -308,8 +308,8 @@ CV_HD cv_sc_tab_t cv_sc_table(void) {
 
 /* sin/cos of K*pi/64 + (y + yl), |y| <= pi/128:
  *   sin = S + [ C*y + ( S_lo + S*(cos y - 1) + C*(sin y - y) ) ],   cos = C + [ -S*y + ( C_lo + C*(cos y - 1) - S*(sin y - y) ) ]
- * with sin y - y = y^3 (s1 + s2 z + s3 z^2) + yl and cos y - 1 = z (c1 + c2 z + c3 z^2) - y*yl, z = y^2 (Taylor
- * coefficients: truncation < 2^-61 on this interval).  The bracket is evaluated with one fma, so each
+ * with sin y - y = y^3 (s1 + s2 z + s3 z^2) + yl and cos y - 1 = z (c1 + c2 z + c3 z^2), z = y^2 (Taylor
+ * coefficients: truncation < 2^-61 on this interval; the term -y*yl of cos(y + yl) is below 2^-63 and left out).  The bracket is evaluated with one fma, so each
  * result carries two roundings; the error is < 0.6 ulp except where the result is much smaller than pi/64
  * times its partner (next to the zeros of sin resp. cos), where it stays below 1 ulp. */
 CV_HD void cv_sincos_core(int K, double y, double yl, cv_sc_tab_t T, double *sn, double *cs) {
@@ -319,7 +319,7 @@ CV_HD void cv_sincos_core(int K, double y, double yl, cv_sc_tab_t T, double *sn,
   const double pc = cv_fma_ks(z, cv_fma_ks(z, -1.38888888888888894189e-03, 4.16666666666666643537e-02), -0.5);
   const double yz = y * z;
   const double sl = CV_FMA(yz, ps, yl);
-  const double cm = CV_FMA(-y, yl, z * pc);
+  const double cm = z * pc;
   double e = CV_FMA(Sh, cm, Sl);
   e = CV_FMA(Ch, sl, e);
   *sn = Sh + CV_FMA(Ch, y, e);
@@ -330,28 +330,29 @@ CV_HD void cv_sincos_core(int K, double y, double yl, cv_sc_tab_t T, double *sn,
 
 /* sin and cos of x together, table-driven.
  *
- * Main path (|x| < 1024 and x not within 2^-20 of a multiple of pi/64), branch-free:
- *   k  = nearest integer to x * 64/pi        |k| < 2^15 (magic-number rounding, see CV_RND_MAGIC)
- *   r1 = fma(-k, Q1, x)                      exact: Q1 has 38 bits, the difference fits 53 bits
- *   t  = fma(-k, Q2, r1)                     head of the reduced argument, |t| <= pi/128
- *   u  = r1 - t                              exact (|u| < 2^-27, a multiple of ulp(t) >= 2^-72)
- *   tl = fma(-k, Q3, fma(-k, Q2, u))         tail: rounding error of t plus the third piece of pi/64
- * with pi/64 = Q1 + Q2 + Q3 to 2^-134.  Every other argument (tiny, huge, non-finite, or deeply cancelling
+ * Main path (|x| < 16 and x not within 2^-20 of a multiple of pi/64), branch-free:
+ *   k  = nearest integer to x * 64/pi        |k| <= 326 < 2^9 (magic-number rounding, see CV_RND_MAGIC)
+ *   r1 = fma(-k, A, x)                       exact: A has 44 bits, k A is a double, the difference fits 53 bits
+ *   t  = fma(-k, B, r1)                      head of the reduced argument, |t| <= pi/128; k B is a double too
+ *   u  = r1 - t                              exact (|u| < 2^-39, a multiple of ulp(t) >= 2^-72)
+ *   tl = fma(-k, B, u)                       exact: the rounding error of t
+ * with pi/64 = A + B + 1.1e-28 (two 44-bit pieces): what is left out is |k| 1.1e-28 < 2^-84, below 2^-64 of
+ * |t| >= 2^-20.  Every other argument (larger, tiny, non-finite, or deeply cancelling
  * such as theta == fl(pi/2), which the equatorial rays hold for ever) is first reduced modulo pi/2 by
- * cv_rem_pio2 (fdlibm-style iterations / 192-bit Payne-Hanek) and then by the same three-piece step with
- * |k| <= 17.  Which path an argument takes is a function of the argument alone, and both paths end in
+ * cv_rem_pio2 (fdlibm-style iterations / 192-bit Payne-Hanek) and then by a three-piece step (38 + 38 + 53 bits
+ * of pi/64, to 2^-134) with |k| <= 17.  Which path an argument takes is a function of the argument alone, and both paths end in
  * cv_sincos_core, so host and device agree bit for bit. */
 CV_HD void cv_sincos_t(double x, cv_sc_tab_t T, double *sn, double *cs) {
   const double kb = CV_FMA(x, CV_64OPI, CV_RND_MAGIC);
   const double k = kb - CV_RND_MAGIC;
-  const double r1 = CV_FMA(-k, CV_PIO64_1, x);
-  const double t = CV_FMA(-k, CV_PIO64_2, r1);
+  const double r1 = CV_FMA(-k, CV_PIO64_A, x);
+  const double t = CV_FMA(-k, CV_PIO64_B, r1);
   double y, yl;
   int K;
-  if (CV_FABS(x) < 1024.0 && CV_FABS(t) >= 9.5367431640625e-07 /* 2^-20 */) {
+  if (CV_FABS(x) < 16.0 && CV_FABS(t) >= 9.5367431640625e-07 /* 2^-20 */) {
     const double u = r1 - t;
     y = t;
-    yl = CV_FMA(-k, CV_PIO64_3, CV_FMA(-k, CV_PIO64_2, u));
+    yl = CV_FMA(-k, CV_PIO64_B, u);
     K = (int)cv_lo(kb);
   } else {
     const uint32_t ix = cv_hi(x) & 0x7fffffffu;
