@@ -100,11 +100,15 @@ struct ShadeParams {
 /* Per-workgroup LDS copy of the sin/cos table (4 KiB): the Euler loop evaluates sincos once per step per
  * lane with a data-dependent index; two ds_read_b128 from LDS instead of divergent __constant__ loads. */
 template <int KIND>
-struct MathTablesLds {
-  static constexpr unsigned LOG_ROWS = (KIND == cvk::METRIC_INTERSTELLAR) ? 256u : 1u;
-  double sc[128][4];
+struct alignas(16) MathTablesLds {
+  static constexpr unsigned LOG_ROWS = (KIND == cvk::METRIC_INTERSTELLAR) ? 256u : 2u;
   static constexpr unsigned ATAN_ROWS = (KIND == cvk::METRIC_INTERSTELLAR) ? (unsigned)CV_ATAN_TABLE_N : 1u;
+  /* Order and alignment are chosen for the address arithmetic of the lookups: the 24-byte log rows sit at offset
+   * 0, so ds_read2_b64 (whose offset field is short) and ds_read_b64 share one address register; the 32- and
+   * 64-byte rows of the other two tables are read with ds_read_b128, whose offset field reaches any LDS
+   * address, so their base offsets cost no instruction either. */
   double lg[LOG_ROWS][3]; /* only the Interstellar metric evaluates a logarithm and an arc tangent per step */
+  double sc[128][4];
   double at[ATAN_ROWS][8];
 };
 

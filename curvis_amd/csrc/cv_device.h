@@ -62,7 +62,7 @@ CV_HD void metric_eval(const MetricParams &M, double l, double &r, double &r2, d
          *   2*(al - a)        = fma(2, al, -2a)           scaling by two commutes with the rounding
          *   xn / (pi m)       Markstein with the host-rounded reciprocal
          *   x*at - lg/2       = fma(-0.5, lg, RN(x*at))   lg/2 is exact
-         *   (2/pi)*signum(l)*at = copysign(2/pi, l) * at  multiplying by +-1 is exact; l is not NaN here
+         *   (2/pi)*signum(l)*at = copysign((2/pi) * at, l)  multiplying by +-1 is exact, at >= +0; l is not NaN here
          * and x >= +0, 1 + x^2 finite and >= 1 (|l| <= max_radius < 2^90 on the guarded path), so atan / log
          * need neither sign nor special-case handling. */
         const double xn = CV_FMA(2.0, al, -2.0 * M.a);
@@ -71,7 +71,7 @@ CV_HD void metric_eval(const MetricParams &M, double l, double &r, double &r2, d
         const double at = cv_atan_nonneg_t(x, M.AT);
         const double lg = cv_log_ge1_t(1.0 + x * x, M.LT);
         r = M.rho + M.m * CV_FMA(-0.5, lg, x * at);
-        rd = cv_from_bits(cv_bits(M.two_o_pi) | (cv_bits(l) & 0x8000000000000000ULL)) * at;
+        rd = __builtin_copysign(M.two_o_pi * at, l); /* one v_bfi_b32; rounding is sign-symmetric */
       } else {
         const double xn = 2.0 * (al - M.a);
         const double x = xn / M.pim;

@@ -53,6 +53,7 @@
 /* 1.5 * 2^52: fma(x, c, MAGIC) - MAGIC is the integer nearest to the exact product x*c (|x*c| < 2^31), and the
  * low word of the biased sum is that integer in two's complement -- rounding and int conversion in two ops */
 #define CV_RND_MAGIC 6755399441055744.0
+#define CV_RND_MAGIC_128TH 52776558133248.0 /* 1.5 * 2^45: ulp 2^-7 */
 
 #define CV_PI 3.14159265358979311600e+00 /* 0x400921FB54442D18 = Rust std::f64::consts::PI */
 
@@ -111,16 +112,15 @@ CV_HD double cv_fma_ks(double a, double b, double c) {
 }
 
 /* n/d for operands and quotient well inside the normal range (as inside atan/log below).  Host: the IEEE
- * operator.  Device: the AMDGPU fdiv expansion (v_rcp_f64, two Newton steps, quotient, exact remainder,
- * final fma) without its div_scale/div_fixup range handling -- the same instructions the compiler emits
- * for `/` when no scaling is needed, hence the same correctly rounded result. */
+ * operator.  Device: the shape of the AMDGPU fdiv expansion (v_rcp_f64, refinement of the reciprocal
+ * to ~1 ulp -- one third-order step instead of the compiler's two Newton steps --, quotient, exact remainder,
+ * final fma) without its div_scale/div_fixup range handling.  The final fma rounds q + rem/d computed to
+ * ~2^-100 relative, i.e. the correctly rounded quotient (Markstein); device == host is asserted on sweeps. */
 CV_HD double cv_div_nr(double n, double d) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double y = __builtin_amdgcn_rcp(d);
-  double e = CV_FMA(-d, y, 1.0);
-  y = CV_FMA(y, e, y);
-  e = CV_FMA(-d, y, 1.0);
-  y = CV_FMA(y, e, y);
+  const double y0 = __builtin_amdgcn_rcp(d);
+  const double e = CV_FMA(-d, y0, 1.0);
+  const double y = CV_FMA(y0, CV_FMA(e, e, e), y0); /* y0 (1 + e + e^2) = (1 - e^3)/d: one third-order step */
   const double q = n * y;
   const double r = CV_FMA(-d, q, n);
   return CV_FMA(r, y, q);
@@ -410,7 +410,7 @@ CV_HD double cv_cos(double x) {
  * __constant__ copy unless the caller passes its own (the Interstellar kernels keep one in LDS). */
 typedef const double (*cv_atan_tab_t)[8];
 #if defined(__HIPCC__) || defined(__HIP__)
-__device__ __constant__ static const double cv_atan_table_dev[CV_ATAN_TABLE_N][8] = {CV_ATAN_TABLE_ROWS};
+__device__ __constant__ static const double cv_atan_table_dev[CV_ATAN_TABLE_N][8] __attribute__((aligned(16))) = {CV_ATAN_TABLE_ROWS};
 #endif
 static const double cv_atan_table_host[CV_ATAN_TABLE_N][8] = {CV_ATAN_TABLE_ROWS};
 CV_HD cv_atan_tab_t cv_atan_table(void) {
@@ -451,7 +451,7 @@ CV_HD double cv_atan_edge(double x) {
 
 /* atan x, table-driven for 0.4375 <= |x| < 2^66 (branch-free):
  *   u = |x| < 2 ? |x| : -1/|x|        (correctly rounded reciprocal; u in [-1/2, 0) or [0.4375, 2))
- *   j = rint(128 u), h = u - j/128    exact, |h| <= 2^-8
+ *   j = rint(128 u), h = u - j/128    exact, |h| <= 2^-8 (magic-number rounding to multiples of 2^-7)
  *   atan|x| = X_j + h (q1 + q2 h + ... + q6 h^2..h^5),   X_j = atan(j/128) (+ pi/2 on the reciprocal branch)
  * evaluated as X_hi + fma(h, Q, X_lo).  Error: 0.5 ulp of the last addition + the rounding of the reciprocal
  * (<= 2^-53 u/(1+u^2) <= 0.2 ulp of a result >= atan 2) + Taylor truncation h^7/7 (< 0.03 ulp): < 0.75 ulp. */
@@ -459,12 +459,24 @@ CV_HD double cv_atan_edge(double x) {
 CV_HD double cv_atan_main(double ax, uint32_t ix, cv_atan_tab_t T) {
   const double inv = cv_div_nr(-1.0, ax);
   const double u = (ix >= 0x40000000u) ? inv : ax;
-  const double jb = CV_FMA(u, 128.0, CV_RND_MAGIC);
-  const double jf = jb - CV_RND_MAGIC;
-  const double h = CV_FMA(jf, -0.0078125, u);
+  /* u + 1.5 2^45 rounds u to the nearest multiple of 2^-7 (ties to even j, like rint(128 u)) and leaves j in the
+   * low mantissa bits; plain additions, so the constant can sit in a scalar register */
+  const double jb = u + CV_RND_MAGIC_128TH;
+  const double jq = jb - CV_RND_MAGIC_128TH; /* j / 128 */
+  const double h = u - jq;                   /* exact */
+#if defined(__HIP_DEVICE_COMPILE__)
+  /* the 64-byte row as four 16-byte loads (tables are 16-byte aligned): from LDS that is four ds_read_b128
+   * off ONE address register (their offset field reaches the whole LDS; ds_read2_b64's does not) */
+  typedef double cv_f64x2 __attribute__((ext_vector_type(2)));
+  const cv_f64x2 *R = (const cv_f64x2 *)T[(int)cv_lo(jb) + 64];
+  const cv_f64x2 r01 = R[0], r23 = R[1], r45 = R[2], r67 = R[3];
+  const double Q = cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, r67.y, r67.x), r45.y), r45.x), r23.y), r23.x);
+  return r01.x + CV_FMA(h, Q, r01.y);
+#else
   const double *R = T[(int)cv_lo(jb) + 64];
   const double Q = cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, R[7], R[6]), R[5]), R[4]), R[3]), R[2]);
   return R[0] + CV_FMA(h, Q, R[1]);
+#endif
 }
 
 CV_HD double cv_atan_t(double x, cv_atan_tab_t T) {
