@@ -97,8 +97,9 @@ struct ShadeParams {
   unsigned long long *counters;
 };
 
-/* Per-workgroup LDS copy of the sin/cos table (4 KiB): the Euler loop evaluates sincos once per step per
- * lane with a data-dependent index; two ds_read_b128 from LDS instead of divergent __constant__ loads. */
+/* Per-workgroup LDS copy of the sin/cos table (4 KiB; 8 KiB in its 256-row form): the Euler loop evaluates
+ * sincos once per step per lane with a data-dependent index; two ds_read_b128 from LDS instead of divergent
+ * __constant__ loads. */
 template <int KIND>
 struct alignas(16) MathTablesLds {
   static constexpr unsigned LOG_ROWS = (KIND == cvk::METRIC_INTERSTELLAR) ? 256u : 2u;
@@ -107,8 +108,11 @@ struct alignas(16) MathTablesLds {
    * 0, so ds_read2_b64 (whose offset field is short) and ds_read_b64 share one address register; the 32- and
    * 64-byte rows of the other two tables are read with ds_read_b128, whose offset field reaches any LDS
    * address, so their base offsets cost no instruction either. */
+  /* 256-row form of the sin/cos table (cv_sincos_tw: no index mask) where the LDS has room: the Interstellar
+   * kernels' five workgroups per CU already use 30 of their 32 KiB */
+  static constexpr bool WIDE_SC = KIND != cvk::METRIC_INTERSTELLAR;
   double lg[LOG_ROWS][3]; /* only the Interstellar metric evaluates a logarithm and an arc tangent per step */
-  double sc[128][4];
+  double sc[WIDE_SC ? 256 : 128][4];
   double at[ATAN_ROWS][8];
 };
 
@@ -117,7 +121,7 @@ template <int KIND>
 __device__ __forceinline__ void load_math_tables(MathTablesLds<KIND> &L, cvk::MetricParams &M) {
   const double *src = &cv_sc_table_dev[0][0];
   double *dst = &L.sc[0][0];
-  for (unsigned i = threadIdx.x; i < 512u; i += blockDim.x) dst[i] = src[i];
+  for (unsigned i = threadIdx.x; i < (MathTablesLds<KIND>::WIDE_SC ? 1024u : 512u); i += blockDim.x) dst[i] = src[i & 511u];
   M.T = L.sc;
   if (KIND == cvk::METRIC_INTERSTELLAR) {
     const double *lsrc = &cv_log_table_dev[0][0];
@@ -169,9 +173,9 @@ __device__ __forceinline__ int escape_code(double l) { return l > 0.0 ? cvk::COD
 template <int KIND, bool PHI, bool FAST>
 __device__ __forceinline__ void one_step(const cvk::MetricParams &M, double delta, cvk::Ray &q, bool lane_ok) {
   if (FAST)
-    cvk::ray_step_fast<KIND, PHI>(M, q, delta, lane_ok);
+    cvk::ray_step_fast<KIND, PHI, MathTablesLds<KIND>::WIDE_SC>(M, q, delta, lane_ok);
   else
-    cvk::ray_step<KIND, PHI>(M, q, delta);
+    cvk::ray_step<KIND, PHI, MathTablesLds<KIND>::WIDE_SC>(M, q, delta);
 }
 
 __device__ __forceinline__ void flush_steps(const IntegrateParams &P, unsigned long long steps, unsigned rays) {
@@ -678,9 +682,9 @@ __global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParam
   int code = cvk::CODE_NONE;
   while (steps < P.max_iter) {
     if (FAST)
-      cvk::ray_step_fast<KIND, true>(M, q, P.delta, lane_ok);
+      cvk::ray_step_fast<KIND, true, MathTablesLds<KIND>::WIDE_SC>(M, q, P.delta, lane_ok);
     else
-      cvk::ray_step<KIND, true>(M, q, P.delta);
+      cvk::ray_step<KIND, true, MathTablesLds<KIND>::WIDE_SC>(M, q, P.delta);
     ++steps;
     if (q.l > P.max_radius) {
       code = cvk::CODE_POS;

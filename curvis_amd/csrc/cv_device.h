@@ -130,10 +130,14 @@ CV_HD void ray_step_core(const MetricParams &M, Ray &q, double delta, double s, 
   q.p2 = q.p2 + dp2 * delta;
 }
 
-template <int KIND, bool PHI>
+/* WIDE_T: M.T is the 256-row form of the sin/cos table (cv_sincos_tw) */
+template <int KIND, bool PHI, bool WIDE_T = false>
 CV_HD void ray_step(const MetricParams &M, Ray &q, double delta) {
   double s, c;
-  cv_sincos_t(q.th, M.T, &s, &c);
+  if (WIDE_T)
+    cv_sincos_tw(q.th, M.T, &s, &c);
+  else
+    cv_sincos_t(q.th, M.T, &s, &c);
   ray_step_core<KIND, PHI>(M, q, delta, s, c);
 }
 
@@ -220,10 +224,13 @@ CV_HD bool metric_fast_ok(int kind, const MetricParams &M, double max_radius) {
   return ok;
 }
 
-template <int KIND, bool PHI>
+template <int KIND, bool PHI, bool WIDE_T = false>
 CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_ok) {
   double s, c;
-  cv_sincos_t(q.th, M.T, &s, &c);
+  if (WIDE_T)
+    cv_sincos_tw(q.th, M.T, &s, &c);
+  else
+    cv_sincos_t(q.th, M.T, &s, &c);
   /* guard (branch-free, one compare each): sin(theta) and l non-zero, not NaN and far from the underflow
    * limit.  Upper bounds are implied: |sin| <= 1, and a step is only executed for a ray that has not
    * escaped, |l| <= max_radius < 2^90 (metric_fast_ok; an infinite l has escaped, a NaN fails the compare).

@@ -330,30 +330,33 @@ CV_HD void cv_sincos_core(int K, double y, double yl, cv_sc_tab_t T, double *sn,
 
 /* sin and cos of x together, table-driven.
  *
- * Main path (|x| < 16 and x not within 2^-20 of a multiple of pi/64), branch-free:
- *   k  = nearest integer to x * 64/pi        |k| <= 326 < 2^9 (magic-number rounding, see CV_RND_MAGIC)
+ * Main path (|x| < 6.25 and x not within 2^-20 of a multiple of pi/64), branch-free:
+ *   k  = nearest integer to x * 64/pi        |k| <= 127 (magic-number rounding, see CV_RND_MAGIC)
  *   r1 = fma(-k, A, x)                       exact: A has 44 bits, k A is a double, the difference fits 53 bits
  *   t  = fma(-k, B, r1)                      head of the reduced argument, |t| <= pi/128; k B is a double too
  *   u  = r1 - t                              exact (|u| < 2^-39, a multiple of ulp(t) >= 2^-72)
  *   tl = fma(-k, B, u)                       exact: the rounding error of t
- * with pi/64 = A + B + 1.1e-28 (two 44-bit pieces): what is left out is |k| 1.1e-28 < 2^-84, below 2^-64 of
+ * with pi/64 = A + B + 1.1e-28 (two 44-bit pieces): what is left out is |k| 1.1e-28 < 2^-86, below 2^-66 of
  * |t| >= 2^-20.  Every other argument (larger, tiny, non-finite, or deeply cancelling
  * such as theta == fl(pi/2), which the equatorial rays hold for ever) is first reduced modulo pi/2 by
  * cv_rem_pio2 (fdlibm-style iterations / 192-bit Payne-Hanek) and then by a three-piece step (38 + 38 + 53 bits
  * of pi/64, to 2^-134) with |k| <= 17.  Which path an argument takes is a function of the argument alone, and both paths end in
  * cv_sincos_core, so host and device agree bit for bit. */
-CV_HD void cv_sincos_t(double x, cv_sc_tab_t T, double *sn, double *cs) {
-  const double kb = CV_FMA(x, CV_64OPI, CV_RND_MAGIC);
-  const double k = kb - CV_RND_MAGIC;
+/* WIDE (a compile-time constant at every call): T has 256 rows, the 128 rows twice, and the main path indexes it
+ * with k + 128 = 1..255 straight from the low word of the rounding sum -- no "& 127".  Same values either way. */
+CV_HD void cv_sincos_impl(double x, cv_sc_tab_t T, int wide, double *sn, double *cs) {
+  const double magic = wide ? CV_RND_MAGIC + 128.0 : CV_RND_MAGIC;
+  const double kb = CV_FMA(x, CV_64OPI, magic);
+  const double k = kb - magic;
   const double r1 = CV_FMA(-k, CV_PIO64_A, x);
   const double t = CV_FMA(-k, CV_PIO64_B, r1);
   double y, yl;
   int K;
-  if (CV_FABS(x) < 16.0 && CV_FABS(t) >= 9.5367431640625e-07 /* 2^-20 */) {
+  if (CV_FABS(x) < 6.25 && CV_FABS(t) >= 9.5367431640625e-07 /* 2^-20 */) {
     const double u = r1 - t;
     y = t;
     yl = CV_FMA(-k, CV_PIO64_B, u);
-    K = (int)cv_lo(kb);
+    K = wide ? (int)cv_lo(kb) : ((int)cv_lo(kb) & 127);
   } else {
     const uint32_t ix = cv_hi(x) & 0x7fffffffu;
     if (ix >= 0x7ff00000u) { /* inf / nan */
@@ -379,10 +382,13 @@ CV_HD void cv_sincos_t(double x, cv_sc_tab_t T, double *sn, double *cs) {
     const double u2 = a1 - t2;
     y = t2;
     yl = CV_FMA(-k2, CV_PIO64_3, CV_FMA(-k2, CV_PIO64_2, u2)) + y1;
-    K = n * 32 + (int)k2;
+    K = (n * 32 + (int)k2) & 127;
   }
-  cv_sincos_core(K & 127, y, yl, T, sn, cs);
+  cv_sincos_core(K, y, yl, T, sn, cs);
 }
+CV_HD void cv_sincos_t(double x, cv_sc_tab_t T, double *sn, double *cs) { cv_sincos_impl(x, T, 0, sn, cs); }
+/* T = the 128 rows twice (the hot kernels' LDS copy where there is room for it) */
+CV_HD void cv_sincos_tw(double x, cv_sc_tab_t T, double *sn, double *cs) { cv_sincos_impl(x, T, 1, sn, cs); }
 
 CV_HD void cv_sincos(double x, double *sn, double *cs) { cv_sincos_t(x, cv_sc_table(), sn, cs); }
 
