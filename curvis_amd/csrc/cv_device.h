@@ -205,6 +205,15 @@ CV_HD void sqrt_and_rsqrt(double x, double &root, double &y) {
   root = CV_FMA(d, h, g);
   y = h + h;
 }
+/* finite, non-zero, not subnormal (one v_cmp_class_f64) */
+CV_HD bool is_normal_number(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_class(v, 0x108); /* -normal | +normal */
+#else
+  const uint32_t e = (cv_hi(v) >> 20) & 0x7ffu;
+  return e != 0u && e != 0x7ffu;
+#endif
+}
 /* lo_hi <= (high word of |v|) < hi_hi : exponent-range test with two integer ops */
 CV_HD bool hi_word_in(double v, uint32_t lo_hi, uint32_t hi_hi) {
   return ((cv_hi(v) & 0x7fffffffu) - lo_hi) < (hi_hi - lo_hi);
@@ -260,11 +269,19 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
   const double b2 = q.p2 * q.p2 + div_with_recip(q.p3sq, ss, y_ss);
   const double num = b2 * rd;
   const double r3 = r * (r * r);
-  double dp1;
-  const double anum = CV_FABS(num);
-  if ((int)(anum > 0x1p-300) & (int)(anum < 0x1p300)) {
-    dp1 = div_with_recip(num, r3, y_r2 * y_r);
-  } else { /* zero (r' == 0 inside the Interstellar throat), huge (|p_theta| exploding at a pole) or NaN */
+  /* dp_l = num / r^3: the shared-reciprocal quotient is checked AFTERWARDS with one class test.  Inside the guarded
+   * domain a non-zero num has |num| >= 2^-300 |r'| >= 2^-745 (Ellis: |r'| = |l|/r >= 2^-191; Interstellar:
+   * |l| - a >= ulp(a) >= 2^-352, so atan x >= 2^-444), hence the remainder fma cannot underflow and the true quotient
+   * is a normal number (>= 2^-745 / 2^273) or overflows.  Whatever else can happen shows in the result: num == 0
+   * (r' == 0 inside the Interstellar throat) gives 0 -- possibly with the wrong sign --, an overflowing n*y or a
+   * non-finite num (|p_theta| exploding at a pole) gives inf or NaN; all of those are "not a normal number" and
+   * take the IEEE division. */
+  double dp1 = div_with_recip(num, r3, y_r2 * y_r);
+  if (!is_normal_number(dp1)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("; IEEE division for dp_l"); /* not speculatable: keeps this a branch around ~25 instructions
+                                                 (as a select they would run in every step) */
+#endif
     dp1 = num / r3;
   }
   const double dp2 = q.p3sq * div_with_recip(c, r2 * (s * ss), y_r2 * (y_ss * y_s));
