@@ -187,23 +187,21 @@ CV_HD double div_with_recip(double n, double d, double y) {
   return CV_FMA(rem, y, q0);
 }
 /* root = sqrt(x) correctly rounded, y ~ 1/sqrt(x) to about an ulp (Goldschmidt on the hardware seed, no
- * scaling).  With g0 = x y0, h0 = y0 / 2 and e = 1/2 - h0 g0:  sqrt(x) = g0 (1 - 2e)^(-1/2) = g0 (1 + e + 3/2 e^2
- * + 5/2 e^3 ...), and the same factor takes h0 to 1/(2 sqrt(x)).  One third-order step p = e + 3/2 e^2 brings
- * BOTH to rounding accuracy (seed 2^-23 -> 2^-70 before rounding); the final residual step g + (x - g^2) h then
- * sees the exact residual (fma) and an h good to 2^-53, i.e. a value within ~2^-53 ulp of sqrt(x) before its
- * single rounding, and 1/sqrt(x) = h + h needs no Newton step of its own.  11 instructions; the compiler's
- * expansion (second-order step, two residual steps with a 2^-45 h) plus a reciprocal refinement took 13. */
+ * scaling).  With g0 = x y0 and E = 1 - g0 y0 (= 1 - x y0^2):  sqrt(x) = g0 (1 - E)^(-1/2) = g0 (1 + E/2 + 3/8 E^2
+ * + 5/16 E^3 ...), and the same factor takes y0 to 1/sqrt(x).  One third-order step p = E/2 + 3/8 E^2 brings BOTH
+ * to rounding accuracy (seed 2^-23 -> 2^-70 before rounding); the final residual step g + (x - g^2) y/2 then sees
+ * the exact residual (fma) and a y good to 2^-53, i.e. a value within ~2^-53 ulp of sqrt(x) before its single
+ * rounding.  10 instructions; the compiler's expansion (second-order step, two residual steps with a 2^-45
+ * multiplier) plus a reciprocal refinement took 13. */
 CV_HD void sqrt_and_rsqrt(double x, double &root, double &y) {
   const double y0 = rsq_seed(x);
   double g = x * y0;
-  double h = 0.5 * y0;
-  const double e = CV_FMA(-h, g, 0.5);
-  const double p = e * CV_FMA(1.5, e, 1.0);
+  const double E = CV_FMA(-g, y0, 1.0);
+  const double p = E * CV_FMA(0.375, E, 0.5);
   g = CV_FMA(g, p, g);
-  h = CV_FMA(h, p, h);
+  y = CV_FMA(y0, p, y0);
   const double d = CV_FMA(-g, g, x);
-  root = CV_FMA(d, h, g);
-  y = h + h;
+  root = CV_FMA(d, 0.5 * y, g);
 }
 /* finite, non-zero, not subnormal (one v_cmp_class_f64) */
 CV_HD bool is_normal_number(double v) {

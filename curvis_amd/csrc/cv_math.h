@@ -346,7 +346,8 @@ CV_HD void cv_sincos_core(int K, double y, double yl, cv_sc_tab_t T, double *sn,
  * with k + 128 = 1..255 straight from the low word of the rounding sum -- no "& 127".  Same values either way. */
 CV_HD void cv_sincos_impl(double x, cv_sc_tab_t T, int wide, double *sn, double *cs) {
   const double magic = wide ? CV_RND_MAGIC + 128.0 : CV_RND_MAGIC;
-  const double kb = CV_FMA(x, CV_64OPI, magic);
+  const double kb = cv_fma_ks(x, CV_64OPI, magic); /* addend from a scalar pair: as a plain fma the compiler emits
+                                                      v_mov_b64 + v_fmac_f64 to keep the constant's VGPR pair */
   const double k = kb - magic;
   const double r1 = CV_FMA(-k, CV_PIO64_A, x);
   const double t = CV_FMA(-k, CV_PIO64_B, r1);
