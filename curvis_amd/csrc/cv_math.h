@@ -52,6 +52,13 @@
 #define CV_RINT(a) __builtin_rint((a))
 /* 1.5 * 2^52: fma(x, c, MAGIC) - MAGIC is the integer nearest to the exact product x*c (|x*c| < 2^31), and the
  * low word of the biased sum is that integer in two's complement -- rounding and int conversion in two ops */
+/* an empty, non-speculatable statement: keeps the assignments of a rarely taken branch inside that branch (the
+ * compiler otherwise hoists them, as v_mov_b64, in front of it -- into the hot path) */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CV_KEEP_BRANCH() asm volatile("")
+#else
+#define CV_KEEP_BRANCH() ((void)0)
+#endif
 #define CV_RND_MAGIC 6755399441055744.0
 #define CV_RND_MAGIC_128TH 52776558133248.0 /* 1.5 * 2^45: ulp 2^-7 */
 
@@ -448,7 +455,10 @@ CV_HD double cv_atan_edge(double x) {
     const double z = 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
     return (hx >> 31) ? -z : z;
   }
-  if (ix < 0x3e400000u) return x; /* |x| < 2^-27 */
+  if (ix < 0x3e400000u) { /* |x| < 2^-27 */
+    CV_KEEP_BRANCH();
+    return x;
+  }
   const double z = x * x;
   const double w = z * z;
   const double s1 = z * cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, aT10, aT8), aT6), aT4), aT2), aT0);
