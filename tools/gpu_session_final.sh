@@ -30,6 +30,6 @@ cd $GRAFT_REPO_ROOT
 SPECS=0,4,6,8 BATCHES=8,30 python tools/gpu_efficient_sweep.py 2>&1 | grep spec > $OUT/efficient_sweep.txt
 python tools/gpu_tail.py 2>&1 | grep frames > $OUT/tail.txt
 python tools/gpu_trace.py > /dev/null 2>&1 && python tools/analyze_trace.py gpurun_out/trace_config2.bin > $OUT/wave_trace_config2.txt && python tools/analyze_trace.py gpurun_out/trace_config2_relay.bin > $OUT/wave_trace_config2_relay.txt
-timeout 900 python tools/gpu_deep_fuzz.py 2000 7 2>&1 | grep -E "MISMATCH|scenes" | tail -5 > $OUT/deep_fuzz.txt
+(timeout 900 python tools/gpu_deep_fuzz.py 2000 7; timeout 900 python tools/gpu_deep_fuzz.py 2000 11; timeout 900 python tools/gpu_deep_fuzz.py 2000 23) 2>&1 | grep -E "MISMATCH|scenes" | tail -9 > $OUT/deep_fuzz.txt
 python tools/gpu_eff_phases.py 2>&1 | grep -E "frames|curvis\]" > $OUT/efficient_phases.txt
 ls -R $OUT | head -80
