@@ -22,7 +22,9 @@ def pmc(kind):
             else "geodesic_relay" if "geodesic_relay" in name else "shade_kernel" if "shade_kernel" in name else None
         if short:
             agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+    # median over the dispatches of the run: one launch in a dozen shows a several-fold FETCH_SIZE (first touch of
+    # a buffer by that process); the mean of three or four launches would report that, not the kernel
+    return {k: sorted(v)[len(v) // 2] if len(v) % 2 else 0.5 * (sorted(v)[len(v) // 2 - 1] + sorted(v)[len(v) // 2]) for k, v in agg.items()}
 
 
 bench = json.loads(open(os.path.join(G, "bench_default.json")).read().strip().splitlines()[-1])
@@ -100,7 +102,7 @@ lines.append("# %s profile summary (MI355X gfx950, ROCm 7.2) -- `python bench.py
 lines.append("Collected by tools/gpu_session_final.sh; assembled by tools/make_profiles.py.\n")
 lines.append("## bench.py line (un-profiled run)\n```\n%s\n```\n" % json.dumps({k: bench[k] for k in ("value", "unit", "ms_per_step", "roofline", "cpu_baseline") if k in bench}, indent=1))
 lines.append("## rocprofv3 --kernel-trace --stats\n```\n%s```\n" % open(os.path.join(G, "stats", "bench_kernel_stats.csv")).read())
-lines.append("## PMC (mean per dispatch; SQ set, FETCH_SIZE and WRITE_SIZE in separate passes)\n```")
+lines.append("## PMC (median over the dispatches; SQ set, FETCH_SIZE and WRITE_SIZE in separate passes)\n```")
 for d in (sq, fe, wr):
     for (k, c), v in sorted(d.items()):
         lines.append("%-22s %-22s %.6g" % (k, c, v))
