@@ -351,48 +351,62 @@ CV_HD void cv_sincos_core(int K, double y, double yl, cv_sc_tab_t T, double *sn,
  * cv_sincos_core, so host and device agree bit for bit. */
 /* WIDE (a compile-time constant at every call): T has 256 rows, the 128 rows twice, and the main path indexes it
  * with k + 128 = 1..255 straight from the low word of the rounding sum -- no "& 127".  Same values either way. */
-CV_HD void cv_sincos_impl(double x, cv_sc_tab_t T, int wide, double *sn, double *cs) {
+/* main path: returns 1 with the arguments of cv_sincos_core, or 0 when x belongs to the other path */
+CV_HD int cv_sincos_main_args(double x, int wide, int *K, double *y, double *yl) {
   const double magic = wide ? CV_RND_MAGIC + 128.0 : CV_RND_MAGIC;
   const double kb = cv_fma_ks(x, CV_64OPI, magic); /* addend from a scalar pair: as a plain fma the compiler emits
                                                       v_mov_b64 + v_fmac_f64 to keep the constant's VGPR pair */
   const double k = kb - magic;
   const double r1 = CV_FMA(-k, CV_PIO64_A, x);
   const double t = CV_FMA(-k, CV_PIO64_B, r1);
+  if (!(CV_FABS(x) < 6.25 && CV_FABS(t) >= 9.5367431640625e-07 /* 2^-20 */)) return 0;
+  const double u = r1 - t;
+  *y = t;
+  *yl = CV_FMA(-k, CV_PIO64_B, u);
+  *K = wide ? (int)cv_lo(kb) : ((int)cv_lo(kb) & 127);
+  return 1;
+}
+/* every other argument: returns 1 with the arguments of cv_sincos_core (K in 0..127), or 0 with *sn, *cs final */
+CV_HD int cv_sincos_other_args(double x, int *K, double *y, double *yl, double *sn, double *cs) {
+  const uint32_t ix = cv_hi(x) & 0x7fffffffu;
+  if (ix >= 0x7ff00000u) { /* inf / nan */
+    *sn = *cs = x - x;
+    return 0;
+  }
+  if (ix < 0x3e400000u) { /* |x| < 2^-27: sin x = x (keeps the sign of zero), cos x = 1 */
+    *sn = x;
+    *cs = 1.0;
+    return 0;
+  }
+  double y0, y1;
+  int n = 0;
+  if (ix <= 0x3fe921fbu) { /* |x| <= ~pi/4 */
+    y0 = x;
+    y1 = 0.0;
+  } else {
+    n = cv_rem_pio2(x, &y0, &y1);
+  }
+  const double k2 = CV_RINT(y0 * CV_64OPI);
+  const double a1 = CV_FMA(-k2, CV_PIO64_1, y0);
+  const double t2 = CV_FMA(-k2, CV_PIO64_2, a1);
+  const double u2 = a1 - t2;
+  *y = t2;
+  *yl = CV_FMA(-k2, CV_PIO64_3, CV_FMA(-k2, CV_PIO64_2, u2)) + y1;
+  *K = (n * 32 + (int)k2) & 127;
+  return 1;
+}
+CV_HD void cv_sincos_other(double x, cv_sc_tab_t T, double *sn, double *cs) {
   double y, yl;
   int K;
-  if (CV_FABS(x) < 6.25 && CV_FABS(t) >= 9.5367431640625e-07 /* 2^-20 */) {
-    const double u = r1 - t;
-    y = t;
-    yl = CV_FMA(-k, CV_PIO64_B, u);
-    K = wide ? (int)cv_lo(kb) : ((int)cv_lo(kb) & 127);
-  } else {
-    const uint32_t ix = cv_hi(x) & 0x7fffffffu;
-    if (ix >= 0x7ff00000u) { /* inf / nan */
-      *sn = *cs = x - x;
-      return;
-    }
-    if (ix < 0x3e400000u) { /* |x| < 2^-27: sin x = x (keeps the sign of zero), cos x = 1 */
-      *sn = x;
-      *cs = 1.0;
-      return;
-    }
-    double y0, y1;
-    int n = 0;
-    if (ix <= 0x3fe921fbu) { /* |x| <= ~pi/4 */
-      y0 = x;
-      y1 = 0.0;
-    } else {
-      n = cv_rem_pio2(x, &y0, &y1);
-    }
-    const double k2 = CV_RINT(y0 * CV_64OPI);
-    const double a1 = CV_FMA(-k2, CV_PIO64_1, y0);
-    const double t2 = CV_FMA(-k2, CV_PIO64_2, a1);
-    const double u2 = a1 - t2;
-    y = t2;
-    yl = CV_FMA(-k2, CV_PIO64_3, CV_FMA(-k2, CV_PIO64_2, u2)) + y1;
-    K = (n * 32 + (int)k2) & 127;
-  }
-  cv_sincos_core(K, y, yl, T, sn, cs);
+  if (cv_sincos_other_args(x, &K, &y, &yl, sn, cs)) cv_sincos_core(K, y, yl, T, sn, cs);
+}
+CV_HD void cv_sincos_impl(double x, cv_sc_tab_t T, int wide, double *sn, double *cs) {
+  double y, yl;
+  int K;
+  if (cv_sincos_main_args(x, wide, &K, &y, &yl))
+    cv_sincos_core(K, y, yl, T, sn, cs);
+  else
+    cv_sincos_other(x, T, sn, cs);
 }
 CV_HD void cv_sincos_t(double x, cv_sc_tab_t T, double *sn, double *cs) { cv_sincos_impl(x, T, 0, sn, cs); }
 /* T = the 128 rows twice (the hot kernels' LDS copy where there is room for it) */
