@@ -47,10 +47,13 @@ def test_sincos_accuracy(name):
     sets = [
         [rng.uniform(-0.79, 0.79) for _ in range(N)],
         [rng.uniform(-4, 7) for _ in range(N)],
-        [rng.uniform(-1024, 1024) for _ in range(N)],                      # main path
+        [rng.uniform(-6.25, 6.25) for _ in range(N)],                      # main path (two 44-bit pieces of pi/64)
+        [rng.choice([-1, 1]) * (6.25 + rng.uniform(-1e-9, 1e-9)) for _ in range(N // 8)],  # main <-> other path at 6.25
+        [rng.uniform(-1024, 1024) for _ in range(N)],                      # fdlibm-style pi/2 reduction first
         [rng.uniform(1024, 1.1e6) * rng.choice([-1, 1]) for _ in range(N)],  # Cody-Waite 33-bit pieces
         [rng.choice([-1, 1]) * math.ldexp(rng.uniform(1, 2), rng.randint(20, 1023)) for _ in range(N)],  # Payne-Hanek
-        near_multiples(rng, 650, (-45, -10)),                              # main <-> slow path switch at 2^-20
+        near_multiples(rng, 3, (-45, -10)),                                # main <-> other path switch at 2^-20
+        near_multiples(rng, 650, (-45, -10)),
         near_multiples(rng, 10 ** 15, (-30, 5)),
         [10.0 ** rng.uniform(-320, -1) for _ in range(N // 4)],
     ]

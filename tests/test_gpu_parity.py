@@ -19,7 +19,9 @@ def test_device_math_bit_identical_to_host(gpu_ctx):
     u = rng.uniform
     cases = {
         0: np.concatenate([u(-4, 7, n), u(-1e6, 1e6, n // 4), np.ldexp(u(1, 2, n // 4), rng.integers(20, 1023, n // 4)),
-                           np.array([0.0, -0.0, np.pi / 2, np.pi, np.inf, np.nan, 1e-310, 5e-324])]),
+                           np.array([0.0, -0.0, np.pi / 2, np.pi, np.inf, np.nan, 1e-310, 5e-324]),
+                           np.concatenate([sg * (6.25 + u(-1e-9, 1e-9, 4096)) for sg in (1.0, -1.0)]),   # main <-> other path
+                           np.arange(-400, 401) * (np.pi / 64) + np.ldexp(u(-2, 2, 801), -20)]),     # ... and at 2^-20
         2: np.concatenate([u(-700, 700, n), 10.0 ** u(-12, 25, n // 4), np.array([0.0, np.inf, -np.inf, np.nan])]),
         3: np.concatenate([u(-1, 1, n), 1 - 10.0 ** u(-16, -1, n // 4), np.array([1.0, -1.0, 1.0000000000000002, np.nan])]),
         4: np.concatenate([u(1, 1e6, n), 10.0 ** u(-300, 300, n // 4), np.array([0.0, -1.0, 1.0, np.inf, 5e-324])]),
