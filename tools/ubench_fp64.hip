@@ -25,6 +25,10 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, double b, doubl
       else if (OP == 7) { double s, cs; cv_sincos(a[i], &s, &cs); a[i] = s + cs + b; }
       else if (OP == 8) a[i] = cv_atan(a[i]) + b;
       else if (OP == 9) a[i] = cv_log(a[i]) + b;
+      else if (OP == 10) a[i] = __builtin_amdgcn_frexp_mant(a[i]) + b;                 // v_frexp_mant_f64 + add
+      else if (OP == 11) a[i] = c * (double)__builtin_amdgcn_frexp_exp(a[i]) + b;      // v_frexp_exp_i32_f64 + v_cvt_f64_i32 + fma
+      else if (OP == 12) a[i] = cv_from_bits((cv_bits(a[i]) & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL) + b;  // v_and + v_or + add
+      else if (OP == 13) a[i] = c * (double)(int)((cv_hi(a[i]) >> 20) - 0x3ffu) + b;   // v_lshr + v_add + v_cvt_f64_i32 + fma
     }
   }
   double s = 0;
@@ -73,6 +77,14 @@ int main() {
   run<7, 2>("cv_sincos (+2 add)", 1, B, 1 << 12, d_out);
   run<8, 2>("cv_atan (+add)", 1, B, 1 << 12, d_out);
   run<9, 2>("cv_log (+add)", 1, B, 1 << 12, d_out);
+  run<10, 4>("v_frexp_mant_f64 (+add)", 1, B, 1 << 14, d_out);
+  run<11, 4>("frexp_exp+cvt (+fma)", 1, B, 1 << 14, d_out);
+  run<12, 4>("and+or (+add)", 1, B, 1 << 14, d_out);
+  run<13, 4>("lshr+add+cvt (+fma)", 1, B, 1 << 14, d_out);
+  for (int occ = 1; occ <= 2; occ *= 2) {   // what ONE wave per SIMD can issue: independent vs dependent instructions
+    run<0, 4>("fma, few waves", 2, p.multiProcessorCount * occ, 1 << 15, d_out);
+    run<0, 8>("fma, few waves", 2, p.multiProcessorCount * occ, 1 << 15, d_out);
+  }
   for (int occ = 1; occ <= 8; occ *= 2) run<3, 1>("ieee div dependent", 1, p.multiProcessorCount * occ, 1 << 13, d_out);
   return 0;
 }
