@@ -22,6 +22,11 @@ for m, nf in ((curvis_amd.EllisMetric(1.0), 1), (curvis_amd.EllisMetric(1.0), 6)
         _, st = ctx.render_brute(m, cam if nf == 1 else [cam] * nf, 4096, 100.0, 0.05, download=False)
         ts.append(st.integrate_ms / nf)
     out.append(float(np.median(ts[2:])))
+ts = []
+for _ in range(8):
+    _, st = ctx.render_efficient(curvis_amd.EllisMetric(1.0), cam, 40000, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
+    ts.append(st.integrate_ms)
+out.append(float(np.median(ts[2:])))   # efficient renderer, one image: sampling kernels (lone waves)
 print(" ".join("%%.4f" %% v for v in out))
 ''' % root
 res = {"old": [], "new": []}
@@ -32,4 +37,4 @@ for rnd in range(int(os.environ.get("ROUNDS", "4"))):
         print(name, r.stdout.strip() if vals else r.stderr[-400:], flush=True)
         if vals: res[name].append(vals)
 for name in res:
-    print(name, "median over rounds [ellis x1, ellis x6 per frame, interstellar x1] ms:", np.median(np.array(res[name]), axis=0))
+    print(name, "median over rounds [ellis x1, ellis x6 per frame, interstellar x1, efficient-image sampling kernels] ms:", np.median(np.array(res[name]), axis=0))
