@@ -174,7 +174,7 @@ CV_HD double rsq_seed(double x) {
 }
 /* y ~ 1/d to about an ulp: hardware seed (2^-23) + ONE third-order step, y0 (1 + e + e^2) with e = 1 - d y0,
  * i.e. 1/d (1 - e^3): 2^-69 before the final rounding, in three fmas (two Newton steps take four) */
-CV_HD double recip_nr2(double d) {
+CV_HD double recip_refined(double d) {
   const double y0 = rcp_seed(d);
   const double e = CV_FMA(-d, y0, 1.0);
   const double p = CV_FMA(e, e, e);
@@ -257,9 +257,9 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
     rd = div_with_recip(q.l, r, y_r);
   } else {
     metric_eval<KIND, true>(M, q.l, r, r2, rd);
-    y_r = recip_nr2(r);
+    y_r = recip_refined(r);
   }
-  const double y_s = recip_nr2(s);
+  const double y_s = recip_refined(s);
   const double y_r2 = y_r * y_r;
   const double y_ss = y_s * y_s;
   const double ss = s * s;
