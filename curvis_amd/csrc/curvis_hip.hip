@@ -1301,15 +1301,18 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   if (dbg_out) {
     /* dead lanes of the integrator, replayed on the host: t_{k+1} = t_k + (p_t * g^tt) * delta with
      * p_t = 1, g^tt = -1 (src/metrics.rs:237, :295); p_t = p_t + 0*delta stays 1. */
-    std::vector<double> t_of_steps((size_t)max_iterations + 1);
+    std::vector<double> t_of_steps;
     for (uint32_t f = 0; f < n_frames; ++f) {
+      curvis_ray_debug *d = dbg_out + (size_t)f * npix;
+      uint32_t most = 0; /* the table only needs to reach the largest step count of the frame, not the cap */
+      for (size_t i = 0; i < npix; ++i) most = std::max(most, d[i].steps);
+      t_of_steps.resize((size_t)most + 1);
       double t = cams[f].pos[0];
       t_of_steps[0] = t;
-      for (uint32_t k = 1; k <= max_iterations; ++k) {
+      for (uint32_t k = 1; k <= most; ++k) {
         t = t + (1.0 * -1.0) * delta;
         t_of_steps[k] = t;
       }
-      curvis_ray_debug *d = dbg_out + (size_t)f * npix;
       for (size_t i = 0; i < npix; ++i) d[i].x[0] = t_of_steps[d[i].steps];
     }
   }
