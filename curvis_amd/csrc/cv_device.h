@@ -54,33 +54,38 @@ CV_HD void metric_eval(const MetricParams &M, double l, double &r, double &r2, d
     r2 = M.rho2 + l * l;
     r = CV_SQRT(r2);
     rd = l / r;
+  } else if (KIND == METRIC_INTERSTELLAR && FASTDIV) {
+    /* Same values with fewer instructions (each rewrite is exact, not merely close):
+     *   2*(|l| - a)       = fma(2, |l|, -2a)          scaling by two commutes with the rounding
+     *   xn / (pi m)       Markstein with the host-rounded reciprocal
+     *   x*at - lg/2       = fma(-0.5, lg, RN(x*at))   lg/2 is exact
+     *   (2/pi)*signum(l)*at = fma(copysign(2/pi, l), at, +0)   multiplying by +-1 is exact, at >= +0
+     * and NO branch for the throat: x = max(x, 0).  For |l| <= a (and for a NaN l, which fails the reference's
+     * `abs(l) > a` too) that is x = +0, hence at = atan(+0) = +0, lg = log(1) = +0 (the table's first slice has
+     * invc = 1, logc = 0), x*at - lg/2 = +0, r = rho + m*0 = rho, and r' = fma(+-2/pi, +0, +0) = +0 (the added
+     * +0 turns the product's -0 for l < 0 into the +0 of the reference's literal 0.0): exactly the values of the
+     * `else` branch below, without the compare, the branch and the two constant moves in front of it.
+     * x >= +0 and 1 + x^2 is finite and >= 1 (|l| <= max_radius < 2^90 on the guarded path), so atan / log need
+     * neither sign nor special-case handling. */
+    const double al = CV_FABS(l);
+    const double xn = CV_FMA(2.0, al, -2.0 * M.a);
+    const double q0 = xn * M.inv_pim;
+    const double x = __builtin_fmax(CV_FMA(CV_FMA(-M.pim, q0, xn), M.inv_pim, q0), 0.0);
+    const double at = cv_atan_nonneg_t(x, M.AT);
+    const double lg = cv_log_ge1_t(1.0 + x * x, M.LT);
+    r = M.rho + M.m * CV_FMA(-0.5, lg, x * at);
+    rd = CV_FMA(__builtin_copysign(M.two_o_pi, l), at, 0.0);
+    r2 = r * r;
   } else if (KIND == METRIC_INTERSTELLAR) {
     double al = CV_FABS(l);
     if (al > M.a) {
-      if (FASTDIV) {
-        /* Same values with fewer instructions (each rewrite is exact, not merely close):
-         *   2*(al - a)        = fma(2, al, -2a)           scaling by two commutes with the rounding
-         *   xn / (pi m)       Markstein with the host-rounded reciprocal
-         *   x*at - lg/2       = fma(-0.5, lg, RN(x*at))   lg/2 is exact
-         *   (2/pi)*signum(l)*at = copysign((2/pi) * at, l)  multiplying by +-1 is exact, at >= +0; l is not NaN here
-         * and x >= +0, 1 + x^2 finite and >= 1 (|l| <= max_radius < 2^90 on the guarded path), so atan / log
-         * need neither sign nor special-case handling. */
-        const double xn = CV_FMA(2.0, al, -2.0 * M.a);
-        const double q0 = xn * M.inv_pim;
-        const double x = CV_FMA(CV_FMA(-M.pim, q0, xn), M.inv_pim, q0);
-        const double at = cv_atan_nonneg_t(x, M.AT);
-        const double lg = cv_log_ge1_t(1.0 + x * x, M.LT);
-        r = M.rho + M.m * CV_FMA(-0.5, lg, x * at);
-        rd = __builtin_copysign(M.two_o_pi * at, l); /* one v_bfi_b32; rounding is sign-symmetric */
-      } else {
-        const double xn = 2.0 * (al - M.a);
-        const double x = xn / M.pim;
-        const double at = cv_atan_t(x, M.AT);
-        r = M.rho + M.m * (x * at - cv_log_t(1.0 + x * x, M.LT) / 2.0);
-        double sg = (cv_bits(l) >> 63) ? -1.0 : 1.0; /* l.signum(), l != NaN-safe below */
-        if (l != l) sg = l;
-        rd = M.two_o_pi * sg * at;
-      }
+      const double xn = 2.0 * (al - M.a);
+      const double x = xn / M.pim;
+      const double at = cv_atan_t(x, M.AT);
+      r = M.rho + M.m * (x * at - cv_log_t(1.0 + x * x, M.LT) / 2.0);
+      double sg = (cv_bits(l) >> 63) ? -1.0 : 1.0; /* l.signum(), l != NaN-safe below */
+      if (l != l) sg = l;
+      rd = M.two_o_pi * sg * at;
     } else {
       r = M.rho;
       rd = 0.0;
