@@ -999,11 +999,13 @@ int launch_relay(curvis_ctx *ctx, const IntegrateParams &P, bool relay_only) {
   const unsigned bt = integrate_block_threads(ctx, KIND);
   const unsigned long long fresh_blocks = relay_only ? 0ull : (P.total_rays + bt - 1ull) / bt;
   A.fresh_blocks = (unsigned)fresh_blocks;
-  /* segment = about half the length of an ordinary ray, (R / delta) / 2 steps: one or two hand-over points per
-   * tile in flight (measured optimum 512-1024 for ~2000-step rays; shorter segments cost more in boundary
-   * checks and workgroup launches than the finer balance returns) */
+  /* segment = 0.6 R / delta steps: an ordinary ray (about R / delta steps from a camera near the throat, +-10 %)
+   * then crosses ONE hand-over point and ends well inside its second segment.  With 0.5 R / delta the second
+   * boundary falls inside the spread of ray lengths and a third of the tiles is handed over a second time for their
+   * last few dozen steps (1080p: 10.8 ms against 10.6 with 0.4 or 0.6; tools/gpu_seg_sweep.py); segments below
+   * ~0.3 R / delta cost more in boundary checks and workgroup launches than the finer balance returns. */
   {
-    const double half = 0.5 * P.max_radius / P.delta;
+    const double half = 0.6 * P.max_radius / P.delta;
     unsigned seg = (half >= 256.0 && half <= 65536.0) ? (unsigned)half : 1024u;
     A.seg = ctx->relay_segment > 0 ? (unsigned)ctx->relay_segment : seg;
   }
