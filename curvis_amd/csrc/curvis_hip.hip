@@ -886,8 +886,8 @@ struct curvis_ctx {
   unsigned char *d_rq = nullptr;    /* RelayQueue + ticket ring of the relay kernel */
   int relay_segment = 0;            /* steps between two hand-over points; 0 = automatic */
   long long relay_min_blocks = -1;  /* smallest grid (fresh workgroups) the relay kernel is used for; -1 = automatic
-                                       (7 per CU, a little more than the ~6 resident ones: below that there is no
-                                       dispatch phase and the static kernel is better) */
+                                       (4 per CU: with fewer workgroups than that nearly the whole grid is resident at
+                                       once, there is no dispatch phase, and the static kernel is as good) */
   uint32_t last_relay_launches = 0;
   uint64_t last_relay_parks = 0, last_relay_waiters = 0;
   unsigned relay_resident_blocks[3][2] = {{0, 0}, {0, 0}, {0, 0}}; /* cached occupancy query per kernel instantiation */
@@ -1139,11 +1139,12 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   const bool fused = ctx->variant != 0 && ctx->fuse_shade != 0 && dbg_out == nullptr;
   /* relay kernel ("variant" = 2, and the automatic choice for big enough single images): end-game hand-over of
    * tiles; only launches of one or two frames have a tail worth its staging area (56 B per ray) -- larger batches
-   * use the static kernel, and so do frames too small to have a dispatch phase (measured: 640x360 +9 %,
-   * 960x540 -11 %, 1280x720 -6 %, 1920x1080 -1..-4 %, 4K -0.5 %; tools/gpu_relay_sizes.py) */
+   * use the static kernel, and so do frames too small to have a dispatch phase (measured against the static
+   * kernel: 640x360 +2 %, 720x405 -9 %, 800x450 -9 %, 960x540 -15 %, 1280x720 -6 %, 1920x1080 -3..-5 %,
+   * 2560x1440 -1 %; tools/gpu_relay_sizes.py, tools/gpu_relay_threshold.py) */
   const unsigned long long relay_fresh_blocks = ((unsigned long long)((W + 7) / 8) * ((H + 7) / 8) * n_frames + 3ull) / 4ull;
   const unsigned long long relay_min = ctx->relay_min_blocks >= 0 ? (unsigned long long)ctx->relay_min_blocks
-                                                                   : 7ull * (unsigned long long)ctx->prop.multiProcessorCount;
+                                                                   : 4ull * (unsigned long long)ctx->prop.multiProcessorCount;
   const bool relay = (ctx->variant == 2 || ctx->variant < 0) && fused && n_frames <= 2 && relay_fresh_blocks >= relay_min;
   uint32_t chunk = n_frames;
   if (relay) {

@@ -1,3 +1,4 @@
+"""Relay kernel: segment length sweep on one frame (env SEGS, RES); variant 1 = static kernel for comparison."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -7,8 +8,11 @@ ctx = curvis_amd.Context(0)
 ctx.set_sky(0, curvis_amd.SphericalImage(skies.smooth(512, 256, 0))); ctx.set_sky(1, curvis_amd.SphericalImage(skies.smooth(512, 256, 1)))
 cam = curvis_amd.Camera((0.0, 5.0, np.pi / 2, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 15.0, 43.0, 1920, 1080)
 m = curvis_amd.EllisMetric(1.0)
+SEGS = [int(v) for v in os.environ.get("SEGS", "400,600,800,1200,1500,2000").split(",")]
+W, H = [int(v) for v in os.environ.get("RES", "1920x1080").split("x")]
+cam = curvis_amd.Camera((0.0, 5.0, np.pi / 2, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 15.0, 43.0, W, H)
 for rnd in range(3):
-    for variant, seg in ((1, 0), (2, 0), (2, 400), (2, 600), (2, 800), (2, 1200), (2, 1500), (2, 2000)):
+    for variant, seg in [(1, 0), (2, 0)] + [(2, v) for v in SEGS]:
         ctx.set_option("variant", variant); ctx.set_option("relay_segment", seg)
         ts = []
         for _ in range(10):
