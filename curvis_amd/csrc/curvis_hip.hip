@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
 }
 
 /* ------------------------------------------------------------------------------------------------
- * K1, relay form ("variant" = 2, launches of one or two frames): the static kernel plus a hand-over of
+ * K1, relay form ("variant" = 2, launches of up to "relay_max_frames" = 8 frames): the static kernel plus a hand-over of
  * unfinished tiles in the END-GAME of the launch, with the hardware workgroup dispatcher as load balancer.
  *
  * A single-frame launch ends with ~2 ms in which no fresh workgroup is left and every SIMD finishes the 5-6
@@ -885,6 +885,9 @@ struct curvis_ctx {
   unsigned char *d_store = nullptr; /* RayStore arrays, carved from one allocation */
   unsigned char *d_rq = nullptr;    /* RelayQueue + ticket ring of the relay kernel */
   int relay_segment = 0;            /* steps between two hand-over points; 0 = automatic */
+  int relay_max_frames = 8;         /* largest launch (frames) the relay kernel is used for: the end-game it repairs is
+                                       ~5 % of a one-frame launch and 1-2 % of a launch of three to six frames;
+                                       beyond that its staging area (56 B per ray) buys nothing */
   long long relay_min_blocks = -1;  /* smallest grid (fresh workgroups) the relay kernel is used for; -1 = automatic
                                        (4 per CU: with fewer workgroups than that nearly the whole grid is resident at
                                        once, there is no dispatch phase, and the static kernel is as good) */
@@ -1138,14 +1141,16 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
    * Otherwise frames are rendered in chunks whose ray store stays below max_store_bytes. */
   const bool fused = ctx->variant != 0 && ctx->fuse_shade != 0 && dbg_out == nullptr;
   /* relay kernel ("variant" = 2, and the automatic choice for big enough single images): end-game hand-over of
-   * tiles; only launches of one or two frames have a tail worth its staging area (56 B per ray) -- larger batches
+   * tiles; only launches of a few frames have a tail worth its staging area (56 B per ray) -- larger batches
    * use the static kernel, and so do frames too small to have a dispatch phase (measured against the static
    * kernel: 640x360 +2 %, 720x405 -9 %, 800x450 -9 %, 960x540 -15 %, 1280x720 -6 %, 1920x1080 -3..-5 %,
    * 2560x1440 -1 %; tools/gpu_relay_sizes.py, tools/gpu_relay_threshold.py) */
   const unsigned long long relay_fresh_blocks = ((unsigned long long)((W + 7) / 8) * ((H + 7) / 8) * n_frames + 3ull) / 4ull;
   const unsigned long long relay_min = ctx->relay_min_blocks >= 0 ? (unsigned long long)ctx->relay_min_blocks
                                                                    : 4ull * (unsigned long long)ctx->prop.multiProcessorCount;
-  const bool relay = (ctx->variant == 2 || ctx->variant < 0) && fused && n_frames <= 2 && relay_fresh_blocks >= relay_min;
+  const size_t relay_staging = (size_t)((W + 7) / 8) * ((H + 7) / 8) * 64u * n_frames * kStoreBytesPerPixel;
+  const bool relay = (ctx->variant == 2 || ctx->variant < 0) && fused && n_frames <= (uint32_t)ctx->relay_max_frames &&
+                     relay_fresh_blocks >= relay_min && relay_staging <= ctx->max_store_bytes;
   uint32_t chunk = n_frames;
   if (relay) {
     const size_t rays = (size_t)((W + 7) / 8) * ((H + 7) / 8) * 64u * n_frames;
@@ -2188,6 +2193,8 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->block_threads = (int)value;
   else if (k == "relay_segment")
     ctx->relay_segment = (int)value;
+  else if (k == "relay_max_frames")
+    ctx->relay_max_frames = (int)value;
   else if (k == "relay_min_blocks")
     ctx->relay_min_blocks = (long long)value;
 
@@ -2219,6 +2226,8 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->block_threads;
   else if (k == "relay_segment")
     *value = ctx->relay_segment;
+  else if (k == "relay_max_frames")
+    *value = ctx->relay_max_frames;
   else if (k == "relay_min_blocks")
     *value = ctx->relay_min_blocks;
   else if (k == "last_relay_launches")

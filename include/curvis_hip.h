@@ -201,7 +201,7 @@ int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);
 int curvis_ctx_synchronize(curvis_ctx *ctx);
 
 /* tuning knobs (not part of the reference surface): "variant" (-1 = automatic, the default: the static
- * one-ray-per-thread kernel, and for launches of one or two frames with at least "relay_min_blocks" workgroups
+ * one-ray-per-thread kernel, and for launches of up to "relay_max_frames" (default 8) frames with at least "relay_min_blocks" workgroups
  * -- default 4 per CU, i.e. from about 700x400 -- the relay kernel; 0 = persistent lane-refill kernel;
  * 1 = static kernel always; 2 = relay kernel = the static kernel with end-game hand-over of unfinished tiles
  * between waves, still subject to "relay_min_blocks"; "relay_segment" = steps between hand-over points,

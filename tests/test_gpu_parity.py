@@ -100,11 +100,14 @@ def test_relay_kernel_bit_exact(gpu_ctx, metric, res, pos, fwd, cap):
                 parks += gpu_ctx.get_option("last_relay_parks")
         if cap >= 1000 and metric != "flat":
             assert parks > 0   # the hand-over path was really exercised
-        # two frames in one relay launch (the largest batch the relay kernel is used for)
+        # several frames in one relay launch (up to "relay_max_frames" = 8)
         gpu_ctx.set_option("relay_segment", 50)
-        rgb2, s2 = gpu_ctx.render_brute(pm, [pc, pc], cap, 100.0, 0.05)
-        assert np.array_equal(rgb2[0], want_rgb) and np.array_equal(rgb2[1], want_rgb)
-        assert (s2.rays, s2.steps) == (2 * st.rays, 2 * st.steps) and gpu_ctx.get_option("last_relay_launches") >= 1
+        for nf in (2, 5):
+            rgbn, sn_ = gpu_ctx.render_brute(pm, [pc] * nf, cap, 100.0, 0.05)
+            assert all(np.array_equal(rgbn[i], want_rgb) for i in range(nf))
+            assert (sn_.rays, sn_.steps) == (nf * st.rays, nf * st.steps) and gpu_ctx.get_option("last_relay_launches") >= 1
+        rgb9, _ = gpu_ctx.render_brute(pm, [pc] * 9, cap, 100.0, 0.05)       # beyond it: static kernel
+        assert np.array_equal(rgb9[8], want_rgb) and gpu_ctx.get_option("last_relay_launches") == 0
         # other workgroup sizes ("block_threads"): one and two waves per workgroup, relay and static kernels
         for bt in (64, 128):
             gpu_ctx.set_option("block_threads", bt)
