@@ -913,7 +913,8 @@ struct curvis_ctx {
   unsigned long long *d_counters = nullptr;
   unsigned long long *h_counters = nullptr; /* pinned */
   /* options */
-  int variant = -1;         /* -1 automatic (default): static kernel, relay kernel for single images of >= ~1800 workgroups;
+  int variant = -1;         /* -1 automatic (default): relay kernel for launches of up to relay_max_frames frames and at least
+                               relay_min_blocks workgroups, static kernel otherwise;
                                1 static one-ray-per-thread, 2 relay (subject to relay_min_blocks), 0 persistent lane-refill */
   int refill_threshold = 16;
   int blocks_per_cu = 0;    /* 0 = occupancy query */
