@@ -678,21 +678,29 @@ __global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParam
   cvk::Ray q;
   cvk::ray_init_dir<KIND>(M, pos, ca, 0.0, sa, q);
   const bool lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
-  unsigned steps = 0;
+  /* same loop shape as geodesic_static: wave-uniform step counter (all lanes start together), one escape compare,
+   * the per-lane step count captured under a scalar branch in the iterations in which some lane escapes */
+  unsigned steps = P.max_iter;
   int code = cvk::CODE_NONE;
-  while (steps < P.max_iter) {
-    if (FAST)
-      cvk::ray_step_fast<KIND, true, MathTablesLds<KIND>::WIDE_SC>(M, q, P.delta, lane_ok);
-    else
-      cvk::ray_step<KIND, true, MathTablesLds<KIND>::WIDE_SC>(M, q, P.delta);
-    ++steps;
-    if (q.l > P.max_radius) {
-      code = cvk::CODE_POS;
-      break;
-    } else if (q.l < -P.max_radius) {
-      code = cvk::CODE_NEG;
-      break;
+  if (P.max_iter != 0) {
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned k = 0;
+    for (;;) {
+      ++k;
+      one_step<KIND, true, FAST>(M, P.delta, q, lane_ok);
+      const bool esc = ray_escaped(q.l, P.max_radius);
+      const unsigned long long em = __builtin_amdgcn_ballot_w64(esc);
+      if (em) {
+        unsigned kv;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kv) : "s"(k));
+        if ((em >> lane) & 1ull) steps = kv;
+      }
+      if (esc) break;
+      if (k >= P.max_iter) break;
     }
+    if (ray_escaped(q.l, P.max_radius)) code = escape_code(q.l);
+  } else {
+    steps = 0;
   }
   const double nan = __builtin_nan("");
   double angle = nan, space = nan;
