@@ -1498,7 +1498,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   struct EvalCache {
     std::vector<Cached> slots;
     size_t used = 0;
-    EvalCache() : slots(4096, Cached{0, 0.0, 0.0, 0, 0, 0}) {}
+    explicit EvalCache(size_t capacity = 4096) : slots(capacity, Cached{0, 0.0, 0.0, 0, 0, 0}) {}
     static size_t hash(uint64_t k) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20); }
     Cached *find(uint64_t k) { /* the slot holding k, or the empty slot where it would go */
       const size_t mask = slots.size() - 1;
@@ -1526,10 +1526,19 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   };
   const int spec = ctx->sampling_speculation < 0 ? (n_frames <= 2 ? 8 : 4)
                                                  : (ctx->sampling_speculation > 8 ? 8 : ctx->sampling_speculation);
-  std::vector<EvalCache> cache(n_frames);
   /* depth of the subtrees evaluated below the intervals of the initial uniform grid (first launch) */
   const int first_cap = ctx->sampling_speculation_first < 0 ? (n_frames <= 2 ? 7 : 3)
                                                             : (ctx->sampling_speculation_first > 8 ? 8 : ctx->sampling_speculation_first);
+  /* sized for the first launch (grid x subtree) plus as much again, so that the table is not rebuilt four times on
+   * the way up from a small default (a quarter of the host time of a single image) */
+  size_t cache_cap = 4096;
+  {
+    const size_t first = (size_t)alpha_nums << (spec > 0 ? (spec > first_cap ? first_cap : spec) : 0);
+    while (cache_cap < 4 * first && cache_cap < ((size_t)1 << 22)) cache_cap *= 2;
+  }
+  std::vector<EvalCache> cache;
+  cache.reserve(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) cache.emplace_back(cache_cap);
   std::vector<char> planned(n_frames, 0);
   double sample_ms = 0.0;
   uint64_t evaluated = 0;
