@@ -930,8 +930,9 @@ struct curvis_ctx {
   int fuse_shade = 1;       /* static kernel shades in its epilogue (no ray store, no shade launch) */
   int sampling_speculation = -1; /* efficient renderer: depth of the speculative subtree evaluated below every
                                     refined interval (0 = one launch per refinement round, no speculation;
-                                    -1 = automatic: 10 for one or two frames, 4 for larger batches; at most 11) */
-  int sampling_speculation_first = -1; /* the same for the first launch (below the uniform grid); -1 = automatic: 8 / 3 */
+                                    -1 = automatic: 10 for one or two frames, 6 for three to five, 4 for larger batches;
+                                    at most 11) */
+  int sampling_speculation_first = -1; /* the same for the first launch (below the uniform grid); -1 = automatic: 8 / 4 / 3 */
   uint32_t last_sampling_launches = 0;
   uint64_t last_sampling_evaluated = 0;
   size_t max_store_bytes = (size_t)8 << 30; /* frames of a batch are rendered in chunks below this */
@@ -1524,10 +1525,11 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
     std::memcpy(&u, &a, sizeof u);
     return u;
   };
-  const int spec = ctx->sampling_speculation < 0 ? (n_frames <= 2 ? 10 : 4)
+  /* automatic depths: about 30-50 k points per launch (tools/gpu_eff_two_launch.py, tools/gpu_eff_batch_spec.py) */
+  const int spec = ctx->sampling_speculation < 0 ? (n_frames <= 2 ? 10 : n_frames <= 5 ? 6 : 4)
                                                  : (ctx->sampling_speculation > 11 ? 11 : ctx->sampling_speculation);
   /* depth of the subtrees evaluated below the intervals of the initial uniform grid (first launch) */
-  const int first_cap = ctx->sampling_speculation_first < 0 ? (n_frames <= 2 ? 8 : 3)
+  const int first_cap = ctx->sampling_speculation_first < 0 ? (n_frames <= 2 ? 8 : n_frames <= 5 ? 4 : 3)
                                                             : (ctx->sampling_speculation_first > 11 ? 11 : ctx->sampling_speculation_first);
   /* sized for the first launch (grid x subtree) plus as much again, so that the table is not rebuilt four times on
    * the way up from a small default (a quarter of the host time of a single image) */

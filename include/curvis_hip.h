@@ -212,9 +212,9 @@ int curvis_ctx_synchronize(curvis_ctx *ctx);
  * (1 = the static kernel shades in its epilogue, 0 = final states staged in HBM + separate shade kernel),
  * "max_store_bytes" (ray-store budget that bounds the frames per launch of a batch),
  * "sampling_speculation" (efficient renderer: depth of the speculative dyadic subtree evaluated below every
- * refined interval; 0 = one launch per refinement round; default -1 = automatic, 10 for one or two frames and 4
+ * refined interval; 0 = one launch per refinement round; default -1 = automatic, 10 for one or two frames, 6 for three to five and 4
  * for larger batches) and "sampling_speculation_first" (the same below the intervals of the initial uniform grid,
- * i.e. for the first launch; default -1 = automatic, 8 / 3; depths up to 11); read-only after an efficient render:
+ * i.e. for the first launch; default -1 = automatic, 8 / 4 / 3; depths up to 11); read-only after an efficient render:
  * "last_sampling_launches", "last_sampling_evaluated"; after a relay render: "last_relay_launches",
  * "last_relay_parks". */
 int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value);
