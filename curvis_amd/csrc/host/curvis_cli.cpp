@@ -17,7 +17,7 @@
  * reference renders; brute = RelativisticSystem::render_image, the per-pixel integrator),
  * --devices N (image --mode brute: rows of the frame split over N GPUs; video: frames k mod N across N GPUs, one host thread + one context per GPU, skies uploaded to
  * each or broadcast from GPU 0 with RCCL: --sky-broadcast rccl|upload), --batch B (frames per kernel launch),
- * --writers T (PNG encoder threads), --stats FILE (per-frame JSON lines).
+ * --writers T (PNG encoder threads; default: a quarter of the host threads, 4..64), --stats FILE (per-frame JSON lines).
  * Backgrounds must be PNG (any colour type / bit depth); no JPEG decoder is linked.
  */
 #include <sys/stat.h>
@@ -402,7 +402,7 @@ int path_camera(const CameraPath &p, double t, double pos[4], double fwd[3], dou
 struct Args {
   std::string sub, bg1, bg2, out, image_toml, video_toml, metric_toml, camera_toml, sim_toml, mode = "efficient", stats,
       sky_broadcast = "rccl";
-  int devices = 1, device = 0, batch = 8, writers = 8;
+  int devices = 1, device = 0, batch = 8, writers = 0; /* writers 0 = automatic: a quarter of the host's threads, 4..64 */
 };
 [[noreturn]] void die(const std::string &msg, int code = 1) {
   std::fprintf(stderr, "%s\n", msg.c_str());
@@ -471,7 +471,10 @@ Args parse_args(int argc, char **argv) {
   if (a.sky_broadcast != "rccl" && a.sky_broadcast != "upload") die("error: --sky-broadcast must be rccl or upload", 2);
   if (a.devices < 1) a.devices = 1;
   if (a.batch < 1) a.batch = 1;
-  if (a.writers < 1) a.writers = 1;
+  if (a.writers < 1) { /* zlib costs ~100 ms per 1080p frame and thread: the GPU renders a frame in 0.4-10 ms */
+    const unsigned hw = std::thread::hardware_concurrency();
+    a.writers = (int)std::min(64u, std::max(4u, hw / 4u));
+  }
   return a;
 }
 
