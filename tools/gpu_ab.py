@@ -30,8 +30,10 @@ out.append(float(np.median(ts[2:])))   # efficient renderer, one image: sampling
 print(" ".join("%%.4f" %% v for v in out))
 ''' % root
 res = {"old": [], "new": []}
+NAMES = os.environ.get("LIBS", "old,new").split(",")
+res = {n: [] for n in NAMES}
 for rnd in range(int(os.environ.get("ROUNDS", "4"))):
-    for name in ("old", "new"):
+    for name in NAMES:
         r = subprocess.run([sys.executable, "-c", CHILD, os.path.join(root, "build", "ab", name + ".so")], capture_output=True, text=True)
         vals = [float(v) for v in r.stdout.split()] if r.returncode == 0 else None
         print(name, r.stdout.strip() if vals else r.stderr[-400:], flush=True)
