@@ -368,6 +368,15 @@ CV_HD int cv_sincos_main_args(double x, int wide, int *K, double *y, double *yl)
 }
 /* every other argument: returns 1 with the arguments of cv_sincos_core (K in 0..127), or 0 with *sn, *cs final */
 CV_HD int cv_sincos_other_args(double x, int *K, double *y, double *yl, double *sn, double *cs) {
+  /* theta == fl(pi/2), bit for bit: the rays of the equatorial plane (p_theta == 0) keep this value for ever and
+   * come here in every step.  The general route below gives sin = 1 and cos = RN(pi/2 - fl(pi/2)) for it
+   * (tests/test_cv_math.py checks the shortcut against that route); returning them at once keeps the waves that
+   * hold such rays from paying ~100 instructions per step -- they are the last to finish in small frames. */
+  if (cv_bits(x) == 0x3FF921FB54442D18ULL) {
+    *sn = 1.0;
+    *cs = 6.123233995736766036e-17; /* 0x3C91A62633145C07 */
+    return 0;
+  }
   const uint32_t ix = cv_hi(x) & 0x7fffffffu;
   if (ix >= 0x7ff00000u) { /* inf / nan */
     *sn = *cs = x - x;

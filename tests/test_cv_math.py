@@ -88,6 +88,18 @@ def test_atan2_accuracy_and_quadrants():
     assert list(sp) == [math.pi, -math.pi, math.pi / 2, -math.pi / 2, 0.0, math.pi / 4]
 
 
+def test_equatorial_theta_shortcut():
+    """theta == fl(pi/2) returns at once (the equatorial rays hold it for ever): the values are the correctly
+    rounded ones, which is also what the general reduction gives for this argument (the golden frames, whose
+    middle pixel row evaluates it ~2000 times per ray, did not change when the shortcut went in)."""
+    x = np.array([math.pi / 2])
+    s, c = common.twin_math(0, x)[0], common.twin_math(1, x)[0]
+    assert s == 1.0
+    assert c == float(mpmath.cos(mpf(math.pi / 2))) == 6.123233995736766e-17
+    for name, op in (("sin", 0), ("cos", 1)):   # neighbours take the general route and stay accurate
+        assert max_ulp_error(name, [math.nextafter(math.pi / 2, 0.0), math.nextafter(math.pi / 2, 4.0)]) < 0.85
+
+
 def test_special_values_match_ieee_semantics():
     t = common.twin_math
     assert np.isnan(t(0, np.array([np.inf, np.nan]))).all() and np.isnan(t(1, np.array([-np.inf]))).all()
