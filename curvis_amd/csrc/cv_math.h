@@ -371,7 +371,7 @@ CV_HD int cv_sincos_other_args(double x, int *K, double *y, double *yl, double *
   /* theta == fl(pi/2), bit for bit: the rays of the equatorial plane (p_theta == 0) keep this value for ever and
    * come here in every step.  The general route below gives sin = 1 and cos = RN(pi/2 - fl(pi/2)) for it
    * (tests/test_cv_math.py checks the shortcut against that route); returning them at once keeps the waves that
-   * hold such rays from paying ~100 instructions per step -- they are the last to finish in small frames. */
+   * hold such rays from paying ~100 instructions per step -- they are among the last to finish in every frame (the default camera's middle pixel column). */
   if (cv_bits(x) == 0x3FF921FB54442D18ULL) {
     *sn = 1.0;
     *cs = 6.123233995736766036e-17; /* 0x3C91A62633145C07 */
