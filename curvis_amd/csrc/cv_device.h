@@ -223,8 +223,18 @@ CV_HD bool hi_word_in(double v, uint32_t lo_hi, uint32_t hi_hi) {
 }
 #define CV_HI_2POW(e) ((uint32_t)(1023 + (e)) << 20)
 
-/* per-ray part of the guard (p_phi^2 is a constant of the motion) */
-CV_HD bool ray_fast_ok(const Ray &q) { return hi_word_in(q.p3sq, CV_HI_2POW(-300), CV_HI_2POW(300)); }
+/* per-ray part of the guard.  p_phi^2 is a constant of the motion; the bounds keep b^2 = p_theta^2 + p_phi^2 /
+ * sin^2 >= 2^-300 (the dp_l class test relies on it) and the products away from overflow.  A ray with p_phi == 0
+ * exactly -- the middle pixel ROW of an axis-aligned camera: 1920 rays of a 1080p frame -- is served as well:
+ * with a zero numerator the shared-reciprocal quotients are exact zeros of the IEEE sign (0 * y = 0, fma(-d, 0, 0)
+ * = +0, fma(+0, y, 0) = 0), dp_theta = 0 * q = +-0 adds nothing, so p_theta is a constant of the motion too
+ * and b^2 = p_theta^2 is bounded once, here.  (p_theta == 0 as well -- the central pixel -- keeps the strict
+ * step.)  Before this, that row executed the IEEE step in every iteration, and the 240 waves holding it were
+ * among the last to finish. */
+CV_HD bool ray_fast_ok(const Ray &q) {
+  if (q.p3sq == 0.0) return hi_word_in(q.p2 * q.p2, CV_HI_2POW(-300), CV_HI_2POW(300));
+  return hi_word_in(q.p3sq, CV_HI_2POW(-300), CV_HI_2POW(300));
+}
 
 /* host-side part of the guard: metric parameters / escape radius far from the exponent limits */
 CV_HD bool metric_fast_ok(int kind, const MetricParams &M, double max_radius) {
