@@ -29,6 +29,8 @@ for it in range(N):
     l = float(rng.uniform(0.5, 12.0) * rng.choice([-1.0, 1.0]))
     th = float(rng.uniform(0.25, np.pi - 0.25)) if rng.random() < 0.7 else float(np.pi / 2)
     fwd = rng.normal(size=3); fwd[0] -= np.sign(l) * 1.5
+    if it % 3 == 0:   # axis-aligned camera in the equatorial plane: middle pixel column with theta == fl(pi/2), middle row with p_phi == 0
+        th = float(np.pi / 2); fwd = np.array([-np.sign(l), 0.0, 0.0])
     cam = curvis_amd.Camera((0.0, l, th, float(rng.uniform(0, 6.28))), tuple(float(v) for v in fwd), (0.0, 0.0, 1.0),
                             float(rng.uniform(10, 40)), 43.0, 1920, 1080)
     cap = int(rng.choice([2500, 4096]))
