@@ -47,14 +47,72 @@
 
 namespace {
 
-enum { CNT_NEXT = 0, CNT_STEPS, CNT_POS, CNT_NEG, CNT_NONE, CNT_OOB, CNT_RAYS, CNT_N };
-/* The statistics counters are replicated CNT_SLOTS times, one 128-byte line each, and a workgroup adds to the
- * replica blockIdx.x mod CNT_SLOTS: tens of thousands of waves adding to ONE address serialise in a single
- * L2 channel (it made the 0.06 ms per-pixel kernel of the efficient renderer take 0.40 ms).  The host sums
- * the replicas.  CNT_NEXT (the persistent kernel's queue head) lives in replica 0 only. */
-enum { CNT_SLOTS = 64, CNT_STRIDE = 16, CNT_WORDS = CNT_SLOTS * CNT_STRIDE };
-__device__ __forceinline__ unsigned long long *counter_replica(unsigned long long *base) {
-  return base + (size_t)(blockIdx.x & (CNT_SLOTS - 1)) * CNT_STRIDE;
+/* Statistics counters, PER FRAME (src/rendering.rs:291-316 renders frame by frame; BASELINE configs[4] asks for
+ * per-frame early-termination statistics, and a batch of frames is ONE launch here).  Layout of the counter block,
+ * in 128-byte lines of CNT_STRIDE words: line 0 holds the persistent kernel's queue head (CNT_NEXT) and nothing
+ * else; then `slots` replica lines per frame, each {FC_STEPS, FC_RAYS, FC_POS, FC_NEG, FC_NONE, FC_OOB}.  A wave
+ * adds its sums to the replica (blockIdx.x mod slots) of its frame: tens of thousands of waves adding to ONE
+ * address serialise in a single L2 channel (it made the 0.06 ms per-pixel kernel of the efficient renderer take
+ * 0.40 ms), so a frame's counters are spread over 64 lines in launches of a few frames and over 8 in larger
+ * batches.  The host sums the replicas of a frame, and the frames for the totals of the call. */
+enum { CNT_NEXT = 0 };
+enum { FC_STEPS = 0, FC_RAYS, FC_POS, FC_NEG, FC_NONE, FC_OOB, FC_N };
+enum { CNT_STRIDE = 16 };
+struct FrameCounters {
+  unsigned long long *base; /* device: CNT_STRIDE * (1 + n_frames * slots) words */
+  unsigned slots;           /* replica lines per frame, a power of two */
+};
+__host__ __device__ inline unsigned counter_slots_for(unsigned n_frames) { return n_frames >= 8u ? 8u : 64u; }
+__host__ __device__ inline size_t counter_words(unsigned n_frames, unsigned slots) {
+  return (size_t)CNT_STRIDE * (1u + (size_t)n_frames * slots);
+}
+__device__ __forceinline__ unsigned long long *frame_counter_line(const FrameCounters &C, unsigned frame) {
+  return C.base + (size_t)CNT_STRIDE * (1u + (size_t)frame * C.slots + (blockIdx.x & (C.slots - 1u)));
+}
+/* frame of a wave's 8x8 tile, as a scalar: computed in the epilogue from the wave-uniform tile number so that no
+ * per-lane frame index stays live across the Euler loop (it cost the Interstellar relay kernel its fifth wave) */
+__device__ __forceinline__ unsigned frame_of_tile(unsigned long long tile, unsigned rays_per_frame) {
+  const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tile); /* tiles < 2^32 (checked on the host) */
+  return t / (rays_per_frame >> 6);
+}
+/* Add a wave's contribution to the per-frame counters.  `frame` is per lane; lanes with !valid contribute
+ * nothing.  When every valid lane of the wave belongs to one frame (always true for the 8x8-tile kernels, and for
+ * all but the waves straddling a frame boundary in the per-pixel kernels) the wave reduces first and one lane
+ * issues the atomics; otherwise each valid lane adds its own. */
+__device__ __forceinline__ void flush_frame_counts(const FrameCounters &C, unsigned frame, bool valid,
+                                                   unsigned long long steps, unsigned rays, unsigned pos, unsigned neg,
+                                                   unsigned none, unsigned oob) {
+  const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+  if (!vm) return;
+  const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)frame, (int)__builtin_ctzll(vm));
+  if (!valid) steps = 0ull, rays = pos = neg = none = oob = 0u;
+  if (__builtin_amdgcn_ballot_w64(valid && frame != f0) == 0ull) {
+    for (int off = 32; off > 0; off >>= 1) {
+      steps += __shfl_xor(steps, off);
+      rays += __shfl_xor(rays, off);
+      pos += __shfl_xor(pos, off);
+      neg += __shfl_xor(neg, off);
+      none += __shfl_xor(none, off);
+      oob += __shfl_xor(oob, off);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+      unsigned long long *c = frame_counter_line(C, f0);
+      if (steps) atomicAdd(&c[FC_STEPS], steps);
+      if (rays) atomicAdd(&c[FC_RAYS], (unsigned long long)rays);
+      if (pos) atomicAdd(&c[FC_POS], (unsigned long long)pos);
+      if (neg) atomicAdd(&c[FC_NEG], (unsigned long long)neg);
+      if (none) atomicAdd(&c[FC_NONE], (unsigned long long)none);
+      if (oob) atomicAdd(&c[FC_OOB], (unsigned long long)oob);
+    }
+  } else if (valid) {
+    unsigned long long *c = frame_counter_line(C, frame);
+    if (steps) atomicAdd(&c[FC_STEPS], steps);
+    if (rays) atomicAdd(&c[FC_RAYS], (unsigned long long)rays);
+    if (pos) atomicAdd(&c[FC_POS], (unsigned long long)pos);
+    if (neg) atomicAdd(&c[FC_NEG], (unsigned long long)neg);
+    if (none) atomicAdd(&c[FC_NONE], (unsigned long long)none);
+    if (oob) atomicAdd(&c[FC_OOB], (unsigned long long)oob);
+  }
 }
 
 /* Final ray states, structure-of-arrays in HBM, indexed by pixel id = frame*W*H + py*W + px.
@@ -76,7 +134,7 @@ struct IntegrateParams {
   unsigned max_iter;
   double max_radius, delta;
   RayStore store;
-  unsigned long long *counters; /* CNT_N */
+  FrameCounters counters;
   int refill_threshold;
   int fast_ok; /* host-side part of the fast-step guard */
   /* fused shading (static kernel, non-debug): the epilogue looks the sky up and writes RGB8 itself */
@@ -94,7 +152,8 @@ struct ShadeParams {
   unsigned long long n_pixels; /* n_frames*W*H */
   unsigned char *fb;           /* RGB8 */
   curvis_ray_debug *dbg;       /* or null */
-  unsigned long long *counters;
+  unsigned long long npix;     /* pixels per frame: frame of pixel o = o / npix */
+  FrameCounters counters;
 };
 
 /* Per-workgroup LDS copy of the sin/cos table (4 KiB; 8 KiB in its 256-row form): the Euler loop evaluates
@@ -178,18 +237,6 @@ __device__ __forceinline__ void one_step(const cvk::MetricParams &M, double delt
     cvk::ray_step<KIND, PHI, MathTablesLds<KIND>::WIDE_SC>(M, q, delta);
 }
 
-__device__ __forceinline__ void flush_steps(const IntegrateParams &P, unsigned long long steps, unsigned rays) {
-  for (int off = 32; off > 0; off >>= 1) {
-    steps += __shfl_xor(steps, off);
-    rays += __shfl_xor(rays, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    unsigned long long *c = counter_replica(P.counters);
-    atomicAdd(&c[CNT_STEPS], steps);
-    atomicAdd(&c[CNT_RAYS], (unsigned long long)rays);
-  }
-}
-
 /* final photon -> tangent direction -> nearest sky texel (rows R9-R10 of SURVEY.md 8a) */
 template <int KIND>
 __device__ __forceinline__ unsigned shade_ray(const cvk::MetricParams &M, const cvk::SkyParams *sky, const cvk::Ray &q,
@@ -210,23 +257,6 @@ __device__ __forceinline__ unsigned shade_ray(const cvk::MetricParams &M, const 
   return texel;
 }
 
-__device__ __forceinline__ void flush_escape_counts(unsigned long long *counters, unsigned pos, unsigned neg, unsigned none,
-                                                    unsigned oob) {
-  for (int off = 32; off > 0; off >>= 1) {
-    pos += __shfl_xor(pos, off);
-    neg += __shfl_xor(neg, off);
-    none += __shfl_xor(none, off);
-    oob += __shfl_xor(oob, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    unsigned long long *c = counter_replica(counters);
-    if (pos) atomicAdd(&c[CNT_POS], (unsigned long long)pos);
-    if (neg) atomicAdd(&c[CNT_NEG], (unsigned long long)neg);
-    if (none) atomicAdd(&c[CNT_NONE], (unsigned long long)none);
-    if (oob) atomicAdd(&c[CNT_OOB], (unsigned long long)oob);
-  }
-}
-
 /* K1, persistent form: lanes draw rays from a global queue with one wave-aggregated atomic whenever
  * `refill_threshold` lanes are free; terminated rays are stored together at that point. */
 template <int KIND, bool PHI, bool FAST>
@@ -244,14 +274,10 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
   bool done = false;   /* lane holds a terminated ray that has not been stored yet */
   bool dry = false;    /* queue exhausted (wave-uniform) */
   bool lane_ok = false;
-  unsigned long long st_steps = 0;
-  unsigned st_rays = 0;
 
   for (;;) {
-    if (done) {
+    if (done) { /* staged path: shade_kernel reads the store and keeps the per-frame statistics */
       store_ray<PHI>(P.store, slot, q, steps, code);
-      st_steps += steps;
-      st_rays++;
       done = false;
     }
     if (!dry) {
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
         const unsigned n = (unsigned)__popcll(mask);
         const int leader = __ffsll((long long)mask) - 1;
         unsigned long long base = 0;
-        if ((int)lane == leader) base = atomicAdd(&P.counters[CNT_NEXT], (unsigned long long)n);
+        if ((int)lane == leader) base = atomicAdd(&P.counters.base[CNT_NEXT], (unsigned long long)n);
         base = __shfl(base, leader);
         const unsigned rank =
             __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -304,7 +330,6 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
       if (__popcll(__ballot(!active)) >= thr) break;
     }
   }
-  flush_steps(P, st_steps, st_rays);
 }
 
 /* K1, static form: one ray per thread, hardware block scheduling does the load balancing.
@@ -318,13 +343,10 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
   load_math_tables<KIND>(s_tab, M);
   const unsigned long long id = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long t_start = P.trace ? wall_clock64() : 0ull;
-  unsigned long long st_steps = 0;
-  unsigned st_rays = 0;
   unsigned frame, px, py;
   cvk::Ray q;
   q.l = q.th = q.ph = q.p1 = q.p2 = q.p3 = q.p3sq = 0.0;
   bool valid = false, active = false, lane_ok_w = false;
-  size_t slot = 0;
   unsigned steps = 0;
   int code = cvk::CODE_NONE;
   if (id < P.total_rays && decode_ray(P, id, frame, px, py)) {
@@ -332,7 +354,6 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
     lane_ok_w = FAST && P.fast_ok && cvk::ray_fast_ok(q);
     valid = true;
     active = P.max_iter != 0;
-    slot = (size_t)frame * P.W * P.H + (size_t)py * P.W + px;
   }
   /* All lanes of a wave start together, so the step counter is wave-uniform (an SGPR).  The loop is a plain
    * divergent loop: a lane leaves it (drops out of EXEC) when it escapes; the back-edge is "EXEC still
@@ -361,6 +382,13 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
     if (ray_escaped(q.l, P.max_radius)) code = escape_code(q.l); /* the state is final: same test as in the loop */
   }
   unsigned pos = 0, neg = 0, none = 0, oob = 0;
+  /* The pixel position is decoded AGAIN here, from the laundered block index, instead of being kept in registers
+   * across the Euler loop (frame, px, py or a 64-bit slot: 3-4 VGPRs the loop is better off without). */
+  unsigned bid = blockIdx.x;
+  asm volatile("" : "+s"(bid));
+  const unsigned long long id2 = (unsigned long long)bid * blockDim.x + threadIdx.x;
+  valid = id2 < P.total_rays && decode_ray(P, id2, frame, px, py);
+  const size_t slot = valid ? (size_t)frame * P.W * P.H + (size_t)py * P.W + px : 0;
   if (valid) {
     if (FUSED) {
       unsigned tx, ty;
@@ -375,11 +403,10 @@ __global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) 
     } else {
       store_ray<PHI>(P.store, slot, q, steps, code);
     }
-    st_steps = steps;
-    st_rays = 1;
   }
-  flush_steps(P, st_steps, st_rays);
-  if (FUSED) flush_escape_counts(P.counters, pos, neg, none, oob);
+  /* statistics of the wave's tile go to the counters of ITS frame (a tile never straddles frames); on the staged
+   * path shade_kernel keeps them */
+  if (FUSED) flush_frame_counts(P.counters, frame_of_tile(id2 >> 6, P.rays_per_frame), valid, steps, 1u, pos, neg, none, oob);
   if (P.trace && (threadIdx.x & 63u) == 0) {
     unsigned hw_id, xcc_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
@@ -550,8 +577,7 @@ __global__ __launch_bounds__(256) void geodesic_relay(const IntegrateParams P, c
     parked = true;
     break;
   }
-  unsigned long long st_steps = 0;
-  unsigned st_rays = 0, pos = 0, neg = 0, none = 0, oob = 0;
+  unsigned pos = 0, neg = 0, none = 0, oob = 0;
   if (parked) {
     st_sys(&P.store.l[id], q.l);
     st_sys(&P.store.th[id], q.th);
@@ -566,23 +592,26 @@ __global__ __launch_bounds__(256) void geodesic_relay(const IntegrateParams P, c
       st_sys(Q->ring + ((unsigned)tk & (kRelayRing - 1u)), (unsigned)tile + 1u);
     }
   } else {
-    if (valid) {
+    /* pixel position decoded again from the laundered tile number rather than kept live across the loop */
+    unsigned tile_s = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tile);
+    asm volatile("" : "+s"(tile_s));
+    unsigned frame2, px2, py2;
+    const unsigned long long id2 = (unsigned long long)tile_s * 64ull + lane;
+    if (id2 < P.total_rays && decode_ray(P, id2, frame2, px2, py2)) {
       unsigned tx, ty;
       const unsigned texel = shade_ray<KIND>(M, P.sky, q, code, tx, ty, oob);
-      unsigned char *dst = P.fb + ((size_t)frame * P.W * P.H + (size_t)py * P.W + px) * 3;
+      unsigned char *dst = P.fb + ((size_t)frame2 * P.W * P.H + (size_t)py2 * P.W + px2) * 3;
       dst[0] = (unsigned char)(texel & 0xFF);
       dst[1] = (unsigned char)((texel >> 8) & 0xFF);
       dst[2] = (unsigned char)((texel >> 16) & 0xFF);
       pos = (code == cvk::CODE_POS);
       neg = (code == cvk::CODE_NEG);
       none = (code == cvk::CODE_NONE);
-      st_steps = steps;
-      st_rays = 1;
     }
     if (lane == 0 && tile < A.n_tiles) atomicAdd(&Q->finished, 1ull);
   }
-  flush_steps(P, st_steps, st_rays);
-  flush_escape_counts(P.counters, pos, neg, none, oob);
+  /* a tile is counted once, by the wave that finishes it, in the counters of its frame */
+  flush_frame_counts(P.counters, frame_of_tile(tile, P.rays_per_frame), valid && !parked, steps, 1u, pos, neg, none, oob);
   if (P.trace && lane == 0) { /* CURVIS_TRACE_FILE: {start, end, HW_ID, XCC_ID | flags, got-tile time, tile} per wave */
     unsigned hw_id, xcc_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
@@ -601,8 +630,9 @@ __global__ __launch_bounds__(256) void geodesic_relay(const IntegrateParams P, c
 template <int KIND, bool DEBUG>
 __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams P) {
   const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned pos = 0, neg = 0, none = 0, oob = 0;
-  if (o < P.n_pixels) {
+  unsigned pos = 0, neg = 0, none = 0, oob = 0, n_steps = 0;
+  const bool valid = o < P.n_pixels;
+  if (valid) {
     cvk::Ray q;
     q.l = P.store.l[o];
     q.th = P.store.th[o];
@@ -613,6 +643,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams P) {
     q.p3sq = 0.0;
     const int code = P.store.code[o];
     const unsigned steps = P.store.steps[o];
+    n_steps = steps;
     unsigned tx, ty;
     cvk::MetricParams M = P.metric;
     M.T = cv_sc_table();
@@ -642,7 +673,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeParams P) {
       d->ty = ty;
     }
   }
-  flush_escape_counts(P.counters, pos, neg, none, oob);
+  flush_frame_counts(P.counters, (unsigned)(o / P.npix), valid, n_steps, 1u, pos, neg, none, oob);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -728,7 +759,7 @@ struct EfficientPixelParams {
   const double *sx, *m_e, *c_e, *m_s, *c_s;
   unsigned n_frames, W, H;
   unsigned char *fb;
-  unsigned long long *counters;
+  FrameCounters counters;
 };
 
 /* K3: steps 2, 4, 5 of render_image_efficient + sky lookup, one thread per pixel. */
@@ -736,8 +767,9 @@ __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPix
   const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long npix = (unsigned long long)P.W * P.H;
   unsigned pos = 0, neg = 0, none = 0, oob = 0;
-  if (o < npix * P.n_frames) {
-    const unsigned f = (unsigned)(o / npix);
+  const bool valid = o < npix * P.n_frames;
+  const unsigned f = valid ? (unsigned)(o / npix) : 0u;
+  if (valid) {
     const unsigned pix = (unsigned)(o - (unsigned long long)f * npix);
     const unsigned py = pix / P.W, px = pix - py * P.W;
     const unsigned off = P.tab_off[f], n = P.tab_n[f];
@@ -763,19 +795,7 @@ __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPix
     dst[1] = (unsigned char)((texel >> 8) & 0xFF);
     dst[2] = (unsigned char)((texel >> 16) & 0xFF);
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    pos += __shfl_xor(pos, off);
-    neg += __shfl_xor(neg, off);
-    none += __shfl_xor(none, off);
-    oob += __shfl_xor(oob, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    unsigned long long *c = counter_replica(P.counters);
-    if (pos) atomicAdd(&c[CNT_POS], (unsigned long long)pos);
-    if (neg) atomicAdd(&c[CNT_NEG], (unsigned long long)neg);
-    if (none) atomicAdd(&c[CNT_NONE], (unsigned long long)none);
-    if (oob) atomicAdd(&c[CNT_OOB], (unsigned long long)oob);
-  }
+  flush_frame_counts(P.counters, f, valid, 0ull, 1u, pos, neg, none, oob);
 }
 
 /* compute_photon_trajectory (src/systems.rs:77-92): the state BEFORE each of `iterations` Euler steps,
@@ -918,8 +938,12 @@ struct curvis_ctx {
   size_t cams_cap = 0;
   cvk::CameraParams *h_cams = nullptr; /* pinned */
   size_t h_cams_cap = 0;
-  unsigned long long *d_counters = nullptr;
-  unsigned long long *h_counters = nullptr; /* pinned */
+  unsigned long long *d_counters = nullptr; /* FrameCounters block, sized for the largest launch so far */
+  size_t counters_cap = 0;
+  unsigned long long *h_counters = nullptr; /* pinned mirror (+ 8 words for the relay queue header) */
+  size_t h_counters_cap = 0;
+  /* statistics of the last render, per frame (curvis_ctx_frame_stats) */
+  std::vector<curvis_stats> last_frame_stats;
   /* options */
   int variant = -1;         /* -1 automatic (default): relay kernel for launches of up to relay_max_frames frames and at least
                                relay_min_blocks workgroups, static kernel otherwise;
@@ -965,6 +989,32 @@ int ensure_device(curvis_ctx *ctx, T *&ptr, size_t &cap, size_t need) {
   HIP_TRY(ctx, hipMalloc((void **)&ptr, need * sizeof(T)));
   cap = need;
   return CURVIS_OK;
+}
+
+/* counter block for a launch of n_frames frames: device block + pinned mirror, zeroed on the stream */
+int prepare_counters(curvis_ctx *ctx, unsigned n_frames, FrameCounters &C) {
+  C.slots = counter_slots_for(n_frames);
+  const size_t words = counter_words(n_frames, C.slots);
+  int rc = ensure_device(ctx, ctx->d_counters, ctx->counters_cap, words);
+  if (rc) return rc;
+  if (ctx->h_counters_cap < words + 8) {
+    if (ctx->h_counters) HIP_TRY(ctx, hipHostFree(ctx->h_counters));
+    ctx->h_counters = nullptr;
+    ctx->h_counters_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned long long) * (words + 8)));
+    ctx->h_counters_cap = words + 8;
+  }
+  C.base = ctx->d_counters;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * words, ctx->stream));
+  return CURVIS_OK;
+}
+/* sum the replicas of frame f of the mirrored block into out[FC_N] */
+void sum_frame_counters(const unsigned long long *h, unsigned slots, unsigned f, uint64_t out[FC_N]) {
+  for (int k = 0; k < FC_N; ++k) out[k] = 0;
+  for (unsigned r = 0; r < slots; ++r) {
+    const unsigned long long *line = h + (size_t)CNT_STRIDE * (1u + (size_t)f * slots + r);
+    for (int k = 0; k < FC_N; ++k) out[k] += line[k];
+  }
 }
 
 cvk::MetricParams make_metric(const curvis_metric &m) {
@@ -1188,12 +1238,16 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   const cvk::MetricParams MP = make_metric(*metric);
   const bool phi = dbg_out != nullptr; /* phi is only read by the debug dump on this path */
   const bool fast = ctx->fast_math != 0;
-  uint64_t tot[CNT_N] = {0};
+  uint64_t tot[FC_N] = {0};
   double integrate_ms = 0.0, shade_ms = 0.0;
+  ctx->last_frame_stats.assign(n_frames, curvis_stats{});
 
   for (uint32_t f0 = 0; f0 < n_frames; f0 += chunk) {
     const uint32_t nf = std::min(chunk, n_frames - f0);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_WORDS, ctx->stream));
+    FrameCounters FC;
+    rc = prepare_counters(ctx, nf, FC);
+    if (rc) return rc;
+    const size_t cnt_words = counter_words(nf, FC.slots);
     IntegrateParams P;
     P.metric = MP;
     P.cams = ctx->d_cams + f0;
@@ -1204,7 +1258,7 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     P.tiles_x = (W + 7) / 8;
     P.tiles_y = (H + 7) / 8;
     const unsigned long long rpf = (unsigned long long)P.tiles_x * P.tiles_y * 64ull;
-    if (rpf > 0xFFFFFFFFull) return fail(ctx, CURVIS_E_INVALID, "frame too large");
+    if (rpf > 0xFFFFFFFFull || rpf * nf / 64ull > 0xFFFFFFFFull) return fail(ctx, CURVIS_E_INVALID, "frame or batch too large");
     P.rays_per_frame = (unsigned)rpf;
     P.total_rays = rpf * nf;
     P.max_iter = max_iterations;
@@ -1212,7 +1266,7 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     P.delta = delta;
     P.store = relay ? carve_store(ctx->d_store, (size_t)P.total_rays)
                     : fused ? RayStore{} : carve_store(ctx->d_store, (size_t)nf * npix);
-    P.counters = ctx->d_counters;
+    P.counters = FC;
     for (int k = 0; k < 2; ++k) {
       P.sky[k].texels = (const unsigned *)ctx->d_sky[k];
       P.sky[k].w = ctx->sky_w[k];
@@ -1244,7 +1298,8 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     Q.n_pixels = (unsigned long long)nf * npix;
     Q.fb = ctx->d_fb + (size_t)f0 * npix * 3;
     Q.dbg = dbg_out ? ctx->d_dbg + (size_t)f0 * npix : nullptr;
-    Q.counters = ctx->d_counters;
+    Q.npix = npix;
+    Q.counters = FC;
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     rc = launch_integrate_any(ctx, metric->kind, phi, fast, fused, relay ? 1 : 0, P);
@@ -1277,16 +1332,16 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
     ctx->last_relay_launches = relay ? 1 : 0;
     for (;;) {
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_WORDS,
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words,
                                   hipMemcpyDeviceToHost, ctx->stream));
       if (relay) /* queue header rides along with the counters: finished / error */
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + CNT_WORDS, ctx->d_rq, sizeof(unsigned long long) * 8,
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters + cnt_words, ctx->d_rq, sizeof(unsigned long long) * 8,
                                     hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       if (!relay) break;
       /* normally the one launch finished every tile; more relay workgroups only if the grid ran out of them
        * with tiles still parked */
-      const RelayQueue *hq = (const RelayQueue *)(ctx->h_counters + CNT_WORDS);
+      const RelayQueue *hq = (const RelayQueue *)(ctx->h_counters + cnt_words);
       const unsigned long long n_tiles = P.total_rays / 64ull;
       if (hq->error != 0)
         return fail(ctx, CURVIS_E_HIP, "relay kernel: " + std::to_string(hq->error) + " waves gave up waiting, " +
@@ -1301,13 +1356,38 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
       HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
       HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
     }
-    for (int r = 0; r < CNT_SLOTS; ++r)
-      for (int k = 0; k < CNT_N; ++k) tot[k] += ctx->h_counters[r * CNT_STRIDE + k];
-    float ms = 0.f;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    integrate_ms += ms;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
-    shade_ms += ms;
+    float ms_i = 0.f, ms_s = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms_i, ctx->ev0, ctx->ev1));
+    integrate_ms += ms_i;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms_s, ctx->ev1, ctx->ev2));
+    shade_ms += ms_s;
+    for (uint32_t f = 0; f < nf; ++f) {
+      uint64_t fc[FC_N];
+      sum_frame_counters(ctx->h_counters, FC.slots, f, fc);
+      for (int k = 0; k < FC_N; ++k) tot[k] += fc[k];
+      curvis_stats &fs = ctx->last_frame_stats[f0 + f];
+      fs.rays = fc[FC_RAYS];
+      fs.steps = fc[FC_STEPS];
+      fs.n_pos = fc[FC_POS];
+      fs.n_neg = fc[FC_NEG];
+      fs.n_none = fc[FC_NONE];
+      fs.n_oob = fc[FC_OOB];
+      /* the frames of a launch run interleaved on the GPU: times are the launch's, shared out by executed steps */
+      fs.integrate_ms = ms_i;
+      fs.shade_ms = ms_s;
+    }
+    { /* time share of each frame of this launch, in proportion to its Euler steps */
+      uint64_t launch_steps = 0;
+      for (uint32_t f = 0; f < nf; ++f) launch_steps += ctx->last_frame_stats[f0 + f].steps;
+      for (uint32_t f = 0; f < nf; ++f) {
+        curvis_stats &fs = ctx->last_frame_stats[f0 + f];
+        const double share = launch_steps ? (double)fs.steps / (double)launch_steps : 1.0 / nf;
+        fs.integrate_ms *= share;
+        fs.shade_ms *= share;
+        fs.kernel_ms = fs.integrate_ms + fs.shade_ms;
+        fs.total_ms = fs.kernel_ms;
+      }
+    }
   }
   ctx->last_integrate_ms = integrate_ms;
   ctx->last_shade_ms = shade_ms;
@@ -1335,12 +1415,12 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     }
   }
   if (stats) {
-    stats->rays = tot[CNT_RAYS];
-    stats->steps = tot[CNT_STEPS];
-    stats->n_pos = tot[CNT_POS];
-    stats->n_neg = tot[CNT_NEG];
-    stats->n_none = tot[CNT_NONE];
-    stats->n_oob = tot[CNT_OOB];
+    stats->rays = tot[FC_RAYS];
+    stats->steps = tot[FC_STEPS];
+    stats->n_pos = tot[FC_POS];
+    stats->n_neg = tot[FC_NEG];
+    stats->n_none = tot[FC_NONE];
+    stats->n_oob = tot[FC_OOB];
     stats->kernel_ms = integrate_ms + shade_ms;
     stats->integrate_ms = integrate_ms;
     stats->shade_ms = shade_ms;
@@ -1741,7 +1821,10 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   std::memcpy(stage.data() + o_ms, m_s.data(), sizeof(double) * T);
   std::memcpy(stage.data() + o_cs, c_s.data(), sizeof(double) * T);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eff, stage.data(), off, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_WORDS, ctx->stream));
+  FrameCounters FC;
+  rc = prepare_counters(ctx, n_frames, FC);
+  if (rc) return rc;
+  const size_t cnt_words = counter_words(n_frames, FC.slots);
   EfficientPixelParams Q;
   for (int k = 0; k < 2; ++k) {
     Q.sky[k].texels = (const unsigned *)ctx->d_sky[k];
@@ -1762,28 +1845,44 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   Q.W = W;
   Q.H = H;
   Q.fb = ctx->d_fb;
-  Q.counters = ctx->d_counters;
+  Q.counters = FC;
   const unsigned long long blocks = ((unsigned long long)npix * n_frames + 255ull) / 256ull;
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, Q);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * CNT_WORDS,
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words,
                               hipMemcpyDeviceToHost, ctx->stream));
   if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0.f;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  uint64_t tot[FC_N] = {0};
+  ctx->last_frame_stats.assign(n_frames, curvis_stats{});
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    uint64_t fc[FC_N];
+    sum_frame_counters(ctx->h_counters, FC.slots, f, fc);
+    for (int k = 0; k < FC_N; ++k) tot[k] += fc[k];
+    curvis_stats &fs = ctx->last_frame_stats[f];
+    fs.rays = (uint64_t)npix; /* pixels; the integrator calls of the frame's sampler are in curvis_ctx_sampling_info */
+    fs.steps = smp[f].steps;
+    fs.n_pos = fc[FC_POS];
+    fs.n_neg = fc[FC_NEG];
+    fs.n_none = fc[FC_NONE];
+    fs.n_oob = fc[FC_OOB];
+    /* the samplers of a batch share their launches: times are the batch's, shared out evenly */
+    fs.integrate_ms = sample_ms / n_frames;
+    fs.shade_ms = ms / n_frames;
+    fs.kernel_ms = fs.integrate_ms + fs.shade_ms;
+    fs.total_ms = fs.kernel_ms;
+  }
   if (stats) {
     stats->rays = (uint64_t)npix * n_frames;
     stats->steps = total_steps;
-    uint64_t tot[CNT_N] = {0};
-    for (int r = 0; r < CNT_SLOTS; ++r)
-      for (int k = 0; k < CNT_N; ++k) tot[k] += ctx->h_counters[r * CNT_STRIDE + k];
-    stats->n_pos = tot[CNT_POS];
-    stats->n_neg = tot[CNT_NEG];
-    stats->n_none = tot[CNT_NONE];
-    stats->n_oob = tot[CNT_OOB];
+    stats->n_pos = tot[FC_POS];
+    stats->n_neg = tot[FC_NEG];
+    stats->n_none = tot[FC_NONE];
+    stats->n_oob = tot[FC_OOB];
     stats->integrate_ms = sample_ms;
     stats->shade_ms = ms;
     stats->kernel_ms = sample_ms + ms;
@@ -1839,10 +1938,6 @@ int curvis_ctx_create(int device, curvis_ctx **out) {
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
       (e = hipEventCreate(&ctx->ev2)) != hipSuccess)
     return bail(std::string("hipEventCreate: ") + hipGetErrorString(e));
-  if ((e = hipMalloc((void **)&ctx->d_counters, sizeof(unsigned long long) * CNT_WORDS)) != hipSuccess)
-    return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
-  if ((e = hipHostMalloc((void **)&ctx->h_counters, sizeof(unsigned long long) * (CNT_WORDS + 8))) != hipSuccess)
-    return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   *out = ctx;
   return CURVIS_OK;
 }
@@ -1938,24 +2033,27 @@ int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rank = -1;
   if (ncclCommUserRank(comm, &rank) != ncclSuccess) return fail(ctx, CURVIS_E_RCCL, "ncclCommUserRank failed");
-  /* shapes first (4 x u32), then the two textures */
-  uint32_t *d_shape = nullptr;
-  HIP_TRY(ctx, hipMalloc((void **)&d_shape, 4 * sizeof(uint32_t)));
-  uint32_t shape[4] = {ctx->sky_w[0], ctx->sky_h[0], ctx->sky_w[1], ctx->sky_h[1]};
+  /* header first: {root_ok, w0, h0, w1, h1}, then the two textures.  root_ok travels with the shapes so that a
+   * root without skies makes EVERY rank return CURVIS_E_NO_SKY together -- a root that returned before the
+   * collective would leave its peers waiting inside ncclBroadcast for ever. */
+  uint32_t *d_hdr = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d_hdr, 5 * sizeof(uint32_t)));
+  uint32_t hdr[5] = {0u, ctx->sky_w[0], ctx->sky_h[0], ctx->sky_w[1], ctx->sky_h[1]};
   if (rank == root) {
-    if (!ctx->d_sky[0] || !ctx->d_sky[1]) {
-      (void)hipFree(d_shape);
-      return fail(ctx, CURVIS_E_NO_SKY, "root rank must hold both skies before the broadcast");
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(d_shape, shape, sizeof shape, hipMemcpyHostToDevice, ctx->stream));
+    hdr[0] = (ctx->d_sky[0] && ctx->d_sky[1]) ? 1u : 0u;
+    HIP_TRY(ctx, hipMemcpyAsync(d_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream));
   }
-  if (ncclBroadcast(d_shape, d_shape, 4, ncclUint32, root, comm, ctx->stream) != ncclSuccess) {
-    (void)hipFree(d_shape);
-    return fail(ctx, CURVIS_E_RCCL, "ncclBroadcast(shape) failed");
+  if (ncclBroadcast(d_hdr, d_hdr, 5, ncclUint32, root, comm, ctx->stream) != ncclSuccess) {
+    (void)hipFree(d_hdr);
+    return fail(ctx, CURVIS_E_RCCL, "ncclBroadcast(header) failed");
   }
-  HIP_TRY(ctx, hipMemcpyAsync(shape, d_shape, sizeof shape, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(hdr, d_hdr, sizeof hdr, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  (void)hipFree(d_shape);
+  (void)hipFree(d_hdr);
+  if (hdr[0] != 1u)
+    return fail(ctx, CURVIS_E_NO_SKY, rank == root ? "root rank must hold both skies before the broadcast"
+                                                   : "the root rank of the sky broadcast holds no skies");
+  const uint32_t *shape = hdr + 1;
   for (int s = 0; s < 2; ++s) {
     const uint32_t w = shape[2 * s], h = shape[2 * s + 1];
     if (rank != root) {
@@ -2070,6 +2168,12 @@ int curvis_render_efficient_batch(curvis_ctx *ctx, const curvis_metric *metric, 
 int curvis_ctx_sampling_info(const curvis_ctx *ctx, uint32_t frame, curvis_sampling_info *info) {
   if (!ctx || !info || frame >= ctx->last_sampling_info.size()) return CURVIS_E_INVALID;
   *info = ctx->last_sampling_info[frame];
+  return CURVIS_OK;
+}
+
+int curvis_ctx_frame_stats(const curvis_ctx *ctx, uint32_t frame, curvis_stats *stats) {
+  if (!ctx || !stats || frame >= ctx->last_frame_stats.size()) return CURVIS_E_INVALID;
+  *stats = ctx->last_frame_stats[frame];
   return CURVIS_OK;
 }
 
@@ -2250,6 +2354,8 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->relay_max_frames;
   else if (k == "relay_min_blocks")
     *value = ctx->relay_min_blocks;
+  else if (k == "last_frames")
+    *value = (int64_t)ctx->last_frame_stats.size();
   else if (k == "last_relay_launches")
     *value = ctx->last_relay_launches;
   else if (k == "last_relay_parks")

@@ -17,7 +17,11 @@
  * reference renders; brute = RelativisticSystem::render_image, the per-pixel integrator),
  * --devices N (image --mode brute: rows of the frame split over N GPUs; video: frames k mod N across N GPUs, one host thread + one context per GPU, skies uploaded to
  * each or broadcast from GPU 0 with RCCL: --sky-broadcast rccl|upload), --batch B (frames per kernel launch),
- * --writers T (PNG encoder threads; default: a quarter of the host threads, 4..64), --stats FILE (per-frame JSON lines).
+ * --writers T (PNG encoder threads; default: a quarter of the host threads, 4..64), --stats FILE (JSON lines, one per
+ * frame, with that frame's own early-termination counters: rays, executed Euler steps, escaped +l / -l, capped),
+ * --resume (video: keep <out>/tmp and skip the frames whose frame_{k}.png is already there; default off = the
+ * reference's behaviour of deleting and recreating tmp, src/rendering.rs:276-287).  A batch of frames whose render
+ * call fails is re-queued on another GPU (frames are independent) before the run is declared failed.
  * Backgrounds must be PNG (any colour type / bit depth); no JPEG decoder is linked.
  */
 #include <sys/stat.h>
@@ -26,6 +30,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <filesystem>
 #include <functional>
 #include <cerrno>
 #include <cmath>
@@ -402,6 +407,7 @@ int path_camera(const CameraPath &p, double t, double pos[4], double fwd[3], dou
 struct Args {
   std::string sub, bg1, bg2, out, image_toml, video_toml, metric_toml, camera_toml, sim_toml, mode = "efficient", stats,
       sky_broadcast = "rccl";
+  bool sky_broadcast_explicit = false, resume = false;
   int devices = 1, device = 0, batch = 8, writers = 0; /* writers 0 = automatic: a quarter of the host's threads, 4..64 */
 };
 [[noreturn]] void die(const std::string &msg, int code = 1) {
@@ -415,7 +421,8 @@ void usage() {
       "curvis image <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-i|--image-settings <TOML FILE>]\n"
       "curvis video <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-v|--video-settings <TOML FILE>]\n"
       "  common: [-m|--metric-settings <TOML FILE>] [-c|--camera-settings <TOML FILE>] [-s|--simulation-settings <TOML FILE>]\n"
-      "  extensions: [--mode efficient|brute] [--device N] [--devices N] [--batch B] [--stats FILE]\n");
+      "  extensions: [--mode efficient|brute] [--device N] [--devices N] [--batch B] [--stats FILE]\n"
+      "              [--sky-broadcast rccl|upload] [--writers T] [--resume]\n");
 }
 Args parse_args(int argc, char **argv) {
   Args a;
@@ -449,7 +456,8 @@ Args parse_args(int argc, char **argv) {
     else if (key == "-s" || key == "--simulation-settings") take(a.sim_toml);
     else if (key == "--mode") take(a.mode);
     else if (key == "--stats") take(a.stats);
-    else if (key == "--sky-broadcast") take(a.sky_broadcast);
+    else if (key == "--sky-broadcast") { take(a.sky_broadcast); a.sky_broadcast_explicit = true; }
+    else if (key == "--resume") a.resume = true;
     else if (key == "--devices") { take(val); a.devices = std::atoi(val.c_str()); }
     else if (key == "--device") { take(val); a.device = std::atoi(val.c_str()); }
     else if (key == "--batch") { take(val); a.batch = std::atoi(val.c_str()); }
@@ -615,7 +623,8 @@ int image_main(const Args &a) {
   } else {
     check(render_frames(ctx, a, c, &cam, 1, c.sim.sampling_convergence_threshold_2, rgb.data(), &st), ctx, "image");
   }
-  const std::string file = c.out + "/" + is.image_name + ".png";
+  /* PathBuf::join(image_name).with_extension("png") (src/rendering.rs:108): an existing extension is REPLACED */
+  const std::string file = (std::filesystem::path(c.out) / std::filesystem::path(is.image_name).replace_extension("png")).string();
   if (!pngio::save_rgb8(file, rgb.data(), cam.res_x, cam.res_y, err))
     die("Error in rendering image: Could not save image frame \"" + file + "\" due to error: " + err);
   if (!a.stats.empty()) {
@@ -631,9 +640,11 @@ int image_main(const Args &a) {
   return 0;
 }
 
-int rm_rf(const std::string &dir) { /* tmp folder only contains frame files */
-  const std::string cmd = "rm -rf -- '" + dir + "'";
-  return std::system(cmd.c_str());
+/* std::fs::remove_dir_all (src/rendering.rs:278): no shell involved, the path is never interpreted */
+int rm_rf(const std::string &dir) {
+  std::error_code ec;
+  std::filesystem::remove_all(std::filesystem::path(dir), ec);
+  return ec ? 1 : 0;
 }
 
 /* frame writers: PNG encoding (zlib) costs more host time per frame than the GPU needs to render it, so
@@ -709,9 +720,14 @@ int video_main(const Args &a) {
   if (!path_exists(c.out) && ::mkdir(c.out.c_str(), 0777) != 0)
     die("Error in rendering video: Could not create video output folder \"" + c.out + "\"");
   const std::string tmp = c.out + "/tmp";
-  if (path_exists(tmp) && rm_rf(tmp) != 0)
-    die("Error in rendering video: Could not remove pre-existing tmp folder \"" + tmp + "\"");
-  if (::mkdir(tmp.c_str(), 0777) != 0) die("Error in rendering video: Could not create tmp output folder \"" + tmp + "\"");
+  if (a.resume) { /* opt-in: keep the frames a previous (interrupted) run has written */
+    if (!path_exists(tmp) && ::mkdir(tmp.c_str(), 0777) != 0)
+      die("Error in rendering video: Could not create tmp output folder \"" + tmp + "\"");
+  } else {
+    if (path_exists(tmp) && rm_rf(tmp) != 0)
+      die("Error in rendering video: Could not remove pre-existing tmp folder \"" + tmp + "\"");
+    if (::mkdir(tmp.c_str(), 0777) != 0) die("Error in rendering video: Could not create tmp output folder \"" + tmp + "\"");
+  }
   std::printf("Rendering %zu frames...\n", times.size());
 
   /* cameras of all frames; the reference panics when it reaches the broken last segment, after having
@@ -744,52 +760,145 @@ int video_main(const Args &a) {
    * --devices > 1) the other GPUs receive them with ncclBroadcast over xGMI (curvis_ctx_bcast_skies),
    * otherwise every GPU uploads from host memory. */
   std::vector<ncclComm_t> comms;
-  bool use_rccl = a.sky_broadcast == "rccl" && (a.devices > 1 || std::getenv("CURVIS_FORCE_RCCL"));
+  const bool share_device = std::getenv("CURVIS_TEST_SHARE_DEVICE") != nullptr; /* test hook: every worker on GPU a.device */
+  bool use_rccl = a.sky_broadcast == "rccl" && !share_device && (a.devices > 1 || std::getenv("CURVIS_FORCE_RCCL"));
   if (use_rccl) {
     std::vector<int> devs;
     for (int r = 0; r < a.devices; ++r) devs.push_back(a.device + r);
     comms.resize(a.devices);
-    if (ncclCommInitAll(comms.data(), a.devices, devs.data()) != ncclSuccess) {
-      std::fprintf(stderr, "warning: ncclCommInitAll failed, uploading the skies to every device instead\n");
+    const ncclResult_t nrc = ncclCommInitAll(comms.data(), a.devices, devs.data());
+    if (nrc != ncclSuccess) {
+      /* asked for explicitly: a broken xGMI broadcast must not hide behind a silent fallback */
+      if (a.sky_broadcast_explicit)
+        die(std::string("Error in rendering video: --sky-broadcast rccl: ncclCommInitAll failed (") + ncclGetErrorString(nrc) + ")");
+      std::fprintf(stderr, "warning: ncclCommInitAll failed (%s), uploading the skies to every device instead\n", ncclGetErrorString(nrc));
       comms.clear();
       use_rccl = false;
     }
   }
+  /* Work list: frame k belongs to device k mod N (src/rendering.rs:291-316 has no cross-frame state), in batches of
+   * --batch frames per launch.  With --resume the frames already on disk are dropped first.  A batch whose render
+   * call fails goes to a shared retry queue and is taken by a DIFFERENT device (by the same one when there is only
+   * one); after max(2, N) failed attempts the run fails. */
+  struct Batch {
+    std::vector<size_t> frames;
+    int attempts = 0, last_device = -1;
+  };
+  std::vector<std::deque<Batch>> own((size_t)a.devices);
+  size_t n_skipped = 0, n_batches = 0;
+  for (int r = 0; r < a.devices; ++r) {
+    Batch cur;
+    for (size_t k = (size_t)r; k < n_frames; k += (size_t)a.devices) {
+      if (a.resume) {
+        struct stat sb;
+        const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
+        if (::stat(file.c_str(), &sb) == 0 && sb.st_size > 0) {
+          ++n_skipped;
+          continue;
+        }
+      }
+      cur.frames.push_back(k);
+      if (cur.frames.size() == (size_t)a.batch) {
+        own[(size_t)r].push_back(cur);
+        cur.frames.clear();
+      }
+    }
+    if (!cur.frames.empty()) own[(size_t)r].push_back(cur);
+    n_batches += own[(size_t)r].size();
+  }
+  if (a.resume) std::printf("Resuming: %zu of %zu frames already present in \"%s\"\n", n_skipped, n_frames, tmp.c_str());
+  std::mutex q_mu;
+  std::condition_variable q_cv;
+  std::deque<Batch> retry;
+  size_t batches_done = 0;
+  const int max_attempts = std::max(2, a.devices);
+  /* fault injection for the tests: "rank:n" makes the n-th render call of that worker fail once */
+  int fail_rank = -1, fail_call = -1;
+  if (const char *fi = std::getenv("CURVIS_TEST_FAIL_BATCH")) std::sscanf(fi, "%d:%d", &fail_rank, &fail_call);
   auto worker = [&](int rank) {
-    curvis_ctx *ctx = make_ctx_bare(a.device + rank, "video");
+    curvis_ctx *ctx = make_ctx_bare(share_device ? a.device : a.device + rank, "video");
     if (use_rccl) {
       if (rank == 0) upload_skies(ctx, c, "video");
       check(curvis_ctx_bcast_skies(ctx, comms[rank], 0), ctx, "video");
     } else {
       upload_skies(ctx, c, "video");
     }
-    std::vector<size_t> mine;
-    for (size_t k = (size_t)rank; k < n_frames; k += (size_t)a.devices) mine.push_back(k);
     std::vector<curvis_camera> bc;
     std::vector<uint8_t> rgb;
-    for (size_t b0 = 0; b0 < mine.size() && !failed; b0 += (size_t)a.batch) {
-      const size_t nb = std::min((size_t)a.batch, mine.size() - b0);
+    int calls = 0;
+    for (;;) {
+      Batch b;
+      {
+        std::unique_lock<std::mutex> g(q_mu);
+        for (;;) {
+          if (failed || batches_done == n_batches) {
+            g.unlock();
+            curvis_ctx_destroy(ctx);
+            return;
+          }
+          auto it = retry.begin();
+          while (it != retry.end() && it->last_device == rank && a.devices > 1) ++it;
+          if (it != retry.end()) {
+            b = *it;
+            retry.erase(it);
+            break;
+          }
+          if (!own[(size_t)rank].empty()) {
+            b = own[(size_t)rank].front();
+            own[(size_t)rank].pop_front();
+            break;
+          }
+          q_cv.wait(g);
+        }
+      }
+      const size_t nb = b.frames.size();
       bc.clear();
-      for (size_t j = 0; j < nb; ++j) bc.push_back(cams[mine[b0 + j]]);
+      for (size_t j = 0; j < nb; ++j) bc.push_back(cams[b.frames[j]]);
       rgb.resize(nb * fbytes);
       curvis_stats st;
       /* src/rendering.rs:305-306: threshold_1 is passed for both thresholds */
-      const int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, rgb.data(), &st);
+      int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, rgb.data(), &st);
+      const bool injected = rank == fail_rank && calls == fail_call;
+      if (injected) rc = CURVIS_E_HIP;
+      ++calls;
       if (rc != CURVIS_OK) {
-        std::lock_guard<std::mutex> g(io_mu);
-        std::fprintf(stderr, "Error in rendering video: %s (code %d)\n", curvis_last_error(ctx), rc);
-        failed = 1;
-        break;
+        std::lock_guard<std::mutex> g(q_mu);
+        {
+          std::lock_guard<std::mutex> gi(io_mu);
+          std::fprintf(stderr, "warning: device %d: rendering frames %zu.. failed: %s (code %d), attempt %d of %d%s\n",
+                       a.device + rank, b.frames[0], injected ? "injected test fault" : curvis_last_error(ctx), rc,
+                       b.attempts + 1, max_attempts, b.attempts + 1 < max_attempts ? "; re-queued" : "");
+        }
+        b.attempts++;
+        b.last_device = rank;
+        if (b.attempts >= max_attempts) {
+          std::lock_guard<std::mutex> gi(io_mu);
+          std::fprintf(stderr, "Error in rendering video: frames %zu.. could not be rendered on any device\n", b.frames[0]);
+          failed = 1;
+        } else {
+          retry.push_back(b);
+        }
+        q_cv.notify_all();
+        continue;
       }
-      /* hand the frames of this batch to the writer pool (each job owns a copy of its frame) */
+      /* hand the frames of this batch to the writer pool (each job owns a copy of its frame and ITS statistics:
+       * the kernels keep one set of counters per frame of a launch) */
       for (size_t j = 0; j < nb; ++j) {
-        const size_t k = mine[b0 + j];
+        const size_t k = b.frames[j];
         auto frame = std::make_shared<std::vector<uint8_t>>(rgb.begin() + j * fbytes, rgb.begin() + (j + 1) * fbytes);
-        const curvis_stats stc = st;
-        writers.submit([&, k, frame, stc, nb, rank] {
+        curvis_stats fs;
+        std::memset(&fs, 0, sizeof fs);
+        (void)curvis_ctx_frame_stats(ctx, (uint32_t)j, &fs);
+        const double batch_ms = st.kernel_ms;
+        writers.submit([&, k, frame, fs, nb, rank, batch_ms] {
           const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
+          const std::string part = file + ".part"; /* written under another name, then renamed: --resume never sees half a file */
           std::string e;
-          const bool ok = pngio::save_rgb8(file, frame->data(), c.cam.resolution_x, c.cam.resolution_y, e, 1);
+          bool ok = pngio::save_rgb8(part, frame->data(), c.cam.resolution_x, c.cam.resolution_y, e, 1);
+          if (ok && std::rename(part.c_str(), file.c_str()) != 0) {
+            ok = false;
+            e = std::strerror(errno);
+          }
           std::lock_guard<std::mutex> g(io_mu);
           if (!ok) {
             std::fprintf(stderr, "Error in rendering video: Could not save image frame \"%s\" due to error: %s\n", file.c_str(), e.c_str());
@@ -798,13 +907,18 @@ int video_main(const Args &a) {
           }
           std::printf("Rendering frame %zu/%zu...\n", k + 1, times.size());
           if (stats_f)
-            std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"batch_frames\": %zu, \"batch_rays\": %llu, \"batch_steps\": %llu, \"batch_n_pos\": %llu, \"batch_n_neg\": %llu, \"batch_n_none\": %llu, \"batch_kernel_ms\": %.4f}\n",
-                         k, times[k], a.device + rank, a.mode.c_str(), nb, (unsigned long long)stc.rays, (unsigned long long)stc.steps,
-                         (unsigned long long)stc.n_pos, (unsigned long long)stc.n_neg, (unsigned long long)stc.n_none, stc.kernel_ms);
+            std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"rays\": %llu, \"steps\": %llu, \"n_pos\": %llu, \"n_neg\": %llu, \"n_none\": %llu, \"n_oob\": %llu, \"kernel_ms\": %.4f, \"batch_frames\": %zu, \"batch_kernel_ms\": %.4f}\n",
+                         k, times[k], a.device + rank, a.mode.c_str(), (unsigned long long)fs.rays, (unsigned long long)fs.steps,
+                         (unsigned long long)fs.n_pos, (unsigned long long)fs.n_neg, (unsigned long long)fs.n_none,
+                         (unsigned long long)fs.n_oob, fs.kernel_ms, nb, batch_ms);
         });
       }
+      {
+        std::lock_guard<std::mutex> g(q_mu);
+        ++batches_done;
+      }
+      q_cv.notify_all();
     }
-    curvis_ctx_destroy(ctx);
   };
   std::vector<std::thread> th;
   for (int r = 0; r < a.devices; ++r) th.emplace_back(worker, r);

@@ -116,10 +116,19 @@ def render_image_sharded(context, metric, camera, max_iterations, max_radius, de
 
 
 class VideoRenderingSystem:
-    """VideoRenderingSystem<M> (src/rendering.rs:178-327) over one curvis Context per rank."""
+    """VideoRenderingSystem<M> (src/rendering.rs:178-327) over one curvis Context per rank.
+
+    mode="efficient" (default) is what the reference's video loop calls: render_image_efficient with
+    alphas_num AND max_iterations_sampling both taken from `sampling_initial_nums` (src/main.rs:91-110 wires
+    max_iterations_sampling to sampling_initial_nums) and `sampling_convergence_threshold_1` passed for both
+    thresholds (src/rendering.rs:299-307) -- reproduced.  mode="brute" renders every frame with the per-pixel
+    integrator (RelativisticSystem::render_image, src/systems.rs:307-330), the path bench.py measures."""
 
     def __init__(self, metric, context, interpolator, frame_rate, resolution, camera_diagonal, camera_focal_length,
-                 escape_radius, max_iterations_propagation, ray_integration_step, rank=0, world_size=1, batch=8):
+                 escape_radius, max_iterations_propagation, ray_integration_step, rank=0, world_size=1, batch=8,
+                 mode="efficient", sampling_initial_nums=100, sampling_convergence_threshold_1=1e-5):
+        if mode not in ("efficient", "brute"):
+            raise ValueError("mode must be 'efficient' or 'brute'")
         self.metric = metric
         self.context = context
         self.interpolator = interpolator
@@ -131,6 +140,9 @@ class VideoRenderingSystem:
         self.max_iterations_propagation = int(max_iterations_propagation)
         self.ray_integration_step = float(ray_integration_step)
         self.rank, self.world_size, self.batch = int(rank), int(world_size), max(1, int(batch))
+        self.mode = mode
+        self.sampling_initial_nums = int(sampling_initial_nums)
+        self.sampling_convergence_threshold_1 = float(sampling_convergence_threshold_1)
 
     def times_of_frames(self):
         return times_of_frames(self.interpolator.min_time(), self.interpolator.max_time(), self.frame_rate)
@@ -141,32 +153,36 @@ class VideoRenderingSystem:
         return Camera(it.camera_position(t), it.camera_forward(t), it.camera_up(t), self.camera_focal_length,
                       self.camera_diagonal, self.resolution[0], self.resolution[1])
 
+    def _render_batch(self, cams, download):
+        if self.mode == "brute":
+            return self.context.render_brute(self.metric, cams, self.max_iterations_propagation, self.escape_radius,
+                                             self.ray_integration_step, download=download)
+        thr1 = self.sampling_convergence_threshold_1
+        return self.context.render_efficient(self.metric, cams, self.max_iterations_propagation, self.escape_radius,
+                                             self.ray_integration_step, self.sampling_initial_nums,
+                                             self.sampling_initial_nums, thr1, thr1, download=download)
+
     def render(self, on_frame=None, download=True):
-        """Render this rank's shard.  on_frame(index, rgb_or_None, stats_dict) is called per frame in
-        index order of the shard.  Returns the list of per-frame statistics dicts (early-termination
-        statistics included: executed steps, escaped +/-, capped rays)."""
+        """Render this rank's shard, `batch` frames per launch.  on_frame(index, rgb_or_None, stats_dict) is
+        called per frame in index order of the shard.  Returns the list of per-frame statistics dicts: the
+        early-termination statistics (rays, executed Euler steps, escaped +l / -l, capped, clamped texels) are
+        exact PER FRAME -- the kernels keep one set of counters per frame of a launch
+        (curvis_ctx_frame_stats); kernel_ms is the frame's share of its launch."""
         times = self.times_of_frames()
         mine = frames_of_rank(len(times), self.rank, self.world_size)
         out = []
         for b0 in range(0, len(mine), self.batch):
             idx = mine[b0:b0 + self.batch]
             cams = [self.camera_at(times[k]) for k in idx]
-            if len(cams) == 1:
-                rgb, st = self.context.render_brute(self.metric, cams[0], self.max_iterations_propagation,
-                                                    self.escape_radius, self.ray_integration_step, download=download)
-                frames = [rgb] if download else [None]
-                per = [st]
-            else:
-                # one launch for the whole batch; per-frame statistics need per-frame launches, so the
-                # batch statistics are attributed evenly unless batch == 1
-                rgb, st = self.context.render_brute(self.metric, cams, self.max_iterations_propagation,
-                                                    self.escape_radius, self.ray_integration_step, download=download)
-                frames = list(rgb) if download else [None] * len(cams)
-                per = [st] * len(cams)
+            rgb, st = self._render_batch(cams, download)
+            frames = list(rgb) if download else [None] * len(cams)
+            per = self.context.frame_stats()
+            assert len(per) == len(idx)
             for k, frame, s in zip(idx, frames, per):
-                d = dict(frame=k, time=times[k], rank=self.rank, batch_frames=len(idx), rays=s.rays // len(idx),
-                         steps=s.steps // len(idx), n_pos=s.n_pos // len(idx), n_neg=s.n_neg // len(idx),
-                         n_none=s.n_none // len(idx), kernel_ms=s.kernel_ms / len(idx))
+                d = dict(frame=k, time=times[k], rank=self.rank, mode=self.mode, batch_frames=len(idx),
+                         rays=int(s.rays), steps=int(s.steps), n_pos=int(s.n_pos), n_neg=int(s.n_neg),
+                         n_none=int(s.n_none), n_oob=int(s.n_oob), kernel_ms=float(s.kernel_ms),
+                         batch_kernel_ms=float(st.kernel_ms))
                 out.append(d)
                 if on_frame is not None:
                     on_frame(k, frame, d)

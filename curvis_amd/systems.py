@@ -220,6 +220,17 @@ class Context:
             rgb = rgb[0]
         return rgb, st
 
+    def frame_stats(self, frame=None):
+        """Statistics of one frame (or the list for all frames) of the last render call: the per-frame
+        early-termination counters (rays, executed steps, escaped +l / -l, capped, out-of-range texels)."""
+        def one(k):
+            st = Stats()
+            check(lib().curvis_ctx_frame_stats(self._h, k, C.byref(st)), self._h)
+            return st
+        if frame is not None:
+            return one(int(frame))
+        return [one(k) for k in range(self.get_option("last_frames"))]
+
     def sampling_info(self, frame=0):
         info = _abi.SamplingInfo()
         check(lib().curvis_ctx_sampling_info(self._h, frame, C.byref(info)), self._h)

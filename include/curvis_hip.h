@@ -175,6 +175,13 @@ typedef struct curvis_sampling_info {
   int32_t _pad;
 } curvis_sampling_info;
 int curvis_ctx_sampling_info(const curvis_ctx *ctx, uint32_t frame, curvis_sampling_info *info);
+/* Statistics of frame `frame` of the last render call (brute, rows, batch, efficient, efficient batch): the
+ * per-frame loop of VideoRenderingSystem::render (src/rendering.rs:291-316) is ONE launch per batch here, so the
+ * kernels keep one set of counters per frame.  rays / steps / n_pos / n_neg / n_none / n_oob are exact for that
+ * frame (for the efficient renderer: rays = pixels, steps = Euler steps of the frame's sampler, n_* = pixels by
+ * escape space); the *_ms fields are the frame's share of the launch time (by executed steps), not a separate
+ * measurement.  "last_frames" (curvis_ctx_get_option) = number of frames available. */
+int curvis_ctx_frame_stats(const curvis_ctx *ctx, uint32_t frame, curvis_stats *stats);
 /* the (alpha, escape angle, escape space) table of a frame of the last efficient render; cap >= n_samples */
 int curvis_ctx_samples(const curvis_ctx *ctx, uint32_t frame, double *alpha, double *escape_angle,
                        double *escape_space, size_t cap);
@@ -215,7 +222,7 @@ int curvis_ctx_synchronize(curvis_ctx *ctx);
  * refined interval; 0 = one launch per refinement round; default -1 = automatic, 10 for one or two frames, 6 for three to five and 4
  * for larger batches) and "sampling_speculation_first" (the same below the intervals of the initial uniform grid,
  * i.e. for the first launch; default -1 = automatic, 8 / 4 / 3; depths up to 11); read-only after an efficient render:
- * "last_sampling_launches", "last_sampling_evaluated"; after a relay render: "last_relay_launches",
+ * "last_sampling_launches", "last_sampling_evaluated"; after any render: "last_frames"; after a relay render: "last_relay_launches",
  * "last_relay_parks". */
 int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value);
 int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value);

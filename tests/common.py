@@ -113,6 +113,43 @@ def twin_render_efficient(pm, pc, sky_pos, sky_neg, max_iter, max_radius, delta,
     return rgb, dict(a=a[:k].copy(), e=e[:k].copy(), s=s[:k].copy(), calls=calls.value, steps=steps.value)
 
 
+def oracle_full_frame(fl, om, oc, sky_pos, sky_neg, cap, threads=None):
+    """whole-frame oracle render with the rows striped over host threads (ctypes drops the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    T = threads or min(64, os.cpu_count() or 1)
+    W, H = oc.res_x, oc.res_y
+    rgb = np.zeros((H, W, 3), np.uint8)
+    dbg = np.zeros((H, W), O.RAY_DEBUG)
+    sp, sn = O.sky(sky_pos), O.sky(sky_neg)
+
+    def work(i):
+        r, d, st = O.render_image(fl, om, oc, sp, sn, cap, 100.0, 0.05, row_begin=i, row_step=T, debug=True)
+        rgb[i::T] = r[i::T]
+        dbg[i::T] = d[i::T]
+        return st.steps
+    with ThreadPoolExecutor(T) as ex:
+        steps = sum(ex.map(work, range(T)))
+    return rgb, dbg, steps
+
+
+def oracle_full_frame_stats(fl, om, oc, sky_pos, sky_neg, cap, threads=None):
+    """as oracle_full_frame, without the per-ray dump (88 B per ray and thread): returns (rgb, (rays, steps, n_pos,
+    n_neg, n_none, n_oob)) -- what a 4K frame needs to stay inside a test's time budget."""
+    from concurrent.futures import ThreadPoolExecutor
+    T = threads or min(64, os.cpu_count() or 1)
+    W, H = oc.res_x, oc.res_y
+    rgb = np.zeros((H, W, 3), np.uint8)
+    sp, sn = O.sky(sky_pos), O.sky(sky_neg)
+
+    def work(i):
+        r, _, st = O.render_image(fl, om, oc, sp, sn, cap, 100.0, 0.05, row_begin=i, row_step=T)
+        rgb[i::T] = r[i::T]
+        return (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none, st.n_oob)
+    with ThreadPoolExecutor(T) as ex:
+        parts = list(ex.map(work, range(T)))
+    return rgb, tuple(int(sum(p[k] for p in parts)) for k in range(6))
+
+
 def random_scene(rng, res=(16, 9)):
     """a random but valid scene: (oracle metric, oracle camera, product metric, product camera, delta, cap, R)"""
     kind = rng.choice(["ellis", "interstellar", "flat"], p=[0.5, 0.4, 0.1])

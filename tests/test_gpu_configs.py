@@ -1,0 +1,210 @@
+"""BASELINE.json configs[3] and configs[4] under -m gpu: the two VIDEO configurations rendered with the per-pixel
+integrator (RelativisticSystem::render_image, src/systems.rs:307-330) frame by frame as
+VideoRenderingSystem::render does (src/rendering.rs:291-316), camera poses from the Interpolator
+(src/interpolation.rs:63-91) on the reference's two camera paths:
+
+  configs[3]  Ellis, path_orbit.csv   @ 4 fps  = 240 frames, 1920x1080, cap 4096
+  configs[4]  Interstellar, path_through.csv @ 24 fps = 480 frames, 3840x2160, cap 8192, per-frame
+              early-termination statistics
+
+Every frame of both videos is rendered at a reduced resolution (what the oracle can follow in seconds) through
+curvis_render_brute_batch and compared with the oracle frame by frame: pixels, and the PER-FRAME counters
+(rays, executed Euler steps, escaped +l / -l, capped) that curvis_ctx_frame_stats returns for each frame of a
+multi-frame launch.  Selected frames -- first / quarter / half / last of the orbit; the first frame and the two
+frames nearest the throat (l = 0) of the fly-through -- are rendered at the FULL size of the config and compared
+the same way.  The same two videos then go through the `curvis video --mode brute --stats` binary."""
+import json
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import common
+import oracle_lib as O
+import curvis_amd
+from curvis_amd import paths, pngio, rendering
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
+THREADS = min(128, os.cpu_count() or 1)
+
+VIDEOS = {
+    # name: (metric, csv, fps, frames, small res, full res, cap)
+    "orbit": ("ellis", "path_orbit.csv", 4.0, 240, (96, 54), (1920, 1080), 4096),
+    "through": ("interstellar", "path_through.csv", 24.0, 480, (64, 36), (3840, 2160), 8192),
+}
+
+
+def video_poses(csv, fps):
+    it = rendering.Interpolator.from_file(paths.path_file(csv))
+    times = rendering.times_of_frames(it.min_time(), it.max_time(), fps)
+    return times, [(tuple(it.camera_position(t)), tuple(it.camera_forward(t)), tuple(it.camera_up(t))) for t in times]
+
+
+def metrics_of(name):
+    if name == "ellis":
+        return O.ellis(1.0), curvis_amd.EllisMetric(1.0)
+    return O.interstellar(0.1, 1e-4, 1.0), curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0)
+
+
+def oracle_frames(om, poses, res, sp, sn, cap):
+    """oracle (cv flavour) render of every pose, frames spread over the host threads: [(rgb, Stats)]"""
+    osp, osn = O.sky(sp), O.sky(sn)
+
+    def work(p):
+        oc = O.camera(p[0], p[1], p[2], 15.0, 43.0, res)
+        rgb, _, st = O.render_image(O.CV, om, oc, osp, osn, cap, 100.0, 0.05)
+        return rgb, (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none, st.n_oob)
+    with ThreadPoolExecutor(THREADS) as ex:
+        return list(ex.map(work, poses))
+
+
+def stats_tuple(s):
+    return (int(s.rays), int(s.steps), int(s.n_pos), int(s.n_neg), int(s.n_none), int(s.n_oob))
+
+
+@pytest.mark.parametrize("video", ["orbit", "through"])
+def test_video_config_every_frame_small(gpu_ctx, video):
+    """all 240 / 480 frames at reduced resolution: pixels and per-frame counters of multi-frame launches"""
+    metric, csv, fps, n_frames, res, _, cap = VIDEOS[video]
+    times, poses = video_poses(csv, fps)
+    assert len(times) == n_frames
+    om, pm = metrics_of(metric)
+    sp, sn = common.make_skies(512, 256, "check")
+    want = oracle_frames(om, poses, res, sp, sn, cap)
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    cams = [curvis_amd.Camera(p[0], p[1], p[2], 15.0, 43.0, res[0], res[1]) for p in poses]
+    # launch shapes: 7 frames (relay kernel territory, 64 counter replicas), 48 (static kernel, 8 replicas), the rest
+    k = 0
+    for batch in (7, 48, 10 ** 6):
+        part = cams[k:k + batch]
+        if not part:
+            break
+        rgb, st = gpu_ctx.render_brute(pm, part, cap, 100.0, 0.05)
+        per = gpu_ctx.frame_stats()
+        assert len(per) == len(part)
+        for j in range(len(part)):
+            assert np.array_equal(rgb[j], want[k + j][0]), "frame %d pixels" % (k + j)
+            assert stats_tuple(per[j]) == want[k + j][1], "frame %d counters %s vs %s" % (
+                k + j, stats_tuple(per[j]), want[k + j][1])
+        assert stats_tuple(st)[:5] == tuple(sum(w[1][i] for w in want[k:k + len(part)]) for i in range(5))
+        k += len(part)
+    assert k == n_frames
+    # the persistent kernel (staged path: shade_kernel keeps the counters) on a few frames that straddle waves
+    gpu_ctx.set_option("variant", 0)
+    try:
+        sel = [0, n_frames // 2, n_frames - 1]
+        rgb, _ = gpu_ctx.render_brute(pm, [cams[i] for i in sel], cap, 100.0, 0.05)
+        per = gpu_ctx.frame_stats()
+        for j, i in enumerate(sel):
+            assert np.array_equal(rgb[j], want[i][0]) and stats_tuple(per[j]) == want[i][1]
+    finally:
+        gpu_ctx.set_option("variant", -1)
+    # the fly-through's frames are not alike: the per-frame numbers really differ from frame to frame.  (The orbit's
+    # are all the SAME frame: render_image never rotates into the world frame, src/systems.rs:540-561, and the
+    # metric is spherically symmetric, so phi of the camera does not enter -- 240 identical sets of counters.)
+    if video == "through":
+        assert len({w[1][1] for w in want}) > n_frames // 4
+    else:
+        assert len({w[1] for w in want}) == 1
+
+
+def full_size_frames(video, n_frames, poses):
+    if video == "orbit":
+        return [0, 60, 120, 239]
+    ls = np.array([abs(p[0][1]) for p in poses])
+    near = sorted(np.argsort(ls)[:2].tolist())
+    return [0] + near
+
+
+@pytest.mark.parametrize("video", ["orbit", "through"])
+def test_video_config_full_size_frames(gpu_ctx, video):
+    """frames {0, 60, 120, 239} of the orbit at 1920x1080 cap 4096; frame 0 (l = -4) and the two frames nearest
+    l = 0 of the fly-through at 3840x2160 cap 8192 (Interstellar): ONE launch per video, per-frame counters and
+    every pixel against the oracle."""
+    metric, csv, fps, n_frames, _, res, cap = VIDEOS[video]
+    times, poses = video_poses(csv, fps)
+    sel = full_size_frames(video, n_frames, poses)
+    if video == "through":
+        assert abs(poses[sel[1]][0][1]) < 0.02 and abs(poses[sel[2]][0][1]) < 0.02 and poses[0][0][1] == -4.0
+    om, pm = metrics_of(metric)
+    sp, sn = common.make_skies(2048, 1024, "check")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    cams = [curvis_amd.Camera(poses[i][0], poses[i][1], poses[i][2], 15.0, 43.0, res[0], res[1]) for i in sel]
+    rgb, st = gpu_ctx.render_brute(pm, cams, cap, 100.0, 0.05)
+    per = gpu_ctx.frame_stats()
+    assert len(per) == len(sel)
+    for j, i in enumerate(sel):
+        oc = O.camera(poses[i][0], poses[i][1], poses[i][2], 15.0, 43.0, res)
+        want_rgb, want = common.oracle_full_frame_stats(O.CV, om, oc, sp, sn, cap, threads=THREADS)
+        assert want[0] == res[0] * res[1]
+        assert stats_tuple(per[j]) == want, "frame %d: %s vs %s" % (i, stats_tuple(per[j]), want)
+        assert np.array_equal(rgb[j], want_rgb), "frame %d pixels" % i
+        print("%s frame %d (l = %.4f): %d steps, +l %d, -l %d, capped %d" % ((video, i, poses[i][0][1]) + want[1:5]))
+
+
+SIM = ("escape_radius = 100.0\nray_integration_max_itarations = %d\nray_integration_step = 0.05\n"
+       "sampling_initial_nums = 100\nsampling_max_iterations = 50\n"
+       "sampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 2e-5\n")
+
+
+@pytest.mark.parametrize("video", ["orbit", "through"])
+def test_video_config_through_the_binary(tmp_path, video):
+    """`curvis video --mode brute --stats`: all frames of the config's video at reduced resolution, PNG frames and the
+    per-frame JSON statistics against the oracle; two devices' worth of workers on the one GPU, one of whose render
+    calls is made to fail once (the batch is re-queued on the other worker), then --resume after deleting frames."""
+    metric, csv, fps, n_frames, res, _, cap = VIDEOS[video]
+    times, poses = video_poses(csv, fps)
+    om, _ = metrics_of(metric)
+    sp, sn = common.make_skies(512, 256, "check")
+    want = oracle_frames(om, poses, res, sp, sn, cap)
+    d = tmp_path
+    (d / "out").mkdir()
+    pngio.write_png(d / "pos.png", sp)
+    pngio.write_png(d / "neg.png", sn)
+    (d / "sim.toml").write_text(SIM % cap)
+    (d / "cam.toml").write_text("resolution_x = %d\nresolution_y = %d\ndiagonal = 43.0\nfocal_length = 15.0\n" % res)
+    (d / "vid.toml").write_text('video_name = "v"\nframe_rate = %r\nfilepath_to_camera_path = "%s"\n' % (fps, paths.path_file(csv)))
+    args = [BIN, "video", d / "pos.png", d / "neg.png", d / "out", "-v", d / "vid.toml", "-s", d / "sim.toml", "-c", d / "cam.toml",
+            "--mode", "brute", "--batch", "16", "--devices", "2", "--sky-broadcast", "upload", "--stats", d / "st.jsonl"]
+    if metric == "interstellar":
+        (d / "met.toml").write_text("m = 0.1\na = 0.0001\nrho = 1.0\n")
+        args += ["-m", d / "met.toml"]
+    env = dict(os.environ, CURVIS_TEST_SHARE_DEVICE="1", CURVIS_TEST_FAIL_BATCH="1:2")
+    r = subprocess.run([str(a) for a in args], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "injected test fault" in r.stderr and "re-queued" in r.stderr
+    assert "Rendering %d frames..." % n_frames in r.stdout
+    lines = {}
+    for ln in (d / "st.jsonl").read_text().splitlines():
+        rec = json.loads(ln)
+        lines[rec["frame"]] = rec
+    assert sorted(lines) == list(range(n_frames))
+    for k in range(n_frames):
+        rec = lines[k]
+        got = (rec["rays"], rec["steps"], rec["n_pos"], rec["n_neg"], rec["n_none"], rec["n_oob"])
+        assert got == want[k][1], "frame %d statistics %s vs %s" % (k, got, want[k][1])
+        assert rec["time"] == times[k] and rec["mode"] == "brute"
+    for k in range(0, n_frames, 7):
+        assert np.array_equal(pngio.read_png(d / "out" / "tmp" / ("frame_%d.png" % k)), want[k][0]), k
+    # --resume: frames already on disk are kept (and not rendered again), missing ones are rendered
+    gone = [3, n_frames // 2, n_frames - 1]
+    for k in gone:
+        os.remove(d / "out" / "tmp" / ("frame_%d.png" % k))
+    keep = d / "out" / "tmp" / "frame_5.png"
+    stamp = os.stat(keep).st_mtime_ns
+    r = subprocess.run([str(a) for a in args] + ["--resume"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, CURVIS_TEST_SHARE_DEVICE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Resuming: %d of %d frames already present" % (n_frames - len(gone), n_frames) in r.stdout
+    assert os.stat(keep).st_mtime_ns == stamp
+    resumed = sorted(json.loads(ln)["frame"] for ln in (d / "st.jsonl").read_text().splitlines())
+    assert resumed == sorted(gone)
+    for k in gone:
+        assert np.array_equal(pngio.read_png(d / "out" / "tmp" / ("frame_%d.png" % k)), want[k][0]), k
+    assert len(os.listdir(d / "out" / "tmp")) == n_frames

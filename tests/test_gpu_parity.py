@@ -151,24 +151,7 @@ def test_row_bands_equal_the_full_frame(gpu_ctx, metric, res, pos, fwd, cap):
         gpu_ctx.set_option("relay_min_blocks", -1)
 
 
-def oracle_full_frame(fl, om, oc, sky_pos, sky_neg, cap, threads=None):
-    """whole-frame oracle render with the rows striped over host threads (ctypes drops the GIL)."""
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-    T = threads or min(64, os.cpu_count() or 1)
-    W, H = oc.res_x, oc.res_y
-    rgb = np.zeros((H, W, 3), np.uint8)
-    dbg = np.zeros((H, W), O.RAY_DEBUG)
-    sp, sn = O.sky(sky_pos), O.sky(sky_neg)
-
-    def work(i):
-        r, d, st = O.render_image(fl, om, oc, sp, sn, cap, 100.0, 0.05, row_begin=i, row_step=T, debug=True)
-        rgb[i::T] = r[i::T]
-        dbg[i::T] = d[i::T]
-        return st.steps
-    with ThreadPoolExecutor(T) as ex:
-        steps = sum(ex.map(work, range(T)))
-    return rgb, dbg, steps
+oracle_full_frame = common.oracle_full_frame
 
 
 @pytest.mark.parametrize("metric,res,cap", [("ellis", (1920, 1080), 4096), ("interstellar", (960, 540), 8192)])
@@ -332,11 +315,11 @@ def test_config3_full_size_4k_interstellar(gpu_ctx):
     8 294 400 rays, 1.6e10 Euler steps -- pixels, step total and escape counts bit-exact against the oracle
     (rows striped over the host cores)."""
     import os
-    if (os.cpu_count() or 1) < 16:
-        pytest.skip("needs a many-core host for the 1.6e10-step oracle run")
+    # never skipped: a silently skipped BASELINE config must not read as green.  On a small host the oracle run is
+    # just slower (1.6e10 steps at ~25 M steps/s per core); the GPU boxes have 128+ cores.
     sp, sn = common.make_skies(2048, 1024, "check")
     om, oc, pm, pc = common.scene("interstellar", res=(3840, 2160))
-    want_rgb, want_dbg, steps = oracle_full_frame(O.CV, om, oc, sp, sn, 8192, threads=min(128, os.cpu_count()))
+    want_rgb, want_dbg, steps = oracle_full_frame(O.CV, om, oc, sp, sn, 8192, threads=min(128, os.cpu_count() or 1))
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
                                          context=gpu_ctx)
     got = sys_.render_image(8192, 100.0, 0.05)

@@ -48,7 +48,7 @@ def main():
     def video(name, metric, csv, fps, res, cap, batch, max_frames=None):
         it = rendering.Interpolator.from_file(paths.path_file(csv))
         v = rendering.VideoRenderingSystem(metric, ctx, it, fps, res, 43.0, 15.0, 100.0, cap, 0.05, rank=0,
-                                           world_size=args.world, batch=batch)
+                                           world_size=args.world, batch=batch, mode="brute")
         n_total = len(v.times_of_frames())
         mine = rendering.frames_of_rank(n_total, 0, args.world)
         if max_frames:
