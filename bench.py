@@ -9,6 +9,11 @@ resident in HBM.  The frame stays in HBM (no D2H inside the timed region).
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started WITHOUT a launcher (no WORLD_SIZE in the environment) and with --gpus N > 1 it launches itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, rendezvous on 127.0.0.1).  It refuses to
+run when the node has fewer than N GPUs or when the rank count it ends up with is not --gpus: a run never
+reports fewer GPUs than it was asked for.
+
 With N > 1 every rank renders its own K frames (video frames are independent: weak scaling, no
 data-path collective); the only communication is the RCCL broadcast of the two sky textures from
 rank 0 before the timed region.  Rank 0 prints ONE JSON line.
@@ -16,6 +21,7 @@ rank 0 before the timed region.  Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -49,18 +55,48 @@ def parse():
     ap.add_argument("--download", action="store_true",
                     help="copy every frame to host memory inside the timed region (PCIe-inclusive rate, "
                          "reported in DESIGN.md; never the headline value)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="report roofline.traffic as null when profiles/traffic.json has no entry for this workload "
+                         "(default: such a run fails, so a missing PMC profile cannot go unnoticed)")
+    ap.add_argument("--multi-frame", type=int, default=6,
+                    help="frames per launch of the secondary multi-frame measurement (value_multi_frame); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=8)
     return ap.parse_args()
 
 
+def self_launch(args):
+    """--gpus N > 1 from a plain shell: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`"""
+    import torch
+    share = os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if have < args.gpus and not share:
+        raise SystemExit("bench.py: --gpus %d but this node has %d GPU(s); refusing to measure fewer GPUs than asked "
+                         "for (CURVIS_BENCH_SHARE_DEVICE=1 maps every rank to GPU 0 for control-flow tests)" % (args.gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: no launcher in the environment, starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the JSON line would not describe the run that was "
+                         "asked for" % (args.gpus, world))
 
     import torch  # device memory / streams / torch.distributed plumbing only
     import curvis_amd
@@ -68,6 +104,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("CURVIS_BENCH_SHARE_DEVICE") != "1" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible" % (world, torch.cuda.device_count()))
     # test hooks (1-GPU boxes): CURVIS_BENCH_SHARE_DEVICE=1 maps every rank to GPU 0 and
     # CURVIS_BENCH_BACKEND=gloo replaces RCCL, so the N>1 control flow can be exercised on one GPU.
     device_index = 0 if os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1" else local_rank
@@ -97,11 +135,24 @@ def main():
     if rank == 0:
         host_skies = (skies.smooth(sw, sh, 128), skies.smooth(sw, sh, 32))
     sky_dev = []
+    comm_info = None
+    if world > 1:
+        # how many ranks the collective backend really spans (an all-reduce of ones on the device), before it is
+        # trusted with the skies
+        one = torch.ones(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        comm_info = {"backend": "rccl (torch nccl)" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
+                     "allreduce_of_ones": int(one.item()), "sky_bytes_each": sw * sh * 4, "sky_broadcast_ms": []}
+        if comm_info["allreduce_of_ones"] != world:
+            raise SystemExit("bench.py: the %s communicator spans %d ranks, not %d" % (backend, comm_info["allreduce_of_ones"], world))
     for which in range(2):
         if world > 1:
             t = torch.empty((sh, sw, 4), dtype=torch.uint8, device="cuda")
             if rank == 0:
                 t.copy_(torch.from_numpy(host_skies[which]))
+            torch.cuda.synchronize()
+            dist.barrier()
+            tb = time.perf_counter()
             if backend == "nccl":
                 dist.broadcast(t, src=0)  # RCCL over xGMI, w*h*4 bytes
             else:  # test hook: stage through host memory
@@ -109,6 +160,12 @@ def main():
                 dist.broadcast(h, src=0)
                 t.copy_(h)
             torch.cuda.synchronize()
+            comm_info["sky_broadcast_ms"].append(round((time.perf_counter() - tb) * 1e3, 3))
+            if rank != 0:  # the texture really arrived: same closed form as rank 0 generated (first and last row)
+                want = skies.smooth(sw, sh, 128 if which == 0 else 32)
+                got0, got1 = t[0].cpu().numpy(), t[sh - 1].cpu().numpy()
+                if not (np.array_equal(got0, want[0]) and np.array_equal(got1, want[sh - 1])):
+                    raise SystemExit("bench.py: rank %d received a corrupted sky texture" % rank)
             ctx.set_sky_device(which, t.data_ptr(), sw, sh, copy=False)
             sky_dev.append(t)  # keep alive
         else:
@@ -150,6 +207,30 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    # secondary figure, outside the contract's timed region: launches of several frames amortise the ramp and the
+    # end-game of a launch (~5 % of a single 1080p frame), which is what a video shard runs as
+    multi = None
+    if args.multi_frame > 1 and world == 1:
+        nf = args.multi_frame
+        reps = max(2, (args.steps + nf - 1) // nf)
+        ctx.render_brute(metric, [cam] * nf, args.max_iter, R, DELTA, download=False)
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        m_steps, m_kernel = 0, 0.0
+        for _ in range(reps):
+            _, stm = ctx.render_brute(metric, [cam] * nf, args.max_iter, R, DELTA, download=False)
+            m_steps += stm.steps
+            m_kernel += stm.integrate_ms
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - tm
+        multi = {"value": round(m_steps / dtm / 1e6, 1), "frames_per_launch": nf, "launches": reps,
+                 "ms_per_frame": round(dtm / (reps * nf) * 1e3, 3), "kernel_ms_per_frame": round(m_kernel / (reps * nf), 4),
+                 "kernel": ("geodesic_persistent" if args.variant == 0 else
+                            "geodesic_relay" if ctx.get_option("last_relay_launches") > 0 else "geodesic_static") +
+                           ("<fast>" if args.fast_math else "<strict>"),
+                 "note": "same frame %d times per launch; not the contract's `value` (one frame per step)" % nf}
+        ctx.render_brute(metric, cam, args.max_iter, R, DELTA, download=False)  # so that last_relay_launches below describes a single-frame launch
+
     if dist is not None:
         red_dev = "cuda" if backend == "nccl" else "cpu"
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -182,6 +263,8 @@ def main():
             "value": round(value, 1),
             "unit": "Mray-steps/s (executed Euler steps, all GPUs)",
             "value_nominal_cap": round(nominal, 1),
+            "value_note": "single-frame launches (one frame per step): each carries the ramp and end-game tail of a launch",
+            "value_multi_frame": multi,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -221,6 +304,8 @@ def main():
                         "note": "7 B/ray algorithmic; the loop is register-resident, HBM fraction is ~0 by construction"},
             },
         }
+        if comm_info is not None:
+            out["collective"] = comm_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, host_skies)
         print(json.dumps(out), flush=True)
@@ -243,10 +328,18 @@ def pmc_traffic(args, kernel_name):
         key = "%s_%dx%d_cap%d_%s" % (args.metric, args.width, args.height, args.max_iter, kernel_name)
         e = t.get(key)
         if e is None:
-            return None, "no PMC profile committed for " + key
+            if args.no_traffic:
+                return None, {"measured_in_this_run": False, "note": "no PMC profile committed for " + key}
+            raise SystemExit("bench.py: profiles/traffic.json has no PMC entry for %s (collect one with "
+                             "tools/make_profiles.py, or pass --no-traffic to report null)" % key)
+        e = dict(e)
+        e["measured_in_this_run"] = False  # PMC counters cannot be read from inside an un-profiled run
+        e["origin"] = "committed profile: rocprofv3 --pmc passes of this same command (see `source`)"
         return e["integrate_kernel_bytes"], e
     except (OSError, ValueError, KeyError) as exc:
-        return None, "profiles/traffic.json unavailable: %s" % exc
+        if args.no_traffic:
+            return None, {"measured_in_this_run": False, "note": "profiles/traffic.json unavailable: %s" % exc}
+        raise SystemExit("bench.py: profiles/traffic.json unavailable: %s" % exc)
 
 
 def cpu_baseline(args, host_skies):

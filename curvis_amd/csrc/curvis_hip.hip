@@ -476,9 +476,17 @@ __global__ __launch_bounds__(256) void geodesic_relay(const IntegrateParams P, c
   const unsigned long long t_start = P.trace ? wall_clock64() : 0ull;
   unsigned long long t_work = 0ull; /* diagnostics: when the wave had its tile */
   const bool fresh = blockIdx.x < A.fresh_blocks;
-  /* a relay workgroup that starts when every tile is finished leaves at once (workgroup-uniform branch, taken
-   * before the table load and its barrier): the grid holds many more relay workgroups than are usually needed */
-  if (!fresh && __hip_atomic_load(&Q->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.n_tiles) return;
+  /* a relay workgroup that starts when every tile is finished leaves at once, before the table load: the grid
+   * holds many more relay workgroups than are usually needed.  The decision is made ONCE per workgroup (thread 0
+   * reads the counter, LDS + barrier hand it to the other waves): waves reading it on their own could disagree,
+   * and a workgroup of which only some waves reach load_math_tables' barrier must not exist. */
+  if (!fresh) {
+    __shared__ int s_leave;
+    if (threadIdx.x == 0)
+      s_leave = __hip_atomic_load(&Q->finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.n_tiles ? 1 : 0;
+    __syncthreads();
+    if (s_leave) return;
+  }
   cvk::MetricParams M = P.metric;
   load_math_tables<KIND>(s_tab, M);
   const unsigned lane = threadIdx.x & 63u;

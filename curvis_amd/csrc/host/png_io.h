@@ -100,6 +100,11 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
       return false;
     }
     const uint8_t *data = &file[pos + 8];
+    /* every chunk carries a CRC-32 of type + data (the png crate rejects a mismatch for critical chunks) */
+    if ((uint32_t)crc32(0L, &file[pos + 4], (uInt)(4 + len)) != be32(&file[pos + 8 + len])) {
+      err = "PNG chunk CRC mismatch";
+      return false;
+    }
     if (!std::memcmp(type, "IHDR", 4)) {
       if (len != 13) { err = "bad IHDR"; return false; }
       W = be32(data); H = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
@@ -125,7 +130,17 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
     case 6: channels = 4; break;
     default: err = "unsupported PNG colour type"; return false;
   }
-  if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3)))) { err = "unsupported PNG bit depth"; return false; }
+  /* allowed bit depths per colour type (PNG specification, table 11.1): grey 1/2/4/8/16, palette 1/2/4/8,
+   * everything else 8/16.  Anything else (0, 3, 5, 6, 7, ...) is a forged header: depth 0 would divide by zero. */
+  const bool small_depth = depth == 1 || depth == 2 || depth == 4;
+  const bool depth_ok = ctype == 0 ? (small_depth || depth == 8 || depth == 16)
+                        : ctype == 3 ? (small_depth || depth == 8)
+                                     : (depth == 8 || depth == 16);
+  if (!depth_ok) { err = "unsupported PNG bit depth"; return false; }
+  if (interlace != 0 && interlace != 1) { err = "unsupported PNG interlace method"; return false; }
+  /* untrusted dimensions go straight into allocations: bound them (65536 x 32768 is four times the largest sky
+   * that makes sense here; RGBA8 of that is 8 GiB) */
+  if (W > 65536u || H > 65536u || (uint64_t)W * H > ((uint64_t)1 << 31)) { err = "PNG dimensions out of range"; return false; }
   const size_t bits_pp = (size_t)channels * depth;
   const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
   /* inflate */
@@ -136,12 +151,15 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
     if (inflateInit(&zs) != Z_OK) { err = "zlib init failed"; return false; }
     zs.next_in = idat.data();
     zs.avail_in = (uInt)idat.size();
-    size_t cap = ((size_t)W * bits_pp / 8 + 2) * H + 64 * 1024;
+    /* the inflated stream of a valid file is exactly the filtered scanlines; an interlaced image adds at most one
+     * filter byte per pass row (< 2 H rows in total) plus rounding: the buffer never grows beyond that, so a
+     * decompression bomb fails instead of exhausting memory */
+    const size_t cap = (((size_t)W * bits_pp + 7) / 8 + 1) * ((size_t)H + 8) * (interlace ? 2 : 1) + 64;
     raw.resize(cap);
     size_t have = 0;
     int rc;
     do {
-      if (have == raw.size()) raw.resize(raw.size() * 2);
+      if (have == raw.size()) { inflateEnd(&zs); err = "PNG data stream larger than its header allows"; return false; }
       zs.next_out = raw.data() + have;
       zs.avail_out = (uInt)std::min<size_t>(raw.size() - have, 1u << 30);
       rc = inflate(&zs, Z_NO_FLUSH);

@@ -241,6 +241,38 @@ void cvo_samples_free(cvo_samples *s) {
 
 #define DISPATCH(fl, name, ...) ((fl) == CVO_CV ? name##_cv(__VA_ARGS__) : name##_libm(__VA_ARGS__))
 
+/* the six elementary functions of a flavour over arrays (op: 0 sin, 1 cos, 2 atan, 3 acos, 4 log, 5 atan2(a, b)):
+ * lets the tests compare cv_math.h with glibc -- an independent libm -- on the very arguments the Euler loop
+ * produces, not only on random ones */
+void cvo_math_array(int fl, int op, const double *a, const double *b, double *out, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const double x = a[i], y = b ? b[i] : 0.0;
+    double r;
+    if (fl == CVO_CV) {
+      r = op == 0 ? cv_sin(x) : op == 1 ? cv_cos(x) : op == 2 ? cv_atan(x) : op == 3 ? cv_acos(x) : op == 4 ? cv_log(x) : cv_atan2(x, y);
+    } else {
+      r = op == 0 ? sin(x) : op == 1 ? cos(x) : op == 2 ? atan(x) : op == 3 ? acos(x) : op == 4 ? log(x) : atan2(x, y);
+    }
+    out[i] = r;
+  }
+}
+
+/* compute_photon_trajectory (src/systems.rs:77-92): out[k][0..7] = (x, p_cov) BEFORE the k-th Euler step */
+void cvo_photon_trajectory(int fl, const cvo_metric *m, const double x0[4], const double p0[4], uint32_t iterations,
+                           double delta, double *out) {
+  double x[4], p[4];
+  memcpy(x, x0, sizeof x);
+  memcpy(p, p0, sizeof p);
+  for (uint32_t k = 0; k < iterations; ++k) {
+    memcpy(out + 8 * (size_t)k, x, sizeof x);
+    memcpy(out + 8 * (size_t)k + 4, p, sizeof p);
+    if (fl == CVO_CV)
+      update_cv(m, x, p, delta);
+    else
+      update_libm(m, x, p, delta);
+  }
+}
+
 int cvo_rotation_between(int fl, const double a[3], const double b[3], double m[9]) {
   return DISPATCH(fl, rotation_between, a, b, m);
 }

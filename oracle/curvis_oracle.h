@@ -77,6 +77,11 @@ typedef struct {
 /* --- algebra (src/algebra.rs) + nalgebra restatements --- */
 int cvo_orientation_new(const double fwd[3], const double up[3], double rot[9], double inv_rot[9], double up_out[3]);
 void cvo_face_towards(const double dir[3], const double up[3], double m[9]);
+/* elementary functions of a flavour over arrays; op: 0 sin, 1 cos, 2 atan, 3 acos, 4 log, 5 atan2(a, b) */
+void cvo_math_array(int fl, int op, const double *a, const double *b, double *out, size_t n);
+/* compute_photon_trajectory (src/systems.rs:77-92): out[iterations][8] = (x, p_cov) before each Euler step */
+void cvo_photon_trajectory(int fl, const cvo_metric *m, const double x0[4], const double p0[4], uint32_t iterations,
+                           double delta, double *out);
 int cvo_rotation_between(int fl, const double a[3], const double b[3], double m[9]); /* nalgebra; -1 = None */
 int cvo_rotation_from_two_vectors(int fl, const double a[3], const double b[3], double m[9]); /* -1 = panic */
 void cvo_from_axis_angle(int fl, const double unit_axis[3], double angle, double m[9]);

@@ -101,6 +101,8 @@ def lib():
     sig("cvo_path_free", None, [C.POINTER(Path)])
     sig("cvo_path_camera", i32, [C.POINTER(Path), d, dp, dp, dp])
     sig("cvo_times_of_frames", C.c_size_t, [d, d, d, dp, C.c_size_t])
+    sig("cvo_math_array", None, [i32, i32, dp, dp, dp, C.c_size_t])
+    sig("cvo_photon_trajectory", None, [i32, MP, dp, dp, u32, d, dp])
     _lib = L
     return L
 
@@ -195,3 +197,44 @@ def compute_escape_angle(fl, metric, l, alpha, delta, max_iter, max_radius):
     code = lib().cvo_compute_escape_angle(fl, C.byref(metric), l, alpha, delta, max_iter, max_radius, C.byref(ang),
                                           C.byref(steps))
     return code, ang.value, steps.value
+
+
+def math_array(fl, op, a, b=None):
+    """elementary function `op` (0 sin, 1 cos, 2 atan, 3 acos, 4 log, 5 atan2(a, b)) of flavour fl over an array"""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+    out = np.empty_like(a)
+    lib().cvo_math_array(fl, op, _dp(a), _dp(bb) if bb is not None else None, _dp(out), a.size)
+    return out
+
+
+def photon_trajectory(fl, metric, pos, direction, iterations, delta):
+    """compute_photon_trajectory (src/systems.rs:77-92): [iterations, 8] = (x, p_cov) before each Euler step"""
+    x = np.zeros(4)
+    p = np.zeros(4)
+    lib().cvo_new_photon(fl, C.byref(metric), _dp(vec(*pos)), _dp(vec(*direction)), _dp(x), _dp(p))
+    out = np.zeros((iterations, 8))
+    lib().cvo_photon_trajectory(fl, C.byref(metric), _dp(x), _dp(p), iterations, delta, _dp(out))
+    return out
+
+
+_quad = None
+
+
+def quad_ulp_errors(op, a, got, b=None):
+    """|got - f(a)| in ulps of the exact value, f evaluated in binary128 by libquadmath (oracle/curvis_quad.c)"""
+    global _quad
+    if _quad is None:
+        so = os.path.join(ORACLE_DIR, "libcurvis_quad.so")
+        if not os.path.exists(so):
+            build()
+        _quad = C.CDLL(so)
+        dp = C.POINTER(C.c_double)
+        _quad.cvq_ulp_errors.restype = None
+        _quad.cvq_ulp_errors.argtypes = [C.c_int, dp, dp, dp, dp, C.c_size_t]
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    got = np.ascontiguousarray(got, dtype=np.float64)
+    bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+    err = np.empty_like(a)
+    _quad.cvq_ulp_errors(op, _dp(a), _dp(bb) if bb is not None else None, _dp(got), _dp(err), a.size)
+    return err

@@ -37,6 +37,88 @@ def test_struct_layouts_match_header():
     assert _abi.RAY_DEBUG.itemsize == 80 and O.RAY_DEBUG.itemsize == 80
 
 
+def c_layout():
+    """{struct: {"size": n, "align": a, "fields": [(name, offset, size)]}} from the C header, via tests/abi/abi_layout.c"""
+    import subprocess
+    import tempfile
+    exe = os.path.join(tempfile.mkdtemp(prefix="curvis_abi_"), "abi_layout")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "abi", "abi_layout.c")], check=True)
+    out = {}
+    for line in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines():
+        st, f, off, size = line.split()
+        d = out.setdefault(st, {"fields": []})
+        if f == ".":
+            d["align"], d["size"] = int(off), int(size)
+        else:
+            d["fields"].append((f, int(off), int(size)))
+    return out
+
+
+RUST_NAMES = {"curvis_metric": "CurvisMetric", "curvis_camera": "CurvisCamera", "curvis_ray_debug": "CurvisRayDebug",
+              "curvis_stats": "CurvisStats", "curvis_sampling_info": "CurvisSamplingInfo"}
+CTYPES = {"curvis_metric": _abi.Metric, "curvis_camera": _abi.CameraC, "curvis_stats": _abi.Stats,
+          "curvis_sampling_info": _abi.SamplingInfo}
+
+
+def rust_block():
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    return re.search(r"```rust\n(.*?extern \"C\" \{.*?\n\}\n)```", txt, flags=re.S).group(1)
+
+
+def rust_layout(body):
+    """#[repr(C)] layout rules (= the C ABI's) applied to `name: type` fields of a struct body"""
+    prim = {"i32": 4, "u32": 4, "f64": 8, "u64": 8, "i64": 8, "u8": 1}
+    off, align, fields = 0, 1, []
+    for name, ty in re.findall(r"(?:pub\s+)?(\w+)\s*:\s*(\[[^\]]+\]|\w+)", body):
+        m = re.match(r"\[(\w+);\s*(\d+)\]", ty)
+        a = prim[m.group(1)] if m else prim[ty]
+        size = a * int(m.group(2)) if m else a
+        off = (off + a - 1) // a * a
+        fields.append((name, off, size))
+        off += size
+        align = max(align, a)
+    return {"size": (off + align - 1) // align * align, "align": align, "fields": fields}
+
+
+def test_struct_offsets_c_header_rust_stub_ctypes_and_table_agree():
+    """offset-level ABI check: C header (compiled) == INTEGRATION.md's #[repr(C)] structs == its layout table ==
+    curvis_amd/_abi.py's ctypes structures == the numpy record dtypes of the debug dump"""
+    lay = c_layout()
+    assert lay.pop("CURVIS_ABI_VERSION")["align"] == 1          # printed as "CURVIS_ABI_VERSION . 1 0"
+    assert set(lay) == set(RUST_NAMES)
+    rust = rust_block()
+    table = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = table[table.index("<!-- abi-layout:begin -->"):table.index("<!-- abi-layout:end -->")]
+    for cname, L in lay.items():
+        body = re.search(r"pub struct %s \{(.*?)\}" % RUST_NAMES[cname], rust, flags=re.S).group(1)
+        assert rust_layout(body) == L, (cname, rust_layout(body), L)
+        row = [ln for ln in table.splitlines() if ln.startswith("| `%s` |" % cname)][0].split("|")
+        assert row[2].strip() == "`%s`" % RUST_NAMES[cname] and int(row[3]) == L["size"]
+        got = [(n, int(o), int(z)) for n, o, z in re.findall(r"(\w+) @(\d+) \((\d+)\)", row[4])]
+        assert got == L["fields"], (cname, got)
+        if cname in CTYPES:
+            T = CTYPES[cname]
+            assert C.sizeof(T) == L["size"] and C.alignment(T) == L["align"]
+            assert [(n, getattr(T, n).offset, getattr(T, n).size) for n, _ in T._fields_] == L["fields"]
+    for dt in (_abi.RAY_DEBUG, O.RAY_DEBUG):
+        assert dt.itemsize == lay["curvis_ray_debug"]["size"]
+        assert [(n, dt.fields[n][1], dt.fields[n][0].itemsize) for n in dt.names] == lay["curvis_ray_debug"]["fields"]
+
+
+def test_rust_extern_block_declares_every_function_with_the_header_arity():
+    hdr = open(os.path.join(ROOT, "include", "curvis_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    rust = rust_block()
+
+    def arity(params):
+        params = params.strip()
+        return 0 if params in ("", "void") else params.count(",") + 1
+    c_fns = {n: arity(p) for n, p in re.findall(r"\b(curvis_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", hdr)}
+    r_fns = {n: arity(p) for n, p in re.findall(r"pub fn (curvis_[a-z_0-9]+)\s*\(([^;]*?)\)\s*(?:->[^;]*)?;", rust)}
+    assert set(c_fns) == set(declared_symbols())
+    assert r_fns == c_fns, {k: (c_fns.get(k), r_fns.get(k)) for k in set(c_fns) | set(r_fns) if c_fns.get(k) != r_fns.get(k)}
+
+
 @pytest.mark.skipif(_abi.lib().curvis_device_count() > 0, reason="a GPU is present")
 def test_no_gpu_fails_loudly():
     with pytest.raises(curvis_amd.CurvisError) as e:

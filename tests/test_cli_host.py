@@ -144,3 +144,40 @@ def test_python_png_helpers_round_trip(tmp_path):
         a = rng.integers(0, 255, shape, dtype=np.uint8)
         pngio.write_png(tmp_path / "x.png", a)
         assert np.array_equal(pngio.read_png(tmp_path / "x.png"), a)
+
+
+def _png(chunks):
+    import zlib
+    out = b"\x89PNG\r\n\x1a\n"
+    for typ, data in chunks:
+        out += struct.pack(">I", len(data)) + typ + data + struct.pack(">I", zlib.crc32(typ + data) & 0xFFFFFFFF)
+    return out
+
+
+def test_png_decoder_rejects_hostile_files(tmp_path):
+    """untrusted sky files: forged bit depths (depth 0 used to divide by zero), absurd dimensions, a decompression
+    bomb, a corrupted chunk -- each must be an error message, never a crash or a multi-GB allocation"""
+    import zlib
+    def ihdr(w, h, depth, ctype, interlace=0):
+        return struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace)
+    row = b"\x00" + bytes(4)
+    good = _png([(b"IHDR", ihdr(4, 1, 8, 0)), (b"IDAT", zlib.compress(row)), (b"IEND", b"")])
+    cases = {
+        "depth0": _png([(b"IHDR", ihdr(4, 1, 0, 0)), (b"IDAT", zlib.compress(row)), (b"IEND", b"")]),
+        "depth3": _png([(b"IHDR", ihdr(4, 1, 3, 0)), (b"IDAT", zlib.compress(row)), (b"IEND", b"")]),
+        "depth7pal": _png([(b"IHDR", ihdr(4, 1, 7, 3)), (b"IDAT", zlib.compress(row)), (b"IEND", b"")]),
+        "depth4rgb": _png([(b"IHDR", ihdr(4, 1, 4, 2)), (b"IDAT", zlib.compress(row)), (b"IEND", b"")]),
+        "huge": _png([(b"IHDR", ihdr(0x7FFFFFFF, 0x7FFFFFFF, 8, 6)), (b"IDAT", zlib.compress(row)), (b"IEND", b"")]),
+        "bomb": _png([(b"IHDR", ihdr(4, 1, 8, 0)), (b"IDAT", zlib.compress(bytes(64 << 20))), (b"IEND", b"")]),
+        "interlace9": _png([(b"IHDR", ihdr(4, 1, 8, 0, 9)), (b"IDAT", zlib.compress(row)), (b"IEND", b"")]),
+        "crc": good[:-20] + bytes([good[-20] ^ 1]) + good[-19:],
+    }
+    p = tmp_path / "good.png"
+    p.write_bytes(good)
+    assert _decode_with_binary(p, tmp_path).shape == (1, 4, 4)
+    for name, blob in cases.items():
+        p = tmp_path / (name + ".png")
+        p.write_bytes(blob)
+        r = run("selftest-png", p, tmp_path / "out.rgba")
+        assert r.returncode == 1, (name, r.returncode, r.stderr)   # an error exit, not a signal
+        assert "selftest-png:" in r.stderr, name

@@ -116,3 +116,50 @@ def test_table_row_boundaries():
     at, lg = common.table_edge_inputs()
     assert max_ulp_error("atan", [float(v) for v in at]) < 0.8
     assert max_ulp_error("log", [float(v) for v in lg]) < 0.6
+
+
+def loop_arguments(metric_name, n_rays=96, iterations=2200):
+    """the arguments the Euler loop really hands to the elementary functions: theta of every step of a fan of rays
+    from the default camera (and, for the Interstellar metric, x = 2(|l| - a)/(pi m) and 1 + x^2 of r(l))"""
+    import oracle_lib as O
+    om = O.ellis(1.0) if metric_name == "ellis" else O.interstellar(0.1, 1e-4, 1.0)
+    oc = O.camera(res=(16, 6))
+    th, ls = [], []
+    for px in range(16):
+        for py in range(6):
+            d = np.zeros(3)
+            O.lib().cvo_camera_outward_world(O.C.byref(oc), px, py, O._dp(d))
+            tr = O.photon_trajectory(O.CV, om, (0.0, 5.0, math.pi / 2, 0.0), tuple(d), iterations, 0.05)
+            keep = np.abs(tr[:, 1]) <= 100.0
+            th.append(tr[keep, 2])
+            ls.append(tr[keep, 1])
+    th, ls = np.concatenate(th), np.concatenate(ls)
+    if metric_name == "ellis":
+        return {"sin": th, "cos": th}
+    x = 2.0 * (np.abs(ls) - 1e-4) / (math.pi * 0.1)
+    x = x[np.abs(ls) > 1e-4]
+    return {"sin": th, "cos": th, "atan": x, "log": 1.0 + x * x}
+
+
+@pytest.mark.parametrize("metric_name", ["ellis", "interstellar"])
+def test_loop_arguments_against_glibc_and_binary128(metric_name):
+    """The bit-exact GPU-vs-oracle tests share cv_math.h between both sides, so they cannot see an error IN it.
+    This covers that blind spot with two independent references on the arguments the loop produces (not random
+    ones): glibc (what a Linux build of the reference calls) and binary128 (libquadmath).  cv_math.h must stay
+    below 0.8 ulp (sin, cos), 0.65 (atan, log) of the truth, and within one ulp of glibc."""
+    import oracle_lib as O
+    bounds = {"sin": 0.8, "cos": 0.8, "atan": 0.65, "log": 0.65}
+    for name, xs in loop_arguments(metric_name).items():
+        op = OPS[name]
+        cv = common.twin_math(op, xs)                     # the product header, compiled for x86
+        assert np.array_equal(cv.view(np.uint64), O.math_array(O.CV, op, xs).view(np.uint64))
+        gl = O.math_array(O.LIBM, op, xs)
+        e_cv, e_gl = O.quad_ulp_errors(op, xs, cv), O.quad_ulp_errors(op, xs, gl)
+        assert e_cv.max() < bounds[name], (name, e_cv.max())
+        assert e_gl.max() < 0.56                          # glibc 2.35 claims < 0.55 ulp for these
+        same = cv == gl
+        off = np.abs(cv[~same] - gl[~same]) / np.spacing(np.abs(gl[~same])) if (~same).any() else np.zeros(1)
+        assert off.max() <= 1.0                           # never more than one ulp apart
+        assert same.mean() > 0.95, (name, same.mean())
+        print("%s/%s: %d arguments, identical to glibc %.4f %%, max error cv %.3f ulp, glibc %.3f ulp" % (
+            metric_name, name, xs.size, 100 * same.mean(), e_cv.max(), e_gl.max()))

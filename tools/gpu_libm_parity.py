@@ -1,0 +1,171 @@
+"""GPU (cv_math.h) against the oracle's glibc flavour -- the arithmetic a Linux build of the reference performs
+(Rust f64::sin/cos/atan/ln -> llvm intrinsics -> glibc libm, src/metrics.rs:68,257,262) -- at the FULL size of
+BASELINE configs[0..2], ray by ray, and the elementary functions themselves on the arguments the Euler loop
+produces, against glibc and against binary128 (libquadmath).  Writes profiles/round2_libm_parity.txt (run on the
+GPU box: python tools/gpu_libm_parity.py > gpurun_out/libm_parity.txt).  The numbers this prints are the ones the
+parity tests assert (tests/test_gpu_parity.py, tests/test_golden.py)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common  # noqa: E402
+import oracle_lib as O  # noqa: E402
+import curvis_amd  # noqa: E402
+from curvis_amd import skies  # noqa: E402
+
+THREADS = min(128, os.cpu_count() or 1)
+
+
+def ulp_diff(a, b):
+    """|a - b| in ulps of b, for finite same-sign doubles (bit distance)"""
+    ia = np.ascontiguousarray(a).view(np.int64)
+    ib = np.ascontiguousarray(b).view(np.int64)
+    return np.abs(ia - ib)
+
+
+def compare_frame(ctx, name, metric, res, cap, sky_res):
+    om, oc, pm, pc = common.scene(metric, res=res)
+    sp, sn = skies.smooth(sky_res[0], sky_res[1], 128), skies.smooth(sky_res[0], sky_res[1], 32)
+    cp, cn = skies.checker(sky_res[0], sky_res[1], seed=0xC0FFEE), skies.checker(sky_res[0], sky_res[1], seed=0xBADC0DE)
+    t0 = time.time()
+    want_rgb, want, _ = common.oracle_full_frame(O.LIBM, om, oc, sp, sn, cap, threads=THREADS)
+    t_or = time.time() - t0
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc, context=ctx)
+    got_rgb, got = sys_.render_image_debug(cap, 100.0, 0.05)
+    n = got.size
+    d = np.abs(got_rgb.astype(int) - want_rgb.astype(int)).max(axis=2)
+    same_steps = got["steps"] == want["steps"]
+    same_code = got["code"] == want["code"]
+    same_texel = (got["tx"] == want["tx"]) & (got["ty"] == want["ty"])
+    # checkerboard sky: colours from the raw indices of both sides (nearest texel, src/images.rs:115-121)
+    def lookup(dbg):
+        H, W = cp.shape[:2]
+        ty, tx = np.minimum(dbg["ty"], H - 1), np.minimum(dbg["tx"], W - 1)
+        out = np.where((dbg["code"] == 1)[..., None], cp[ty, tx, :3], cn[ty, tx, :3])
+        out[dbg["code"] == 0] = 0
+        return out
+    same_check = (lookup(got) == lookup(want)).all(axis=2)
+    cls = same_steps & same_code
+    state_same = np.ones(got.shape, bool)
+    worst = 0
+    for f, idx in (("x", (1, 2)), ("p", (1, 2))):  # l, theta, p_l, p_theta (phi is not read by render_image)
+        for i in idx:
+            g, w = got[f][..., i], want[f][..., i]
+            eq = g.view(np.uint64) == w.view(np.uint64)
+            state_same &= eq
+            sel = cls & ~eq & np.isfinite(g) & np.isfinite(w) & (np.sign(g) == np.sign(w))
+            if sel.any():
+                worst = max(worst, int(ulp_diff(g[sel], w[sel]).max()))
+    bad_rows = sorted(set(np.nonzero(~(d == 0))[0].tolist()))
+    print("## %s: %s %dx%d cap %d, skies %dx%d, %d rays (oracle libm flavour %.1f s on %d threads)" % (
+        name, metric, res[0], res[1], cap, sky_res[0], sky_res[1], n, t_or, THREADS))
+    print("pixels, smooth sky: identical %d of %d (%.6f), <= 1 LSB per channel %.6f, max difference %d" % (
+        int((d == 0).sum()), n, (d == 0).mean(), (d <= 1).mean(), int(d.max())))
+    print("pixels, checkerboard sky (exact texel needed): identical %d of %d (%.6f)" % (int(same_check.sum()), n, same_check.mean()))
+    print("raw texel indices (tx, ty) identical: %d of %d (%.6f)" % (int(same_texel.sum()), n, same_texel.mean()))
+    print("step counts identical: %d (%.6f); escape codes identical: %d (%.6f)" % (
+        int(same_steps.sum()), same_steps.mean(), int(same_code.sum()), same_code.mean()))
+    print("final (l, theta, p_l, p_theta) bit-identical: %d of %d (%.4f); largest difference among rays with the same "
+          "step count and code: %d ulp" % (int(state_same.sum()), n, state_same.mean(), worst))
+    if bad_rows:
+        print("rows with differing pixels: %s%s" % (bad_rows[:40], " ..." if len(bad_rows) > 40 else ""))
+    print()
+    return dict(exact=(d == 0).mean(), le1=(d <= 1).mean(), texel=same_texel.mean(), steps=same_steps.mean(),
+                code=same_code.mean())
+
+
+def compare_efficient(ctx):
+    om, oc, pm, pc = common.scene("ellis", res=(960, 540))
+    sp, sn = common.make_skies(2048, 1024, "smooth")
+    want, smp, _ = O.render_image_efficient(O.LIBM, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc, context=ctx)
+    got = sys_.render_image_efficient(40000, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+    a, e, s = ctx.samples(0)
+    d = np.abs(got.astype(int) - want.astype(int)).max(axis=2)
+    print("## render_image_efficient, default image 960x540 (cap 40000, n0 = 100, thr 1e-5), smooth 2048x1024 skies")
+    print("sample tables: %d vs %d points, alphas identical %s, escape spaces identical %s, max |escape angle difference| %.3g" % (
+        len(a), len(smp["a"]), bool(np.array_equal(a, smp["a"])), bool(np.array_equal(s, smp["s"])),
+        float(np.nanmax(np.abs(e - smp["e"]))) if len(a) == len(smp["a"]) else float("nan")))
+    print("pixels: identical %d of %d (%.6f), <= 1 LSB %.6f, max difference %d" % (
+        int((d == 0).sum()), d.size, (d == 0).mean(), (d <= 1).mean(), int(d.max())))
+    print()
+
+
+def function_sweep(ctx):
+    """cv_math.h ON THE DEVICE against glibc and binary128 on the arguments of the loop: theta of every step of
+    2048 rays of the config-2 camera (Ellis) and of 1024 rays of the Interstellar camera (+ x and 1 + x^2 of r(l)),
+    the acos / atan2 arguments of the sky lookup of a whole 960x540 frame."""
+    print("## elementary functions on the arguments the loop produces: device cv_math.h vs glibc vs binary128")
+    print("| metric | function | arguments | device == host twin | identical to glibc | max |cv - glibc| (ulp) | max error cv (ulp) | max error glibc (ulp) |")
+    print("|---|---|---|---|---|---|---|---|")
+    rng = np.random.default_rng(7)
+    for metric, nrays in (("ellis", 2048), ("interstellar", 1024)):
+        om, oc, pm, pc = common.scene(metric, res=(1920, 1080))
+        px = rng.integers(0, 1920, nrays)
+        py = rng.integers(0, 1080, nrays)
+        dirs = np.zeros((nrays, 3))
+        for i in range(nrays):
+            O.lib().cvo_camera_outward_world(O.C.byref(oc), int(px[i]), int(py[i]), O._dp(dirs[i]))
+        pos = np.tile(np.array([0.0, 5.0, np.pi / 2, 0.0]), (nrays, 1))
+        tr = ctx.compute_photon_trajectory(pm, pos, dirs, 2200, 0.05)
+        keep = np.abs(tr[:, :, 1]) <= 100.0
+        th, ls = tr[:, :, 2][keep], tr[:, :, 1][keep]
+        args = {"sin": (0, th), "cos": (1, th)}
+        if metric == "interstellar":
+            x = 2.0 * (np.abs(ls) - 1e-4) / (np.pi * 0.1)
+            x = x[np.abs(ls) > 1e-4]
+            args.update({"atan": (2, x), "log": (4, 1.0 + x * x)})
+        for name, (op, xs) in args.items():
+            dev = ctx.selftest_math(op, xs)
+            host = common.twin_math(op, xs)
+            gl = O.math_array(O.LIBM, op, xs)
+            same = dev == gl
+            off = ulp_diff(dev[~same], gl[~same]).max() if (~same).any() else 0
+            print("| %s | %s | %d | %s | %.4f %% | %d | %.3f | %.3f |" % (
+                metric, name, xs.size, bool(np.array_equal(dev.view(np.uint64), host.view(np.uint64))), 100 * same.mean(),
+                off, O.quad_ulp_errors(op, xs, dev).max(), O.quad_ulp_errors(op, xs, gl).max()))
+    # sky lookup: acos(z / |v|) and atan2(y, x) of the final directions of a frame
+    om, oc, pm, pc = common.scene("ellis", res=(960, 540))
+    sp, sn = common.make_skies(512, 256, "smooth")
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc, context=ctx)
+    _, dbg = sys_.render_image_debug(4096, 100.0, 0.05)
+    esc = dbg["code"] != 0
+    x, p = dbg["x"][esc], dbg["p"][esc]
+    r2 = 1.0 + x[:, 1] * x[:, 1]
+    r = np.sqrt(r2)
+    s = np.sin(x[:, 2])
+    d0, d1, d2 = p[:, 1], p[:, 2] * (1.0 / r2) * r, p[:, 3] * (1.0 / (r2 * (s * s))) * r
+    rn = np.sqrt(d0 * d0 + d1 * d1 + d2 * d2)
+    for name, op, a, b in (("acos", 3, d2 / rn, None), ("atan2", 5, d1, d0)):
+        dev = ctx.selftest_math(op, a, b)
+        host = common.twin_math(op, a, b)
+        gl = O.math_array(O.LIBM, op, a, b)
+        same = dev == gl
+        off = ulp_diff(dev[~same], gl[~same]).max() if (~same).any() else 0
+        print("| ellis (sky lookup) | %s | %d | %s | %.4f %% | %d | %.3f | %.3f |" % (
+            name, a.size, bool(np.array_equal(dev.view(np.uint64), host.view(np.uint64))), 100 * same.mean(), off,
+            O.quad_ulp_errors(op, a, dev, b).max(), O.quad_ulp_errors(op, a, gl, b).max()))
+    print()
+
+
+def main():
+    ctx = curvis_amd.Context(0)
+    print("# GPU (fast step, cv_math.h) vs oracle CVO_LIBM (glibc %s) -- full-size BASELINE configurations" % (
+        os.confstr("CS_GNU_LIBC_VERSION")))
+    print("device: %s; host threads used by the oracle: %d" % (ctx.device_info()["name"], THREADS))
+    print()
+    compare_frame(ctx, "configs[0]", "ellis", (256, 144), 40000, (512, 256))
+    compare_frame(ctx, "configs[1]", "ellis", (1920, 1080), 4096, (8192, 4096))
+    compare_frame(ctx, "configs[2]", "interstellar", (3840, 2160), 8192, (8192, 4096))
+    compare_efficient(ctx)
+    function_sweep(ctx)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
