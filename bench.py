@@ -108,8 +108,10 @@ def main():
         raise SystemExit("bench.py: %d ranks but %d GPU(s) visible" % (world, torch.cuda.device_count()))
     # test hooks (1-GPU boxes): CURVIS_BENCH_SHARE_DEVICE=1 maps every rank to GPU 0 and
     # CURVIS_BENCH_BACKEND=gloo replaces RCCL, so the N>1 control flow can be exercised on one GPU.
-    device_index = 0 if os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1" else local_rank
-    backend = os.environ.get("CURVIS_BENCH_BACKEND", "nccl")
+    share_device = os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1"
+    device_index = 0 if share_device else local_rank
+    # RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so the share-device hook implies gloo
+    backend = os.environ.get("CURVIS_BENCH_BACKEND", "gloo" if share_device else "nccl")
     torch.cuda.set_device(device_index)
     dist = None
     if world > 1:

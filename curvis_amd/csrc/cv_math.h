@@ -495,10 +495,8 @@ CV_HD double cv_atan_edge(double x) {
  *   atan|x| = X_j + h (q1 + q2 h + ... + q6 h^2..h^5),   X_j = atan(j/128) (+ pi/2 on the reciprocal branch)
  * evaluated as X_hi + fma(h, Q, X_lo).  Error: 0.5 ulp of the last addition + the rounding of the reciprocal
  * (<= 2^-53 u/(1+u^2) <= 0.2 ulp of a result >= atan 2) + Taylor truncation h^7/7 (< 0.03 ulp): < 0.75 ulp. */
-/* table path for 0.4375 <= ax < 2^66 (ix = high word of ax): atan(ax) */
-CV_HD double cv_atan_main(double ax, uint32_t ix, cv_atan_tab_t T) {
-  const double inv = cv_div_nr(-1.0, ax);
-  const double u = (ix >= 0x40000000u) ? inv : ax;
+/* the table step for a given u in [-1/2, 0] or [0.4375, 2): X_j + h Q(h), j = rint(128 u), h = u - j/128 */
+CV_HD double cv_atan_row(double u, cv_atan_tab_t T) {
   /* u + 1.5 2^45 rounds u to the nearest multiple of 2^-7 (ties to even j, like rint(128 u)) and leaves j in the
    * low mantissa bits; plain additions, so the constant can sit in a scalar register */
   const double jb = u + CV_RND_MAGIC_128TH;
@@ -518,6 +516,11 @@ CV_HD double cv_atan_main(double ax, uint32_t ix, cv_atan_tab_t T) {
   return R[0] + CV_FMA(h, Q, R[1]);
 #endif
 }
+/* table path for 0.4375 <= ax < 2^66 (ix = high word of ax): atan(ax) */
+CV_HD double cv_atan_main(double ax, uint32_t ix, cv_atan_tab_t T) {
+  const double inv = cv_div_nr(-1.0, ax);
+  return cv_atan_row((ix >= 0x40000000u) ? inv : ax, T);
+}
 
 CV_HD double cv_atan_t(double x, cv_atan_tab_t T) {
   const uint64_t ux = cv_bits(x);
@@ -528,11 +531,16 @@ CV_HD double cv_atan_t(double x, cv_atan_tab_t T) {
   return cv_from_bits(cv_bits(r) | (ux & 0x8000000000000000ULL));
 }
 
-/* the same value for an argument known to be >= +0 (the Interstellar radial coordinate): no sign handling */
+/* the same value for a FINITE argument known to be >= +0 (the Interstellar radial coordinate x = 2(|l| - a)/(pi m),
+ * which is >= 2 for all but the dozen steps a ray spends inside |l| < a + pi m): ONE compare selects the reciprocal
+ * branch, which then needs neither the range test on the high word nor the select between x and -1/x (4 VALU
+ * instructions per Euler step less than going through cv_atan_main).  For 2^66 <= x < inf the row step returns
+ * X_0 + fma(u, Q, X_0lo) with |u| <= 2^-66, which rounds to the RN(pi/2) cv_atan_edge returns. */
 CV_HD double cv_atan_nonneg_t(double x, cv_atan_tab_t T) {
+  if (x >= 2.0) return cv_atan_row(cv_div_nr(-1.0, x), T);
   const uint32_t ix = cv_hi(x);
-  if (ix - 0x3fdc0000u >= 0x44100000u - 0x3fdc0000u) return cv_atan_edge(x);
-  return cv_atan_main(x, ix, T);
+  if (ix < 0x3fdc0000u || ix >= 0x7ff00000u) return cv_atan_edge(x); /* x < 0.4375, or NaN */
+  return cv_atan_row(x, T);
 }
 
 CV_HD double cv_atan(double x) { return cv_atan_t(x, cv_atan_table()); }
@@ -692,7 +700,13 @@ CV_HD double cv_log_main(uint64_t ux, uint32_t hx, int k0, cv_log_tab_t T) {
       LN2_LO = 1.90821492927058770002e-10;          /* 0x3DEA39EF35793C76 */
   const int k = k0 + (int)(hx >> 20) - 0x3ff;
   const unsigned i = (hx >> 12) & 0xffu;
-  const double z = cv_from_bits(((uint64_t)((hx & 0x000fffffu) | 0x3ff00000u) << 32) | (ux & 0xffffffffULL));
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t zh; /* (hx & 0xfffff) | 0x3ff00000 as ONE bit-field insert (the compiler emits and + or) */
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(zh) : "s"(0x000fffffu), "v"(hx), "v"(0x3ff00000u));
+#else
+  const uint32_t zh = (hx & 0x000fffffu) | 0x3ff00000u;
+#endif
+  const double z = cv_from_bits(((uint64_t)zh << 32) | (ux & 0xffffffffULL));
   const double invc = T[i][0], lch = T[i][1], lcl = T[i][2];
   const double r = CV_FMA(z, invc, -1.0);
   const double kd = (double)k;
