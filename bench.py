@@ -278,8 +278,11 @@ def main():
             "data": ("synthetic (procedural %dx%d RGBA8 skies, default camera/metric settings)" % (sw, sh)) +
                     ("; frames copied to host inside the timed region" if args.download else ""),
             "config": {
-                "workload": "configs[1]: %s wormhole, %dx%d, cap %d Euler steps, R=100, delta=0.05, single image; "
-                            "%d frame(s)/GPU/step" % (args.metric, args.width, args.height, args.max_iter, 1),
+                "workload": "%s: %s wormhole, %dx%d, cap %d Euler steps, R=100, delta=0.05, single image; "
+                            "%d frame(s)/GPU/step" % (
+                                "configs[1]" if (args.metric, args.width, args.height, args.max_iter) == ("ellis", 1920, 1080, 4096)
+                                else "configs[2]" if (args.metric, args.width, args.height, args.max_iter) == ("interstellar", 3840, 2160, 8192)
+                                else "non-BASELINE variant", args.metric, args.width, args.height, args.max_iter, 1),
                 "kernel": kernel_name + ("<fast>" if args.fast_math else "<strict>"),
                 "frames_per_gpu": args.steps,
                 "rays_per_frame": int(per_launch_rays),

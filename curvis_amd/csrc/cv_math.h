@@ -488,6 +488,31 @@ CV_HD double cv_atan_edge(double x) {
   const double s2 = w * cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, cv_fma_c(w, aT9, aT7), aT5), aT3), aT1);
   return x - x * (s1 + s2);
 }
+/* the unrounded pair behind cv_atan(ax) for a finite ax >= 2^-27 and < 2^66 (atan2 adds its own corrections before
+ * the one final rounding): atan(ax) = *hi + *lo with |*lo| << |*hi|; hi + lo rounded is exactly cv_atan(ax) */
+CV_HD void cv_atan_pair(double ax, cv_atan_tab_t T, double *hi, double *lo) {
+  const uint32_t ix = cv_hi(ax);
+  if (ix < 0x3fdc0000u) { /* the odd polynomial of cv_atan_edge */
+    const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
+                 aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+                 aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
+                 aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
+    const double z = ax * ax;
+    const double w = z * z;
+    const double s1 = z * CV_FMA(w, CV_FMA(w, CV_FMA(w, CV_FMA(w, CV_FMA(w, aT10, aT8), aT6), aT4), aT2), aT0);
+    const double s2 = w * CV_FMA(w, CV_FMA(w, CV_FMA(w, CV_FMA(w, aT9, aT7), aT5), aT3), aT1);
+    *hi = ax;
+    *lo = -(ax * (s1 + s2));
+    return;
+  }
+  const double u = (ix >= 0x40000000u) ? cv_div_nr(-1.0, ax) : ax;
+  const double jb = u + CV_RND_MAGIC_128TH;
+  const double h = u - (jb - CV_RND_MAGIC_128TH);
+  const double *R = T[(int)cv_lo(jb) + 64];
+  const double Q = CV_FMA(h, CV_FMA(h, CV_FMA(h, CV_FMA(h, CV_FMA(h, R[7], R[6]), R[5]), R[4]), R[3]), R[2]);
+  *hi = R[0];
+  *lo = CV_FMA(h, Q, R[1]);
+}
 
 /* atan x, table-driven for 0.4375 <= |x| < 2^66 (branch-free):
  *   u = |x| < 2 ? |x| : -1/|x|        (correctly rounded reciprocal; u in [-1/2, 0) or [0.4375, 2))
@@ -594,23 +619,40 @@ CV_HD double cv_atan2(double y, double x) {
   }
   if (iy == 0x7ff00000u) return (hy >> 31) ? -PI_O_2 - TINY : PI_O_2 + TINY; /* y inf */
   const int k = (int)(iy >> 20) - (int)(ix >> 20);
-  double z;
+  double zh, zl; /* atan(|y/x|) = zh + zl, unrounded */
   if (k > 60) { /* |y/x| > 2^60 */
-    z = PI_O_2 + 0.5 * PI_LO;
+    zh = PI_O_2;
+    zl = 0.5 * PI_LO;
   } else if ((hx >> 31) && k < -60) {
-    z = 0.0; /* |y|/x < -2^-60 with x < 0 */
+    zh = zl = 0.0; /* |y|/x < -2^-60 with x < 0 */
   } else {
-    z = cv_atan(CV_FABS(y / x));
+    /* q = RN(|y/x|) is off by up to half an ulp, which alone would cost up to 0.5 ulp of the result (fdlibm's
+     * atan2, 1.45 ulp measured on the sky-lookup arguments): the exact remainder rem = |y| - q |x| (one fma) puts
+     * it back, atan(q + rem/|x|) = atan q + (rem/|x|)/(1 + q^2) + O(2^-106).  The pair (zh, zl) keeps what cv_atan
+     * would round away, and pi - z is formed with a Fast2Sum, so the result is rounded ONCE: < 0.65 ulp measured. */
+    const double ay = CV_FABS(y), ax = CV_FABS(x);
+    const double q = ay / ax;
+    const uint32_t iq = cv_hi(q);
+    if (iq < 0x3e400000u || iq >= 0x44100000u || !(ay - ay == 0.0)) { /* tiny (subnormal remainder), huge, overflowed quotient */
+      zh = cv_atan(q);
+      zl = 0.0;
+    } else {
+      const double rem = CV_FMA(-q, ax, ay);
+      cv_atan_pair(q, cv_atan_table(), &zh, &zl);
+      zl = zl + (rem / ax) / CV_FMA(q, q, 1.0);
+    }
   }
   switch (m) {
     case 0:
-      return z;
+      return zh + zl;
     case 1:
-      return -z;
-    case 2:
-      return CV_PI - (z - PI_LO);
-    default:
-      return (z - PI_LO) - CV_PI;
+      return -(zh + zl);
+    default: { /* pi - z with z <= pi/2 < pi: Fast2Sum of the leading parts, the tails added in one go */
+      const double s = CV_PI - zh;
+      const double e = (CV_PI - s) - zh;
+      const double r = s + ((e + PI_LO) - zl);
+      return m == 2 ? r : -r;
+    }
   }
 }
 

@@ -83,7 +83,7 @@ def test_atan2_accuracy_and_quadrants():
     for y, x, g in zip(ys, xs, got):
         ex = mpmath.atan2(mpf(y), mpf(x))
         worst = max(worst, float(abs(mpf(float(g)) - ex) / math.ulp(abs(float(ex)))))
-    assert worst < 1.5
+    assert worst < 0.7   # fdlibm-style atan2 measured 1.45; with the remainder correction and one final rounding 0.65
     sp = common.twin_math(5, np.array([0.0, -0.0, 1.0, -1.0, 0.0, 1.0]), np.array([-1.0, -1.0, 0.0, 0.0, 1.0, 1.0]))
     assert list(sp) == [math.pi, -math.pi, math.pi / 2, -math.pi / 2, 0.0, math.pi / 4]
 

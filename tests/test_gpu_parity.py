@@ -458,6 +458,16 @@ def test_rccl_sky_broadcast_entry_point(gpu_ctx):
         after, _ = gpu_ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
         want, _, _ = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
         assert np.array_equal(before, want) and np.array_equal(after, want)
+        # a root WITHOUT skies: the "no skies" flag travels with the shapes, so every rank (here: the one) comes
+        # back with CURVIS_E_NO_SKY after the header broadcast instead of the root returning early and its peers
+        # waiting inside ncclBroadcast for ever
+        bare = curvis_amd.Context(0)
+        try:
+            rc = _abi.lib().curvis_ctx_bcast_skies(bare._h, comm, 0)
+            assert rc == _abi.E_NO_SKY
+            assert b"root rank" in _abi.lib().curvis_last_error(bare._h)
+        finally:
+            bare.close()
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)

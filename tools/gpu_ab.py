@@ -10,6 +10,10 @@ import numpy as np
 sys.path.insert(0, %r)
 import curvis_amd._abi as A
 A.LIB_PATH = sys.argv[1]
+import ctypes
+_L = ctypes.CDLL(A.LIB_PATH)   # an older build may lack the newest entry points: bind what it has
+for _n in list(A.SYMBOLS):
+    if not hasattr(_L, _n): A.SYMBOLS.pop(_n)
 import curvis_amd
 from curvis_amd import skies
 ctx = curvis_amd.Context(0)
