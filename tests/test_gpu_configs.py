@@ -208,3 +208,37 @@ def test_video_config_through_the_binary(tmp_path, video):
     for k in gone:
         assert np.array_equal(pngio.read_png(d / "out" / "tmp" / ("frame_%d.png" % k)), want[k][0]), k
     assert len(os.listdir(d / "out" / "tmp")) == n_frames
+
+
+@pytest.mark.parametrize("mode", ["efficient", "brute"])
+def test_python_video_driver_modes(gpu_ctx, mode):
+    """curvis_amd.rendering.VideoRenderingSystem (mirror of src/rendering.rs:178-327): the default mode renders what
+    the reference's video loop renders -- render_image_efficient with sampling_initial_nums for BOTH alphas_num and
+    max_iterations_sampling and threshold_1 for BOTH thresholds (src/main.rs:91-110, src/rendering.rs:299-307) --,
+    mode="brute" the per-pixel integrator; frames and per-frame statistics against the oracle."""
+    sp, sn = common.make_skies(512, 256, "check")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    it = rendering.Interpolator.from_file(paths.path_file("path_through.csv"))
+    res, cap = (40, 24), 4096
+    v = rendering.VideoRenderingSystem(curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0), gpu_ctx, it, 1.5, res, 43.0, 15.0, 100.0,
+                                       cap, 0.05, batch=7, mode=mode, sampling_initial_nums=60,
+                                       sampling_convergence_threshold_1=2e-5)
+    frames = {}
+    stats = v.render(on_frame=lambda k, rgb, d: frames.__setitem__(k, rgb))
+    times = v.times_of_frames()
+    assert [d["frame"] for d in stats] == list(range(len(times))) == sorted(frames) and len(times) == 30
+    om = O.interstellar(0.1, 1e-4, 1.0)
+    for d in stats:
+        k = d["frame"]
+        t = times[k]
+        oc = O.camera(tuple(it.camera_position(t)), tuple(it.camera_forward(t)), tuple(it.camera_up(t)), 15.0, 43.0, res)
+        if mode == "efficient":
+            want, smp, st = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, 60, 60, 2e-5, 2e-5)
+            assert d["steps"] == smp["steps"] and d["rays"] == res[0] * res[1], k
+            assert (d["n_pos"], d["n_neg"], d["n_none"]) == (st.n_pos, st.n_neg, st.n_none), k
+        else:
+            want, _, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05)
+            assert (d["rays"], d["steps"], d["n_pos"], d["n_neg"], d["n_none"]) == (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none), k
+        assert np.array_equal(frames[k], want), k
+        assert d["mode"] == mode and d["batch_frames"] in (7, 2)
