@@ -22,7 +22,8 @@
  * --resume (video: keep <out>/tmp and skip the frames whose frame_{k}.png is already there; default off = the
  * reference's behaviour of deleting and recreating tmp, src/rendering.rs:276-287).  A batch of frames whose render
  * call fails is re-queued on another GPU (frames are independent) before the run is declared failed.
- * Backgrounds must be PNG (any colour type / bit depth); no JPEG decoder is linked.
+ * Backgrounds: PNG (any colour type / bit depth) or JPEG (8-bit Huffman, baseline / progressive, grey or YCbCr; own
+ * decoder in jpeg_io.h -- JPEG input is outside the pixel-parity claims, see there).
  */
 #include <sys/stat.h>
 #include <unistd.h>
@@ -50,6 +51,7 @@
 
 #include "../../../include/curvis_hip.h"
 #include "png_io.h"
+#include "jpeg_io.h"
 
 namespace {
 
@@ -526,8 +528,8 @@ void load_common(const Args &a, Common &c, const char *what) {
   if (curvis_metric_validate(&c.metric) != CURVIS_OK)
     die(std::string("Error in rendering ") + what + ": metric parameters must be positive (src/metrics.rs:409-456)", 101);
   if (!validate(c.cam, err) || !validate(c.sim, err)) die(std::string("Error in rendering ") + what + ": " + err);
-  if (!pngio::load(a.bg1, c.sky1, err)) die(std::string("Error in rendering ") + what + ": background image 1: " + err);
-  if (!pngio::load(a.bg2, c.sky2, err)) die(std::string("Error in rendering ") + what + ": background image 2: " + err);
+  if (!jpegio::load_image(a.bg1, c.sky1, err)) die(std::string("Error in rendering ") + what + ": background image 1: " + err);
+  if (!jpegio::load_image(a.bg2, c.sky2, err)) die(std::string("Error in rendering ") + what + ": background image 2: " + err);
 }
 
 void check(int rc, curvis_ctx *ctx, const char *what) {
@@ -944,7 +946,7 @@ int main(int argc, char **argv) {
     if (argc != 4) die("usage: curvis selftest-png <in.png> <out.rgba>", 2);
     pngio::Image img;
     std::string err;
-    if (!pngio::load(argv[2], img, err)) die("selftest-png: " + err);
+    if (!jpegio::load_image(argv[2], img, err)) die("selftest-png: " + err);
     FILE *f = std::fopen(argv[3], "wb");
     if (!f) die("selftest-png: cannot write output");
     const uint32_t hdr[2] = {img.w, img.h};

@@ -181,3 +181,67 @@ def test_png_decoder_rejects_hostile_files(tmp_path):
         r = run("selftest-png", p, tmp_path / "out.rgba")
         assert r.returncode == 1, (name, r.returncode, r.stderr)   # an error exit, not a signal
         assert "selftest-png:" in r.stderr, name
+
+
+def _jpeg_test_image(h=77, w=131, seed=3):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([127 + 120 * np.sin(xx / 9.0) * np.cos(yy / 7.0), xx * 255.0 / w, yy * 255.0 / h], axis=2)
+    return np.clip(img + rng.normal(0, 6, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def test_jpeg_decoder_against_libjpeg(tmp_path):
+    """JPEG skies (the reference's README suggests .jpg star maps; image::open -> zune-jpeg): baseline and
+    progressive, 4:4:4 / 4:2:2 / 4:2:0, grey, optimised Huffman tables, restart intervals, odd sizes -- against
+    libjpeg (Pillow) within what two conforming decoders differ by (different IDCT / upsampling / colour arithmetic:
+    measured max 3, mean 0.5 of 255); the PNG path is untouched by format detection."""
+    PIL = pytest.importorskip("PIL.Image")
+    img = _jpeg_test_image()
+    variants = [("444", dict(subsampling=0)), ("422", dict(subsampling=1)), ("420", dict(subsampling=2)),
+                ("prog420", dict(subsampling=2, progressive=True)), ("prog444", dict(subsampling=0, progressive=True)),
+                ("q30", dict(quality=30)), ("opt", dict(optimize=True, quality=95)),
+                ("rst", dict(subsampling=2, restart_marker_blocks=3)), ("rstprog", dict(progressive=True, restart_marker_rows=1))]
+    for name, kw in variants:
+        p = tmp_path / ("t_%s.jpg" % name)
+        try:
+            PIL.fromarray(img).save(p, **dict({"quality": 90}, **kw))
+        except TypeError:
+            continue
+        got = _decode_with_binary(p, tmp_path)
+        want = np.asarray(PIL.open(p).convert("RGB"))
+        d = np.abs(got[..., :3].astype(int) - want.astype(int))
+        assert got.shape == (77, 131, 4) and (got[..., 3] == 255).all()
+        assert d.max() <= 4 and d.mean() < 0.8, (name, d.max(), d.mean())
+    for size in ((1, 1), (8, 8), (9, 17), (16, 16), (33, 7)):
+        small = _jpeg_test_image(size[0], size[1], seed=9)
+        for sub in (0, 2):
+            p = tmp_path / "small.jpg"
+            PIL.fromarray(small).save(p, quality=92, subsampling=sub)
+            got = _decode_with_binary(p, tmp_path)
+            want = np.asarray(PIL.open(p).convert("RGB"))
+            assert got.shape[:2] == size and np.abs(got[..., :3].astype(int) - want.astype(int)).max() <= 5, (size, sub)
+    p = tmp_path / "grey.jpg"
+    PIL.fromarray(img[..., 0]).save(p, quality=90)
+    got = _decode_with_binary(p, tmp_path)
+    want = np.asarray(PIL.open(p).convert("L"))
+    assert np.abs(got[..., 0].astype(int) - want.astype(int)).max() <= 1 and (got[..., 0] == got[..., 1]).all()
+    # unsupported / damaged files are an error message, not a crash
+    p = tmp_path / "cmyk.jpg"
+    PIL.fromarray(np.dstack([img, img[..., :1]]), "CMYK").save(p)
+    r = run("selftest-png", p, tmp_path / "o.rgba")
+    assert r.returncode == 1 and "CMYK" in r.stderr
+    blob = (tmp_path / "t_420.jpg").read_bytes()
+    for cut in (3, 20, 200, len(blob) // 2, len(blob) - 2):
+        p = tmp_path / "cut.jpg"
+        p.write_bytes(blob[:cut])
+        r = run("selftest-png", p, tmp_path / "o.rgba")
+        assert r.returncode in (0, 1), (cut, r.returncode)   # decoded what is there, or said why not; never a signal
+    rng = np.random.default_rng(4)
+    for _ in range(30):   # random corruption of the entropy-coded data and the headers
+        b = bytearray(blob)
+        for pos in rng.integers(2, len(b), 8):
+            b[pos] = int(rng.integers(0, 256))
+        p = tmp_path / "fuzz.jpg"
+        p.write_bytes(bytes(b))
+        r = run("selftest-png", p, tmp_path / "o.rgba")
+        assert r.returncode in (0, 1), r.returncode

@@ -146,3 +146,28 @@ def test_video_rccl_sky_broadcast_path(scene_files):
     assert names == sorted(os.listdir(outs[1] / "tmp")) and len(names) == 6
     for n in names:
         assert np.array_equal(pngio.read_png(outs[0] / "tmp" / n), pngio.read_png(outs[1] / "tmp" / n))
+
+
+def test_image_with_jpeg_skies(scene_files):
+    """`.jpg` backgrounds (what the reference's README suggests): the binary decodes them with its own decoder
+    (jpeg_io.h); the frame equals the oracle's render over the very texels that decoder produced -- the render path
+    is format-agnostic, and JPEG decoding itself is outside the pixel-parity claims (zune-jpeg cannot be run here)."""
+    PIL = pytest.importorskip("PIL.Image")
+    import struct
+    d, sp, sn = scene_files
+    out = d / "out_jpg"
+    out.mkdir()
+    PIL.fromarray(sp[..., :3]).save(d / "pos.jpg", quality=92, subsampling=2)
+    PIL.fromarray(sn[..., :3]).save(d / "neg.jpg", quality=92, progressive=True)
+    skies = []
+    for name in ("pos.jpg", "neg.jpg"):
+        r = run("selftest-png", d / name, d / "dump.rgba")
+        assert r.returncode == 0, r.stderr
+        raw = (d / "dump.rgba").read_bytes()
+        w, h = struct.unpack("<II", raw[:8])
+        skies.append(np.frombuffer(raw[8:], np.uint8).reshape(h, w, 4).copy())
+    r = run("image", d / "pos.jpg", d / "neg.jpg", out, "-s", d / "sim.toml", "-c", d / "cam.toml", "--mode", "brute")
+    assert r.returncode == 0, r.stderr
+    om, oc, _, _ = common.scene("ellis", res=(96, 54))
+    want, _, _ = O.render_image(O.CV, om, oc, O.sky(skies[0]), O.sky(skies[1]), 4096, 100.0, 0.05)
+    assert np.array_equal(pngio.read_png(out / "output_image.png"), want)

@@ -573,3 +573,66 @@ def test_efficient_speculation_is_transparent(gpu_ctx):
             assert np.array_equal(common.bits(a), common.bits(b))
         assert o[3] < base[3] and o[4] > base[4]
     assert out[6][3] <= 5
+
+
+@pytest.mark.parametrize("res", [(1, 1), (1, 9), (9, 1), (7, 9), (257, 3), (3, 257)])
+def test_degenerate_frame_shapes(gpu_ctx, res):
+    """one pixel, one row, one column, frames smaller than an 8x8 tile or a wave, widths that are no multiple of the
+    tile: every kernel variant against the oracle, alone and as a three-frame batch (per-frame counters included)"""
+    sp, sn = common.make_skies(128, 64, "check")
+    om, oc, pm, pc = common.scene("ellis", res=res, pos=(0.0, 3.0, 1.3, 0.4), fwd=(-1.0, 0.2, 0.1))
+    want, _, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 3000, 100.0, 0.05)
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    ref = (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none, st.n_oob)
+    try:
+        for variant in (-1, 0, 1, 2):
+            gpu_ctx.set_option("variant", variant)
+            gpu_ctx.set_option("relay_min_blocks", 0)
+            rgb, s = gpu_ctx.render_brute(pm, pc, 3000, 100.0, 0.05)
+            assert rgb.shape == (res[1], res[0], 3) and np.array_equal(rgb, want), variant
+            assert (s.rays, s.steps, s.n_pos, s.n_neg, s.n_none, s.n_oob) == ref, variant
+            rgb3, s3 = gpu_ctx.render_brute(pm, [pc, pc, pc], 3000, 100.0, 0.05)
+            per = gpu_ctx.frame_stats()
+            assert all(np.array_equal(rgb3[k], want) for k in range(3)), variant
+            assert [(f.rays, f.steps, f.n_pos, f.n_neg, f.n_none, f.n_oob) for f in per] == [ref] * 3, variant
+        eff, _ = gpu_ctx.render_efficient(pm, pc, 3000, 100.0, 0.05, 40, 40, 1e-4, 1e-4)
+        weff, _, _ = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), 3000, 100.0, 0.05, 40, 40, 1e-4, 1e-4)
+        assert np.array_equal(eff, weff)
+    finally:
+        gpu_ctx.set_option("variant", -1)
+        gpu_ctx.set_option("relay_min_blocks", -1)
+
+
+def test_largest_frame_8k(gpu_ctx):
+    """a frame of 7680x4320 (33.2 M rays, four times BASELINE's largest): every 64th row against the oracle, and the
+    frame's counters against themselves across kernels (relay staging area 1.9 GB, framebuffer 100 MB)"""
+    import os
+    sp, sn = common.make_skies(2048, 1024, "check")
+    om, oc, pm, pc = common.scene("ellis", res=(7680, 4320))
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    rgb, s = gpu_ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+    assert s.rays == 7680 * 4320 and s.n_pos + s.n_neg + s.n_none == s.rays
+    from concurrent.futures import ThreadPoolExecutor
+    T = min(64, os.cpu_count() or 1)
+    rows = list(range(5, 4320, 64))
+    osp, osn = O.sky(sp), O.sky(sn)
+
+    def work(i):   # rows i, i + T*64, ... of the 64-row comb
+        mine = rows[i::T]
+        out = {}
+        for r in mine:
+            img, _, _ = O.render_image(O.CV, om, oc, osp, osn, 4096, 100.0, 0.05, row_begin=r, row_step=1 << 30)
+            out[r] = img[r].copy()
+        return out
+    with ThreadPoolExecutor(T) as ex:
+        for part in ex.map(work, range(T)):
+            for r, line in part.items():
+                assert np.array_equal(rgb[r], line), r
+    gpu_ctx.set_option("variant", 1)
+    try:
+        rgb1, s1 = gpu_ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+    finally:
+        gpu_ctx.set_option("variant", -1)
+    assert np.array_equal(rgb1, rgb) and (s1.steps, s1.n_pos, s1.n_neg, s1.n_none) == (s.steps, s.n_pos, s.n_neg, s.n_none)

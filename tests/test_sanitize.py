@@ -16,3 +16,43 @@ def test_oracle_and_host_twin_are_clean_under_asan_and_ubsan():
     r = subprocess.run([os.path.join(D, "san_driver")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert "sanitize ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
+def test_image_decoders_are_clean_under_asan_and_ubsan_on_hostile_files(tmp_path):
+    """PNG and JPEG decoders of the host binary on ~400 mutated files (bit flips in headers, tables and entropy-coded
+    data, truncations): any outcome is fine except a sanitizer report"""
+    import numpy as np
+    PIL = __import__("pytest").importorskip("PIL.Image")
+    subprocess.run(["make", "-s", "-C", D, "san_images"], check=True)
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:40, 0:56]
+    img = np.clip(np.stack([127 + 100 * np.sin(xx / 5.0), xx * 4.0, yy * 6.0], axis=2) + rng.normal(0, 8, (40, 56, 3)), 0, 255).astype(np.uint8)
+    seeds = []
+    for name, kw in (("a.jpg", dict(quality=85, subsampling=2)), ("b.jpg", dict(quality=85, progressive=True)),
+                     ("c.jpg", dict(quality=60, subsampling=1, optimize=True)), ("d.png", {}), ("e.png", dict(optimize=True))):
+        p = tmp_path / name
+        PIL.fromarray(img).save(p, **kw)
+        seeds.append(p.read_bytes())
+    PIL.fromarray(img[..., 0]).save(tmp_path / "g.jpg")
+    seeds.append((tmp_path / "g.jpg").read_bytes())
+    files = []
+    for k in range(400):
+        b = bytearray(seeds[k % len(seeds)])
+        mode = k % 4
+        if mode == 0:      # a few random bytes anywhere
+            for pos in rng.integers(0, len(b), 6):
+                b[pos] = int(rng.integers(0, 256))
+        elif mode == 1:    # damage concentrated in the first 600 bytes (headers, tables)
+            for pos in rng.integers(0, min(600, len(b)), 4):
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+        elif mode == 2:    # truncation
+            b = b[:int(rng.integers(1, len(b)))]
+        else:              # a run of 0xFF / zeros
+            pos = int(rng.integers(0, len(b) - 8))
+            b[pos:pos + 8] = bytes([0xFF if k % 8 == 3 else 0x00]) * 8
+        f = tmp_path / ("m%03d.bin" % k)
+        f.write_bytes(bytes(b))
+        files.append(str(f))
+    r = subprocess.run([os.path.join(D, "san_images")] + files, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "decoded" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr

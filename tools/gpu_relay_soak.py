@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Relay kernel soak: random frame sizes (down to a few workgroups per CU), 1-8 frames per launch, random cameras
-and metrics, automatic segment and forced short segments; every launch must reproduce the static kernel's frames and
-statistics.  python tools/gpu_relay_soak.py [launches] [seed]"""
+and metrics, automatic segment and forced short segments; every launch must reproduce the static kernel's frames,
+its statistics and its PER-FRAME counters.  python tools/gpu_relay_soak.py [launches] [seed]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,12 +24,14 @@ for it in range(N):
     cap = int(rng.choice([600, 2500, 4096]))
     ctx.set_option("variant", 1)
     want, sw = ctx.render_brute(m, cams, cap, 100.0, 0.05)
+    fw = [(f.rays, f.steps, f.n_pos, f.n_neg, f.n_none, f.n_oob) for f in ctx.frame_stats()]   # per-frame counters
     ctx.set_option("variant", -1)
     ctx.set_option("relay_min_blocks", 0 if it % 3 == 0 else -1)
     ctx.set_option("relay_segment", int(rng.choice([0, 0, 64, 300])))
     got, sg = ctx.render_brute(m, cams, cap, 100.0, 0.05)
+    fg = [(f.rays, f.steps, f.n_pos, f.n_neg, f.n_none, f.n_oob) for f in ctx.frame_stats()]
     relay_launches += ctx.get_option("last_relay_launches"); parks += ctx.get_option("last_relay_parks")
-    if not (np.array_equal(got, want) and (sg.rays, sg.steps, sg.n_pos, sg.n_neg, sg.n_none) == (sw.rays, sw.steps, sw.n_pos, sw.n_neg, sw.n_none)):
+    if not (np.array_equal(got, want) and fg == fw and len(fg) == nf and (sg.rays, sg.steps, sg.n_pos, sg.n_neg, sg.n_none) == (sw.rays, sw.steps, sw.n_pos, sw.n_neg, sw.n_none)):
         bad += 1
         print("MISMATCH", it, w, h, nf, kind, cap, flush=True)
 print("launches %d, of which relay %d (hand-overs %d), mismatches %d, %.0f s" % (N, relay_launches, parks, bad, time.time() - t0))

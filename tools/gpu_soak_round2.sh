@@ -1,0 +1,9 @@
+#!/bin/bash
+# Re-validation of the round's final kernels beyond the test-suite (run on the GPU box):
+# deep parity fuzz against the oracle, relay-kernel soak (incl. per-frame counters), fast step vs IEEE step.
+cd ${GRAFT_REPO_ROOT:-.}
+OUT=gpurun_out/soak_round2; mkdir -p $OUT
+(timeout 900 python tools/gpu_deep_fuzz.py 2000 101; timeout 900 python tools/gpu_deep_fuzz.py 2000 202; timeout 900 python tools/gpu_deep_fuzz.py 2000 303) 2>&1 | grep -E "MISMATCH|scenes" | tail -9 > $OUT/deep_fuzz.txt
+(timeout 900 python tools/gpu_relay_soak.py 4000 31; timeout 900 python tools/gpu_relay_soak.py 4000 32) 2>&1 | grep -E "MISMATCH|launches" | tail -12 > $OUT/relay_soak.txt
+timeout 1200 python tools/gpu_fast_vs_strict.py 600 77 2>&1 | tail -6 > $OUT/fast_vs_strict.txt
+cat $OUT/*.txt
