@@ -252,10 +252,7 @@ CV_HD bool metric_fast_ok(int kind, const MetricParams &M, double max_radius) {
 template <int KIND, bool PHI, bool WIDE_T = false>
 CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_ok) {
   double s, c;
-  if (WIDE_T)
-    cv_sincos_tw(q.th, M.T, &s, &c);
-  else
-    cv_sincos_t(q.th, M.T, &s, &c);
+  const int s_ok = cv_sincos_guarded(q.th, M.T, WIDE_T ? 1 : 0, &s, &c);
   /* guard (branch-free, one compare each): sin(theta) and l non-zero, not NaN and far from the underflow
    * limit.  Upper bounds are implied: |sin| <= 1, and a step is only executed for a ray that has not
    * escaped, |l| <= max_radius < 2^90 (metric_fast_ok; an infinite l has escaped, a NaN fails the compare).
@@ -263,7 +260,7 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
    * class test below) or >= ulp(a) >= 2^-352 (metric_fast_ok), far above where the quotient's remainder underflows.
    * cos(theta) needs no test of its own: it is finite iff sin(theta) is, and the cosine of a double is never
    * zero or subnormal. */
-  const bool ok = (int)lane_ok & (int)(CV_FABS(s) > 0x1p-60) & (int)(KIND == METRIC_INTERSTELLAR || CV_FABS(q.l) > 0x1p-100);
+  const bool ok = (int)lane_ok & s_ok & (int)(KIND == METRIC_INTERSTELLAR || CV_FABS(q.l) > 0x1p-100);
   if (!ok) {
     ray_step_core<KIND, PHI>(M, q, delta, s, c);
     return;

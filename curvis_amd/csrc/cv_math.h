@@ -417,6 +417,19 @@ CV_HD void cv_sincos_impl(double x, cv_sc_tab_t T, int wide, double *sn, double 
   else
     cv_sincos_other(x, T, sn, cs);
 }
+/* sin and cos as above, and whether |sin x| > 2^-60 (the fast Euler step's guard on the sine).  On the main path
+ * that is implied -- x = K pi/64 + y with 2^-20 <= |y| <= pi/128: for K = 0 (mod 64) |sin x| = |sin y| >= 2^-21,
+ * otherwise |sin x| >= sin(pi/64) cos y - |sin y| > 0.024 -- so the compare is only executed on the other path. */
+CV_HD int cv_sincos_guarded(double x, cv_sc_tab_t T, int wide, double *sn, double *cs) {
+  double y, yl;
+  int K;
+  if (cv_sincos_main_args(x, wide, &K, &y, &yl)) {
+    cv_sincos_core(K, y, yl, T, sn, cs);
+    return 1;
+  }
+  cv_sincos_other(x, T, sn, cs);
+  return CV_FABS(*sn) > 0x1p-60;
+}
 CV_HD void cv_sincos_t(double x, cv_sc_tab_t T, double *sn, double *cs) { cv_sincos_impl(x, T, 0, sn, cs); }
 /* T = the 128 rows twice (the hot kernels' LDS copy where there is room for it) */
 CV_HD void cv_sincos_tw(double x, cv_sc_tab_t T, double *sn, double *cs) { cv_sincos_impl(x, T, 1, sn, cs); }
