@@ -924,6 +924,13 @@ struct curvis_ctx {
   int relay_max_frames = 8;         /* largest launch (frames) the relay kernel is used for: the end-game it repairs is
                                        ~5 % of a one-frame launch and 1-2 % of a launch of three to six frames;
                                        beyond that its staging area (56 B per ray) buys nothing */
+  int relay_disabled = 0;           /* set when a relay launch reported waves that gave up waiting: the context falls back
+                                       to the static kernel for good (the relay kernel leans on the dispatcher starting
+                                       workgroups in blockIdx order, which HIP does not promise) */
+  int relay_verify = 0;             /* debug option: every relay render is repeated with the static kernel and the two
+                                       frames and statistics compared (CURVIS_E_HIP on a difference) */
+  int relay_test_fault = 0;         /* test hook: pretend the next relay launch reported a wave that gave up */
+  uint32_t relay_fallbacks = 0;     /* renders that fell back from the relay to the static kernel */
   long long relay_min_blocks = -1;  /* smallest grid (fresh workgroups) the relay kernel is used for; -1 = automatic
                                        (4 per CU: with fewer workgroups than that nearly the whole grid is resident at
                                        once, there is no dispatch phase, and the static kernel is as good) */
@@ -1217,7 +1224,7 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   const unsigned long long relay_min = ctx->relay_min_blocks >= 0 ? (unsigned long long)ctx->relay_min_blocks
                                                                    : 4ull * (unsigned long long)ctx->prop.multiProcessorCount;
   const size_t relay_staging = (size_t)((W + 7) / 8) * ((H + 7) / 8) * 64u * n_frames * kStoreBytesPerPixel;
-  const bool relay = (ctx->variant == 2 || ctx->variant < 0) && fused && n_frames <= (uint32_t)ctx->relay_max_frames &&
+  const bool relay = (ctx->variant == 2 || ctx->variant < 0) && !ctx->relay_disabled && fused && n_frames <= (uint32_t)ctx->relay_max_frames &&
                      relay_fresh_blocks >= relay_min && relay_staging <= ctx->max_store_bytes;
   uint32_t chunk = n_frames;
   if (relay) {
@@ -1351,9 +1358,18 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
        * with tiles still parked */
       const RelayQueue *hq = (const RelayQueue *)(ctx->h_counters + cnt_words);
       const unsigned long long n_tiles = P.total_rays / 64ull;
-      if (hq->error != 0)
-        return fail(ctx, CURVIS_E_HIP, "relay kernel: " + std::to_string(hq->error) + " waves gave up waiting, " +
-                                           std::to_string(n_tiles - hq->finished) + " tiles unfinished");
+      if (hq->error != 0 || ctx->relay_test_fault) {
+        /* waves gave up waiting for a tile (a logic error, or a dispatcher that did not start the workgroups in
+         * order): not a hang and not a wrong frame -- the frame is rendered again by the static kernel, which has no
+         * inter-workgroup dependency, and this context stops using the relay kernel */
+        ctx->relay_test_fault = 0;
+        ctx->relay_disabled = 1;
+        ctx->relay_fallbacks++;
+        fprintf(stderr, "[curvis] relay kernel: %llu waves gave up waiting (%llu tiles unfinished); falling back to the static kernel for this context\n",
+                (unsigned long long)hq->error, (unsigned long long)(n_tiles - hq->finished));
+        return render_impl(ctx, metric, cams, n_frames, max_iterations, max_radius, delta, rgb_out, dbg_out, stats, row_begin,
+                           row_count);
+      }
       ctx->last_relay_parks = hq->tail;
       ctx->last_relay_waiters = hq->head;
       if (hq->finished >= n_tiles) break;
@@ -1399,6 +1415,27 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   }
   ctx->last_integrate_ms = integrate_ms;
   ctx->last_shade_ms = shade_ms;
+  if (relay && ctx->relay_verify) { /* debug: the same launch by the static kernel must give the same bytes and counters */
+    std::vector<uint8_t> a(fb_bytes), b(fb_bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(a.data(), ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const std::vector<curvis_stats> fs = ctx->last_frame_stats;
+    const uint32_t launches = ctx->last_relay_launches;
+    const uint64_t parks = ctx->last_relay_parks;
+    const int saved = ctx->variant;
+    ctx->variant = 1;
+    rc = render_impl(ctx, metric, cams, n_frames, max_iterations, max_radius, delta, b.data(), nullptr, nullptr, row_begin, row_count);
+    ctx->variant = saved;
+    if (rc) return rc;
+    bool same = a == b && fs.size() == ctx->last_frame_stats.size();
+    for (size_t f = 0; same && f < fs.size(); ++f) {
+      const curvis_stats &x = fs[f], &y = ctx->last_frame_stats[f];
+      same = x.rays == y.rays && x.steps == y.steps && x.n_pos == y.n_pos && x.n_neg == y.n_neg && x.n_none == y.n_none && x.n_oob == y.n_oob;
+    }
+    if (!same) return fail(ctx, CURVIS_E_HIP, "relay_verify: the relay kernel and the static kernel disagree on this launch");
+    ctx->last_relay_launches = launches;
+    ctx->last_relay_parks = parks;
+  }
   if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (dbg_out)
     HIP_TRY(ctx, hipMemcpyAsync(dbg_out, ctx->d_dbg, sizeof(curvis_ray_debug) * npix * n_frames,
@@ -2329,6 +2366,12 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->relay_max_frames = (int)value;
   else if (k == "relay_min_blocks")
     ctx->relay_min_blocks = (long long)value;
+  else if (k == "relay_verify")
+    ctx->relay_verify = (int)value;
+  else if (k == "relay_disabled")
+    ctx->relay_disabled = (int)value;
+  else if (k == "relay_test_fault")
+    ctx->relay_test_fault = (int)value;
 
   else if (k == "fast_math")
     ctx->fast_math = (int)value;
@@ -2362,6 +2405,12 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->relay_max_frames;
   else if (k == "relay_min_blocks")
     *value = ctx->relay_min_blocks;
+  else if (k == "relay_verify")
+    *value = ctx->relay_verify;
+  else if (k == "relay_disabled")
+    *value = ctx->relay_disabled;
+  else if (k == "relay_fallbacks")
+    *value = ctx->relay_fallbacks;
   else if (k == "last_frames")
     *value = (int64_t)ctx->last_frame_stats.size();
   else if (k == "last_relay_launches")

@@ -223,7 +223,10 @@ int curvis_ctx_synchronize(curvis_ctx *ctx);
  * for larger batches) and "sampling_speculation_first" (the same below the intervals of the initial uniform grid,
  * i.e. for the first launch; default -1 = automatic, 8 / 4 / 3; depths up to 11); read-only after an efficient render:
  * "last_sampling_launches", "last_sampling_evaluated"; after any render: "last_frames"; after a relay render: "last_relay_launches",
- * "last_relay_parks". */
+ * "last_relay_parks".  Relay safety net: if a relay launch reports waves that gave up waiting (the kernel leans
+ * on in-order workgroup dispatch, which HIP does not promise), the frame is rendered again by the static kernel and
+ * "relay_disabled" becomes 1 for the context ("relay_fallbacks" counts such renders); "relay_verify" = 1 (debug)
+ * repeats every relay render with the static kernel and fails with CURVIS_E_HIP if frames or counters differ. */
 int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value);
 int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value);
 

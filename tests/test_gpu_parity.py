@@ -636,3 +636,34 @@ def test_largest_frame_8k(gpu_ctx):
     finally:
         gpu_ctx.set_option("variant", -1)
     assert np.array_equal(rgb1, rgb) and (s1.steps, s1.n_pos, s1.n_neg, s1.n_none) == (s.steps, s.n_pos, s.n_neg, s.n_none)
+
+
+def test_relay_safety_net_and_verify_option(gpu_ctx):
+    """the relay kernel leans on in-order workgroup dispatch (not promised by HIP): a launch that reports waves that
+    gave up waiting is rendered again by the static kernel and the context stops using the relay kernel -- neither a
+    hang nor a wrong frame (fault injected through "relay_test_fault"); "relay_verify" repeats every relay render with
+    the static kernel and compares frames and per-frame counters."""
+    sp, sn = common.make_skies(256, 128, "check")
+    om, oc, pm, pc = common.scene("interstellar", res=(61, 35), pos=(0.0, 3.0, 1.2, 1.0), fwd=(-1.0, 0.1, 0.05))
+    want, _, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 3000, 100.0, 0.05)
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    try:
+        gpu_ctx.set_option("variant", 2)
+        gpu_ctx.set_option("relay_min_blocks", 0)
+        gpu_ctx.set_option("relay_segment", 64)
+        gpu_ctx.set_option("relay_verify", 1)
+        rgb, s = gpu_ctx.render_brute(pm, [pc, pc], 3000, 100.0, 0.05)
+        assert np.array_equal(rgb[0], want) and np.array_equal(rgb[1], want) and s.steps == 2 * st.steps
+        assert gpu_ctx.get_option("last_relay_launches") >= 1 and gpu_ctx.get_option("relay_fallbacks") == 0
+        gpu_ctx.set_option("relay_verify", 0)
+        before = gpu_ctx.get_option("relay_fallbacks")
+        gpu_ctx.set_option("relay_test_fault", 1)
+        rgb, s = gpu_ctx.render_brute(pm, pc, 3000, 100.0, 0.05)
+        assert np.array_equal(rgb, want) and (s.rays, s.steps, s.n_pos, s.n_neg, s.n_none) == (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none)
+        assert gpu_ctx.get_option("relay_disabled") == 1 and gpu_ctx.get_option("relay_fallbacks") == before + 1
+        rgb, _ = gpu_ctx.render_brute(pm, pc, 3000, 100.0, 0.05)          # stays on the static kernel
+        assert np.array_equal(rgb, want) and gpu_ctx.get_option("last_relay_launches") == 0
+    finally:
+        for k, v in (("relay_disabled", 0), ("relay_verify", 0), ("variant", -1), ("relay_min_blocks", -1), ("relay_segment", 0)):
+            gpu_ctx.set_option(k, v)
