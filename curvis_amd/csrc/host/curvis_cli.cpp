@@ -619,6 +619,7 @@ int image_main(const Args &a) {
       st.n_pos += sts[(size_t)r].n_pos;
       st.n_neg += sts[(size_t)r].n_neg;
       st.n_none += sts[(size_t)r].n_none;
+      st.n_oob += sts[(size_t)r].n_oob;
       st.kernel_ms = std::max(st.kernel_ms, sts[(size_t)r].kernel_ms);
       if (r > 0) curvis_ctx_destroy(ctxs[(size_t)r]);
     }
@@ -632,9 +633,10 @@ int image_main(const Args &a) {
   if (!a.stats.empty()) {
     FILE *f = std::fopen(a.stats.c_str(), "w");
     if (f) {
-      std::fprintf(f, "{\"frame\": 0, \"mode\": \"%s\", \"rays\": %llu, \"steps\": %llu, \"n_pos\": %llu, \"n_neg\": %llu, \"n_none\": %llu, \"kernel_ms\": %.4f}\n",
+      std::fprintf(f, "{\"frame\": 0, \"mode\": \"%s\", \"rays\": %llu, \"steps\": %llu, \"n_pos\": %llu, \"n_neg\": %llu, \"n_none\": %llu, \"n_oob\": %llu, \"kernel_ms\": %.4f, \"mray_steps_per_s\": %.1f}\n",
                    a.mode.c_str(), (unsigned long long)st.rays, (unsigned long long)st.steps, (unsigned long long)st.n_pos,
-                   (unsigned long long)st.n_neg, (unsigned long long)st.n_none, st.kernel_ms);
+                   (unsigned long long)st.n_neg, (unsigned long long)st.n_none, (unsigned long long)st.n_oob, st.kernel_ms,
+                   st.kernel_ms > 0.0 ? (double)st.steps / st.kernel_ms / 1e3 : 0.0);
       std::fclose(f);
     }
   }
@@ -909,10 +911,11 @@ int video_main(const Args &a) {
           }
           std::printf("Rendering frame %zu/%zu...\n", k + 1, times.size());
           if (stats_f)
-            std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"rays\": %llu, \"steps\": %llu, \"n_pos\": %llu, \"n_neg\": %llu, \"n_none\": %llu, \"n_oob\": %llu, \"kernel_ms\": %.4f, \"batch_frames\": %zu, \"batch_kernel_ms\": %.4f}\n",
+            std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"rays\": %llu, \"steps\": %llu, \"n_pos\": %llu, \"n_neg\": %llu, \"n_none\": %llu, \"n_oob\": %llu, \"kernel_ms\": %.4f, \"mray_steps_per_s\": %.1f, \"batch_frames\": %zu, \"batch_kernel_ms\": %.4f}\n",
                          k, times[k], a.device + rank, a.mode.c_str(), (unsigned long long)fs.rays, (unsigned long long)fs.steps,
                          (unsigned long long)fs.n_pos, (unsigned long long)fs.n_neg, (unsigned long long)fs.n_none,
-                         (unsigned long long)fs.n_oob, fs.kernel_ms, nb, batch_ms);
+                         (unsigned long long)fs.n_oob, fs.kernel_ms, fs.kernel_ms > 0.0 ? (double)fs.steps / fs.kernel_ms / 1e3 : 0.0, nb,
+                         batch_ms);
         });
       }
       {
