@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void geodesic_persistent(const IntegrateParams
  * final state in HBM for shade_kernel -- the epilogue needs fewer registers than the loop, so the fusion is
  * free in occupancy and removes ~200 MB of HBM traffic and one launch per frame. */
 template <int KIND, bool PHI, bool FAST, bool FUSED>
-__global__ __launch_bounds__(256) void geodesic_static(const IntegrateParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == cvk::METRIC_INTERSTELLAR ? 5 : 7)))
+void geodesic_static(const IntegrateParams P) {
   __shared__ MathTablesLds<KIND> s_tab;
   cvk::MetricParams M = P.metric;
   load_math_tables<KIND>(s_tab, M);
@@ -469,8 +470,11 @@ __device__ __forceinline__ void st_sys(T *p, T v) { __hip_atomic_store(p, v, __A
 template <typename T>
 __device__ __forceinline__ T ld_sys(const T *p) { return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+/* register budget: the Interstellar instantiation must stay at 5 waves per SIMD (<= 96 VGPRs; its LDS tables allow
+ * no more anyway): left alone the allocator takes 97 and drops to four (+6 % time) */
 template <int KIND, bool FAST>
-__global__ __launch_bounds__(256) void geodesic_relay(const IntegrateParams P, const RelayArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == cvk::METRIC_INTERSTELLAR ? 5 : 7)))
+void geodesic_relay(const IntegrateParams P, const RelayArgs A) {
   __shared__ MathTablesLds<KIND> s_tab;
   RelayQueue *const Q = A.q;
   const unsigned long long t_start = P.trace ? wall_clock64() : 0ull;

@@ -71,8 +71,17 @@ CV_HD void metric_eval(const MetricParams &M, double l, double &r, double &r2, d
     const double xn = CV_FMA(2.0, al, -2.0 * M.a);
     const double q0 = xn * M.inv_pim;
     const double x = __builtin_fmax(CV_FMA(CV_FMA(-M.pim, q0, xn), M.inv_pim, q0), 0.0);
-    const double at = cv_atan_nonneg_t(x, M.AT);
-    const double lg = cv_log_ge1_t(1.0 + x * x, M.LT);
+    /* ONE compare picks the forms of atan and log for x >= 2 (all but the dozen steps inside |l| < a + pi m):
+     * the reciprocal branch of atan without a range test or a select, and the k >= 1 formula of log (1 + x^2 >= 5)
+     * without its Fast2Sum -- the same values cv_atan / cv_log return for these arguments. */
+    double at, lg;
+    if (x >= 2.0) {
+      at = cv_atan_row(cv_div_nr(-1.0, x), M.AT);
+      lg = cv_log_ge2_t(1.0 + x * x, M.LT);
+    } else {
+      at = cv_atan_nonneg_t(x, M.AT);
+      lg = cv_log_ge1_t(1.0 + x * x, M.LT);
+    }
     r = M.rho + M.m * CV_FMA(-0.5, lg, x * at);
     rd = CV_FMA(__builtin_copysign(M.two_o_pi, l), at, 0.0);
     r2 = r * r;
