@@ -46,45 +46,36 @@ struct MetricParams {
   cv_atan_tab_t AT;
 };
 
-/* r(l), r^2(l), r'(l): src/metrics.rs:417-421 / 467-485 / 501-505.
- * FASTDIV (fast step only): the division by the constant PI*m uses M.inv_pim. */
-template <int KIND, bool FASTDIV = false>
+/* Interstellar metric of the FAST step: x = 2(|l| - a)/(pi m) first, the rest only for x >= 2.
+ * Same values as metric_eval below with fewer instructions (each rewrite is exact, not merely close):
+ *   2*(|l| - a)       = fma(2, |l|, -2a)          scaling by two commutes with the rounding
+ *   xn / (pi m)       Markstein with the host-rounded reciprocal M.inv_pim (exact for a correctly rounded one)
+ *   x*at - lg/2       = fma(-0.5, lg, RN(x*at))   lg/2 is exact
+ *   (2/pi)*signum(l)*at = fma(copysign(2/pi, l), at, +0)   multiplying by +-1 is exact
+ * x >= 2 holds for every step outside |l| < a + pi m (a dozen steps of a ray that crosses the throat): it is part of
+ * the fast step's guard, so the throat (|l| <= a: r = rho, r' = 0), negative x, NaN and the small-argument forms
+ * of atan / log never reach this code -- they take the strict step, i.e. the reference's own branches -- and the
+ * fast path carries neither `max(x, 0)` nor a second form of either function. */
+CV_HD double interstellar_x(const MetricParams &M, double l) {
+  const double xn = CV_FMA(2.0, CV_FABS(l), -2.0 * M.a);
+  const double q0 = xn * M.inv_pim;
+  return CV_FMA(CV_FMA(-M.pim, q0, xn), M.inv_pim, q0);
+}
+CV_HD void interstellar_eval_x_ge2(const MetricParams &M, double l, double x, double &r, double &r2, double &rd) {
+  const double at = cv_atan_row(cv_div_nr(-1.0, x), M.AT); /* = cv_atan(x) for x >= 2: reciprocal branch, no range test */
+  const double lg = cv_log_ge2_t(1.0 + x * x, M.LT);       /* = cv_log(1 + x^2): the k >= 1 formula, no Fast2Sum */
+  r = M.rho + M.m * CV_FMA(-0.5, lg, x * at);
+  rd = CV_FMA(__builtin_copysign(M.two_o_pi, l), at, 0.0);
+  r2 = r * r;
+}
+
+/* r(l), r^2(l), r'(l): src/metrics.rs:417-421 / 467-485 / 501-505. */
+template <int KIND>
 CV_HD void metric_eval(const MetricParams &M, double l, double &r, double &r2, double &rd) {
   if (KIND == METRIC_ELLIS) {
     r2 = M.rho2 + l * l;
     r = CV_SQRT(r2);
     rd = l / r;
-  } else if (KIND == METRIC_INTERSTELLAR && FASTDIV) {
-    /* Same values with fewer instructions (each rewrite is exact, not merely close):
-     *   2*(|l| - a)       = fma(2, |l|, -2a)          scaling by two commutes with the rounding
-     *   xn / (pi m)       Markstein with the host-rounded reciprocal
-     *   x*at - lg/2       = fma(-0.5, lg, RN(x*at))   lg/2 is exact
-     *   (2/pi)*signum(l)*at = fma(copysign(2/pi, l), at, +0)   multiplying by +-1 is exact, at >= +0
-     * and NO branch for the throat: x = max(x, 0).  For |l| <= a (and for a NaN l, which fails the reference's
-     * `abs(l) > a` too) that is x = +0, hence at = atan(+0) = +0, lg = log(1) = +0 (the table's first slice has
-     * invc = 1, logc = 0), x*at - lg/2 = +0, r = rho + m*0 = rho, and r' = fma(+-2/pi, +0, +0) = +0 (the added
-     * +0 turns the product's -0 for l < 0 into the +0 of the reference's literal 0.0): exactly the values of the
-     * `else` branch below, without the compare, the branch and the two constant moves in front of it.
-     * x >= +0 and 1 + x^2 is finite and >= 1 (|l| <= max_radius < 2^90 on the guarded path), so atan / log need
-     * neither sign nor special-case handling. */
-    const double al = CV_FABS(l);
-    const double xn = CV_FMA(2.0, al, -2.0 * M.a);
-    const double q0 = xn * M.inv_pim;
-    const double x = __builtin_fmax(CV_FMA(CV_FMA(-M.pim, q0, xn), M.inv_pim, q0), 0.0);
-    /* ONE compare picks the forms of atan and log for x >= 2 (all but the dozen steps inside |l| < a + pi m):
-     * the reciprocal branch of atan without a range test or a select, and the k >= 1 formula of log (1 + x^2 >= 5)
-     * without its Fast2Sum -- the same values cv_atan / cv_log return for these arguments. */
-    double at, lg;
-    if (x >= 2.0) {
-      at = cv_atan_row(cv_div_nr(-1.0, x), M.AT);
-      lg = cv_log_ge2_t(1.0 + x * x, M.LT);
-    } else {
-      at = cv_atan_nonneg_t(x, M.AT);
-      lg = cv_log_ge1_t(1.0 + x * x, M.LT);
-    }
-    r = M.rho + M.m * CV_FMA(-0.5, lg, x * at);
-    rd = CV_FMA(__builtin_copysign(M.two_o_pi, l), at, 0.0);
-    r2 = r * r;
   } else if (KIND == METRIC_INTERSTELLAR) {
     double al = CV_FABS(l);
     if (al > M.a) {
@@ -265,11 +256,13 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
   /* guard (branch-free, one compare each): sin(theta) and l non-zero, not NaN and far from the underflow
    * limit.  Upper bounds are implied: |sin| <= 1, and a step is only executed for a ray that has not
    * escaped, |l| <= max_radius < 2^90 (metric_fast_ok; an infinite l has escaped, a NaN fails the compare).
-   * The Interstellar step needs no test of l: l enters through |l| - a only, which is 0 (throat: r' = 0, the dp_l
-   * class test below) or >= ulp(a) >= 2^-352 (metric_fast_ok), far above where the quotient's remainder underflows.
+   * The Interstellar step tests x = 2(|l| - a)/(pi m) >= 2 instead of l (false for a NaN l): inside |l| < a + pi m
+   * -- the throat and the few steps next to it -- a ray takes the strict step; outside, atan x >= atan 2, so r' is
+   * far from zero and from the underflow of the quotient's remainder.
    * cos(theta) needs no test of its own: it is finite iff sin(theta) is, and the cosine of a double is never
    * zero or subnormal. */
-  const bool ok = (int)lane_ok & s_ok & (int)(KIND == METRIC_INTERSTELLAR || CV_FABS(q.l) > 0x1p-100);
+  const double x_i = KIND == METRIC_INTERSTELLAR ? interstellar_x(M, q.l) : 0.0;
+  const bool ok = (int)lane_ok & s_ok & (int)(KIND == METRIC_INTERSTELLAR ? x_i >= 2.0 : CV_FABS(q.l) > 0x1p-100);
   if (!ok) {
     ray_step_core<KIND, PHI>(M, q, delta, s, c);
     return;
@@ -279,8 +272,11 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
     r2 = M.rho2 + q.l * q.l;
     sqrt_and_rsqrt(r2, r, y_r);
     rd = div_with_recip(q.l, r, y_r);
+  } else if (KIND == METRIC_INTERSTELLAR) {
+    interstellar_eval_x_ge2(M, q.l, x_i, r, r2, rd);
+    y_r = recip_refined(r);
   } else {
-    metric_eval<KIND, true>(M, q.l, r, r2, rd);
+    metric_eval<KIND>(M, q.l, r, r2, rd);
     y_r = recip_refined(r);
   }
   const double y_s = recip_refined(s);
@@ -295,11 +291,10 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
   const double r3 = r * (r * r);
   /* dp_l = num / r^3: the shared-reciprocal quotient is checked AFTERWARDS with one class test.  Inside the guarded
    * domain a non-zero num has |num| >= 2^-300 |r'| >= 2^-745 (Ellis: |r'| = |l|/r >= 2^-191; Interstellar:
-   * |l| - a >= ulp(a) >= 2^-352, so atan x >= 2^-444), hence the remainder fma cannot underflow and the true quotient
-   * is a normal number (>= 2^-745 / 2^273) or overflows.  Whatever else can happen shows in the result: num == 0
-   * (r' == 0 inside the Interstellar throat) gives 0 -- possibly with the wrong sign --, an overflowing n*y or a
-   * non-finite num (|p_theta| exploding at a pole) gives inf or NaN; all of those are "not a normal number" and
-   * take the IEEE division. */
+   * |r'| >= (2/pi) atan 2), hence the remainder fma cannot underflow and the true quotient
+   * is a normal number (>= 2^-745 / 2^273) or overflows.  Whatever else can happen shows in the result: an
+   * overflowing n*y or a non-finite num (|p_theta| exploding at a pole) gives inf or NaN; those are "not a normal
+   * number" and take the IEEE division. */
   double dp1 = div_with_recip(num, r3, y_r2 * y_r);
   if (!is_normal_number(dp1)) {
 #if defined(__HIP_DEVICE_COMPILE__)
