@@ -167,9 +167,10 @@ struct alignas(16) MathTablesLds {
    * 0, so ds_read2_b64 (whose offset field is short) and ds_read_b64 share one address register; the 32- and
    * 64-byte rows of the other two tables are read with ds_read_b128, whose offset field reaches any LDS
    * address, so their base offsets cost no instruction either. */
-  /* 256-row form of the sin/cos table (cv_sincos_tw: no index mask) where the LDS has room: the Interstellar
-   * kernels' five workgroups per CU already use 30 of their 32 KiB */
-  static constexpr bool WIDE_SC = KIND != cvk::METRIC_INTERSTELLAR;
+  /* 256-row form of the sin/cos table (cv_sincos_tw: no index mask) in every kernel: since only the reciprocal-branch
+   * rows of the atan table live in LDS (8 KiB; the direct-branch rows are read from __constant__ memory by the few
+   * steps next to the throat) the Interstellar kernels need 6 + 8 + 8 = 22 KiB per workgroup instead of 30 */
+  static constexpr bool WIDE_SC = true;
   double lg[LOG_ROWS][3]; /* only the Interstellar metric evaluates a logarithm and an arc tangent per step */
   double sc[WIDE_SC ? 256 : 128][4];
   double at[ATAN_ROWS][8];

@@ -61,6 +61,7 @@
 #endif
 #define CV_RND_MAGIC 6755399441055744.0
 #define CV_RND_MAGIC_128TH 52776558133248.0 /* 1.5 * 2^45: ulp 2^-7 */
+#define CV_RND_MAGIC_256TH 26388279066624.0 /* 1.5 * 2^44: ulp 2^-8 */
 
 #define CV_PI 3.14159265358979311600e+00 /* 0x400921FB54442D18 = Rust std::f64::consts::PI */
 
@@ -456,18 +457,31 @@ CV_HD double cv_cos(double x) {
 /* atan / atan2                                                               */
 /* ------------------------------------------------------------------------- */
 
-/* rows j = -64..256 of cv_atan_table.h: {X_hi, X_lo, q1..q6} (20.1 KiB).  Host: static copy; device:
- * __constant__ copy unless the caller passes its own (the Interstellar kernels keep one in LDS). */
+/* Two tables (cv_atan_table.h).  cv_atan_table(): the RECIPROCAL branch, rows j = -128..0 at c = j/256,
+ * {X_hi, X_lo, q1..q5, 0} (8.1 KiB) -- the one the Euler loop reads in every step; host: static copy; device:
+ * __constant__ copy unless the caller passes its own (the Interstellar kernels keep it in LDS).
+ * cv_atan_dtable(): the DIRECT branch, rows j = 56..256 at c = j/128, {X_hi, X_lo, q1..q6} (12.6 KiB); only
+ * arguments in [0.4375, 2) read it (the throat's neighbourhood, the sky lookup), always from the static /
+ * __constant__ copy. */
 typedef const double (*cv_atan_tab_t)[8];
 #if defined(__HIPCC__) || defined(__HIP__)
 __device__ __constant__ static const double cv_atan_table_dev[CV_ATAN_TABLE_N][8] __attribute__((aligned(16))) = {CV_ATAN_TABLE_ROWS};
+__device__ __constant__ static const double cv_atan_dtable_dev[CV_ATAN_DTABLE_N][8] __attribute__((aligned(16))) = {CV_ATAN_DTABLE_ROWS};
 #endif
 static const double cv_atan_table_host[CV_ATAN_TABLE_N][8] = {CV_ATAN_TABLE_ROWS};
+static const double cv_atan_dtable_host[CV_ATAN_DTABLE_N][8] = {CV_ATAN_DTABLE_ROWS};
 CV_HD cv_atan_tab_t cv_atan_table(void) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return cv_atan_table_dev;
 #else
   return cv_atan_table_host;
+#endif
+}
+CV_HD cv_atan_tab_t cv_atan_dtable(void) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return cv_atan_dtable_dev;
+#else
+  return cv_atan_dtable_host;
 #endif
 }
 
@@ -518,46 +532,66 @@ CV_HD void cv_atan_pair(double ax, cv_atan_tab_t T, double *hi, double *lo) {
     *lo = -(ax * (s1 + s2));
     return;
   }
-  const double u = (ix >= 0x40000000u) ? cv_div_nr(-1.0, ax) : ax;
-  const double jb = u + CV_RND_MAGIC_128TH;
-  const double h = u - (jb - CV_RND_MAGIC_128TH);
-  const double *R = T[(int)cv_lo(jb) + 64];
+  if (ix >= 0x40000000u) { /* reciprocal branch: same operations as cv_atan_row */
+    const double u = cv_div_nr(-1.0, ax);
+    const double jb = u + CV_RND_MAGIC_256TH;
+    const double h = u - (jb - CV_RND_MAGIC_256TH);
+    const double *R = T[(int)cv_lo(jb) + 128];
+    const double Q = CV_FMA(h, CV_FMA(h, CV_FMA(h, CV_FMA(h, R[6], R[5]), R[4]), R[3]), R[2]);
+    *hi = R[0];
+    *lo = CV_FMA(h, Q, R[1]);
+    return;
+  }
+  const double jb = ax + CV_RND_MAGIC_128TH; /* direct branch: same operations as cv_atan_row_direct */
+  const double h = ax - (jb - CV_RND_MAGIC_128TH);
+  const double *R = cv_atan_dtable()[(int)cv_lo(jb) - 56];
   const double Q = CV_FMA(h, CV_FMA(h, CV_FMA(h, CV_FMA(h, CV_FMA(h, R[7], R[6]), R[5]), R[4]), R[3]), R[2]);
   *hi = R[0];
   *lo = CV_FMA(h, Q, R[1]);
 }
 
-/* atan x, table-driven for 0.4375 <= |x| < 2^66 (branch-free):
- *   u = |x| < 2 ? |x| : -1/|x|        (correctly rounded reciprocal; u in [-1/2, 0) or [0.4375, 2))
- *   j = rint(128 u), h = u - j/128    exact, |h| <= 2^-8 (magic-number rounding to multiples of 2^-7)
- *   atan|x| = X_j + h (q1 + q2 h + ... + q6 h^2..h^5),   X_j = atan(j/128) (+ pi/2 on the reciprocal branch)
- * evaluated as X_hi + fma(h, Q, X_lo).  Error: 0.5 ulp of the last addition + the rounding of the reciprocal
- * (<= 2^-53 u/(1+u^2) <= 0.2 ulp of a result >= atan 2) + Taylor truncation h^7/7 (< 0.03 ulp): < 0.75 ulp. */
-/* the table step for a given u in [-1/2, 0] or [0.4375, 2): X_j + h Q(h), j = rint(128 u), h = u - j/128 */
+/* atan x, table-driven for 0.4375 <= |x| < 2^66:
+ *   |x| >= 2:  u = -1/|x|  (correctly rounded reciprocal; u in [-1/2, 0]),  j = rint(256 u), h = u - j/256 exact,
+ *              |h| <= 2^-9:   atan|x| = X_j + h (q1 + q2 h + .. + q5 h^4),   X_j = pi/2 + atan(j/256)
+ *   |x| <  2:  u = |x|,  j = rint(128 u), |h| <= 2^-8:   atan|x| = X_j + h (q1 + .. + q6 h^5),  X_j = atan(j/128)
+ * (magic-number rounding to multiples of 2^-8 resp. 2^-7), evaluated as X_hi + fma(h, Q, X_lo).  Error: 0.5 ulp of
+ * the last addition + the rounding of the reciprocal (<= 2^-53 u/(1+u^2) <= 0.2 ulp of a result >= atan 2) +
+ * Taylor truncation (h^6/6 <= 2^-56.6 resp. h^7/7 <= 2^-58.8, < 0.05 ulp): < 0.75 ulp (measured < 0.62).
+ * The reciprocal branch is the one the Interstellar Euler step takes (x >= 2 outside |l| < a + pi m): its rows
+ * are twice as fine as the direct branch's so that its polynomial is one term shorter. */
+/* the table step of the reciprocal branch for a given u in [-1/2, 0] */
 CV_HD double cv_atan_row(double u, cv_atan_tab_t T) {
-  /* u + 1.5 2^45 rounds u to the nearest multiple of 2^-7 (ties to even j, like rint(128 u)) and leaves j in the
+  /* u + 1.5 2^44 rounds u to the nearest multiple of 2^-8 (ties to even j, like rint(256 u)) and leaves j in the
    * low mantissa bits; plain additions, so the constant can sit in a scalar register */
-  const double jb = u + CV_RND_MAGIC_128TH;
-  const double jq = jb - CV_RND_MAGIC_128TH; /* j / 128 */
+  const double jb = u + CV_RND_MAGIC_256TH;
+  const double jq = jb - CV_RND_MAGIC_256TH; /* j / 256 */
   const double h = u - jq;                   /* exact */
 #if defined(__HIP_DEVICE_COMPILE__)
   /* the 64-byte row as four 16-byte loads (tables are 16-byte aligned): from LDS that is four ds_read_b128
    * off ONE address register (their offset field reaches the whole LDS; ds_read2_b64's does not) */
   typedef double cv_f64x2 __attribute__((ext_vector_type(2)));
-  const cv_f64x2 *R = (const cv_f64x2 *)T[(int)cv_lo(jb) + 64];
+  const cv_f64x2 *R = (const cv_f64x2 *)T[(int)cv_lo(jb) + 128];
   const cv_f64x2 r01 = R[0], r23 = R[1], r45 = R[2], r67 = R[3];
-  const double Q = cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, r67.y, r67.x), r45.y), r45.x), r23.y), r23.x);
+  const double Q = cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, r67.x, r45.y), r45.x), r23.y), r23.x);
   return r01.x + CV_FMA(h, Q, r01.y);
 #else
-  const double *R = T[(int)cv_lo(jb) + 64];
-  const double Q = cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, R[7], R[6]), R[5]), R[4]), R[3]), R[2]);
+  const double *R = T[(int)cv_lo(jb) + 128];
+  const double Q = cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, R[6], R[5]), R[4]), R[3]), R[2]);
   return R[0] + CV_FMA(h, Q, R[1]);
 #endif
 }
+/* the table step of the direct branch for u = |x| in [0.4375, 2) */
+CV_HD double cv_atan_row_direct(double u) {
+  const double jb = u + CV_RND_MAGIC_128TH;
+  const double h = u - (jb - CV_RND_MAGIC_128TH);
+  const double *R = cv_atan_dtable()[(int)cv_lo(jb) - 56];
+  const double Q = cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, cv_fma_c(h, R[7], R[6]), R[5]), R[4]), R[3]), R[2]);
+  return R[0] + CV_FMA(h, Q, R[1]);
+}
 /* table path for 0.4375 <= ax < 2^66 (ix = high word of ax): atan(ax) */
 CV_HD double cv_atan_main(double ax, uint32_t ix, cv_atan_tab_t T) {
-  const double inv = cv_div_nr(-1.0, ax);
-  return cv_atan_row((ix >= 0x40000000u) ? inv : ax, T);
+  if (ix >= 0x40000000u) return cv_atan_row(cv_div_nr(-1.0, ax), T);
+  return cv_atan_row_direct(ax);
 }
 
 CV_HD double cv_atan_t(double x, cv_atan_tab_t T) {
@@ -578,7 +612,7 @@ CV_HD double cv_atan_nonneg_t(double x, cv_atan_tab_t T) {
   if (x >= 2.0) return cv_atan_row(cv_div_nr(-1.0, x), T);
   const uint32_t ix = cv_hi(x);
   if (ix < 0x3fdc0000u || ix >= 0x7ff00000u) return cv_atan_edge(x); /* x < 0.4375, or NaN */
-  return cv_atan_row(x, T);
+  return cv_atan_row_direct(x);
 }
 
 CV_HD double cv_atan(double x) { return cv_atan_t(x, cv_atan_table()); }

@@ -181,17 +181,22 @@ def random_scene(rng, res=(16, 9)):
 
 def table_edge_inputs():
     """Arguments on and next to every row boundary of the cv_math.h tables: atan rows (u = j/128 +- 1/256 for the
-    direct branch, x = -1/u for the reciprocal branch, the 0.4375 / 2 / 2^66 switches) and log slices
+    direct branch, u = j/256 +- 1/512 with x = -1/u for the reciprocal branch, the 0.4375 / 2 / 2^66 switches) and log slices
     (z = 1 + i/256, all exponents incl. subnormal scaling)."""
     import math
     at, lg = [], []
-    for j in range(-64, 257):
+    for j in range(56, 257):          # direct branch: rows at j/128
         for d in (-1.0 / 256, 0.0, 1.0 / 256):
             for e in (-1, 0, 1):
                 c = j / 128.0 + d
                 c = math.nextafter(c, math.inf) if e > 0 else math.nextafter(c, -math.inf) if e < 0 else c
                 if 0.4375 <= c < 2.0:
                     at += [c, -c]
+    for j in range(-128, 1):          # reciprocal branch: rows at j/256, x = -1/u
+        for d in (-1.0 / 512, 0.0, 1.0 / 512):
+            for e in (-1, 0, 1):
+                c = j / 256.0 + d
+                c = math.nextafter(c, math.inf) if e > 0 else math.nextafter(c, -math.inf) if e < 0 else c
                 if -0.5 <= c < 0.0:
                     at += [-1.0 / c, 1.0 / c]
     for x in (0.4375, 2.0, 2.0 ** 66, 128.0, 256.0):
