@@ -161,7 +161,7 @@ struct ShadeParams {
  * __constant__ loads. */
 template <int KIND>
 struct alignas(16) MathTablesLds {
-  static constexpr unsigned LOG_ROWS = (KIND == cvk::METRIC_INTERSTELLAR) ? 256u : 2u;
+  static constexpr unsigned LOG_ROWS = (KIND == cvk::METRIC_INTERSTELLAR) ? (unsigned)CV_LOG_TABLE_N : 2u;
   static constexpr unsigned ATAN_ROWS = (KIND == cvk::METRIC_INTERSTELLAR) ? (unsigned)CV_ATAN_TABLE_N : 1u;
   /* Order and alignment are chosen for the address arithmetic of the lookups: the 24-byte log rows sit at offset
    * 0, so ds_read2_b64 (whose offset field is short) and ds_read_b64 share one address register; the 32- and
@@ -186,7 +186,7 @@ __device__ __forceinline__ void load_math_tables(MathTablesLds<KIND> &L, cvk::Me
   if (KIND == cvk::METRIC_INTERSTELLAR) {
     const double *lsrc = &cv_log_table_dev[0][0];
     double *ldst = &L.lg[0][0];
-    for (unsigned i = threadIdx.x; i < 768u; i += blockDim.x) ldst[i] = lsrc[i];
+    for (unsigned i = threadIdx.x; i < 3u * CV_LOG_TABLE_N; i += blockDim.x) ldst[i] = lsrc[i];
     M.LT = L.lg;
     const double *asrc = &cv_atan_table_dev[0][0];
     double *adst = &L.at[0][0];

@@ -51,7 +51,7 @@ struct MetricParams {
  *   2*(|l| - a)       = fma(2, |l|, -2a)          scaling by two commutes with the rounding
  *   xn / (pi m)       Markstein with the host-rounded reciprocal M.inv_pim (exact for a correctly rounded one)
  *   x*at - lg/2       = fma(-0.5, lg, RN(x*at))   lg/2 is exact
- *   (2/pi)*signum(l)*at = fma(copysign(2/pi, l), at, +0)   multiplying by +-1 is exact
+ *   (2/pi)*signum(l)*at = copysign(RN(2/pi * at), l)        multiplying by +-1 is exact, at > 0
  * x >= 2 holds for every step outside |l| < a + pi m (a dozen steps of a ray that crosses the throat): it is part of
  * the fast step's guard, so the throat (|l| <= a: r = rho, r' = 0), negative x, NaN and the small-argument forms
  * of atan / log never reach this code -- they take the strict step, i.e. the reference's own branches -- and the
@@ -65,7 +65,8 @@ CV_HD void interstellar_eval_x_ge2(const MetricParams &M, double l, double x, do
   const double at = cv_atan_row(cv_div_nr(-1.0, x), M.AT); /* = cv_atan(x) for x >= 2: reciprocal branch, no range test */
   const double lg = cv_log_ge2_t(1.0 + x * x, M.LT);       /* = cv_log(1 + x^2): the k >= 1 formula, no Fast2Sum */
   r = M.rho + M.m * CV_FMA(-0.5, lg, x * at);
-  rd = CV_FMA(__builtin_copysign(M.two_o_pi, l), at, 0.0);
+  rd = __builtin_copysign(M.two_o_pi * at, l); /* (2/pi * signum(l)) * at: the product by +-1 is exact, and at >= atan 2 > 0
+                                                  here, so the sign can be put on afterwards (one v_mul + one v_bfi) */
   r2 = r * r;
 }
 

@@ -760,14 +760,14 @@ CV_HD double cv_acos(double x) {
 /* natural logarithm                                                          */
 /* ------------------------------------------------------------------------- */
 
-/* {invc, logc_hi, logc_lo} per 1/256-wide slice of [1, 2) (cv_log_table.h).  Host code reads the static
- * copy, device code the __constant__ copy unless the caller passes its own (the Interstellar kernels keep
- * one in LDS: 6 KiB per workgroup). */
+/* {invc, logc_hi - LN2_HI, logc_lo - LN2_LO} per 1/512-wide slice of [1, 2) (cv_log_table.h).  Host code reads the
+ * static copy, device code the __constant__ copy unless the caller passes its own (the Interstellar kernels keep
+ * one in LDS: 12 KiB per workgroup). */
 typedef const double (*cv_log_tab_t)[3];
 #if defined(__HIPCC__) || defined(__HIP__)
-__device__ __constant__ static const double cv_log_table_dev[256][3] = {CV_LOG_TABLE_ROWS};
+__device__ __constant__ static const double cv_log_table_dev[CV_LOG_TABLE_N][3] = {CV_LOG_TABLE_ROWS};
 #endif
-static const double cv_log_table_host[256][3] = {CV_LOG_TABLE_ROWS};
+static const double cv_log_table_host[CV_LOG_TABLE_N][3] = {CV_LOG_TABLE_ROWS};
 CV_HD cv_log_tab_t cv_log_table(void) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return cv_log_table_dev;
@@ -776,25 +776,27 @@ CV_HD cv_log_tab_t cv_log_table(void) {
 #endif
 }
 
-/* log x, table-driven.  x = 2^k z, z in [1, 2); i = top 8 mantissa bits; c = 1/invc_i is close to z:
- *   r  = fma(z, invc, -1)             exact (invc is a multiple of 2^-9 and |r| <= 2^-8)
- *   w  = k*LN2_HI + logc_hi           exact (both multiples of 2^-32)
+/* log x, table-driven.  x = 2^k z, z in [1, 2); i = top 9 mantissa bits; c = 1/invc_i is close to z:
+ *   r  = fma(z, invc, -1)             exact (invc is a multiple of 2^-10 and |r| <= 2^-9)
+ *   w  = k*LN2_HI + logc_hi           exact (both multiples of 2^-32); computed as e*LN2_HI + (logc_hi - LN2_HI)
+ *                                     with e = k + 1, the exponent v_frexp_exp_i32_f64 delivers in one instruction
+ *                                     (the table holds logc_hi - LN2_HI, exactly, and logc_lo - LN2_LO)
  *   hi + lo = w + r                   Fast2Sum (w == 0 or |w| >= |r|, checked by the table generator)
  *   log x = hi + (lo + k*LN2_LO + logc_lo + r^2 (-1/2 + r/3 - ... + r^5/7))
  * Taylor truncation < 2^-59 relative even on the slice next to 1 (invc = 1, w = 0, log x = r + ...), so the
  * error is 0.5 ulp of the final addition plus ~0.02 ulp.
- * Arguments outside [1/2, 2) (k >= 1 or k <= -2) have |w| >= 0.69 while |r| <= 2^-8, so w needs no help from r:
- *   log x = w + fma(r^2, P4(r), r + (k*LN2_LO + logc_lo))        P4 = -1/2 + r/3 - r^2/4 + r^3/5 - r^4/6
- * -- no Fast2Sum and one Taylor term less (r^7/7 <= 2^-58.8 absolute against ulp(0.69) = 2^-53): the bracket carries
- * ~2^-58 of error, the result 0.5 ulp + 0.03.  Three additions and one fma fewer per Interstellar Euler step, whose
+ * Arguments outside [1/2, 2) (k >= 1 or k <= -2) have |w| >= 0.69 while |r| <= 2^-9, so w needs no help from r:
+ *   log x = w + fma(r^2, P3(r), r + (k*LN2_LO + logc_lo))        P3 = -1/2 + r/3 - r^2/4 + r^3/5
+ * -- no Fast2Sum and two Taylor terms less (r^6/6 <= 2^-56.6 absolute against ulp(0.69) = 2^-53, on the two slices
+ * next to 1 only; 2^-62.6 elsewhere): the result carries 0.5 ulp + 0.08.  Three additions and two fma fewer per Interstellar Euler step, whose
  * argument 1 + x^2 is >= 5 whenever x >= 2.  WHICH formula applies is a function of the argument alone (its
  * exponent), so cv_log stays one function with one value per argument on host and device. */
 /* log of the normal positive double with bits ux (hx = high word), plus k0 * ln 2 */
 CV_HD double cv_log_main(uint64_t ux, uint32_t hx, int k0, cv_log_tab_t T) {
   const double LN2_HI = 6.93147180369123816490e-01, /* 0x3FE62E42FEE00000 */
       LN2_LO = 1.90821492927058770002e-10;          /* 0x3DEA39EF35793C76 */
-  const int k = k0 + (int)(hx >> 20) - 0x3ff;
-  const unsigned i = (hx >> 12) & 0xffu;
+  const int e = k0 + (int)(hx >> 20) - 0x3fe; /* k + 1 */
+  const unsigned i = (hx >> 11) & 0x1ffu;
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t zh; /* (hx & 0xfffff) | 0x3ff00000 as ONE bit-field insert (the compiler emits and + or) */
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(zh) : "s"(0x000fffffu), "v"(hx), "v"(0x3ff00000u));
@@ -804,13 +806,11 @@ CV_HD double cv_log_main(uint64_t ux, uint32_t hx, int k0, cv_log_tab_t T) {
   const double z = cv_from_bits(((uint64_t)zh << 32) | (ux & 0xffffffffULL));
   const double invc = T[i][0], lch = T[i][1], lcl = T[i][2];
   const double r = CV_FMA(z, invc, -1.0);
-  const double kd = (double)k;
+  const double kd = (double)e;
   const double w = CV_FMA(kd, LN2_HI, lch);
-  if ((unsigned)(k + 1) >= 2u) { /* k >= 1 or k <= -2: |w| >= 0.69 */
-    const double p4 = cv_fma_ks(r, cv_fma_ks(r, cv_fma_ks(r, cv_fma_ks(r, -1.66666666666666657415e-01, 0.2), -0.25),
-                                             3.33333333333333314830e-01),
-                                -0.5);
-    return w + CV_FMA(r * r, p4, r + CV_FMA(kd, LN2_LO, lcl));
+  if ((unsigned)e >= 2u) { /* k >= 1 or k <= -2: |w| >= 0.69 */
+    const double p3 = cv_fma_ks(r, cv_fma_ks(r, cv_fma_ks(r, 0.2, -0.25), 3.33333333333333314830e-01), -0.5);
+    return w + CV_FMA(r * r, p3, r + CV_FMA(kd, LN2_LO, lcl));
   }
   const double hi = w + r;
   const double lo = ((w - hi) + r) + CV_FMA(kd, LN2_LO, lcl);
@@ -850,23 +850,22 @@ CV_HD double cv_log_ge2_t(double x, cv_log_tab_t T) {
   const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
   const uint64_t ux = cv_bits(x);
   const uint32_t hx = (uint32_t)(ux >> 32);
-  const int k = (int)(hx >> 20) - 0x3ff;
-  const unsigned i = (hx >> 12) & 0xffu;
+  const unsigned i = (hx >> 11) & 0x1ffu;
 #if defined(__HIP_DEVICE_COMPILE__)
+  const int e = __builtin_amdgcn_frexp_exp(x); /* v_frexp_exp_i32_f64: k + 1 for a normal number */
   uint32_t zh;
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(zh) : "s"(0x000fffffu), "v"(hx), "v"(0x3ff00000u));
 #else
+  const int e = (int)(hx >> 20) - 0x3fe;
   const uint32_t zh = (hx & 0x000fffffu) | 0x3ff00000u;
 #endif
   const double z = cv_from_bits(((uint64_t)zh << 32) | (ux & 0xffffffffULL));
   const double invc = T[i][0], lch = T[i][1], lcl = T[i][2];
   const double r = CV_FMA(z, invc, -1.0);
-  const double kd = (double)k;
+  const double kd = (double)e;
   const double w = CV_FMA(kd, LN2_HI, lch);
-  const double p4 = cv_fma_ks(r, cv_fma_ks(r, cv_fma_ks(r, cv_fma_ks(r, -1.66666666666666657415e-01, 0.2), -0.25),
-                                           3.33333333333333314830e-01),
-                              -0.5);
-  return w + CV_FMA(r * r, p4, r + CV_FMA(kd, LN2_LO, lcl));
+  const double p3 = cv_fma_ks(r, cv_fma_ks(r, cv_fma_ks(r, 0.2, -0.25), 3.33333333333333314830e-01), -0.5);
+  return w + CV_FMA(r * r, p3, r + CV_FMA(kd, LN2_LO, lcl));
 }
 
 CV_HD double cv_log(double x) { return cv_log_t(x, cv_log_table()); }

@@ -182,7 +182,7 @@ def random_scene(rng, res=(16, 9)):
 def table_edge_inputs():
     """Arguments on and next to every row boundary of the cv_math.h tables: atan rows (u = j/128 +- 1/256 for the
     direct branch, u = j/256 +- 1/512 with x = -1/u for the reciprocal branch, the 0.4375 / 2 / 2^66 switches) and log slices
-    (z = 1 + i/256, all exponents incl. subnormal scaling)."""
+    (z = 1 + i/512, all exponents incl. subnormal scaling)."""
     import math
     at, lg = [], []
     for j in range(56, 257):          # direct branch: rows at j/128
@@ -201,8 +201,8 @@ def table_edge_inputs():
                     at += [-1.0 / c, 1.0 / c]
     for x in (0.4375, 2.0, 2.0 ** 66, 128.0, 256.0):
         at += [x, math.nextafter(x, 0.0), math.nextafter(x, math.inf), -x]
-    for i in range(257):
-        z = 1.0 + i / 256.0
+    for i in range(513):
+        z = 1.0 + i / 512.0
         for zz in (math.nextafter(z, 0.0), z, math.nextafter(z, math.inf)):
             for k in (-1070, -1022, -60, -1, 0, 1, 2, 10, 1023):
                 try:
