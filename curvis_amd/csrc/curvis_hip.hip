@@ -2169,6 +2169,22 @@ int curvis_metric_validate(const curvis_metric *m) {
   }
 }
 
+int curvis_metric_functions(const curvis_metric *m, double l, double *r, double *r_squared, double *r_derivative) {
+  if (!m) return CURVIS_E_INVALID;
+  if (curvis_metric_validate(m) != CURVIS_OK) return CURVIS_E_METRIC;
+  const cvk::MetricParams MP = make_metric(*m);
+  double rr, r2, rd;
+  switch (m->kind) {
+    case CURVIS_METRIC_ELLIS: cvk::metric_eval<cvk::METRIC_ELLIS>(MP, l, rr, r2, rd); break;
+    case CURVIS_METRIC_INTERSTELLAR: cvk::metric_eval<cvk::METRIC_INTERSTELLAR>(MP, l, rr, r2, rd); break;
+    default: cvk::metric_eval<cvk::METRIC_FLAT>(MP, l, rr, r2, rd); break;
+  }
+  if (r) *r = rr;
+  if (r_squared) *r_squared = r2;
+  if (r_derivative) *r_derivative = rd;
+  return CURVIS_OK;
+}
+
 int curvis_render_brute(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
                         uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
                         curvis_stats *stats) {

@@ -19,7 +19,31 @@ from . import _abi
 from ._abi import CameraC, Metric, Stats, check, dptr, lib
 
 
-class EllisMetric:
+class _MetricFunctions:
+    """r(l), r_squared(l), r_derivative(l): the required methods of trait DiagonalSphericalMetric
+    (src/metrics.rs:40-48), through curvis_metric_functions (host-side, the kernels' arithmetic)."""
+
+    def _functions(self, l):
+        m = self._c()
+        out = (C.c_double * 3)()
+        rc = lib().curvis_metric_functions(C.byref(m), float(l), C.cast(C.byref(out, 0), C.POINTER(C.c_double)),
+                                           C.cast(C.byref(out, 8), C.POINTER(C.c_double)),
+                                           C.cast(C.byref(out, 16), C.POINTER(C.c_double)))
+        if rc != 0:
+            raise ValueError("invalid metric parameters")
+        return out[0], out[1], out[2]
+
+    def r(self, l):
+        return self._functions(l)[0]
+
+    def r_squared(self, l):
+        return self._functions(l)[1]
+
+    def r_derivative(self, l):
+        return self._functions(l)[2]
+
+
+class EllisMetric(_MetricFunctions):
     def __init__(self, rho):
         if not rho > 0.0:
             raise ValueError("The rho parameter for Ellis Metrics must be positive.")
@@ -29,7 +53,7 @@ class EllisMetric:
         return Metric(_abi.METRIC_ELLIS, 0, self.rho, 0.0, 0.0)
 
 
-class InterstellarMetric:
+class InterstellarMetric(_MetricFunctions):
     def __init__(self, m, a, rho):
         if not m > 0.0:
             raise ValueError("The mass parameter for Interstellar Metrics must be positive.")
@@ -43,7 +67,7 @@ class InterstellarMetric:
         return Metric(_abi.METRIC_INTERSTELLAR, 0, self.rho, self.m, self.a)
 
 
-class FlatSphericalMetric:
+class FlatSphericalMetric(_MetricFunctions):
     def _c(self):
         return Metric(_abi.METRIC_FLAT, 0, 0.0, 0.0, 0.0)
 

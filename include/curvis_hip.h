@@ -125,6 +125,10 @@ int curvis_orientation_init(const double forward[3], const double up[3], double 
                             double up_out[3]);
 /* EllisMetric::new / InterstellarMetric::new parameter checks (src/metrics.rs:407-459). */
 int curvis_metric_validate(const curvis_metric *m);
+/* The three required methods of trait DiagonalSphericalMetric (src/metrics.rs:40-48: r, r_squared, r_derivative;
+ * Ellis :417-421, Interstellar :467-485, flat :501-505) at radial coordinate l, evaluated on the host with the same
+ * arithmetic (cv_math.h) the kernels use -- what every ray of a render is integrated with.  Any output may be NULL. */
+int curvis_metric_functions(const curvis_metric *m, double l, double *r, double *r_squared, double *r_derivative);
 
 /* RelativisticSystem::render_image (src/systems.rs:307-330): one ray per pixel, forward-Euler
  * integration until |l| > max_radius or max_iterations steps, nearest-texel sky lookup.

@@ -157,3 +157,23 @@ def test_constructor_errors_mirror_reference_panics():
         curvis_amd.InterstellarMetric(0.1, -1.0, 1.0)
     m = _abi.Metric(_abi.METRIC_INTERSTELLAR, 0, 1.0, 0.0, 1e-4)
     assert _abi.lib().curvis_metric_validate(C.byref(m)) == _abi.E_METRIC
+
+
+def test_metric_trait_functions_match_oracle_bitwise():
+    """r, r_squared, r_derivative (the required methods of DiagonalSphericalMetric, src/metrics.rs:40-48) through
+    the ABI == oracle(cv flavour), bit for bit, incl. the Interstellar throat (|l| <= a) and negative l"""
+    rng = np.random.default_rng(8)
+    ls = np.concatenate([rng.uniform(-120, 120, 400), [0.0, -0.0, 1e-4, -1e-4, 5e-5, 0.31, -0.31, 5.0, -5.0, 100.0]])
+    cases = [(O.ellis(1.0), curvis_amd.EllisMetric(1.0)), (O.ellis(0.37), curvis_amd.EllisMetric(0.37)),
+             (O.interstellar(0.1, 1e-4, 1.0), curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0)),
+             (O.interstellar(0.5, 0.2, 2.0), curvis_amd.InterstellarMetric(0.5, 0.2, 2.0)), (O.flat(), curvis_amd.FlatSphericalMetric())]
+    for om, pm in cases:
+        for l in ls:
+            want = (O.lib().cvo_metric_r(O.CV, C.byref(om), l), O.lib().cvo_metric_r_squared(O.CV, C.byref(om), l),
+                    O.lib().cvo_metric_r_derivative(O.CV, C.byref(om), l))
+            got = (pm.r(l), pm.r_squared(l), pm.r_derivative(l))
+            assert np.array_equal(np.array(got).view(np.uint64), np.array(want).view(np.uint64)), (om.kind, l, got, want)
+    # KAT-1 of SURVEY.md 8c (glibc values; cv_math agrees on these arguments to the last bit or one ulp)
+    assert abs(curvis_amd.EllisMetric(1.0).r(5.0) - 5.0990195135927845) < 1e-15
+    assert abs(curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0).r(5.0) - 5.5538415248760264) < 2e-15
+    assert curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0).r(5e-5) == 1.0
