@@ -9,6 +9,7 @@ from ._abi import CurvisError, LIB_PATH, lib  # noqa: F401
 from .systems import (Camera, Context, EllisMetric, FlatSphericalMetric, InterstellarMetric,  # noqa: F401
                       RelativisticSystem, SphericalImage)
 from . import skies  # noqa: F401
+from . import images  # noqa: F401
 
 __all__ = ["Camera", "Context", "EllisMetric", "InterstellarMetric", "FlatSphericalMetric", "SphericalImage",
            "RelativisticSystem", "CurvisError", "skies"]

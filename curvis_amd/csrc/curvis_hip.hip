@@ -42,6 +42,7 @@
 #include "cv_efficient.h"
 #include "cv_host.h"
 #include "cv_sampler.h"
+#include "host/jpeg_io.h" /* PNG + JPEG decoders shared with the curvis binary */
 
 #pragma clang fp contract(off)
 
@@ -2345,6 +2346,30 @@ int curvis_compute_escape_angles(curvis_ctx *ctx, const curvis_metric *metric, d
     if (status[i] == cvk::ESC_PANIC) panic = true;
   }
   if (panic) return fail(ctx, CURVIS_E_PARALLEL, "v1 and v2 must not be parallel (src/algebra.rs:95-97) for at least one sample");
+  return CURVIS_OK;
+}
+
+int curvis_image_load(const char *path, uint8_t **rgba_out, uint32_t *w, uint32_t *h) {
+  if (!path || !rgba_out || !w || !h) return fail(nullptr, CURVIS_E_INVALID, "null argument");
+  *rgba_out = nullptr;
+  pngio::Image img;
+  std::string err;
+  if (!jpegio::load_image(path, img, err)) return fail(nullptr, CURVIS_E_IO, std::string(path) + ": " + err);
+  uint8_t *buf = (uint8_t *)std::malloc(img.rgba.size() ? img.rgba.size() : 1);
+  if (!buf) return fail(nullptr, CURVIS_E_IO, "out of memory");
+  std::memcpy(buf, img.rgba.data(), img.rgba.size());
+  *rgba_out = buf;
+  *w = img.w;
+  *h = img.h;
+  return CURVIS_OK;
+}
+
+void curvis_image_free(uint8_t *rgba) { std::free(rgba); }
+
+int curvis_image_save_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h) {
+  if (!path || !rgb || w == 0 || h == 0) return fail(nullptr, CURVIS_E_INVALID, "null argument or empty image");
+  std::string err;
+  if (!pngio::save_rgb8(path, rgb, w, h, err)) return fail(nullptr, CURVIS_E_IO, err);
   return CURVIS_OK;
 }
 

@@ -115,6 +115,55 @@ def render_image_sharded(context, metric, camera, max_iterations, max_radius, de
     return np.concatenate([p[1] for p in parts], axis=0), [p[0] for p in parts]
 
 
+class ImageRenderingSettings:
+    """ImageRenderingSettings (src/rendering.rs, fields as used by ImageRenderingSystem::new / render :33-117)."""
+
+    def __init__(self, path_to_background_image_1, path_to_background_image_2, path_to_output_folder, output_image_name,
+                 camera_position, camera_forward, camera_up, camera_focal_length=15.0, camera_diagonal=43.0,
+                 resolution_x=960, resolution_y=540, escape_radius=100.0, max_iterations_propagation=40000,
+                 ray_integration_step=0.05, alphas_num=100, max_iterations_sampling=100,
+                 sampling_convergence_threshold_1=1e-5, sampling_convergence_threshold_2=1e-5):
+        self.__dict__.update({k: v for k, v in locals().items() if k != "self"})
+
+
+class ImageRenderingSystem:
+    """ImageRenderingSystem<M> (src/rendering.rs:16-117): two backgrounds + Camera + RelativisticSystem; render()
+    calls render_image_efficient with the settings' seven arguments and saves <folder>/<name>.png (an existing
+    extension of the name is replaced, PathBuf::with_extension).  mode="brute" renders with the per-pixel
+    integrator instead (not in the reference's ImageRenderingSystem)."""
+
+    def __init__(self, metric, image_rendering_settings, context=None, mode="efficient"):
+        from .images import load_image_as_spherical_image
+        from .systems import RelativisticSystem
+        st = self.image_rendering_settings = image_rendering_settings
+        self.mode = mode
+        image_1 = load_image_as_spherical_image(st.path_to_background_image_1)
+        image_2 = load_image_as_spherical_image(st.path_to_background_image_2)
+        camera = Camera(st.camera_position, st.camera_forward, st.camera_up, st.camera_focal_length, st.camera_diagonal,
+                        st.resolution_x, st.resolution_y)
+        self.relativistic_system = RelativisticSystem(metric, image_1, image_2, camera, context=context)
+
+    def render(self):
+        import os
+        from .images import save_image
+        st = self.image_rendering_settings
+        folder = str(st.path_to_output_folder)
+        if not os.path.exists(folder):
+            try:
+                os.mkdir(folder)
+            except OSError as err:
+                raise RuntimeError("Could not create video output folder %r due to error: %s" % (folder, err))
+        if self.mode == "brute":
+            image = self.relativistic_system.render_image(st.max_iterations_propagation, st.escape_radius, st.ray_integration_step)
+        else:
+            image = self.relativistic_system.render_image_efficient(
+                st.max_iterations_propagation, st.escape_radius, st.ray_integration_step, st.alphas_num,
+                st.max_iterations_sampling, st.sampling_convergence_threshold_1, st.sampling_convergence_threshold_2)
+        path_of_image = os.path.join(folder, os.path.splitext(st.output_image_name)[0] + ".png")
+        save_image(path_of_image, image)
+        return path_of_image
+
+
 class VideoRenderingSystem:
     """VideoRenderingSystem<M> (src/rendering.rs:178-327) over one curvis Context per rank.
 

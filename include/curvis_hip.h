@@ -206,6 +206,17 @@ int curvis_new_photon(const curvis_metric *metric, const double position[4], con
 int curvis_photon_trajectories(curvis_ctx *ctx, const curvis_metric *metric, uint32_t n_photons, const double *x0,
                                const double *p0_cov, uint32_t iterations, double delta, double *out);
 
+/* images::load_image / save_image (src/images.rs:7-20; image::open / DynamicImage::save of image 0.25.2) for the
+ * two file formats this library decodes itself: PNG (every colour type and bit depth, converted to Rgba8 the way
+ * DynamicImage::get_pixel does: grey -> (v, v, v, 255), 16 bit -> (v + 128) / 257, palette and tRNS expanded) and
+ * JPEG (8-bit Huffman baseline / progressive; see csrc/host/jpeg_io.h on why JPEG is outside the pixel-parity
+ * claims); the format is taken from the file's signature.  *rgba_out is w*h*4 bytes owned by the library until
+ * curvis_image_free.  Errors: CURVIS_E_IO, message through curvis_last_error(NULL).  Host-only, no GPU needed. */
+int curvis_image_load(const char *path, uint8_t **rgba_out, uint32_t *w, uint32_t *h);
+void curvis_image_free(uint8_t *rgba);
+/* DynamicImage::ImageRgb8(..).save(path) as PNG (8-bit RGB, non-interlaced) */
+int curvis_image_save_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h);
+
 /* device framebuffer of the last render (RGB8, frames back to back) */
 int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes);
 int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);

@@ -245,3 +245,32 @@ def test_jpeg_decoder_against_libjpeg(tmp_path):
         p.write_bytes(bytes(b))
         r = run("selftest-png", p, tmp_path / "o.rgba")
         assert r.returncode in (0, 1), r.returncode
+
+
+def test_library_image_codecs_equal_the_binarys(tmp_path):
+    """curvis_image_load / curvis_image_save_rgb8 (the library's counterpart of images::load_image / save_image,
+    src/images.rs:7-20) are the binary's decoders: same texels for PNG and JPEG, errors as CurvisError"""
+    PIL = pytest.importorskip("PIL.Image")
+    import curvis_amd
+    from curvis_amd import images
+    img = _jpeg_test_image(33, 47)
+    files = []
+    for name, kw in (("a.jpg", dict(quality=88, subsampling=2)), ("b.jpg", dict(quality=88, progressive=True)), ("c.png", {})):
+        p = tmp_path / name
+        PIL.fromarray(img).save(p, **kw)
+        files.append(p)
+    pngio.write_png(tmp_path / "d.png", np.dstack([img, img[..., :1]]))     # RGBA
+    pngio.write_png(tmp_path / "e.png", img[..., 0])                        # grey
+    files += [tmp_path / "d.png", tmp_path / "e.png"]
+    for p in files:
+        assert np.array_equal(images.load_image(p), _decode_with_binary(p, tmp_path)), p.name
+    sky = images.load_image_as_spherical_image(tmp_path / "c.png")
+    assert (sky.width_pixels, sky.height_pixels) == (47, 33) and list(sky.forward) == [1.0, 0.0, 0.0] and list(sky.up) == [0.0, 0.0, 1.0]
+    images.save_image(tmp_path / "out.png", img)
+    assert np.array_equal(np.asarray(PIL.open(tmp_path / "out.png")), img)
+    with pytest.raises(curvis_amd.CurvisError) as e:
+        images.load_image(tmp_path / "missing.png")
+    assert e.value.code == -10
+    (tmp_path / "junk.png").write_bytes(b"not an image at all")
+    with pytest.raises(curvis_amd.CurvisError):
+        images.load_image(tmp_path / "junk.png")

@@ -171,3 +171,26 @@ def test_image_with_jpeg_skies(scene_files):
     om, oc, _, _ = common.scene("ellis", res=(96, 54))
     want, _, _ = O.render_image(O.CV, om, oc, O.sky(skies[0]), O.sky(skies[1]), 4096, 100.0, 0.05)
     assert np.array_equal(pngio.read_png(out / "output_image.png"), want)
+
+
+def test_python_image_rendering_system_equals_the_binary(scene_files):
+    """curvis_amd.rendering.ImageRenderingSystem (mirror of src/rendering.rs:16-117) over the same files as
+    `curvis image`: same PNG, name extension replaced like PathBuf::with_extension"""
+    import curvis_amd
+    d, sp, sn = scene_files
+    out_bin, out_py = d / "out_irs_bin", d / "out_irs_py"
+    out_bin.mkdir()
+    (d / "img.toml").write_text('image_name = "shot.final"\nt = 0.0\nl = 3.0\ntheta = 1.3\nphi = 0.7\nforward_x = -1.0\nforward_y = 0.2\n'
+                                'forward_z = 0.1\nup_x = 0.0\nup_y = 0.0\nup_z = 1.0\n')
+    r = run("image", d / "pos.png", d / "neg.png", out_bin, "-i", d / "img.toml", "-s", d / "sim.toml", "-c", d / "cam.toml")
+    assert r.returncode == 0, r.stderr
+    assert sorted(os.listdir(out_bin)) == ["shot.png"]            # with_extension("png") replaces ".final"
+    st = rendering.ImageRenderingSettings(d / "pos.png", d / "neg.png", out_py, "shot.final", (0.0, 3.0, 1.3, 0.7), (-1.0, 0.2, 0.1),
+                                          (0.0, 0.0, 1.0), 15.0, 43.0, 96, 54, 100.0, 4096, 0.05, 100, 100, 1e-5, 2e-5)
+    path = rendering.ImageRenderingSystem(curvis_amd.EllisMetric(1.0), st).render()   # creates the folder like the reference
+    assert os.path.basename(path) == "shot.png"
+    assert np.array_equal(pngio.read_png(path), pngio.read_png(out_bin / "shot.png"))
+    om = O.ellis(1.0)
+    oc = O.camera((0.0, 3.0, 1.3, 0.7), (-1.0, 0.2, 0.1), (0.0, 0.0, 1.0), 15.0, 43.0, (96, 54))
+    want, _, _ = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05, 100, 100, 1e-5, 2e-5)
+    assert np.array_equal(pngio.read_png(path), want)
