@@ -12,4 +12,4 @@ from . import skies  # noqa: F401
 from . import images  # noqa: F401
 
 __all__ = ["Camera", "Context", "EllisMetric", "InterstellarMetric", "FlatSphericalMetric", "SphericalImage",
-           "RelativisticSystem", "CurvisError", "skies"]
+           "RelativisticSystem", "CurvisError", "skies", "images"]
