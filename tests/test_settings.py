@@ -1,0 +1,96 @@
+"""curvis_amd.settings: the reference's settings groups (src/settings.rs), their TOML keys, validation messages and
+defaults -- and agreement with the `curvis` binary's C++ implementation on the same files."""
+import math
+import os
+import subprocess
+
+import pytest
+
+from curvis_amd import settings as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
+
+
+def test_defaults_are_the_reference_defaults():
+    c, s, i, v = S.CameraSettings(), S.SimulationSettings(), S.ImageSettings(), S.VideoSettings()
+    assert (c.resolution_x, c.resolution_y, c.diagonal, c.focal_length) == (960, 540, 43.0, 15.0)
+    assert (s.escape_radius, s.ray_integration_max_itarations, s.ray_integration_step) == (100.0, 40000, 0.05)
+    assert (s.sampling_initial_nums, s.sampling_max_iterations, s.sampling_convergence_threshold_1,
+            s.sampling_convergence_threshold_2) == (100, 50, 1e-5, 1e-5)
+    assert (i.image_name, i.l, i.theta, i.phi) == ("output_image", 5.0, math.pi / 2, 0.0)
+    assert (i.forward_x, i.forward_y, i.forward_z, i.up_x, i.up_y, i.up_z) == (-1.0, 0.0, 0.0, 0.0, 0.0, 1.0)
+    assert v.frame_rate == 30.0 and v.filepath_to_camera_path.endswith("path_through.csv")
+    assert S.EllisMetricSettings().rho == 1.0
+    m = S.InterstellarMetricSettings()
+    assert (m.m, m.a, m.rho) == (0.1, 1e-4, 1.0)
+    for g in (c, s, i, S.EllisMetricSettings(), m):
+        g.validate()
+
+
+@pytest.mark.parametrize("cls,kw,msg", [
+    (S.CameraSettings, dict(resolution_x=0), "The resolution in the x direction must be larger than zero."),
+    (S.CameraSettings, dict(diagonal=-1.0), "The diagonal of the camera must be larger than zero."),
+    (S.CameraSettings, dict(focal_length=0.0), "The focal length of the camera must be larger than zero."),
+    (S.SimulationSettings, dict(escape_radius=0.0), "The escape radius must be larger than zero."),
+    (S.SimulationSettings, dict(ray_integration_max_itarations=0), "The maximum number of iterations for the ray integration must be larger than zero."),
+    (S.SimulationSettings, dict(ray_integration_step=-0.05), "The step for the ray integration must be larger than zero."),
+    (S.SimulationSettings, dict(sampling_initial_nums=1), "The initial number of samples must be larger than two."),
+    (S.SimulationSettings, dict(sampling_convergence_threshold_2=0.0), "The second convergence threshold for the sampling must be larger than zero."),
+    (S.ImageSettings, dict(image_name=""), "Image name cannot be an empty string."),
+    (S.EllisMetricSettings, dict(rho=0.0), "The density parameter rho must be larger than zero."),
+    (S.InterstellarMetricSettings, dict(a=-1.0), "The spin parameter a must be larger than zero."),
+    (S.InterstellarMetricSettings, dict(m=0.0), "The mass parameter m must be larger than zero."),
+])
+def test_validation_messages(cls, kw, msg):
+    with pytest.raises(S.SettingsError) as e:
+        cls(**kw).validate()
+    assert str(e.value) == msg
+
+
+def test_toml_files_and_agreement_with_the_binary(tmp_path):
+    good = tmp_path / "sim.toml"
+    good.write_text("escape_radius = 50.0\nray_integration_max_itarations = 4096\nray_integration_step = 0.1\n"
+                    "sampling_initial_nums = 60\nsampling_max_iterations = 50\nsampling_convergence_threshold_1 = 1e-4\n"
+                    "sampling_convergence_threshold_2 = 2e-4\n")
+    s = S.SimulationSettings.from_toml_file(good)
+    assert (s.escape_radius, s.ray_integration_max_itarations, s.sampling_initial_nums) == (50.0, 4096, 60)
+    (tmp_path / "missing.toml").write_text("escape_radius = 50.0\n")
+    with pytest.raises(S.SettingsError) as e:
+        S.SimulationSettings.from_toml_file(tmp_path / "missing.toml")
+    assert "missing field `ray_integration_max_itarations`" in str(e.value)
+    (tmp_path / "x.txt").write_text("rho = 1.0\n")
+    with pytest.raises(S.SettingsError) as e:
+        S.EllisMetricSettings.from_toml_file(tmp_path / "x.txt")
+    assert "is not a toml file" in str(e.value)
+    # a metric file is tried as Interstellar first, then as Ellis (src/cli.rs:233-261)
+    (tmp_path / "ellis.toml").write_text("rho = 2.5\n")
+    (tmp_path / "inter.toml").write_text("m = 0.2\na = 0.001\nrho = 1.5\n")
+    assert isinstance(S.metric_settings_from_toml_file(tmp_path / "ellis.toml"), S.EllisMetricSettings)
+    im = S.metric_settings_from_toml_file(tmp_path / "inter.toml")
+    assert isinstance(im, S.InterstellarMetricSettings) and (im.m, im.a, im.rho) == (0.2, 0.001, 1.5)
+    # the binary rejects the same bad file with the same message
+    bad = tmp_path / "bad.toml"
+    bad.write_text(good.read_text().replace("escape_radius = 50.0", "escape_radius = -1.0"))
+    with pytest.raises(S.SettingsError) as e:
+        S.SimulationSettings.from_toml_file(bad)
+    from curvis_amd import pngio
+    import numpy as np
+    pngio.write_png(tmp_path / "a.png", np.zeros((4, 8, 3), np.uint8))
+    r = subprocess.run([BIN, "image", str(tmp_path / "a.png"), str(tmp_path / "a.png"), str(tmp_path), "-s", str(bad)],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and str(e.value) in r.stderr
+
+
+def test_wiring_into_the_rendering_settings_reproduces_the_reference_quirks(tmp_path):
+    sim = S.SimulationSettings(sampling_initial_nums=77, sampling_max_iterations=9, sampling_convergence_threshold_1=3e-5,
+                               sampling_convergence_threshold_2=7e-5)
+    st = S.image_rendering_settings("a.png", "b.png", tmp_path, simulation=sim)
+    # src/main.rs:46-47: alphas_num AND max_iterations_sampling take sampling_initial_nums; sampling_max_iterations is unused
+    assert (st.alphas_num, st.max_iterations_sampling) == (77, 77)
+    assert (st.sampling_convergence_threshold_1, st.sampling_convergence_threshold_2) == (3e-5, 7e-5)
+    assert st.camera_position == (0.0, 5.0, math.pi / 2, 0.0) and st.output_image_name == "output_image"
+    v = S.video_rendering_system(None, None, video=S.VideoSettings(frame_rate=24.0), simulation=sim)
+    assert len(v.times_of_frames()) == 480 and v.mode == "efficient"
+    # src/rendering.rs:305-306: the video path passes threshold_1 for both thresholds
+    assert (v.sampling_initial_nums, v.sampling_convergence_threshold_1) == (77, 3e-5)
