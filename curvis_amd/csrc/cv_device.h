@@ -244,7 +244,7 @@ CV_HD bool metric_fast_ok(int kind, const MetricParams &M, double max_radius) {
   if (kind == METRIC_INTERSTELLAR)
     ok = ok && hi_word_in(M.rho, CV_HI_2POW(-90), CV_HI_2POW(90)) && hi_word_in(M.m, CV_HI_2POW(-90), CV_HI_2POW(90)) &&
          hi_word_in(M.a, CV_HI_2POW(-300), CV_HI_2POW(90)) &&
-         /* x = 2(|l| - a)/(pi m) stays finite and far below overflow for every |l| <= max_radius (cv_atan_nonneg_t
+         /* x = 2(|l| - a)/(pi m) stays finite and far below overflow for every |l| <= max_radius (interstellar_eval_x_ge2
           * takes -1/x of it without range handling) */
          2.0 * max_radius * M.inv_pim < 0x1p200;
   return ok;

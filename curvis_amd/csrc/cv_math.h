@@ -603,18 +603,6 @@ CV_HD double cv_atan_t(double x, cv_atan_tab_t T) {
   return cv_from_bits(cv_bits(r) | (ux & 0x8000000000000000ULL));
 }
 
-/* the same value for a FINITE argument known to be >= +0 (the Interstellar radial coordinate x = 2(|l| - a)/(pi m),
- * which is >= 2 for all but the dozen steps a ray spends inside |l| < a + pi m): ONE compare selects the reciprocal
- * branch, which then needs neither the range test on the high word nor the select between x and -1/x (4 VALU
- * instructions per Euler step less than going through cv_atan_main).  For 2^66 <= x < inf the row step returns
- * X_0 + fma(u, Q, X_0lo) with |u| <= 2^-66, which rounds to the RN(pi/2) cv_atan_edge returns. */
-CV_HD double cv_atan_nonneg_t(double x, cv_atan_tab_t T) {
-  if (x >= 2.0) return cv_atan_row(cv_div_nr(-1.0, x), T);
-  const uint32_t ix = cv_hi(x);
-  if (ix < 0x3fdc0000u || ix >= 0x7ff00000u) return cv_atan_edge(x); /* x < 0.4375, or NaN */
-  return cv_atan_row_direct(x);
-}
-
 CV_HD double cv_atan(double x) { return cv_atan_t(x, cv_atan_table()); }
 
 CV_HD double cv_atan2(double y, double x) {
@@ -839,11 +827,6 @@ CV_HD double cv_log_t(double x, cv_log_tab_t T) {
   return cv_log_main(ux, hx, k, T);
 }
 
-/* the same value for a finite argument >= 1 (1 + x^2 of the Interstellar metric): none of the special cases */
-CV_HD double cv_log_ge1_t(double x, cv_log_tab_t T) {
-  const uint64_t ux = cv_bits(x);
-  return cv_log_main(ux, (uint32_t)(ux >> 32), 0, T);
-}
 /* the same value for a finite argument >= 2 (1 + x^2 with x >= 2: every Euler step outside |l| < a + pi m): only the
  * k >= 1 formula of cv_log_main, no test of k */
 CV_HD double cv_log_ge2_t(double x, cv_log_tab_t T) {
