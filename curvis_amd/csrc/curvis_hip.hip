@@ -231,10 +231,10 @@ __device__ __forceinline__ void store_ray(const RayStore &S, size_t o, const cvk
 __device__ __forceinline__ bool ray_escaped(double l, double R) { return __builtin_fabs(l) > R; }
 __device__ __forceinline__ int escape_code(double l) { return l > 0.0 ? cvk::CODE_POS : cvk::CODE_NEG; }
 
-template <int KIND, bool PHI, bool FAST>
+template <int KIND, bool PHI, bool FAST, bool EQ = false>
 __device__ __forceinline__ void one_step(const cvk::MetricParams &M, double delta, cvk::Ray &q, bool lane_ok) {
   if (FAST)
-    cvk::ray_step_fast<KIND, PHI, MathTablesLds<KIND>::WIDE_SC>(M, q, delta, lane_ok);
+    cvk::ray_step_fast<KIND, PHI, MathTablesLds<KIND>::WIDE_SC, EQ>(M, q, delta, lane_ok);
   else
     cvk::ray_step<KIND, PHI, MathTablesLds<KIND>::WIDE_SC>(M, q, delta);
 }
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParam
     unsigned k = 0;
     for (;;) {
       ++k;
-      one_step<KIND, true, FAST>(M, P.delta, q, lane_ok);
+      one_step<KIND, true, FAST, true>(M, P.delta, q, lane_ok); /* equatorial photons: see ray_step_fast */
       const bool esc = ray_escaped(q.l, P.max_radius);
       const unsigned long long em = __builtin_amdgcn_ballot_w64(esc);
       if (em) {

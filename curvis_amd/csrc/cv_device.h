@@ -250,10 +250,25 @@ CV_HD bool metric_fast_ok(int kind, const MetricParams &M, double max_radius) {
   return ok;
 }
 
-template <int KIND, bool PHI, bool WIDE_T = false>
+/* EQ (the sampling kernel of the efficient renderer only): every photon of compute_escape_angle starts at
+ * theta = fl(pi/2) with p_theta = 0 (src/systems.rs:221-230) and keeps that theta for ever, so
+ * while theta has exactly those bits the step is taken in its equatorial form: sin = 1 and cos = RN(pi/2 - fl(pi/2))
+ * are what cv_sincos returns for this argument, and with s = 1 the generic operations collapse EXACTLY --
+ * 1/s = 1, s^2 = s^3 = 1, p_phi^2/s^2 = p_phi^2 (zero remainder), r^2 s^3 = r^2, 1/(r^2 s^2) = 1/r^2 -- so
+ * the state is the generic step's bit for bit, with ~40 of ~95 instructions less in the dependency chain of the
+ * lone waves these launches consist of.  A ray whose theta has moved takes the generic step (never observed). */
+template <int KIND, bool PHI, bool WIDE_T = false, bool EQ = false>
 CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_ok) {
   double s, c;
-  const int s_ok = cv_sincos_guarded(q.th, M.T, WIDE_T ? 1 : 0, &s, &c);
+  int s_ok;
+  const bool eq = EQ && cv_bits(q.th) == 0x3FF921FB54442D18ULL;
+  if (eq) {
+    s = 1.0;
+    c = 6.123233995736766036e-17; /* 0x3C91A62633145C07 */
+    s_ok = 1;
+  } else {
+    s_ok = cv_sincos_guarded(q.th, M.T, WIDE_T ? 1 : 0, &s, &c);
+  }
   /* guard (branch-free, one compare each): sin(theta) and l non-zero, not NaN and far from the underflow
    * limit.  Upper bounds are implied: |sin| <= 1, and a step is only executed for a ray that has not
    * escaped, |l| <= max_radius < 2^90 (metric_fast_ok; an infinite l has escaped, a NaN fails the compare).
@@ -279,6 +294,27 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
   } else {
     metric_eval<KIND>(M, q.l, r, r2, rd);
     y_r = recip_refined(r);
+  }
+  if (eq) { /* s == 1: see above; same operations as below with the factors that are exactly 1 left out */
+    const double y_r2e = y_r * y_r;
+    const double g22e = div_with_recip(1.0, r2, y_r2e);
+    const double b2e = q.p2 * q.p2 + q.p3sq;
+    const double nume = b2e * rd;
+    const double r3e = r * (r * r);
+    double dp1e = div_with_recip(nume, r3e, y_r2e * y_r);
+    if (!is_normal_number(dp1e)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("; IEEE division for dp_l (equatorial step)");
+#endif
+      dp1e = nume / r3e;
+    }
+    const double dp2e = q.p3sq * div_with_recip(c, r2, y_r2e);
+    if (PHI) q.ph = q.ph + (q.p3 * g22e) * delta;
+    q.l = q.l + q.p1 * delta;
+    q.th = q.th + (q.p2 * g22e) * delta;
+    q.p1 = q.p1 + dp1e * delta;
+    q.p2 = q.p2 + dp2e * delta;
+    return;
   }
   const double y_s = recip_refined(s);
   const double y_r2 = y_r * y_r;

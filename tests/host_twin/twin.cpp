@@ -110,7 +110,7 @@ static int escape_angle_host(const cvk::MetricParams &M, double l, double alpha,
   steps = 0;
   int code = cvk::CODE_NONE;
   while (steps < max_iter) {
-    if (fast) cvk::ray_step_fast<KIND, true>(M, q, delta, lane_ok);
+    if (fast) cvk::ray_step_fast<KIND, true, false, true>(M, q, delta, lane_ok); /* EQ: the sampling kernel's equatorial form */
     else cvk::ray_step<KIND, true>(M, q, delta);
     ++steps;
     if (q.l > R) { code = cvk::CODE_POS; break; }
