@@ -304,6 +304,15 @@ def main():
                 "traffic_detail": traffic_note,
                 "valu_busy_pmc": traffic_note.get("valu_busy") if isinstance(traffic_note, dict) else None,
                 "valu_instr_per_wave_step_pmc": traffic_note.get("valu_instr_per_wave_step") if isinstance(traffic_note, dict) else None,
+                # what the FP64 pipe really executed: instruction mix from the committed PMC profile (fma counted as
+                # two operations) x the steps and the kernel time of THIS run
+                "executed_fp64": ({"ops_per_lane_step": traffic_note["fp64_ops_executed_per_lane_step"],
+                                   "achieved": round(per_launch_steps * traffic_note["fp64_ops_executed_per_lane_step"] / kernel_s / 1e12, 3),
+                                   "unit": "TFLOP/s",
+                                   "frac": round(per_launch_steps * traffic_note["fp64_ops_executed_per_lane_step"] / kernel_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4),
+                                   "mix_per_wave_step": {k: traffic_note.get("fp64_%s_per_wave_step" % k) for k in ("fma", "mul", "add", "trans")},
+                                   "note": "SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 of the committed profile; the algorithmic figure above counts a division, a square root or a sine as ONE flop"}
+                                  if isinstance(traffic_note, dict) and "fp64_ops_executed_per_lane_step" in traffic_note else None),
                 "hbm": {"achieved": round(hbm_gbps, 4), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(hbm_gbps / HBM_PEAK_GBPS, 8),
                         "note": "7 B/ray algorithmic; the loop is register-resident, HBM fraction is ~0 by construction"},

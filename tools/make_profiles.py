@@ -91,6 +91,26 @@ for name in sorted(os.listdir(G)):
     lines.append("| algorithmic FP64 rate (%d flop/step) | %.2f TFLOP/s = %.4f of 78.6 |" % (flop, bench["roofline"]["achieved"], bench["roofline"]["frac"]))
     lines.append("| HBM traffic of the kernel (PMC) vs algorithmic (7 B/ray) | read %.2f MB + write %.2f MB vs %.2f MB |" % (
         fetch_b / 1e6, write_b / 1e6, 7 * rays / 1e6))
+    mix = {}
+    for part in ("pmc_mix1", "pmc_mix2"):
+        f = os.path.join(d, part, "pmc_counter_collection.csv")
+        if os.path.exists(f):
+            mix.update({c: v for (k, c), v in pmc(f).items() if k == kern})
+            shutil.copy(f, os.path.join(P, "%s_%s_%s.csv" % (rnd, name, part)))
+    if "SQ_INSTS_VALU_FMA_F64" in mix:
+        fma, mul, add, trans = (mix.get("SQ_INSTS_VALU_" + n, 0.0) / ws for n in ("FMA_F64", "MUL_F64", "ADD_F64", "TRANS_F64"))
+        lines.append("| FP64 instructions per wave-step: fma / mul / add / transcendental (rcp, rsq) | %.1f / %.1f / %.1f / %.1f |" % (fma, mul, add, trans))
+        hw = (2 * fma + mul + add + trans) * 64 * ws / (bench["roofline"]["kernel_ms_avg"] * 1e-3) / 1e12
+        lines.append("| FP64 operations the hardware executed (fma = 2) | %.1f per lane-step = %.2f TFLOP/s = %.3f of 78.6 |" % (
+            2 * fma + mul + add + trans, hw, hw / 78.6))
+        traffic[key].update({"fp64_fma_per_wave_step": round(fma, 2), "fp64_mul_per_wave_step": round(mul, 2),
+                             "fp64_add_per_wave_step": round(add, 2), "fp64_trans_per_wave_step": round(trans, 2),
+                             "fp64_ops_executed_per_lane_step": round(2 * fma + mul + add + trans, 2)})
+    if "SQ_INSTS_VALU_INT32" in mix:
+        lines.append("| other VALU per wave-step: int32 / conversions; LDS instructions per wave-step | %.1f / %.1f; %.1f |" % (
+            mix["SQ_INSTS_VALU_INT32"] / ws, mix.get("SQ_INSTS_VALU_CVT", 0.0) / ws, mix.get("SQ_INSTS_LDS", 0.0) / ws))
+        if mix.get("SQ_ACTIVE_INST_LDS"):
+            lines.append("| LDS bank-conflict cycles / LDS active cycles | %.3f |" % (mix.get("SQ_LDS_BANK_CONFLICT", 0.0) / mix["SQ_ACTIVE_INST_LDS"]))
     if "cpu_baseline" in bench:
         lines.append("| CPU baseline (oracle, 1 thread) | %.2f %s; %s |" % (bench["cpu_baseline"]["value"], bench["cpu_baseline"]["unit"], bench["cpu_baseline"]["sample"]))
     lines.append("")
