@@ -59,6 +59,7 @@ SYMBOLS = {
     "curvis_ctx_set_sky_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_int]),
     "curvis_ctx_set_sky_orientation": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "curvis_ctx_bcast_skies": (C.c_int, [_vp, _vp, C.c_int]),
+    "curvis_ctx_read_sky": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, _vp]),
     "curvis_camera_init": (C.c_int, [C.POINTER(CameraC), _dp, _dp, _dp, C.c_double, C.c_double, C.c_uint32, C.c_uint32]),
     "curvis_orientation_init": (C.c_int, [_dp, _dp, _dp, _dp, _dp]),
     "curvis_metric_validate": (C.c_int, [C.POINTER(Metric)]),

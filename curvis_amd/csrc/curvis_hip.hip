@@ -2119,6 +2119,18 @@ int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root) {
   return CURVIS_OK;
 }
 
+int curvis_ctx_read_sky(curvis_ctx *ctx, int which, size_t offset, size_t bytes, uint8_t *out) {
+  if (!ctx || !out || which < 0 || which > 1) return fail(ctx, CURVIS_E_INVALID, "bad argument");
+  if (!ctx->d_sky[which]) return fail(ctx, CURVIS_E_NO_SKY, "sky not set");
+  const size_t total = (size_t)ctx->sky_w[which] * ctx->sky_h[which] * 4;
+  if (offset > total || bytes > total - offset) return fail(ctx, CURVIS_E_INVALID, "range outside the texture");
+  if (bytes == 0) return CURVIS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(out, (const uint8_t *)ctx->d_sky[which] + offset, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CURVIS_OK;
+}
+
 int curvis_orientation_init(const double forward[3], const double up[3], double rot[9], double inv_rot[9],
                             double up_out[3]) {
   if (!forward || !up) return CURVIS_E_INVALID;

@@ -824,6 +824,20 @@ int video_main(const Args &a) {
     if (use_rccl) {
       if (rank == 0) upload_skies(ctx, c, "video");
       check(curvis_ctx_bcast_skies(ctx, comms[rank], 0), ctx, "video");
+      /* every GPU checks what arrived over xGMI against the decoded files (head, middle and tail of both textures):
+       * a broken broadcast must stop the run, not colour its frames */
+      const pngio::Image *sk[2] = {&c.sky1, &c.sky2};
+      for (int w = 0; w < 2; ++w) {
+        const size_t total = sk[w]->rgba.size(), piece = std::min<size_t>(total, (size_t)1 << 16);
+        std::vector<uint8_t> got(piece);
+        for (size_t off : {(size_t)0, (total - piece) / 2, total - piece}) {
+          check(curvis_ctx_read_sky(ctx, w, off, piece, got.data()), ctx, "video");
+          if (std::getenv("CURVIS_TEST_CORRUPT_BCAST")) got[piece / 2] ^= 0x10;  /* test hook: pretend a flipped bit */
+          if (std::memcmp(got.data(), sk[w]->rgba.data() + off, piece) != 0)
+            die("Error in rendering video: background " + std::to_string(w + 1) + " arrived corrupted on device " +
+                std::to_string(a.device + rank) + " after the RCCL broadcast");
+        }
+      }
     } else {
       upload_skies(ctx, c, "video");
     }

@@ -178,6 +178,12 @@ class Context:
               self._h)
         self._sky_objs[which] = None
 
+    def read_sky(self, which, offset, nbytes):
+        """bytes [offset, offset + nbytes) of sky texture `which` as it sits in HBM (RGBA8, row-major)"""
+        out = np.empty(int(nbytes), dtype=np.uint8)
+        check(lib().curvis_ctx_read_sky(self._h, int(which), int(offset), int(nbytes), out.ctypes.data), self._h)
+        return out
+
     def set_option(self, key, value):
         check(lib().curvis_ctx_set_option(self._h, key.encode(), int(value)), self._h)
 

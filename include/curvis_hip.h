@@ -117,6 +117,10 @@ int curvis_ctx_set_sky_orientation(curvis_ctx *ctx, int which, const double forw
  * Non-root ranks need no prior set_sky: their textures are allocated from the broadcast shapes. */
 int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root);
 
+/* Read back `bytes` bytes at byte offset `offset` of sky texture `which` from HBM (e.g. to verify on every rank that
+ * a broadcast texture equals the root's file). */
+int curvis_ctx_read_sky(curvis_ctx *ctx, int which, size_t offset, size_t bytes, uint8_t *out);
+
 /* Camera::new (src/cameras.rs:79-122) incl. Orientation::new (src/algebra.rs:16-38). */
 int curvis_camera_init(curvis_camera *out, const double pos[4], const double forward[3], const double up[3],
                        double focal_length, double sensor_diagonal, uint32_t res_x, uint32_t res_y);

@@ -144,6 +144,12 @@ def test_video_rccl_sky_broadcast_path(scene_files):
         outs.append(out)
     names = sorted(os.listdir(outs[0] / "tmp"))
     assert names == sorted(os.listdir(outs[1] / "tmp")) and len(names) == 6
+    # every rank checks the broadcast textures against the decoded files; a flipped bit stops the run
+    bad = d / "out_vid_bad"
+    bad.mkdir()
+    r = run("video", d / "pos.png", d / "neg.png", bad, "-v", d / "vid3.toml", "-s", d / "sim.toml", "-c", d / "cam.toml",
+            "--sky-broadcast", "rccl", env=dict(os.environ, CURVIS_FORCE_RCCL="1", CURVIS_TEST_CORRUPT_BCAST="1"))
+    assert r.returncode != 0 and "arrived corrupted" in r.stderr, (r.returncode, r.stderr)
     for n in names:
         assert np.array_equal(pngio.read_png(outs[0] / "tmp" / n), pngio.read_png(outs[1] / "tmp" / n))
 

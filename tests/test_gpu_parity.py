@@ -455,6 +455,11 @@ def test_rccl_sky_broadcast_entry_point(gpu_ctx):
         gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
         before, _ = gpu_ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
         _abi.check(_abi.lib().curvis_ctx_bcast_skies(gpu_ctx._h, comm, 0), gpu_ctx._h)
+        # what sits in HBM after the broadcast is the texture that went in (curvis_ctx_read_sky, used by the binary to
+        # verify a broadcast on every GPU)
+        assert np.array_equal(gpu_ctx.read_sky(0, 0, sp.size), sp.ravel()) and np.array_equal(gpu_ctx.read_sky(1, 1024, 4096), sn.ravel()[1024:5120])
+        with pytest.raises(curvis_amd.CurvisError):
+            gpu_ctx.read_sky(1, sn.size - 10, 11)
         after, _ = gpu_ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
         want, _, _ = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
         assert np.array_equal(before, want) and np.array_equal(after, want)
