@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true",
                     help="report roofline.traffic as null when profiles/traffic.json has no entry for this workload "
                          "(default: such a run fails, so a missing PMC profile cannot go unnoticed)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not re-run this workload under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` after the "
+                         "timed region (two short child runs, N = 1 only); roofline.traffic then comes from the "
+                         "committed profile alone")
     ap.add_argument("--multi-frame", type=int, default=6,
                     help="frames per launch of the secondary multi-frame measurement (value_multi_frame); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -260,6 +264,21 @@ def main():
         kernel_name = ("geodesic_persistent" if args.variant == 0 else
                        "geodesic_relay" if ctx.get_option("last_relay_launches") > 0 else "geodesic_static")
         traffic, traffic_note = pmc_traffic(args, kernel_name)
+        being_profiled = any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH", "ROCPROFILER_LIBRARY_CTOR"))
+        if world == 1 and not args.no_live_traffic and not being_profiled:  # never a profiler inside a profiler
+            live_bytes, live = live_traffic(args, kernel_name)
+            if not isinstance(traffic_note, dict):
+                traffic_note = {}
+            if live_bytes is not None:
+                traffic_note["committed_profile_bytes"] = traffic
+                traffic_note.update({k: live[k] for k in ("integrate_kernel_bytes", "integrate_fetch_bytes", "integrate_write_bytes")})
+                traffic_note["live"] = live
+                traffic_note["measured_in_this_run"] = True
+                traffic_note["origin"] = ("bytes: PMC passes made by this run (see `live`); instruction counts and VALU busy: "
+                                          "committed profile (see `source`)")
+                traffic = live_bytes
+            else:
+                traffic_note["live"] = {"failed": live}
         out = {
             "metric": "Mrays/s (pixels x steps/s) at 1920x1080, 4096 steps",
             "value": round(value, 1),
@@ -361,6 +380,69 @@ def pmc_traffic(args, kernel_name):
         if args.no_traffic:
             return None, {"measured_in_this_run": False, "note": "profiles/traffic.json unavailable: %s" % exc}
         raise SystemExit("bench.py: profiles/traffic.json unavailable: %s" % exc)
+
+
+def live_traffic(args, kernel_name):
+    """HBM bytes per launch of `kernel_name`, observed in THIS run: two child runs of this same workload (4 launches
+    each) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, no trace domain next to the
+    counters, KiB -> bytes, FETCH doubled (gfx950: 128-byte requests are counted as 64; MI355X_MICROARCH.md).  Runs
+    after the timed region; every failure (no rocprofv3, time limit, unreadable output) returns (None, reason) and the
+    committed profile is reported instead."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1",
+             "--width", str(args.width), "--height", str(args.height), "--max-iter", str(args.max_iter),
+             "--metric", args.metric, "--sky", str(args.sky), "--variant", str(args.variant),
+             "--fast-math", str(args.fast_math), "--fuse-shade", str(args.fuse_shade), "--multi-frame", "0",
+             "--no-traffic", "--no-live-traffic", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    got = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="curvis_pmc_", dir="/tmp")
+        try:
+            proc = subprocess.Popen([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child,
+                                    cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)  # the group this call started, nothing else
+                proc.wait()
+                return None, "rocprofv3 --pmc %s exceeded 150 s" % counter
+            if rc != 0:
+                return None, "rocprofv3 --pmc %s exited with %d" % (counter, rc)
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for r in csv.DictReader(f):
+                        if kernel_name in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                            vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows for %s in the rocprofv3 output" % (counter, kernel_name)
+            vals.sort()  # median over the launches: the first touch of a buffer shows a several-fold FETCH_SIZE
+            n = len(vals)
+            got[counter] = (vals[n // 2] if n % 2 else 0.5 * (vals[n // 2 - 1] + vals[n // 2]), n)
+        except OSError as exc:
+            return None, "rocprofv3 --pmc %s: %s" % (counter, exc)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_b, write_b = got["FETCH_SIZE"][0] * 1024.0 * 2.0, got["WRITE_SIZE"][0] * 1024.0
+    return int(fetch_b + write_b), {
+        "integrate_kernel_bytes": int(fetch_b + write_b), "integrate_fetch_bytes": int(fetch_b), "integrate_write_bytes": int(write_b),
+        "launches_sampled": {"FETCH_SIZE": got["FETCH_SIZE"][1], "WRITE_SIZE": got["WRITE_SIZE"][1]},
+        "seconds": round(time.perf_counter() - t0, 1),
+        "source": "this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two separate child runs of the same workload "
+                  "(1 warm-up + 3 launches each, median over the launches, KiB -> bytes, FETCH doubled per the gfx950 note in "
+                  "MI355X_MICROARCH.md)"}
 
 
 def cpu_baseline(args, host_skies):

@@ -13,7 +13,7 @@ run_workload() { # name, bench arguments...
   local name=$1; shift
   local d=$OUT/$name; mkdir -p "$d"
   cd "$ROOT"
-  python bench.py "$@" --no-traffic > "$d/bench.json" 2> "$d/bench.err"
+  python bench.py "$@" --no-traffic --no-live-traffic > "$d/bench.json" 2> "$d/bench.err"
   cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d "$d/stats" -o bench -- python "$ROOT/bench.py" "$@" --no-traffic --no-cpu-baseline --multi-frame 0 > "$d/stats.log" 2>&1
   rocprofv3 --pmc $SQ --output-format csv -d "$d/pmc_sq" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 > "$d/pmc_sq.log" 2>&1
