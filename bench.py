@@ -266,7 +266,7 @@ def main():
         traffic, traffic_note = pmc_traffic(args, kernel_name)
         being_profiled = any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH", "ROCPROFILER_LIBRARY_CTOR"))
         if world == 1 and not args.no_live_traffic and not being_profiled:  # never a profiler inside a profiler
-            live_bytes, live = live_traffic(args, kernel_name)
+            live_bytes, live = live_traffic(args, kernel_name, per_launch_steps)
             if not isinstance(traffic_note, dict):
                 traffic_note = {}
             if live_bytes is not None:
@@ -274,9 +274,12 @@ def main():
                 traffic_note.update({k: live[k] for k in ("integrate_kernel_bytes", "integrate_fetch_bytes", "integrate_write_bytes")})
                 traffic_note["live"] = live
                 traffic_note["measured_in_this_run"] = True
-                traffic_note["origin"] = ("bytes: PMC passes made by this run (see `live`); instruction counts and VALU busy: "
-                                          "committed profile (see `source`)")
+                traffic_note["origin"] = ("bytes, VALU busy and instructions per wave-step: PMC passes made by this run (see "
+                                          "`live`); FP64 instruction mix: committed profile (see `source`)")
                 traffic = live_bytes
+                if "sq" in live:  # the live SQ pass replaces the committed figures below
+                    traffic_note["committed_profile_sq"] = {k: traffic_note.get(k) for k in ("valu_busy", "valu_instr_per_wave_step", "salu_instr_per_wave_step")}
+                    traffic_note.update({k: live["sq"][k] for k in ("valu_busy", "valu_instr_per_wave_step", "salu_instr_per_wave_step")})
             else:
                 traffic_note["live"] = {"failed": live}
         out = {
@@ -382,7 +385,7 @@ def pmc_traffic(args, kernel_name):
         raise SystemExit("bench.py: profiles/traffic.json unavailable: %s" % exc)
 
 
-def live_traffic(args, kernel_name):
+def live_traffic(args, kernel_name, steps_per_launch):
     """HBM bytes per launch of `kernel_name`, observed in THIS run: two child runs of this same workload (4 launches
     each) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, no trace domain next to the
     counters, KiB -> bytes, FETCH doubled (gfx950: 128-byte requests are counted as 64; MI355X_MICROARCH.md).  Runs
@@ -404,12 +407,13 @@ def live_traffic(args, kernel_name):
              "--no-traffic", "--no-live-traffic", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["TMPDIR"] = "/tmp"
-    got = {}
-    t0 = time.perf_counter()
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    SQ = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")
+
+    def one_pass(counters):
+        """{counter: (median over the launches, launches)} of one child run, or a string saying why not"""
         d = tempfile.mkdtemp(prefix="curvis_pmc_", dir="/tmp")
         try:
-            proc = subprocess.Popen([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child,
+            proc = subprocess.Popen([exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child,
                                     cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                     start_new_session=True)
             try:
@@ -417,32 +421,58 @@ def live_traffic(args, kernel_name):
             except subprocess.TimeoutExpired:
                 os.killpg(proc.pid, signal.SIGKILL)  # the group this call started, nothing else
                 proc.wait()
-                return None, "rocprofv3 --pmc %s exceeded 150 s" % counter
+                return "rocprofv3 --pmc %s exceeded 150 s" % " ".join(counters)
             if rc != 0:
-                return None, "rocprofv3 --pmc %s exited with %d" % (counter, rc)
-            vals = []
+                return "rocprofv3 --pmc %s exited with %d" % (" ".join(counters), rc)
+            vals = {c: [] for c in counters}
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
                     for r in csv.DictReader(f):
-                        if kernel_name in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-                            vals.append(float(r["Counter_Value"]))
-            if not vals:
-                return None, "no %s rows for %s in the rocprofv3 output" % (counter, kernel_name)
-            vals.sort()  # median over the launches: the first touch of a buffer shows a several-fold FETCH_SIZE
-            n = len(vals)
-            got[counter] = (vals[n // 2] if n % 2 else 0.5 * (vals[n // 2 - 1] + vals[n // 2]), n)
+                        if kernel_name in r.get("Kernel_Name", "") and r.get("Counter_Name") in vals:
+                            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            res = {}
+            for c, v in vals.items():
+                if not v:
+                    return "no %s rows for %s in the rocprofv3 output" % (c, kernel_name)
+                v.sort()  # median over the launches: the first touch of a buffer shows a several-fold FETCH_SIZE
+                n = len(v)
+                res[c] = (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]), n)
+            return res
         except OSError as exc:
-            return None, "rocprofv3 --pmc %s: %s" % (counter, exc)
+            return "rocprofv3 --pmc %s: %s" % (" ".join(counters), exc)
         finally:
             shutil.rmtree(d, ignore_errors=True)
+
+    t0 = time.perf_counter()
+    got = {}
+    for counters in (("FETCH_SIZE",), ("WRITE_SIZE",)):
+        res = one_pass(counters)
+        if isinstance(res, str):
+            return None, res
+        got.update(res)
     fetch_b, write_b = got["FETCH_SIZE"][0] * 1024.0 * 2.0, got["WRITE_SIZE"][0] * 1024.0
-    return int(fetch_b + write_b), {
+    live = {
         "integrate_kernel_bytes": int(fetch_b + write_b), "integrate_fetch_bytes": int(fetch_b), "integrate_write_bytes": int(write_b),
         "launches_sampled": {"FETCH_SIZE": got["FETCH_SIZE"][1], "WRITE_SIZE": got["WRITE_SIZE"][1]},
-        "seconds": round(time.perf_counter() - t0, 1),
         "source": "this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two separate child runs of the same workload "
                   "(1 warm-up + 3 launches each, median over the launches, KiB -> bytes, FETCH doubled per the gfx950 note in "
                   "MI355X_MICROARCH.md)"}
+    # third pass, SQ counters: what the issue-bound roofline is argued from (VALU instructions per wave-step, VALU busy)
+    sq = one_pass(SQ)
+    if isinstance(sq, str):
+        live["sq_failed"] = sq
+    else:
+        wave_steps = steps_per_launch / 64.0
+        gui = sq["GRBM_GUI_ACTIVE"][0] / 8.0  # summed over the 8 XCDs
+        live["sq"] = {"valu_instr_per_wave_step": round(sq["SQ_INSTS_VALU"][0] / wave_steps, 1),
+                      "salu_instr_per_wave_step": round(sq["SQ_INSTS_SALU"][0] / wave_steps, 1),
+                      "valu_busy": round(4 * sq["SQ_ACTIVE_INST_VALU"][0] / (1024 * gui), 4),
+                      "shader_cycles_per_launch": int(gui),
+                      "cycles_per_wave_step_per_simd": round(gui * 1024 / wave_steps, 1),
+                      "source": "this run: rocprofv3 --pmc " + " ".join(SQ) + " (third child run); busy = 4 x "
+                                "SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}
+    live["seconds"] = round(time.perf_counter() - t0, 1)
+    return int(fetch_b + write_b), live
 
 
 def cpu_baseline(args, host_skies):
