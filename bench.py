@@ -69,6 +69,15 @@ def parse():
     return ap.parse_args()
 
 
+def flush_c_stdio():
+    """fflush(NULL): whatever native libraries left in the C stdio buffers goes out now, not at exit"""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def self_launch(args):
     """--gpus N > 1 from a plain shell: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`"""
     import torch
@@ -118,9 +127,22 @@ def main():
     backend = os.environ.get("CURVIS_BENCH_BACKEND", "gloo" if share_device else "nccl")
     torch.cuda.set_device(device_index)
     dist = None
-    if world > 1:
+    # test hook (1-GPU boxes): CURVIS_BENCH_FORCE_DIST=1 takes the N > 1 code path -- process group on RCCL, all-reduce
+    # check, sky broadcast, barriers, reductions -- with a single rank
+    use_dist = world > 1 or os.environ.get("CURVIS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL writes a version banner to the C stdout when a communicator comes up: while that happens (process group,
+        # first collective below) file descriptor 1 points at stderr, so the job's stdout carries the JSON line only
+        flush_c_stdio()
+        sys.stdout.flush()
+        saved_stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -142,7 +164,7 @@ def main():
         host_skies = (skies.smooth(sw, sh, 128), skies.smooth(sw, sh, 32))
     sky_dev = []
     comm_info = None
-    if world > 1:
+    if use_dist:
         # how many ranks the collective backend really spans (an all-reduce of ones on the device), before it is
         # trusted with the skies
         one = torch.ones(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -151,8 +173,11 @@ def main():
                      "allreduce_of_ones": int(one.item()), "sky_bytes_each": sw * sh * 4, "sky_broadcast_ms": []}
         if comm_info["allreduce_of_ones"] != world:
             raise SystemExit("bench.py: the %s communicator spans %d ranks, not %d" % (backend, comm_info["allreduce_of_ones"], world))
+        flush_c_stdio()
+        os.dup2(saved_stdout_fd, 1)  # banner written (to stderr); stdout is the job's again
+        os.close(saved_stdout_fd)
     for which in range(2):
-        if world > 1:
+        if use_dist:
             t = torch.empty((sh, sw, 4), dtype=torch.uint8, device="cuda")
             if rank == 0:
                 t.copy_(torch.from_numpy(host_skies[which]))
@@ -344,12 +369,20 @@ def main():
             out["collective"] = comm_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, host_skies)
-        print(json.dumps(out), flush=True)
 
+    # The JSON line must be the LAST thing on the job's stdout: libraries (RCCL's banner) write to the C stdout, which is
+    # block-buffered when redirected and would otherwise be flushed at exit, after the line.  So: tear everything down,
+    # flush the C streams on every rank, meet once more, and only then rank 0 prints.
     ctx.close()
     if dist is not None:
         dist.barrier()
+        flush_c_stdio()
+        dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 def pmc_traffic(args, kernel_name):
@@ -405,7 +438,7 @@ def live_traffic(args, kernel_name, steps_per_launch):
              "--metric", args.metric, "--sky", str(args.sky), "--variant", str(args.variant),
              "--fast-math", str(args.fast_math), "--fuse-shade", str(args.fuse_shade), "--multi-frame", "0",
              "--no-traffic", "--no-live-traffic", "--no-cpu-baseline"]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CURVIS_BENCH_FORCE_DIST")}
     env["TMPDIR"] = "/tmp"
     SQ = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")
 
