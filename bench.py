@@ -528,6 +528,27 @@ def cpu_baseline(args, host_skies):
         d1 = time.perf_counter() - t1
         c1 = {"workload": "config 1 in full: 256x144, cap 40000", "rays": int(st1.rays), "steps": int(st1.steps),
               "seconds": round(d1, 2), "value": round(st1.steps / d1 / 1e6, 2)}
+    # SURVEY 8d, optional: the same restatement on all host cores (rows striped over threads; ctypes drops the GIL) --
+    # NOT the reference's configuration (it is single-threaded, README.md:110), shown for scale only
+    allc = None
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        T = max(1, min(64, (os.cpu_count() or 1) // 2))
+        stride = T * 2  # every second row of the frame in all: thread i takes rows 2i, 2i + 2T, ...
+
+        def band(i):
+            _, _, s_ = O.render_image(O.LIBM, om, oc, sp, sn, args.max_iter, 100.0, 0.05, row_begin=2 * i, row_step=stride)
+            return int(s_.rays), int(s_.steps)
+        ta = time.perf_counter()
+        with ThreadPoolExecutor(T) as ex:
+            parts = list(ex.map(band, range(T)))
+        da = time.perf_counter() - ta
+        allc = {"value": round(sum(p[1] for p in parts) / da / 1e6, 1), "threads": T,
+                "sample": "every 2nd row of the frame striped over %d threads: %d rays, %d Euler steps, %.1f s" % (
+                    T, sum(p[0] for p in parts), sum(p[1] for p in parts), da),
+                "note": "not the reference's configuration (single-threaded); for scale only"}
+    except Exception as exc:  # a baseline extra must never cost the bench line
+        allc = {"failed": str(exc)}
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -547,6 +568,7 @@ def cpu_baseline(args, host_skies):
         "host_cpu": model,
         "host_logical_cpus": os.cpu_count(),
         "config1_full": c1,
+        "all_cores": allc,
     }
 
 
