@@ -528,12 +528,26 @@ def cpu_baseline(args, host_skies):
         d1 = time.perf_counter() - t1
         c1 = {"workload": "config 1 in full: 256x144, cap 40000", "rays": int(st1.rays), "steps": int(st1.steps),
               "seconds": round(d1, 2), "value": round(st1.steps / d1 / 1e6, 2)}
-    # SURVEY 8d, optional: the same restatement on all host cores (rows striped over threads; ctypes drops the GIL) --
-    # NOT the reference's configuration (it is single-threaded, README.md:110), shown for scale only
+    # SURVEY 8d, optional: the same restatement on the host cores this container may use (rows striped over threads,
+    # ctypes drops the GIL; as many threads as the cgroup's CPU quota allows) -- NOT the reference's configuration
+    # (it is single-threaded, README.md:110), shown for scale only
     allc = None
     try:
         from concurrent.futures import ThreadPoolExecutor
-        T = max(1, min(64, (os.cpu_count() or 1) // 2))
+        quota = None  # what the container may really use: CPU affinity and the cgroup's CPU quota, if any
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as f:
+                q = f.read().split()
+            quota = None if q[0] == "max" else round(float(q[0]) / float(q[1]), 2)
+        except (OSError, ValueError, IndexError):
+            try:  # cgroup v1
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                    q1, q2 = float(f1.read()), float(f2.read())
+                quota = round(q1 / q2, 2) if q1 > 0 else None
+            except (OSError, ValueError):
+                pass
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        T = max(1, min(64, int(quota) if quota else usable // 2))  # the quota if there is one, else one per physical core
         stride = T * 2  # every second row of the frame in all: thread i takes rows 2i, 2i + 2T, ...
 
         def band(i):
@@ -544,9 +558,13 @@ def cpu_baseline(args, host_skies):
             parts = list(ex.map(band, range(T)))
         da = time.perf_counter() - ta
         allc = {"value": round(sum(p[1] for p in parts) / da / 1e6, 1), "threads": T,
+                "speedup_over_one_thread": round(sum(p[1] for p in parts) / da / (st.steps / dt), 1),
+                "cpus_in_affinity_mask": usable,
+                "cgroup_cpu_quota": quota,
                 "sample": "every 2nd row of the frame striped over %d threads: %d rays, %d Euler steps, %.1f s" % (
                     T, sum(p[0] for p in parts), sum(p[1] for p in parts), da),
-                "note": "not the reference's configuration (single-threaded); for scale only"}
+                "note": "not the reference's configuration (single-threaded); for scale only; the thread count follows the "
+                        "container's CPU quota, not the machine's core count"}
     except Exception as exc:  # a baseline extra must never cost the bench line
         allc = {"failed": str(exc)}
     model = ""

@@ -113,10 +113,31 @@ def twin_render_efficient(pm, pc, sky_pos, sky_neg, max_iter, max_radius, delta,
     return rgb, dict(a=a[:k].copy(), e=e[:k].copy(), s=s[:k].copy(), calls=calls.value, steps=steps.value)
 
 
+def host_threads(cap=128):
+    """threads worth starting for the striped oracle renders: the container's CPU quota when the cgroup sets one (the
+    GPU boxes show 256 logical CPUs behind a 16-CPU quota; more threads than that only add throttling), else the CPUs
+    of the affinity mask"""
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q = f.read().split()
+        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q1, q2 = float(f1.read()), float(f2.read())
+            quota = q1 / q2 if q1 > 0 else None
+        except (OSError, ValueError):
+            pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = int(quota + 0.5) if quota else usable
+    return max(1, min(cap, n, usable))
+
+
 def oracle_full_frame(fl, om, oc, sky_pos, sky_neg, cap, threads=None):
     """whole-frame oracle render with the rows striped over host threads (ctypes drops the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
-    T = threads or min(64, os.cpu_count() or 1)
+    T = threads or host_threads(64)
     W, H = oc.res_x, oc.res_y
     rgb = np.zeros((H, W, 3), np.uint8)
     dbg = np.zeros((H, W), O.RAY_DEBUG)
@@ -136,7 +157,7 @@ def oracle_full_frame_stats(fl, om, oc, sky_pos, sky_neg, cap, threads=None):
     """as oracle_full_frame, without the per-ray dump (88 B per ray and thread): returns (rgb, (rays, steps, n_pos,
     n_neg, n_none, n_oob)) -- what a 4K frame needs to stay inside a test's time budget."""
     from concurrent.futures import ThreadPoolExecutor
-    T = threads or min(64, os.cpu_count() or 1)
+    T = threads or host_threads(64)
     W, H = oc.res_x, oc.res_y
     rgb = np.zeros((H, W, 3), np.uint8)
     sp, sn = O.sky(sky_pos), O.sky(sky_neg)

@@ -29,7 +29,7 @@ from curvis_amd import paths, pngio, rendering
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
-THREADS = min(128, os.cpu_count() or 1)
+THREADS = common.host_threads(128)
 
 VIDEOS = {
     # name: (metric, csv, fps, frames, small res, full res, cap)

@@ -332,7 +332,7 @@ def test_config3_full_size_4k_interstellar(gpu_ctx):
     # just slower (1.6e10 steps at ~25 M steps/s per core); the GPU boxes have 128+ cores.
     sp, sn = common.make_skies(2048, 1024, "check")
     om, oc, pm, pc = common.scene("interstellar", res=(3840, 2160))
-    want_rgb, want_dbg, steps = oracle_full_frame(O.CV, om, oc, sp, sn, 8192, threads=min(128, os.cpu_count() or 1))
+    want_rgb, want_dbg, steps = oracle_full_frame(O.CV, om, oc, sp, sn, 8192, threads=common.host_threads(128))
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
                                          context=gpu_ctx)
     got = sys_.render_image(8192, 100.0, 0.05)
@@ -620,7 +620,7 @@ def test_largest_frame_8k(gpu_ctx):
     rgb, s = gpu_ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
     assert s.rays == 7680 * 4320 and s.n_pos + s.n_neg + s.n_none == s.rays
     from concurrent.futures import ThreadPoolExecutor
-    T = min(64, os.cpu_count() or 1)
+    T = common.host_threads(64)
     rows = list(range(5, 4320, 64))
     osp, osn = O.sky(sp), O.sky(sn)
 
