@@ -482,7 +482,14 @@ Args parse_args(int argc, char **argv) {
   if (a.devices < 1) a.devices = 1;
   if (a.batch < 1) a.batch = 1;
   if (a.writers < 1) { /* zlib costs ~100 ms per 1080p frame and thread: the GPU renders a frame in 0.4-10 ms */
-    const unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = std::thread::hardware_concurrency();
+    /* a container may see every CPU of the host behind a much smaller cgroup quota ("1600000 100000" = 16 CPUs) */
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      double quota = 0.0, period = 0.0;
+      if (std::fscanf(f, "%lf %lf", &quota, &period) == 2 && quota > 0.0 && period > 0.0)
+        hw = std::min(hw, (unsigned)(quota / period + 0.5) * 4u); /* the quota itself: this many writers at most */
+      std::fclose(f);
+    }
     a.writers = (int)std::min(64u, std::max(4u, hw / 4u));
   }
   return a;
