@@ -2198,6 +2198,20 @@ int curvis_metric_functions(const curvis_metric *m, double l, double *r, double 
   return CURVIS_OK;
 }
 
+int curvis_metric_tensor(const curvis_metric *m, const double position[4], double g_cov[4], double g_contr[4]) {
+  if (!m || !position) return CURVIS_E_INVALID;
+  double r2;
+  const int rc = curvis_metric_functions(m, position[1], nullptr, &r2, nullptr);
+  if (rc != CURVIS_OK) return rc;
+  const double s = cv_sin(position[2]);
+  const double g[4] = {-1.0, 1.0, r2, r2 * (s * s)};
+  for (int i = 0; i < 4; ++i) {
+    if (g_cov) g_cov[i] = g[i];
+    if (g_contr) g_contr[i] = 1.0 / g[i];
+  }
+  return CURVIS_OK;
+}
+
 int curvis_render_brute(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
                         uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
                         curvis_stats *stats) {

@@ -164,6 +164,17 @@ class ImageRenderingSystem:
         return path_of_image
 
 
+class VideoRenderingSettings:
+    """VideoRenderingSettings (src/rendering.rs:356-374), field for field."""
+
+    def __init__(self, frame_rate, resolution_x, resolution_y, camera_diagonal, camera_focal_length,
+                 filepath_to_camera_path, filepath_to_background_image_1, filepath_to_background_image_2,
+                 filepath_to_output_folder, output_video_name="output_video", escape_radius=100.0,
+                 max_iterations_propagation=40000, ray_integration_step=0.05, alphas_num=100, max_iterations_sampling=100,
+                 sampling_convergence_threshold_1=1e-5, sampling_convergence_threshold_2=1e-5):
+        self.__dict__.update({k: v for k, v in locals().items() if k != "self"})
+
+
 class VideoRenderingSystem:
     """VideoRenderingSystem<M> (src/rendering.rs:178-327) over one curvis Context per rank.
 
@@ -193,6 +204,61 @@ class VideoRenderingSystem:
         self.sampling_initial_nums = int(sampling_initial_nums)
         self.sampling_convergence_threshold_1 = float(sampling_convergence_threshold_1)
 
+    @classmethod
+    def new(cls, metric, video_rendering_settings, context=None, rank=0, world_size=1, batch=8, mode="efficient"):
+        """VideoRenderingSystem::new(metric, video_rendering_settings) (src/rendering.rs:188-221): loads the two
+        backgrounds into the context's HBM and the camera path into an Interpolator.  The reference passes
+        `alphas_num` and `max_iterations_sampling` separately and `sampling_convergence_threshold_1` twice (:299-307);
+        so does this (threshold_2 of the settings is never read, as there)."""
+        from .images import load_image_as_spherical_image
+        from .systems import default_context
+        st = video_rendering_settings
+        context = context or default_context()
+        context.set_sky(0, load_image_as_spherical_image(st.filepath_to_background_image_1))
+        context.set_sky(1, load_image_as_spherical_image(st.filepath_to_background_image_2))
+        self = cls(metric, context, Interpolator.from_file(str(st.filepath_to_camera_path)), st.frame_rate,
+                   (st.resolution_x, st.resolution_y), st.camera_diagonal, st.camera_focal_length, st.escape_radius,
+                   st.max_iterations_propagation, st.ray_integration_step, rank=rank, world_size=world_size, batch=batch,
+                   mode=mode, sampling_initial_nums=st.alphas_num,
+                   sampling_convergence_threshold_1=st.sampling_convergence_threshold_1)
+        self.max_iterations_sampling = int(st.max_iterations_sampling)
+        self.video_rendering_settings = st
+        return self
+
+    def render_to_folder(self, output_folder=None):
+        """VideoRenderingSystem::render's file side (src/rendering.rs:258-327): <folder> created if missing, a
+        pre-existing <folder>/tmp removed and recreated (rank 0; with several ranks the caller puts a barrier between
+        this call's start and the first frame, e.g. torch.distributed.barrier), this rank's frames written as
+        <folder>/tmp/frame_{index}.png.  Returns the per-frame statistics (see render)."""
+        import os
+        import shutil
+        from .images import save_image
+        folder = str(output_folder if output_folder is not None else self.video_rendering_settings.filepath_to_output_folder)
+        tmp = os.path.join(folder, "tmp")
+        if self.rank == 0:
+            if not os.path.exists(folder):
+                try:
+                    os.mkdir(folder)
+                except OSError as err:
+                    raise RuntimeError("Could not create video output folder %r due to error: %s" % (folder, err))
+            if os.path.exists(tmp):
+                try:
+                    shutil.rmtree(tmp)
+                except OSError as err:
+                    raise RuntimeError("Could not remove pre-existing tmp folder %r due to error: %s" % (tmp, err))
+            try:
+                os.mkdir(tmp)
+            except OSError as err:
+                raise RuntimeError("Could not create tmp output folder %r due to error: %s" % (tmp, err))
+
+        def write(index, rgb, _stats):
+            path = os.path.join(tmp, "frame_%d.png" % index)
+            try:
+                save_image(path, rgb)
+            except Exception as err:
+                raise RuntimeError("Could not save image frame %r due to error: %s" % (path, err))
+        return self.render(on_frame=write, download=True)
+
     def times_of_frames(self):
         return times_of_frames(self.interpolator.min_time(), self.interpolator.max_time(), self.frame_rate)
 
@@ -209,7 +275,8 @@ class VideoRenderingSystem:
         thr1 = self.sampling_convergence_threshold_1
         return self.context.render_efficient(self.metric, cams, self.max_iterations_propagation, self.escape_radius,
                                              self.ray_integration_step, self.sampling_initial_nums,
-                                             self.sampling_initial_nums, thr1, thr1, download=download)
+                                             getattr(self, "max_iterations_sampling", self.sampling_initial_nums), thr1, thr1,
+                                             download=download)
 
     def render(self, on_frame=None, download=True):
         """Render this rank's shard, `batch` frames per launch.  on_frame(index, rgb_or_None, stats_dict) is

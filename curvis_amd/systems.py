@@ -17,11 +17,14 @@ import numpy as np
 
 from . import _abi
 from ._abi import CameraC, Metric, Stats, check, dptr, lib
+from .vectors import Covariance, CovarianceError, RelativisticObject, RelativisticVector
 
 
-class _MetricFunctions:
-    """r(l), r_squared(l), r_derivative(l): the required methods of trait DiagonalSphericalMetric
-    (src/metrics.rs:40-48), through curvis_metric_functions (host-side, the kernels' arithmetic)."""
+class DiagonalSphericalMetric:
+    """trait DiagonalSphericalMetric (src/metrics.rs:40-349) for the closed set of metrics the kernels implement.
+    Required methods r(l), r_squared(l), r_derivative(l) (:40-48) through curvis_metric_functions; the diagonal of
+    the metric tensor and the index raising / lowering built on it (:49-219) through curvis_metric_tensor;
+    new_photon (:301-334) through curvis_new_photon -- all host-side, in the kernels' arithmetic."""
 
     def _functions(self, l):
         m = self._c()
@@ -42,8 +45,57 @@ class _MetricFunctions:
     def r_derivative(self, l):
         return self._functions(l)[2]
 
+    def _tensor(self, position_contr):
+        if position_contr.covariance != Covariance.Contravariant:  # check_contravariance, src/metrics.rs:9-13
+            raise CovarianceError("The position vector must be contravariant.")
+        m = self._c()
+        pos = np.ascontiguousarray(position_contr.vector, dtype=np.float64)
+        g, gi = np.zeros(4), np.zeros(4)
+        if lib().curvis_metric_tensor(C.byref(m), dptr(pos), dptr(g), dptr(gi)) != 0:
+            raise ValueError("invalid metric parameters")
+        return g, gi
 
-class EllisMetric(_MetricFunctions):
+    def gii(self, i, position_contr):
+        """covariant (i, i) component of the metric tensor (src/metrics.rs:49-79)"""
+        if i not in (0, 1, 2, 3):
+            raise IndexError("Invalid index for the covariant metric components.")
+        return float(self._tensor(position_contr)[0][i])
+
+    def gii_contr(self, i, position_contr):
+        """contravariant (i, i) component: gii.powi(-1) (src/metrics.rs:81-104)"""
+        if i not in (0, 1, 2, 3):
+            raise IndexError("Invalid index for the contravariant metric components.")
+        return float(self._tensor(position_contr)[1][i])
+
+    def to_covariant(self, position_contr, vector_contr):
+        """src/metrics.rs:148-161: v_i = v^i * g_ii"""
+        if vector_contr.covariance == Covariance.Covariant:
+            raise CovarianceError("The vector is already covariant.")
+        return RelativisticVector(vector_contr.vector * self._tensor(position_contr)[0], Covariance.Covariant)
+
+    def to_contravariant(self, position_contr, vector_cov):
+        """src/metrics.rs:190-203: v^i = v_i * g^ii"""
+        if vector_cov.covariance == Covariance.Contravariant:
+            raise CovarianceError("The vector is already contravariant.")
+        return RelativisticVector(vector_cov.vector * self._tensor(position_contr)[1], Covariance.Contravariant)
+
+    def new_photon(self, position, direction):
+        """src/metrics.rs:301-334: a photon at `position` (contravariant t, l, theta, phi) leaving along the
+        tangent-space `direction` (normalised here): covariant momentum (1, d0, d1 r(l), d2 r(l) sin(theta))."""
+        if position.covariance != Covariance.Contravariant:
+            raise CovarianceError("The position vector must be contravariant.")
+        m = self._c()
+        pos = np.ascontiguousarray(position.vector, dtype=np.float64)
+        d = np.ascontiguousarray(direction, dtype=np.float64).reshape(3)
+        x, p = np.zeros(4), np.zeros(4)
+        check(lib().curvis_new_photon(C.byref(m), dptr(pos), dptr(d), dptr(x), dptr(p)))
+        return RelativisticObject(RelativisticVector(x, Covariance.Contravariant), RelativisticVector(p, Covariance.Covariant))
+
+
+_MetricFunctions = DiagonalSphericalMetric  # earlier name
+
+
+class EllisMetric(DiagonalSphericalMetric):
     def __init__(self, rho):
         if not rho > 0.0:
             raise ValueError("The rho parameter for Ellis Metrics must be positive.")
@@ -53,7 +105,7 @@ class EllisMetric(_MetricFunctions):
         return Metric(_abi.METRIC_ELLIS, 0, self.rho, 0.0, 0.0)
 
 
-class InterstellarMetric(_MetricFunctions):
+class InterstellarMetric(DiagonalSphericalMetric):
     def __init__(self, m, a, rho):
         if not m > 0.0:
             raise ValueError("The mass parameter for Interstellar Metrics must be positive.")
@@ -67,7 +119,7 @@ class InterstellarMetric(_MetricFunctions):
         return Metric(_abi.METRIC_INTERSTELLAR, 0, self.rho, self.m, self.a)
 
 
-class FlatSphericalMetric(_MetricFunctions):
+class FlatSphericalMetric(DiagonalSphericalMetric):
     def _c(self):
         return Metric(_abi.METRIC_FLAT, 0, 0.0, 0.0, 0.0)
 
@@ -318,6 +370,59 @@ def default_context(device=0):
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]
+
+
+class EscapeAngle:
+    """enum EscapeAngle (src/systems.rs:54-58): PositiveSpace(angle) / NegativeSpace(angle) / NotEscaped"""
+
+    __slots__ = ("kind", "angle")
+
+    def __init__(self, kind, angle=None):
+        if kind not in ("PositiveSpace", "NegativeSpace", "NotEscaped"):
+            raise ValueError("unknown EscapeAngle variant")
+        self.kind, self.angle = kind, (None if kind == "NotEscaped" else float(angle))
+
+    def __repr__(self):
+        return "EscapeAngle::NotEscaped" if self.angle is None else "EscapeAngle::%s(%r)" % (self.kind, self.angle)
+
+    def __eq__(self, other):
+        return isinstance(other, EscapeAngle) and (self.kind, self.angle) == (other.kind, other.angle)
+
+
+def compute_escape_angle(metric, l, alpha, delta, max_iterations, max_radius, context=None):
+    """compute_escape_angle (src/systems.rs:203-261, re-exported by src/lib.rs:37), same argument order: the photon
+    at (0, l, pi/2, 0) leaving at angle alpha from the radial direction is integrated on the GPU until it escapes."""
+    ctx = context or default_context()
+    angle, space, _ = ctx.compute_escape_angles_range(metric, l, [alpha], delta, max_iterations, max_radius)
+    if space[0] > 0:
+        return EscapeAngle("PositiveSpace", angle[0])
+    if space[0] < 0:
+        return EscapeAngle("NegativeSpace", angle[0])
+    return EscapeAngle("NotEscaped")
+
+
+def compute_photon_trajectory(photon, metric, iterations, delta, context=None):
+    """compute_photon_trajectory (src/systems.rs:77-92, re-exported by src/lib.rs:37), same argument order: the
+    states of `photon` BEFORE each of `iterations` Euler steps as a list of RelativisticObjects; like the reference
+    (`&mut`), `photon` itself ends up advanced by `iterations` steps.  A contravariant momentum is lowered first, as
+    update_relativistic_object does (src/metrics.rs:283-288)."""
+    if photon.covariance_x() != Covariance.Contravariant:
+        raise CovarianceError("The position vector must be contravariant.")
+    if photon.covariance_p() == Covariance.Contravariant:
+        photon.momentum = metric.to_covariant(photon.position, photon.momentum)
+    iterations = int(iterations)
+    if iterations <= 0:
+        return []
+    ctx = context or default_context()
+    m = metric._c()
+    x0 = np.ascontiguousarray(photon.position.vector, dtype=np.float64).reshape(1, 4)
+    p0 = np.ascontiguousarray(photon.momentum.vector, dtype=np.float64).reshape(1, 4)
+    out = np.zeros((1, iterations + 1, 8))  # one more row: the state the reference leaves in `photon`
+    check(lib().curvis_photon_trajectories(ctx._h, C.byref(m), 1, dptr(x0), dptr(p0), iterations + 1, float(delta), dptr(out)), ctx._h)
+    states = [RelativisticObject(RelativisticVector(row[:4], Covariance.Contravariant),
+                                 RelativisticVector(row[4:], Covariance.Covariant)) for row in out[0]]
+    photon.position, photon.momentum = states[-1].position, states[-1].momentum
+    return states[:-1]
 
 
 class RelativisticSystem:

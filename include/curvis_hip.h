@@ -133,6 +133,11 @@ int curvis_metric_validate(const curvis_metric *m);
  * Ellis :417-421, Interstellar :467-485, flat :501-505) at radial coordinate l, evaluated on the host with the same
  * arithmetic (cv_math.h) the kernels use -- what every ray of a render is integrated with.  Any output may be NULL. */
 int curvis_metric_functions(const curvis_metric *m, double l, double *r, double *r_squared, double *r_derivative);
+/* The diagonal of the metric tensor at `position` = (t, l, theta, phi): covariant g_ii = (-1, 1, r^2(l),
+ * r^2(l) sin^2(theta)) (src/metrics.rs:49-68; sin().powi(2) is s * s) and contravariant g^ii = g_ii.powi(-1) = 1 / g_ii
+ * (:84-93) -- what to_covariant / to_contravariant (:163-219) multiply a vector's components by.  Host-side, same
+ * arithmetic as the kernels; either output may be NULL. */
+int curvis_metric_tensor(const curvis_metric *m, const double position[4], double g_cov[4], double g_contr[4]);
 
 /* RelativisticSystem::render_image (src/systems.rs:307-330): one ray per pixel, forward-Euler
  * integration until |l| > max_radius or max_iterations steps, nearest-texel sky lookup.

@@ -1,0 +1,180 @@
+"""The reference's public re-exports (src/lib.rs:28-37) as the Python mirror offers them: value types, Orientation,
+the provided methods of DiagonalSphericalMetric that sit on the metric tensor, and (on the GPU) the two free
+functions compute_photon_trajectory / compute_escape_angle with the reference's argument order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common  # noqa: F401
+import oracle_lib as O
+import curvis_amd
+from curvis_amd import Covariance, CovarianceError, RelativisticObject, RelativisticVector
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_every_lib_rs_reexport_has_a_counterpart():
+    for name in ("ImageRenderingSystem", "ImageRenderingSettings", "VideoRenderingSystem", "VideoRenderingSettings",
+                 "DiagonalSphericalMetric", "EllisMetric", "InterstellarMetric", "CameraSettings", "VideoSettings",
+                 "ImageSettings", "InterstellarMetricSettings", "EllisMetricSettings", "SimulationSettings",
+                 "RelativisticObject", "RelativisticVector", "Covariance", "SphericalImage",
+                 "load_image_as_spherical_image", "Camera", "Orientation", "compute_photon_trajectory",
+                 "compute_escape_angle"):
+        assert getattr(curvis_amd, name) is not None, name
+    assert issubclass(curvis_amd.EllisMetric, curvis_amd.DiagonalSphericalMetric)
+
+
+def test_relativistic_vector_arithmetic_and_panics():
+    """src/vectors.rs:63-128: scalar ops componentwise, vector ops only between equal covariance"""
+    a = RelativisticVector([1.0, 2.0, 3.0, 4.0], Covariance.Contravariant)
+    b = RelativisticVector([0.5, 0.25, -1.0, 8.0], Covariance.Contravariant)
+    c = RelativisticVector([0.5, 0.25, -1.0, 8.0], Covariance.Covariant)
+    assert np.array_equal((a + 0.5).vector, [1.5, 2.5, 3.5, 4.5]) and (a + 0.5).covariance == Covariance.Contravariant
+    assert np.array_equal((a - 1.0).vector, [0.0, 1.0, 2.0, 3.0])
+    assert np.array_equal((a * 0.1).vector, np.array([1.0, 2.0, 3.0, 4.0]) * 0.1)
+    assert np.array_equal((a / 3.0).vector, np.array([1.0, 2.0, 3.0, 4.0]) / 3.0)
+    assert np.array_equal((a + b).vector, [1.5, 2.25, 2.0, 12.0]) and np.array_equal((a - b).vector, [0.5, 1.75, 4.0, -4.0])
+    with pytest.raises(CovarianceError, match="Cannot add vectors with different covariance"):
+        a + c
+    with pytest.raises(CovarianceError, match="Cannot subtract vectors with different covariance"):
+        a - c
+    with pytest.raises(CovarianceError, match="Division by zero"):
+        a / 0.0
+    assert a.v(2) == 3.0 and str(Covariance.Covariant) == "Covariant"
+    assert str(a) == "Contravariant (1.0, 2.0, 3.0, 4.0)"
+    obj = RelativisticObject(a, c)
+    assert obj.x(1) == 2.0 and obj.p(3) == 8.0
+    assert obj.covariance_x() == Covariance.Contravariant and obj.covariance_p() == Covariance.Covariant
+    with pytest.raises(ValueError):
+        RelativisticVector([1.0, 2.0, 3.0], Covariance.Covariant)
+
+
+@pytest.mark.parametrize("kind", ["ellis", "interstellar", "flat"])
+def test_metric_tensor_and_index_gymnastics(kind):
+    """g_ii = (-1, 1, r^2, r^2 sin^2) and g^ii = 1 / g_ii (src/metrics.rs:49-104) in the kernels' arithmetic;
+    to_covariant / to_contravariant multiply by them and refuse the wrong covariance (:148-219)."""
+    pm = {"ellis": curvis_amd.EllisMetric(1.3), "interstellar": curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0),
+          "flat": curvis_amd.FlatSphericalMetric()}[kind]
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        l = float(rng.uniform(0.3, 30.0) * (1 if kind == "flat" else rng.choice([-1, 1])))
+        th = float(rng.uniform(0.05, 3.1))
+        pos = RelativisticVector([float(rng.uniform(-5, 5)), l, th, float(rng.uniform(-7, 7))], Covariance.Contravariant)
+        s = O.math_array(O.CV, 0, [th])[0]
+        r2 = pm.r_squared(l)
+        want = np.array([-1.0, 1.0, r2, r2 * (s * s)])
+        got = np.array([pm.gii(i, pos) for i in range(4)])
+        assert np.array_equal(bits(got), bits(want))
+        assert np.array_equal(bits([pm.gii_contr(i, pos) for i in range(4)]), bits(1.0 / want))
+        assert abs(got[3] - r2 * np.sin(th) ** 2) <= 4 * np.spacing(got[3])     # and close to libm's
+        v = RelativisticVector(rng.uniform(-2, 2, 4), Covariance.Contravariant)
+        low = pm.to_covariant(pos, v)
+        assert low.covariance == Covariance.Covariant and np.array_equal(bits(low.vector), bits(v.vector * want))
+        up = pm.to_contravariant(pos, low)
+        assert up.covariance == Covariance.Contravariant and np.array_equal(bits(up.vector), bits(low.vector * (1.0 / want)))
+        with pytest.raises(CovarianceError, match="already covariant"):
+            pm.to_covariant(pos, low)
+        with pytest.raises(CovarianceError, match="already contravariant"):
+            pm.to_contravariant(pos, up)
+        with pytest.raises(CovarianceError):
+            pm.gii(2, low)  # a covariant "position": check_contravariance, src/metrics.rs:9-13
+    with pytest.raises(IndexError):
+        pm.gii(4, pos)
+
+
+def test_new_photon_is_null_and_matches_the_oracle():
+    """src/metrics.rs:515-541 (the reference's own test): the photon built by new_photon has zero squared norm;
+    components equal the oracle's restatement bit for bit"""
+    om, pm = O.ellis(1.0), curvis_amd.EllisMetric(1.0)
+    pos = RelativisticVector([0.0, 5.0, 1.1, 0.4], Covariance.Contravariant)
+    d = (0.3, -0.5, 0.8)
+    ph = pm.new_photon(pos, d)
+    x, p = np.zeros(4), np.zeros(4)
+    O.lib().cvo_new_photon(O.CV, C.byref(om), O._dp(pos.vector.copy()), O._dp(np.array(d)), O._dp(x), O._dp(p))
+    assert np.array_equal(bits(ph.position.vector), bits(x)) and np.array_equal(bits(ph.momentum.vector), bits(p))
+    contr = pm.to_contravariant(ph.position, ph.momentum)
+    assert abs(float(np.sum(contr.vector * ph.momentum.vector))) < 1e-14      # g^ii p_i p_i = 0 for light
+    with pytest.raises(CovarianceError):
+        pm.new_photon(RelativisticVector(pos.vector, Covariance.Covariant), d)
+
+
+def test_orientation():
+    """src/algebra.rs:16-62 and its tests :154-176 (orthogonalised up, exact)"""
+    o = curvis_amd.Orientation((1.0, 0.0, 0.0), (0.0, 0.0, 1.0))
+    assert np.array_equal(o.rotation_matrix(), np.eye(3)) and np.array_equal(o.up(), [0.0, 0.0, 1.0])
+    o = curvis_amd.Orientation((1.0, 0.0, 0.0), (1.0, 0.0, 1.0))          # up leaning along forward: orthogonalised
+    assert np.array_equal(o.up(), [0.0, 0.0, 1.0]) and np.array_equal(o.forward(), [1.0, 0.0, 0.0])
+    f, u = (-1.0, 0.3, 0.2), (0.1, 0.2, 1.0)
+    o = curvis_amd.Orientation(f, u)
+    cam = curvis_amd.Camera((0.0, 5.0, 1.0, 0.0), f, u, 15.0, 43.0, 16, 9)
+    assert np.array_equal(bits(o.rotation_matrix()), bits(np.asarray(cam.rotation_matrix).reshape(3, 3)))
+    r = o.rotation_matrix()
+    assert np.allclose(r @ r.T, np.eye(3), atol=1e-15) and np.allclose(o.inverse_rotation_matrix(), r.T, atol=1e-15)
+    assert np.allclose(o.to_world((1.0, 0.0, 0.0)), np.array(f) / np.linalg.norm(f), atol=1e-15)
+    assert np.allclose(o.to_object(o.to_world((0.2, -0.4, 0.9))), (0.2, -0.4, 0.9), atol=1e-15)
+    with pytest.raises(curvis_amd.CurvisError):
+        curvis_amd.Orientation((1.0, 0.0, 0.0), (2.0, 0.0, 0.0))           # "Forward and up vectors must not be parallel"
+
+
+@pytest.mark.gpu
+def test_free_functions_with_the_reference_signatures(gpu_ctx):
+    """compute_photon_trajectory(photon, metric, iterations, delta) and compute_escape_angle(metric, l, alpha, delta,
+    max_iterations, max_radius) (src/systems.rs:77-92, :203-261) against the oracle, bit for bit; the photon is
+    advanced in place like the reference's `&mut`, a contravariant momentum is lowered first."""
+    for om, pm in ((O.ellis(), curvis_amd.EllisMetric(1.0)), (O.interstellar(), curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0))):
+        pos = RelativisticVector([0.0, 5.0, np.pi / 2, 0.0], Covariance.Contravariant)
+        d = (np.cos(np.pi / 4), 0.0, np.sin(np.pi / 4))
+        ph = pm.new_photon(pos, d)
+        traj = curvis_amd.compute_photon_trajectory(ph, pm, 100, 0.01, context=gpu_ctx)
+        want = O.photon_trajectory(O.CV, om, tuple(pos.vector), d, 101, 0.01)
+        assert len(traj) == 100
+        for k in range(100):
+            assert np.array_equal(bits(np.concatenate([traj[k].position.vector, traj[k].momentum.vector])), bits(want[k])), k
+        assert np.array_equal(bits(np.concatenate([ph.position.vector, ph.momentum.vector])), bits(want[100]))
+        # the same photon handed over with a contravariant momentum
+        ph2 = pm.new_photon(pos, d)
+        ph2.momentum = pm.to_contravariant(ph2.position, ph2.momentum)
+        lowered = pm.to_covariant(ph2.position, ph2.momentum)
+        traj2 = curvis_amd.compute_photon_trajectory(ph2, pm, 5, 0.01, context=gpu_ctx)
+        assert traj2[0].covariance_p() == Covariance.Covariant
+        assert np.array_equal(bits(traj2[0].momentum.vector), bits(lowered.vector))
+        assert curvis_amd.compute_photon_trajectory(pm.new_photon(pos, d), pm, 0, 0.01, context=gpu_ctx) == []
+        for alpha in (0.0, np.pi / 2, 2.9, 3.0, np.pi, 3.05):
+            got = curvis_amd.compute_escape_angle(pm, 5.0, alpha, 0.05, 4096, 100.0, context=gpu_ctx)
+            code, ang, _ = O.compute_escape_angle(O.CV, om, 5.0, float(alpha), 0.05, 4096, 100.0)
+            assert got.kind == {1: "PositiveSpace", -1: "NegativeSpace", 0: "NotEscaped"}[code]
+            if code:
+                assert np.float64(got.angle).view(np.uint64) == np.float64(ang).view(np.uint64)
+        assert curvis_amd.compute_escape_angle(pm, 5.0, 1.0, 0.05, 10, 100.0, context=gpu_ctx) == curvis_amd.EscapeAngle("NotEscaped")
+
+
+@pytest.mark.gpu
+def test_video_rendering_system_new_and_render_to_folder(gpu_ctx, tmp_path):
+    """VideoRenderingSystem::new(metric, settings) + render (src/rendering.rs:188-327): backgrounds and camera path from
+    files, <folder>/tmp recreated, frame_{k}.png per frame -- equal to the frames of the explicit constructor"""
+    from curvis_amd import images, paths, rendering
+    sp, sn = common.make_skies(256, 128, "check")
+    images.save_image(str(tmp_path / "pos.png"), sp[..., :3])
+    images.save_image(str(tmp_path / "neg.png"), sn[..., :3])
+    out = tmp_path / "out"
+    (out / "tmp").mkdir(parents=True)
+    (out / "tmp" / "stale.txt").write_text("x")
+    st = rendering.VideoRenderingSettings(
+        frame_rate=0.1, resolution_x=96, resolution_y=54, camera_diagonal=43.0, camera_focal_length=15.0,
+        filepath_to_camera_path=paths.path_file("path_orbit.csv"), filepath_to_background_image_1=str(tmp_path / "pos.png"),
+        filepath_to_background_image_2=str(tmp_path / "neg.png"), filepath_to_output_folder=str(out),
+        max_iterations_propagation=4096, alphas_num=40, max_iterations_sampling=30, sampling_convergence_threshold_1=1e-4)
+    pm = curvis_amd.EllisMetric(1.0)
+    vs = curvis_amd.VideoRenderingSystem.new(pm, st, context=gpu_ctx, batch=4)
+    stats = vs.render_to_folder()
+    names = sorted(p.name for p in (out / "tmp").iterdir())
+    assert names == sorted("frame_%d.png" % k for k in range(len(stats))) and len(stats) == 6
+    # the same frames through the context directly, with the reference's wiring of the seven arguments
+    times = vs.times_of_frames()
+    for k in range(len(stats)):
+        want, _ = gpu_ctx.render_efficient(pm, vs.camera_at(times[k]), 4096, 100.0, 0.05, 40, 30, 1e-4, 1e-4)
+        got = images.load_image(str(out / "tmp" / ("frame_%d.png" % k)))
+        assert np.array_equal(np.asarray(got)[..., :3], want), k
