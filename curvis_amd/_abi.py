@@ -65,6 +65,9 @@ SYMBOLS = {
     "curvis_metric_validate": (C.c_int, [C.POINTER(Metric)]),
     "curvis_metric_functions": (C.c_int, [C.POINTER(Metric), C.c_double, _dp, _dp, _dp]),
     "curvis_metric_tensor": (C.c_int, [C.POINTER(Metric), _dp, _dp, _dp]),
+    "curvis_camera_outward_vector": (C.c_int, [C.POINTER(CameraC), C.c_uint32, C.c_uint32, _dp, _dp]),
+    "curvis_vector_to_direction": (C.c_int, [C.POINTER(Metric), _dp, _dp, _dp]),
+    "curvis_sky_texel_index": (C.c_int, [C.c_uint32, C.c_uint32, _dp, _dp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "curvis_render_brute": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_double, C.c_double,
                                       _vp, C.POINTER(Stats)]),
     "curvis_render_brute_rows": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_uint32, C.c_uint32,

@@ -2212,6 +2212,65 @@ int curvis_metric_tensor(const curvis_metric *m, const double position[4], doubl
   return CURVIS_OK;
 }
 
+int curvis_camera_outward_vector(const curvis_camera *camera, uint32_t px, uint32_t py, double camera_space[3],
+                                 double world_space[3]) {
+  if (!camera || camera->res_x == 0 || camera->res_y == 0) return CURVIS_E_INVALID;
+  /* the first half of cvk::ray_init, expression for expression */
+  const double h = 0.5 - ((double)py / (double)camera->res_y);
+  const double w = ((double)px / (double)camera->res_x) - 0.5;
+  double vx = camera->focal * 1.0;
+  double vy = -camera->sensor_w * w;
+  double vz = camera->sensor_h * h;
+  const double n = std::sqrt(vx * vx + vy * vy + vz * vz);
+  vx = vx / n;
+  vy = vy / n;
+  vz = vz / n;
+  if (camera_space) {
+    camera_space[0] = vx;
+    camera_space[1] = vy;
+    camera_space[2] = vz;
+  }
+  if (world_space) cvk::mat3_vec(camera->rot, vx, vy, vz, world_space[0], world_space[1], world_space[2]);
+  return CURVIS_OK;
+}
+
+int curvis_vector_to_direction(const curvis_metric *metric, const double position[4], const double p_cov[4],
+                               double direction[3]) {
+  if (!metric || !position || !p_cov || !direction) return CURVIS_E_INVALID;
+  if (curvis_metric_validate(metric) != CURVIS_OK) return CURVIS_E_METRIC;
+  const cvk::MetricParams MP = make_metric(*metric);
+  cvk::Ray q;
+  q.l = position[1];
+  q.th = position[2];
+  q.ph = position[3];
+  q.p1 = p_cov[1];
+  q.p2 = p_cov[2];
+  q.p3 = p_cov[3];
+  q.p3sq = q.p3 * q.p3;
+  switch (metric->kind) {
+    case CURVIS_METRIC_ELLIS: cvk::ray_direction<cvk::METRIC_ELLIS>(MP, q, direction[0], direction[1], direction[2]); break;
+    case CURVIS_METRIC_INTERSTELLAR:
+      cvk::ray_direction<cvk::METRIC_INTERSTELLAR>(MP, q, direction[0], direction[1], direction[2]);
+      break;
+    default: cvk::ray_direction<cvk::METRIC_FLAT>(MP, q, direction[0], direction[1], direction[2]); break;
+  }
+  return CURVIS_OK;
+}
+
+int curvis_sky_texel_index(uint32_t w, uint32_t h, const double inv_rot[9], const double v[3], uint32_t *x, uint32_t *y) {
+  if (!v || !x || !y || w == 0 || h == 0) return CURVIS_E_INVALID;
+  cvk::SkyParams S;
+  S.texels = nullptr;
+  S.w = w;
+  S.h = h;
+  for (int i = 0; i < 9; ++i) S.inv_rot[i] = inv_rot ? inv_rot[i] : ((i % 4 == 0) ? 1.0 : 0.0);
+  unsigned tx = 0, ty = 0;
+  cvk::sky_indices(S, v[0], v[1], v[2], tx, ty);
+  *x = tx;
+  *y = ty;
+  return (tx >= w || ty >= h) ? CURVIS_E_INVALID : CURVIS_OK;
+}
+
 int curvis_render_brute(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
                         uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
                         curvis_stats *stats) {

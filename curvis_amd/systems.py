@@ -79,6 +79,21 @@ class DiagonalSphericalMetric:
             raise CovarianceError("The vector is already contravariant.")
         return RelativisticVector(vector_cov.vector * self._tensor(position_contr)[1], Covariance.Contravariant)
 
+    def relativistic_vector_to_direction(self, vector, position):
+        """src/metrics.rs:339-349: vector at `position` (a covariant one is raised first, :340-342) ->
+        tangent-space direction (not normalised; the z component uses frame_field_22, as the reference does)"""
+        if position.covariance != Covariance.Contravariant:
+            raise CovarianceError("The position vector must be contravariant.")
+        if vector.covariance == Covariance.Contravariant:  # used as it is: components times the frame field
+            r = np.float64(self.r(position.v(1)))
+            return np.array([np.float64(vector.v(1)) * 1.0, np.float64(vector.v(2)) * r, np.float64(vector.v(3)) * r])
+        m = self._c()
+        pos = np.ascontiguousarray(position.vector, dtype=np.float64)
+        p = np.ascontiguousarray(vector.vector, dtype=np.float64)
+        out = np.zeros(3)
+        check(lib().curvis_vector_to_direction(C.byref(m), dptr(pos), dptr(p), dptr(out)))
+        return out
+
     def new_photon(self, position, direction):
         """src/metrics.rs:301-334: a photon at `position` (contravariant t, l, theta, phi) leaving along the
         tangent-space `direction` (normalised here): covariant momentum (1, d0, d1 r(l), d2 r(l) sin(theta))."""
@@ -164,6 +179,18 @@ class Camera:
     def rotation_matrix(self):
         return np.array(self._c.rot[:]).reshape(3, 3)
 
+    def outward_vector_on_camera_space(self, camera_pixel_x, camera_pixel_y):
+        """src/cameras.rs:150-164: unit vector through pixel (x, y) in camera space (x forward, y left, z up)"""
+        out = np.zeros(3)
+        check(lib().curvis_camera_outward_vector(C.byref(self._c), int(camera_pixel_x), int(camera_pixel_y), dptr(out), None))
+        return out
+
+    def outward_vector_on_world_space_from_x_y(self, camera_pixel_x, camera_pixel_y):
+        """src/cameras.rs:169-172: the same vector in the tangent space of the camera's position"""
+        out = np.zeros(3)
+        check(lib().curvis_camera_outward_vector(C.byref(self._c), int(camera_pixel_x), int(camera_pixel_y), None, dptr(out)))
+        return out
+
     @property
     def sensor_width(self):
         return self._c.sensor_w
@@ -190,6 +217,28 @@ class SphericalImage:
 
     def set_forward_up(self, forward, up):
         self.forward, self.up = _vec(forward, 3), _vec(up, 3)
+
+    def get_pixel(self, x, y):
+        """src/images.rs:107-111 (DynamicImage::get_pixel panics outside the image)"""
+        if not (0 <= x < self.width_pixels and 0 <= y < self.height_pixels):
+            raise IndexError("Image index (%d, %d) out of bounds (%d, %d)" % (x, y, self.width_pixels, self.height_pixels))
+        return tuple(int(c) for c in self.rgba[y, x])
+
+    def pixel_index_from_vector3(self, v):
+        """texel (x, y) a world-space direction lands on (src/images.rs:115-142), in the kernels' arithmetic;
+        IndexError where the reference's get_pixel would panic (x == width or y == height)"""
+        from .algebra import Orientation
+        inv = np.ascontiguousarray(Orientation(self.forward, self.up).inverse_rotation_matrix().reshape(9))
+        vv = _vec(v, 3)
+        x, y = C.c_uint32(0), C.c_uint32(0)
+        rc = lib().curvis_sky_texel_index(self.width_pixels, self.height_pixels, dptr(inv), dptr(vv), C.byref(x), C.byref(y))
+        if rc != 0:
+            raise IndexError("Image index (%d, %d) out of bounds (%d, %d)" % (x.value, y.value, self.width_pixels, self.height_pixels))
+        return x.value, y.value
+
+    def get_pixel_from_vector3(self, v):
+        """src/images.rs:171-174: Rgba of the texel the world-space direction v points at"""
+        return self.get_pixel(*self.pixel_index_from_vector3(v))
 
 
 class Context:

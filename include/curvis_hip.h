@@ -146,6 +146,23 @@ int curvis_metric_tensor(const curvis_metric *m, const double position[4], doubl
 int curvis_render_brute(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera,
                         uint32_t max_iterations, double max_radius, double delta, uint8_t *rgb_out,
                         curvis_stats *stats);
+/* Host-side accessors of the per-ray functions either end of the Euler loop, in the kernels' arithmetic (the same
+ * host/device source): what the kernels do for every pixel, callable for one.
+ * Camera::outward_vector_on_camera_space (src/cameras.rs:150-164; unit vector, x forward / y left / z up) and
+ * outward_vector_on_world_space_from_x_y (:169-172, the former rotated by camera_to_world); either output may be NULL. */
+int curvis_camera_outward_vector(const curvis_camera *camera, uint32_t px, uint32_t py, double camera_space[3],
+                                 double world_space[3]);
+/* DiagonalSphericalMetric::relativistic_vector_to_direction (src/metrics.rs:339-349 with to_contravariant :190-203):
+ * covariant momentum at `position` -> tangent-space direction (not normalised; z uses frame_field_22, as the
+ * reference does). */
+int curvis_vector_to_direction(const curvis_metric *metric, const double position[4], const double p_cov[4],
+                               double direction[3]);
+/* SphericalImage::get_pixel_from_vector3's texel (src/images.rs:115-142, 171-174; src/algebra.rs:106-134) for an image of
+ * w x h texels whose inverse orientation is inv_rot (NULL = the default forward x / up z): raw `as u32` indices.
+ * Returns CURVIS_OK, or CURVIS_E_INVALID with the indices still set when x == w or y == h (the reference's
+ * get_pixel panics there; the kernels clamp and count such rays, curvis_stats.n_oob). */
+int curvis_sky_texel_index(uint32_t w, uint32_t h, const double inv_rot[9], const double v[3], uint32_t *x, uint32_t *y);
+
 /* A band of image rows [row_begin, row_begin + row_count) of the same frame: rays are independent
  * (src/systems.rs:316-326), so a single image can be split across GPUs by rows and assembled on the host
  * (SURVEY 8e).  rgb_out: row_count*res_x*3 or NULL; stats cover the band. */

@@ -178,3 +178,55 @@ def test_video_rendering_system_new_and_render_to_folder(gpu_ctx, tmp_path):
         want, _ = gpu_ctx.render_efficient(pm, vs.camera_at(times[k]), 4096, 100.0, 0.05, 40, 30, 1e-4, 1e-4)
         got = images.load_image(str(out / "tmp" / ("frame_%d.png" % k)))
         assert np.array_equal(np.asarray(got)[..., :3], want), k
+
+
+def test_camera_and_sky_accessors_match_the_oracle():
+    """Camera::outward_vector_* (src/cameras.rs:150-172), relativistic_vector_to_direction (src/metrics.rs:339-349) and
+    SphericalImage::get_pixel_from_vector3 (src/images.rs:115-174) through the product's host-side accessors: bit for
+    bit the oracle's, including the `as u32` corner cases and the out-of-range texel the reference panics on."""
+    rng = np.random.default_rng(11)
+    for _ in range(20):
+        f, u = rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3)
+        res = (int(rng.integers(2, 400)), int(rng.integers(2, 300)))
+        pos = (0.0, float(rng.uniform(-6, 6)), float(rng.uniform(0.2, 2.9)), float(rng.uniform(-3, 3)))
+        oc = O.camera(pos, tuple(f), tuple(u), 15.0, 43.0, res)
+        pc = curvis_amd.Camera(pos, tuple(f), tuple(u), 15.0, 43.0, res[0], res[1])
+        assert (pc.resolution_width, pc.resolution_height) == res
+        for _ in range(10):
+            px, py = int(rng.integers(0, res[0])), int(rng.integers(0, res[1]))
+            want_c, want_w = np.zeros(3), np.zeros(3)
+            O.lib().cvo_camera_outward_camera_space(C.byref(oc), px, py, O._dp(want_c))
+            O.lib().cvo_camera_outward_world(C.byref(oc), px, py, O._dp(want_w))
+            assert np.array_equal(bits(pc.outward_vector_on_camera_space(px, py)), bits(want_c))
+            assert np.array_equal(bits(pc.outward_vector_on_world_space_from_x_y(px, py)), bits(want_w))
+    sp, _ = common.make_skies(64, 32, "check")
+    for fwd, up in (((1.0, 0.0, 0.0), (0.0, 0.0, 1.0)), ((0.3, -0.8, 0.2), (0.1, 0.2, 1.0))):
+        img = curvis_amd.SphericalImage(sp, forward=fwd, up=up)
+        rot, inv = np.zeros(9), np.zeros(9)
+        assert O.lib().cvo_orientation_new(O._dp(np.array(fwd)), O._dp(np.array(up)), O._dp(rot), O._dp(inv), None) == 0
+        osky = O.sky(sp, inv)
+        vs = list(rng.normal(size=(200, 3))) + [np.array(v) for v in ((1.0, 0.0, 0.0), (0.0, 0.0, 1.0), (-1.0, 1e-300, 0.0), (-1.0, -0.0, 0.0), (0.0, 1.0, 0.0))]
+        for v in vs:
+            x, y = C.c_uint32(0), C.c_uint32(0)
+            O.lib().cvo_sky_indices(O.CV, C.byref(osky), O._dp(np.array(v, dtype=np.float64)), C.byref(x), C.byref(y))
+            if x.value >= 64 or y.value >= 32:
+                with pytest.raises(IndexError):
+                    img.get_pixel_from_vector3(v)
+            else:
+                assert img.pixel_index_from_vector3(v) == (x.value, y.value)
+                assert img.get_pixel_from_vector3(v) == tuple(int(c) for c in sp[y.value, x.value])
+    # straight down the negative z axis: theta = pi -> y == height, the reference's get_pixel panics
+    with pytest.raises(IndexError):
+        curvis_amd.SphericalImage(sp).get_pixel_from_vector3((0.0, 0.0, -1.0))
+    for om, pm in ((O.ellis(1.0), curvis_amd.EllisMetric(1.0)), (O.interstellar(), curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0))):
+        for _ in range(30):
+            x = np.array([0.0, rng.uniform(-8, 8), rng.uniform(0.1, 3.0), rng.uniform(-3, 3)])
+            p = np.concatenate([[1.0], rng.uniform(-2, 2, 3)])
+            want = np.zeros(3)
+            O.lib().cvo_vector_to_direction(O.CV, C.byref(om), O._dp(p.copy()), O._dp(x.copy()), O._dp(want))
+            pos = RelativisticVector(x, Covariance.Contravariant)
+            got = pm.relativistic_vector_to_direction(RelativisticVector(p, Covariance.Covariant), pos)
+            assert np.array_equal(bits(got), bits(want))
+            r = pm.r(float(x[1]))
+            got2 = pm.relativistic_vector_to_direction(RelativisticVector(p, Covariance.Contravariant), pos)
+            assert np.array_equal(bits(got2), bits([p[1], p[2] * r, p[3] * r]))
