@@ -230,3 +230,23 @@ def test_camera_and_sky_accessors_match_the_oracle():
             r = pm.r(float(x[1]))
             got2 = pm.relativistic_vector_to_direction(RelativisticVector(p, Covariance.Contravariant), pos)
             assert np.array_equal(bits(got2), bits([p[1], p[2] * r, p[3] * r]))
+
+
+@pytest.mark.gpu
+def test_device_ray_construction_equals_the_host_accessors(gpu_ctx):
+    """With a cap of zero Euler steps the debug dump holds every pixel's INITIAL photon: the kernels' pixel -> direction ->
+    photon (R2, R3) equals Camera.outward_vector_on_world_space_from_x_y + DiagonalSphericalMetric.new_photon on the host,
+    bit for bit, for every pixel."""
+    sp, sn = common.make_skies(64, 32, "check")
+    for pm in (curvis_amd.EllisMetric(1.0), curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0)):
+        cam = curvis_amd.Camera((0.0, 4.0, 1.1, 0.3), (-1.0, 0.2, 0.1), (0.1, 0.0, 1.0), 15.0, 43.0, 24, 16)
+        sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), cam, context=gpu_ctx)
+        _, dbg = sys_.render_image_debug(0, 100.0, 0.05)
+        dbg = np.asarray(dbg).reshape(16, 24)
+        pos = RelativisticVector(cam.position, Covariance.Contravariant)
+        for py in range(16):
+            for px in range(24):
+                ph = pm.new_photon(pos, cam.outward_vector_on_world_space_from_x_y(px, py))
+                assert np.array_equal(bits(dbg[py, px]["x"]), bits(ph.position.vector)), (px, py)
+                assert np.array_equal(bits(dbg[py, px]["p"])[1:], bits(ph.momentum.vector)[1:]), (px, py)
+                assert dbg[py, px]["steps"] == 0 and dbg[py, px]["code"] == 0
