@@ -250,3 +250,32 @@ def test_device_ray_construction_equals_the_host_accessors(gpu_ctx):
                 assert np.array_equal(bits(dbg[py, px]["x"]), bits(ph.position.vector)), (px, py)
                 assert np.array_equal(bits(dbg[py, px]["p"])[1:], bits(ph.momentum.vector)[1:]), (px, py)
                 assert dbg[py, px]["steps"] == 0 and dbg[py, px]["code"] == 0
+
+
+@pytest.mark.gpu
+def test_device_shading_equals_the_host_accessors(gpu_ctx):
+    """The other end of the loop (R9, R10): from every escaped ray's final photon in the debug dump,
+    relativistic_vector_to_direction + SphericalImage.get_pixel_from_vector3 on the host give the texel indices and the
+    pixel the kernel's epilogue produced."""
+    sp, sn = common.make_skies(128, 64, "check")
+    skies_ = {1: curvis_amd.SphericalImage(sp), -1: curvis_amd.SphericalImage(sn)}
+    for pm, l in ((curvis_amd.EllisMetric(1.0), 5.0), (curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0), -3.0)):
+        cam = curvis_amd.Camera((0.0, l, np.pi / 2, 0.0), (-1.0 if l > 0 else 1.0, 0.1, 0.05), (0.0, 0.0, 1.0), 15.0, 43.0, 24, 16)
+        sys_ = curvis_amd.RelativisticSystem(pm, skies_[1], skies_[-1], cam, context=gpu_ctx)
+        rgb, dbg = sys_.render_image_debug(4096, 100.0, 0.05)
+        dbg = np.asarray(dbg).reshape(16, 24)
+        seen = set()
+        for py in range(16):
+            for px in range(24):
+                d = dbg[py, px]
+                code = int(d["code"])
+                seen.add(code)
+                if code == 0:
+                    assert tuple(rgb[py, px]) == (0, 0, 0)
+                    continue
+                pos = RelativisticVector(d["x"], Covariance.Contravariant)
+                direction = pm.relativistic_vector_to_direction(RelativisticVector(d["p"], Covariance.Covariant), pos)
+                tx, ty = skies_[code].pixel_index_from_vector3(direction)
+                assert (tx, ty) == (int(d["tx"]), int(d["ty"])), (px, py)
+                assert tuple(rgb[py, px]) == skies_[code].get_pixel_from_vector3(direction)[:3], (px, py)
+        assert 1 in seen and -1 in seen
