@@ -67,6 +67,7 @@ SYMBOLS = {
     "curvis_metric_tensor": (C.c_int, [C.POINTER(Metric), _dp, _dp, _dp]),
     "curvis_camera_outward_vector": (C.c_int, [C.POINTER(CameraC), C.c_uint32, C.c_uint32, _dp, _dp]),
     "curvis_vector_to_direction": (C.c_int, [C.POINTER(Metric), _dp, _dp, _dp]),
+    "curvis_update_relativistic_object": (C.c_int, [C.POINTER(Metric), _dp, _dp, C.c_double]),
     "curvis_sky_texel_index": (C.c_int, [C.c_uint32, C.c_uint32, _dp, _dp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "curvis_render_brute": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_double, C.c_double,
                                       _vp, C.POINTER(Stats)]),

@@ -1053,6 +1053,28 @@ cvk::MetricParams make_metric(const curvis_metric &m) {
   return M;
 }
 
+/* one Euler step on the host, all eight components: the body of trajectory_kernel's loop */
+template <int KIND>
+void host_euler_step(const cvk::MetricParams &MP, double x[4], double p[4], double delta) {
+  cvk::Ray q;
+  q.l = x[1];
+  q.th = x[2];
+  q.ph = x[3];
+  q.p1 = p[1];
+  q.p2 = p[2];
+  q.p3 = p[3];
+  q.p3sq = q.p3 * q.p3;
+  cvk::ray_step<KIND, true>(MP, q, delta);
+  x[0] = x[0] + (p[0] * (1.0 / -1.0)) * delta; /* dx0 = p0 * g00.powi(-1), as in trajectory_kernel */
+  x[1] = q.l;
+  x[2] = q.th;
+  x[3] = q.ph;
+  p[0] = p[0] + 0.0 * delta;
+  p[1] = q.p1;
+  p[2] = q.p2;
+  p[3] = p[3] + 0.0 * delta;
+}
+
 cvk::CameraParams make_camera(const curvis_camera &c) {
   cvk::CameraParams C;
   for (int i = 0; i < 4; ++i) C.pos[i] = c.pos[i];
@@ -2253,6 +2275,18 @@ int curvis_vector_to_direction(const curvis_metric *metric, const double positio
       cvk::ray_direction<cvk::METRIC_INTERSTELLAR>(MP, q, direction[0], direction[1], direction[2]);
       break;
     default: cvk::ray_direction<cvk::METRIC_FLAT>(MP, q, direction[0], direction[1], direction[2]); break;
+  }
+  return CURVIS_OK;
+}
+
+int curvis_update_relativistic_object(const curvis_metric *metric, double x[4], double p_cov[4], double delta) {
+  if (!metric || !x || !p_cov) return CURVIS_E_INVALID;
+  if (curvis_metric_validate(metric) != CURVIS_OK) return CURVIS_E_METRIC;
+  const cvk::MetricParams MP = make_metric(*metric);
+  switch (metric->kind) {
+    case CURVIS_METRIC_ELLIS: host_euler_step<cvk::METRIC_ELLIS>(MP, x, p_cov, delta); break;
+    case CURVIS_METRIC_INTERSTELLAR: host_euler_step<cvk::METRIC_INTERSTELLAR>(MP, x, p_cov, delta); break;
+    default: host_euler_step<cvk::METRIC_FLAT>(MP, x, p_cov, delta); break;
   }
   return CURVIS_OK;
 }

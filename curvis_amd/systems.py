@@ -94,6 +94,20 @@ class DiagonalSphericalMetric:
         check(lib().curvis_vector_to_direction(C.byref(m), dptr(pos), dptr(p), dptr(out)))
         return out
 
+    def update_relativistic_object(self, obj, delta):
+        """src/metrics.rs:283-297: ONE forward-Euler step of `obj` in place (host-side, the kernels' arithmetic); a
+        contravariant momentum is lowered first (:285-288)"""
+        if obj.covariance_x() != Covariance.Contravariant:
+            raise CovarianceError("The position vector must be contravariant.")
+        if obj.covariance_p() == Covariance.Contravariant:
+            obj.momentum = self.to_covariant(obj.position, obj.momentum)
+        m = self._c()
+        x = np.ascontiguousarray(obj.position.vector, dtype=np.float64).copy()
+        p = np.ascontiguousarray(obj.momentum.vector, dtype=np.float64).copy()
+        check(lib().curvis_update_relativistic_object(C.byref(m), dptr(x), dptr(p), float(delta)))
+        obj.position = RelativisticVector(x, Covariance.Contravariant)
+        obj.momentum = RelativisticVector(p, Covariance.Covariant)
+
     def new_photon(self, position, direction):
         """src/metrics.rs:301-334: a photon at `position` (contravariant t, l, theta, phi) leaving along the
         tangent-space `direction` (normalised here): covariant momentum (1, d0, d1 r(l), d2 r(l) sin(theta))."""

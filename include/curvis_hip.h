@@ -157,6 +157,10 @@ int curvis_camera_outward_vector(const curvis_camera *camera, uint32_t px, uint3
  * reference does). */
 int curvis_vector_to_direction(const curvis_metric *metric, const double position[4], const double p_cov[4],
                                double direction[3]);
+/* DiagonalSphericalMetric::update_relativistic_object (src/metrics.rs:283-297) for a covariant momentum: ONE forward-Euler
+ * step of (x, p_cov) in place, on the host, with the IEEE form of the step the kernels fall back to (the fast step
+ * returns the same bits) -- the body of curvis_photon_trajectories' loop, all eight components. */
+int curvis_update_relativistic_object(const curvis_metric *metric, double x[4], double p_cov[4], double delta);
 /* SphericalImage::get_pixel_from_vector3's texel (src/images.rs:115-142, 171-174; src/algebra.rs:106-134) for an image of
  * w x h texels whose inverse orientation is inv_rot (NULL = the default forward x / up z): raw `as u32` indices.
  * Returns CURVIS_OK, or CURVIS_E_INVALID with the indices still set when x == w or y == h (the reference's

@@ -279,3 +279,36 @@ def test_device_shading_equals_the_host_accessors(gpu_ctx):
                 assert (tx, ty) == (int(d["tx"]), int(d["ty"])), (px, py)
                 assert tuple(rgb[py, px]) == skies_[code].get_pixel_from_vector3(direction)[:3], (px, py)
         assert 1 in seen and -1 in seen
+
+
+@pytest.mark.parametrize("kind", ["ellis", "interstellar", "flat"])
+def test_host_euler_step_matches_the_oracle(kind):
+    """update_relativistic_object (src/metrics.rs:283-297) through curvis_update_relativistic_object: 300 steps from
+    random photons, every component bit-equal to the oracle's step, including the throat crossing of the Interstellar
+    metric and a contravariant momentum handed in"""
+    om, pm = {"ellis": (O.ellis(1.0), curvis_amd.EllisMetric(1.0)),
+              "interstellar": (O.interstellar(0.1, 1.0, 1.0), curvis_amd.InterstellarMetric(0.1, 1.0, 1.0)),
+              "flat": (O.flat(), curvis_amd.FlatSphericalMetric())}[kind]
+    rng = np.random.default_rng(3)
+    for _ in range(6):
+        l = float(rng.uniform(1.5, 4.0))
+        pos = RelativisticVector([0.0, l, float(rng.uniform(0.4, 2.7)), float(rng.uniform(-3, 3))], Covariance.Contravariant)
+        d = np.array([-1.0, rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3)])
+        ph = pm.new_photon(pos, d)
+        x, p = ph.position.vector.copy(), ph.momentum.vector.copy()
+        for k in range(300):
+            pm.update_relativistic_object(ph, 0.02)
+            O.lib().cvo_update(O.CV, C.byref(om), O._dp(x), O._dp(p), 0.02)
+            assert np.array_equal(bits(ph.position.vector), bits(x)) and np.array_equal(bits(ph.momentum.vector), bits(p)), k
+        if kind != "flat":
+            assert ph.x(1) < 0.0       # went through the wormhole
+    ph = pm.new_photon(pos, d)
+    want = ph.copy()
+    pm.update_relativistic_object(want, 0.05)
+    raised = RelativisticObject(ph.position, pm.to_contravariant(ph.position, ph.momentum))
+    lowered = pm.to_covariant(raised.position, raised.momentum)
+    pm.update_relativistic_object(raised, 0.05)
+    assert raised.covariance_p() == Covariance.Covariant
+    ref = RelativisticObject(ph.position.copy(), lowered)
+    pm.update_relativistic_object(ref, 0.05)
+    assert np.array_equal(bits(raised.momentum.vector), bits(ref.momentum.vector))
