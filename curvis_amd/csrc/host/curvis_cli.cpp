@@ -535,8 +535,15 @@ void load_common(const Args &a, Common &c, const char *what) {
   if (curvis_metric_validate(&c.metric) != CURVIS_OK)
     die(std::string("Error in rendering ") + what + ": metric parameters must be positive (src/metrics.rs:409-456)", 101);
   if (!validate(c.cam, err) || !validate(c.sim, err)) die(std::string("Error in rendering ") + what + ": " + err);
-  if (!jpegio::load_image(a.bg1, c.sky1, err)) die(std::string("Error in rendering ") + what + ": background image 1: " + err);
-  if (!jpegio::load_image(a.bg2, c.sky2, err)) die(std::string("Error in rendering ") + what + ": background image 2: " + err);
+  /* both backgrounds are decoded at the same time (an 8192x4096 PNG takes the better part of a second to inflate and
+   * unfilter); errors are reported in the reference's order, image 1 first */
+  std::string err2;
+  bool ok2 = false;
+  std::thread second([&] { ok2 = jpegio::load_image(a.bg2, c.sky2, err2); });
+  const bool ok1 = jpegio::load_image(a.bg1, c.sky1, err);
+  second.join();
+  if (!ok1) die(std::string("Error in rendering ") + what + ": background image 1: " + err);
+  if (!ok2) die(std::string("Error in rendering ") + what + ": background image 2: " + err2);
 }
 
 void check(int rc, curvis_ctx *ctx, const char *what) {
