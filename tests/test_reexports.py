@@ -312,3 +312,20 @@ def test_host_euler_step_matches_the_oracle(kind):
     ref = RelativisticObject(ph.position.copy(), lowered)
     pm.update_relativistic_object(ref, 0.05)
     assert np.array_equal(bits(raised.momentum.vector), bits(ref.momentum.vector))
+
+
+def test_reference_vector_tests():
+    """the reference's own unit tests of RelativisticVector, same inputs and expectations (src/vectors.rs:185-240)"""
+    v1 = RelativisticVector([1.0, 2.0, 3.0, 4.0], Covariance.Covariant)
+    v2 = RelativisticVector([5.0, 6.0, 7.0, 8.0], Covariance.Covariant)
+    assert np.array_equal((v1 + v2).vector, [6.0, 8.0, 10.0, 12.0])
+    assert np.array_equal((v1 - v2).vector, [-4.0, -4.0, -4.0, -4.0])
+    assert np.array_equal((v1 + 5.0).vector, [6.0, 7.0, 8.0, 9.0])
+    assert np.array_equal((v1 - 5.0).vector, [-4.0, -3.0, -2.0, -1.0])
+    with pytest.raises(CovarianceError):
+        v1 / 0.0
+    v3 = RelativisticVector([5.0, 6.0, 7.0, 8.0], Covariance.Contravariant)
+    with pytest.raises(CovarianceError):
+        v1 + v3
+    with pytest.raises(CovarianceError):
+        v1 - v3
