@@ -94,3 +94,28 @@ def test_wiring_into_the_rendering_settings_reproduces_the_reference_quirks(tmp_
     assert len(v.times_of_frames()) == 480 and v.mode == "efficient"
     # src/rendering.rs:305-306: the video path passes threshold_1 for both thresholds
     assert (v.sampling_initial_nums, v.sampling_convergence_threshold_1) == (77, 3e-5)
+
+
+REF_DEFAULTS = "/root/reference/settings/defaults"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DEFAULTS), reason="the reference tree exists in the build container only")
+def test_reference_default_toml_files_parse_to_the_built_in_defaults(tmp_path):
+    """settings/defaults/*.toml of the reference (what `curvis` falls back to without -c / -s / -i / -v / -m) parse,
+    with this package's reader, to exactly the defaults built into the settings classes -- and the binary's own
+    reader accepts the same files"""
+    pairs = [("camera_settings.toml", S.CameraSettings), ("simulation_settings.toml", S.SimulationSettings),
+             ("image_settings.toml", S.ImageSettings), ("video_settings.toml", S.VideoSettings),
+             ("ellis_metric_settings.toml", S.EllisMetricSettings), ("interstellar_metric_settings.toml", S.InterstellarMetricSettings)]
+    for name, cls in pairs:
+        got, want = cls.from_toml_file(os.path.join(REF_DEFAULTS, name)), cls()
+        want.normalize()
+        for field, _, _ in cls.FIELDS:
+            a, b = getattr(got, field), getattr(want, field)
+            if field == "filepath_to_camera_path":   # the class default points at this package's generated copy
+                assert os.path.basename(a) == os.path.basename(b) == "path_through.csv"
+            else:
+                assert a == b and type(a) is type(b), (name, field, a, b)
+    for name, cls in pairs[4:]:
+        m = S.metric_settings_from_toml_file(os.path.join(REF_DEFAULTS, name))
+        assert type(m) is cls
