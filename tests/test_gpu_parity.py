@@ -672,3 +672,43 @@ def test_relay_safety_net_and_verify_option(gpu_ctx):
     finally:
         for k, v in (("relay_disabled", 0), ("relay_verify", 0), ("variant", -1), ("relay_min_blocks", -1), ("relay_segment", 0)):
             gpu_ctx.set_option(k, v)
+
+
+def test_batch_framebuffer_beyond_4_gib(gpu_ctx):
+    """One launch whose frames fill more than 2^32 bytes of framebuffer (100 frames of 5120x2880, 4.4 GB): frame
+    offsets, pixel indices and the per-frame counters must be 64-bit clean.  The escape radius is pulled in to 6 so
+    that rays take ~20-250 steps (the arithmetic is the same; the launch costs a fraction of a second).  Every
+    frame is read back on its own (44 MB at a time) and must equal frame 0, whose comb of rows equals the oracle."""
+    import ctypes as C
+    W, H, N, CAP, R = 5120, 2880, 100, 400, 6.0
+    assert W * H * 3 * N > 2 ** 32
+    sp, sn = common.make_skies(1024, 512, "check")
+    om, oc, pm, pc = common.scene("ellis", res=(W, H))
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    _, st = gpu_ctx.render_brute(pm, [pc] * N, CAP, R, 0.05, download=False)
+    per = gpu_ctx.frame_stats()
+    assert len(per) == N and st.rays == W * H * N
+    f0 = per[0]
+    assert f0.rays == W * H and f0.n_pos + f0.n_neg + f0.n_none == W * H and f0.n_pos > 0 and f0.n_neg > 0
+    for k, s in enumerate(per):
+        assert (s.rays, s.steps, s.n_pos, s.n_neg, s.n_none, s.n_oob) == (f0.rays, f0.steps, f0.n_pos, f0.n_neg, f0.n_none, f0.n_oob), k
+    assert st.steps == f0.steps * N
+    dev, nbytes = gpu_ctx.framebuffer()
+    frame_bytes = W * H * 3
+    assert nbytes == frame_bytes * N
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def frame(k):
+        out = np.empty(frame_bytes, np.uint8)
+        assert hip.hipMemcpy(out.ctypes.data, C.c_void_p(dev + k * frame_bytes), frame_bytes, 2) == 0   # hipMemcpyDeviceToHost
+        return out.reshape(H, W, 3)
+    first = frame(0)
+    osp, osn = O.sky(sp), O.sky(sn)
+    want, _, _ = O.render_image(O.CV, om, oc, osp, osn, CAP, R, 0.05, row_begin=7, row_step=96)
+    assert np.array_equal(first[7::96], want[7::96])
+    assert len(np.unique(first[::16, ::16].reshape(-1, 3), axis=0)) > 50   # a picture, not a constant
+    for k in (1, 2, 31, 32, 33, 50, 97, 98, 99):                       # around the 2^32-byte line (frame 32) and the ends
+        assert np.array_equal(frame(k), first), k
