@@ -712,3 +712,33 @@ def test_batch_framebuffer_beyond_4_gib(gpu_ctx):
     assert len(np.unique(first[::16, ::16].reshape(-1, 3), axis=0)) > 50   # a picture, not a constant
     for k in (1, 2, 31, 32, 33, 50, 97, 98, 99):                       # around the 2^32-byte line (frame 32) and the ends
         assert np.array_equal(frame(k), first), k
+
+
+def test_efficient_batch_framebuffer_beyond_4_gib(gpu_ctx):
+    """the same for the efficient renderer's batch path (render_image_efficient x 100 frames of 5120x2880 in one call)"""
+    import ctypes as C
+    W, H, N = 5120, 2880, 100
+    sp, sn = common.make_skies(1024, 512, "check")
+    om, oc, pm, pc = common.scene("ellis", res=(W, H))
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    gpu_ctx.render_efficient(pm, [pc] * N, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
+    dev, nbytes = gpu_ctx.framebuffer()
+    frame_bytes = W * H * 3
+    assert nbytes == frame_bytes * N and nbytes > 2 ** 32
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def frame(k):
+        out = np.empty(frame_bytes, np.uint8)
+        assert hip.hipMemcpy(out.ctypes.data, C.c_void_p(dev + k * frame_bytes), frame_bytes, 2) == 0
+        return out.reshape(H, W, 3)
+    first = frame(0)
+    single, _ = gpu_ctx.render_efficient(pm, pc, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+    assert np.array_equal(first, single)
+    assert len(np.unique(first[::16, ::16].reshape(-1, 3), axis=0)) > 50
+    gpu_ctx.render_efficient(pm, [pc] * N, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
+    dev, _ = gpu_ctx.framebuffer()
+    for k in (1, 31, 32, 33, 99):
+        assert np.array_equal(frame(k), first), k
