@@ -742,3 +742,38 @@ def test_efficient_batch_framebuffer_beyond_4_gib(gpu_ctx):
     dev, _ = gpu_ctx.framebuffer()
     for k in (1, 31, 32, 33, 99):
         assert np.array_equal(frame(k), first), k
+
+
+def test_single_frame_of_half_a_billion_rays(gpu_ctx):
+    """32768x16384 = 5.4e8 rays in ONE frame (1.6 GB of RGB8; tile and ray indices close to 2^32 / 8), escape radius
+    pulled in to 6 to keep the launch short: counters consistent, a comb of rows read back from HBM equals the oracle.
+    A frame whose padded ray count no longer fits 32 bits is refused, not rendered wrongly."""
+    import ctypes as C
+    W, H, CAP, R = 32768, 16384, 400, 6.0
+    sp, sn = common.make_skies(1024, 512, "check")
+    om, oc, pm, pc = common.scene("ellis", res=(W, H))
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    _, st = gpu_ctx.render_brute(pm, pc, CAP, R, 0.05, download=False)
+    assert st.rays == W * H and st.n_pos + st.n_neg + st.n_none == W * H and st.n_pos > 0 and st.n_neg > 0
+    dev, nbytes = gpu_ctx.framebuffer()
+    assert nbytes == W * H * 3
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rows = list(range(3, H, 1024)) + [H - 1]
+    T = len(rows)
+    osp, osn = O.sky(sp), O.sky(sn)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def check_row(y):
+        got = np.empty(W * 3, np.uint8)
+        assert hip.hipMemcpy(got.ctypes.data, C.c_void_p(dev + y * W * 3), W * 3, 2) == 0
+        want, _, _ = O.render_image(O.CV, om, oc, osp, osn, CAP, R, 0.05, row_begin=y, row_step=H)   # row y only
+        return np.array_equal(got.reshape(W, 3), want[y])
+    with ThreadPoolExecutor(common.host_threads(16)) as ex:
+        assert all(ex.map(check_row, rows)), rows
+    assert T == 17
+    big = curvis_amd.Camera((0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 15.0, 43.0, 65536, 65536)
+    with pytest.raises(curvis_amd.CurvisError):
+        gpu_ctx.render_brute(pm, big, CAP, R, 0.05, download=False)
