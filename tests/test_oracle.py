@@ -342,3 +342,50 @@ def test_disabled_reference_tests_get_pixel_and_orientation_fields():
     assert tuple(s2.forward) == (0.0, 1.0, 0.0) and tuple(s2.up) == (0.0, 0.0, 1.0)
     with pytest.raises(IndexError):
         s.get_pixel(32, 0)
+
+
+# ---- physics pin: independent of the reference's code.  In the equatorial plane of ds^2 = -dt^2 + dl^2 + r(l)^2 dOmega^2 a null
+# geodesic with impact parameter b = r(l0) sin(alpha) obeys dphi/dl = b / (r^2 sqrt(1 - b^2 / r^2)) on a monotone segment
+# (James et al., Am. J. Phys. 83, 486 (2015), the paper the reference cites).  Forward Euler must converge to that at first
+# order in delta; a restatement with a wrong sign, a wrong factor of r or sin, or a wrong p_phi convention cannot.
+
+def _analytic_dphi(metric, l_from, l_to, b):
+    from scipy.integrate import quad
+
+    def f(l):
+        r = L.cvo_metric_r(O.LIBM, C.byref(metric), l)
+        return b / (r * r * math.sqrt(1.0 - b * b / (r * r)))
+    pts = [p for p in (-1e-4, 1e-4, -0.5, 0.5) if min(l_from, l_to) < p < max(l_from, l_to)]
+    val, err = quad(f, l_from, l_to, points=pts or None, limit=400, epsabs=1e-12, epsrel=1e-12)
+    assert err < 1e-9
+    return val
+
+
+@pytest.mark.parametrize("name", ["ellis", "interstellar"])
+def test_euler_converges_to_the_closed_form_geodesic(name):
+    met = O.ellis(1.0) if name == "ellis" else O.interstellar(0.1, 1e-4, 1.0)
+    l0, R = 5.0, 100.0
+    r0 = L.cvo_metric_r(O.LIBM, C.byref(met), l0)
+    # outgoing rays (alpha < pi/2: l grows monotonically) and rays through the throat (b < rho = 1: l falls monotonically)
+    for alpha in (0.3, 0.9, 1.4, 3.00, 3.08, -3.02):
+        b = r0 * math.sin(alpha)
+        through = abs(alpha) > PI / 2
+        assert (abs(b) < 1.0) if through else True
+        errs = []
+        for delta in (0.02, 0.002):
+            c, s, x, p = O.escape_photon(O.LIBM, met, (0.0, l0, PI / 2, 0.0), (math.cos(alpha), 0.0, math.sin(alpha)), delta,
+                                         10 ** 7, R)
+            assert c == (-1 if through else 1)                     # which side a ray leaves on follows from b alone
+            assert abs(x[2] - PI / 2) < 1e-12                      # stays in the equatorial plane
+            assert abs(p[3] - b) < 1e-12 * max(1.0, abs(b))        # p_phi is conserved and equals the impact parameter
+            # to the l the integration actually stopped at; through the throat l runs downwards, dphi/dl changes sign with it
+            want = _analytic_dphi(met, x[1], l0, b) if through else _analytic_dphi(met, l0, x[1], b)
+            errs.append(abs(x[3] - want))
+        assert errs[0] < 3e-2 and errs[1] < 3e-3, (alpha, errs)
+        assert 5.0 < errs[0] / errs[1] < 20.0, (alpha, errs)       # first order in delta
+    # rays that turn around (b > rho, ingoing) come back out on the + side; b < rho go through: the critical angle
+    crit = math.asin(1.0 / r0)                                     # b = rho: the ray that circles the throat for ever
+    for alpha, side in ((PI - crit - 0.05, 1), (PI - crit - 0.01, 1), (PI - crit + 0.01, -1), (PI - crit + 0.08, -1)):
+        assert (r0 * math.sin(alpha) > 1.0) == (side == 1)
+        c, _, _, _ = O.escape_photon(O.LIBM, met, (0.0, l0, PI / 2, 0.0), (math.cos(alpha), 0.0, math.sin(alpha)), 0.01, 10 ** 6, R)
+        assert c == side, alpha
