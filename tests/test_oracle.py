@@ -389,3 +389,20 @@ def test_euler_converges_to_the_closed_form_geodesic(name):
         assert (r0 * math.sin(alpha) > 1.0) == (side == 1)
         c, _, _, _ = O.escape_photon(O.LIBM, met, (0.0, l0, PI / 2, 0.0), (math.cos(alpha), 0.0, math.sin(alpha)), 0.01, 10 ** 6, R)
         assert c == side, alpha
+
+
+@pytest.mark.parametrize("name", ["ellis", "interstellar"])
+def test_total_angular_momentum_is_conserved_to_first_order(name):
+    """Off the equatorial plane the exact flow conserves B^2 = p_theta^2 + p_phi^2 / sin^2(theta) (spherical symmetry) and
+    p_phi; forward Euler keeps p_phi exactly (dp_phi = 0, src/metrics.rs:262-268) and lets B^2 drift by O(delta)."""
+    met = O.ellis(1.0) if name == "ellis" else O.interstellar(0.1, 1e-4, 1.0)
+    for direction, ends in (((-0.9, 0.25, 0.2), "turns around"), ((-0.99, 0.08, 0.06), "goes through")):
+        drifts = []
+        for delta in (0.02, 0.002):
+            traj = O.photon_trajectory(O.LIBM, met, (0.0, 5.0, 1.0, 0.3), direction, int(round(16.0 / delta)), delta)
+            th, pth, pph = traj[:, 2], traj[:, 6], traj[:, 7]
+            assert np.all(pph == pph[0]) and np.all(traj[:, 4] == traj[0, 4])  # p_phi and p_t: constants of the scheme itself
+            b2 = pth ** 2 + pph ** 2 / np.sin(th) ** 2
+            drifts.append(float(np.max(np.abs(b2 / b2[0] - 1.0))))
+            assert (traj[-1, 1] > 8.0 and traj[:, 1].min() > 0.0) if ends == "turns around" else traj[-1, 1] < -8.0
+        assert drifts[0] < 0.1 and 5.0 < drifts[0] / drifts[1] < 20.0, (direction, drifts)
