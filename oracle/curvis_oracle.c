@@ -207,6 +207,12 @@ void cvo_samples_free(cvo_samples *s) {
 }
 
 /* ------------------------------------------------------------------ flavour instantiations */
+static void sincos_two_calls(double x, double *s, double *c) { /* llvm.sin.f64 and llvm.cos.f64 left as two libcalls */
+  *s = sin(x);
+  *c = cos(x);
+}
+static void sincos_glibc(double x, double *s, double *c) { sincos(x, s, c); } /* ... merged into one sincos() libcall */
+
 #define F(name) name##_libm
 #define M_SIN sin
 #define M_COS cos
@@ -214,6 +220,27 @@ void cvo_samples_free(cvo_samples *s) {
 #define M_ATAN atan
 #define M_ATAN2 atan2
 #define M_LOG log
+#define M_SINCOS sincos_two_calls
+#define M_SIN_INL(x, s) sin(x)
+#include "curvis_oracle_impl.inc"
+#undef F
+#undef M_SINCOS
+#undef M_SIN_INL
+
+/* CVO_LIBM_SINCOS: sin and cos of one value inside one reference function come from ONE glibc sincos() call (what
+ * LLVM's FSIN+FCOS -> FSINCOS combine produces on *-linux-gnu when both land in one block); every lone sin stays sin */
+#define F(name) name##_sc
+#define M_SINCOS sincos_glibc
+#define M_SIN_INL(x, s) sin(x)
+#include "curvis_oracle_impl.inc"
+#undef F
+#undef M_SIN_INL
+
+/* CVO_LIBM_SINCOS_INL: as above, and g33's theta.sin() (src/metrics.rs:68) is the sincos() sine too -- the case in
+ * which object_position_diff_contr and object_momentum_diff_cov are both inlined into update_relativistic_object
+ * and the three llvm.sin.f64(theta) are CSE'd before the combine */
+#define F(name) name##_sci
+#define M_SIN_INL(x, s) (s)
 #include "curvis_oracle_impl.inc"
 #undef F
 #undef M_SIN
@@ -222,6 +249,8 @@ void cvo_samples_free(cvo_samples *s) {
 #undef M_ATAN
 #undef M_ATAN2
 #undef M_LOG
+#undef M_SINCOS
+#undef M_SIN_INL
 
 #define F(name) name##_cv
 #define M_SIN cv_sin
@@ -230,6 +259,8 @@ void cvo_samples_free(cvo_samples *s) {
 #define M_ATAN cv_atan
 #define M_ATAN2 cv_atan2
 #define M_LOG cv_log
+#define M_SINCOS cv_sincos /* cv_sin(x) and cv_cos(x) ARE the two results of cv_sincos(x) */
+#define M_SIN_INL(x, s) cv_sin(x)
 #include "curvis_oracle_impl.inc"
 #undef F
 #undef M_SIN
@@ -238,8 +269,14 @@ void cvo_samples_free(cvo_samples *s) {
 #undef M_ATAN
 #undef M_ATAN2
 #undef M_LOG
+#undef M_SINCOS
+#undef M_SIN_INL
 
-#define DISPATCH(fl, name, ...) ((fl) == CVO_CV ? name##_cv(__VA_ARGS__) : name##_libm(__VA_ARGS__))
+#define DISPATCH(fl, name, ...)                                   \
+  ((fl) == CVO_CV                 ? name##_cv(__VA_ARGS__)        \
+   : (fl) == CVO_LIBM_SINCOS      ? name##_sc(__VA_ARGS__)        \
+   : (fl) == CVO_LIBM_SINCOS_INL  ? name##_sci(__VA_ARGS__)       \
+                                  : name##_libm(__VA_ARGS__))
 
 /* the six elementary functions of a flavour over arrays (op: 0 sin, 1 cos, 2 atan, 3 acos, 4 log, 5 atan2(a, b)):
  * lets the tests compare cv_math.h with glibc -- an independent libm -- on the very arguments the Euler loop
@@ -266,10 +303,7 @@ void cvo_photon_trajectory(int fl, const cvo_metric *m, const double x0[4], cons
   for (uint32_t k = 0; k < iterations; ++k) {
     memcpy(out + 8 * (size_t)k, x, sizeof x);
     memcpy(out + 8 * (size_t)k + 4, p, sizeof p);
-    if (fl == CVO_CV)
-      update_cv(m, x, p, delta);
-    else
-      update_libm(m, x, p, delta);
+    DISPATCH(fl, update, m, x, p, delta);
   }
 }
 

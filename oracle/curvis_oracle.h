@@ -18,9 +18,17 @@
  * on whole small frames of both renderers (tests/test_ref_python.py); the libm
  * flavour must be built with -fno-builtin-sin/cos (see the Makefile).
  *
- * Two math flavours, selected by the `fl` argument of every entry point:
+ * Math flavours, selected by the `fl` argument of every entry point:
  *   CVO_LIBM (0): glibc libm sin/cos/acos/atan/atan2/log -- what a Linux build of
- *                 the Rust reference calls (Rust f64::sin -> llvm.sin.f64 -> libm).
+ *                 the Rust reference calls (Rust f64::sin -> llvm.sin.f64 -> libm),
+ *                 every sin and cos a separate libcall.
+ *   CVO_LIBM_SINCOS (2), CVO_LIBM_SINCOS_INL (3): the same, with sin and cos of one
+ *                 value taken inside one function coming from ONE glibc sincos()
+ *                 call -- what LLVM's FSIN+FCOS -> sincos combine emits on
+ *                 *-linux-gnu.  Whether rustc's build of the reference merges them
+ *                 (and how far update_relativistic_object is inlined first: flavour
+ *                 3 also takes g33's sine from that call) cannot be seen here, so
+ *                 all three glibc arithmetics are carried and measured.
  *   CVO_CV   (1): curvis_amd/csrc/cv_math.h -- the deterministic, fma-explicit
  *                 functions the gfx950 kernels use; the GPU must match this
  *                 flavour BIT FOR BIT.  Only elementary functions are shared
@@ -36,7 +44,7 @@
 extern "C" {
 #endif
 
-enum { CVO_LIBM = 0, CVO_CV = 1 };
+enum { CVO_LIBM = 0, CVO_CV = 1, CVO_LIBM_SINCOS = 2, CVO_LIBM_SINCOS_INL = 3 };
 enum { CVO_ELLIS = 0, CVO_INTERSTELLAR = 1, CVO_FLAT = 2 };
 /* escape codes (PhotonEscape, src/systems.rs:39-44) */
 enum { CVO_NOT_ESCAPED = 0, CVO_POSITIVE = 1, CVO_NEGATIVE = -1, CVO_PANIC = -2 };

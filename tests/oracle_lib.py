@@ -8,6 +8,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 LIBM, CV = 0, 1
+# glibc with sin+cos pairs merged into ONE sincos() call (inside one reference function / throughout the inlined update):
+# whether rustc/LLVM merges them in the reference cannot be seen here, so every variant is carried (oracle/curvis_oracle.h)
+LIBM_SINCOS, LIBM_SINCOS_INL = 2, 3
+GLIBC_FLAVOURS = (LIBM, LIBM_SINCOS, LIBM_SINCOS_INL)
+FLAVOUR_NAMES = {LIBM: "CVO_LIBM (sin, cos separate)", CV: "CVO_CV (cv_math.h)", LIBM_SINCOS: "CVO_LIBM_SINCOS (sincos per function)",
+                 LIBM_SINCOS_INL: "CVO_LIBM_SINCOS_INL (sincos, update inlined)"}
 ELLIS, INTERSTELLAR, FLAT = 0, 1, 2
 NOT_ESCAPED, POSITIVE, NEGATIVE, PANIC = 0, 1, -1, -2
 

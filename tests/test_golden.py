@@ -28,7 +28,8 @@ def test_oracle_reproduces_brute_fixtures(name):
     g = load(name)
     sp, sn = common.make_skies(*G.SKY, "check")
     om, oc, _, _ = common.scene(metric, res=res, pos=pos, fwd=fwd)
-    for fl, tag in ((O.CV, "cv"), (O.LIBM, "libm")):
+    # the sincos-merged glibc flavours are held to the glibc fixture too: steps, codes, texels and pixels are the same
+    for fl, tag in ((O.CV, "cv"), (O.LIBM, "libm"), (O.LIBM_SINCOS, "libm"), (O.LIBM_SINCOS_INL, "libm")):
         rgb, dbg, _ = O.render_image(fl, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, debug=True)
         assert np.array_equal(rgb, g["rgb_" + tag]) and np.array_equal(dbg["steps"], g["steps_" + tag])
         assert np.array_equal(dbg["code"], g["code_" + tag]) and np.array_equal(dbg["tx"], g["tx_" + tag])

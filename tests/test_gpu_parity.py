@@ -186,17 +186,20 @@ def test_full_size_frame_bit_exact(gpu_ctx, metric, res, cap):
         gpu_ctx.set_option("fuse_shade", 1)
     gpu_ctx.set_option("variant", -1)
     gpu_ctx.set_option("fast_math", 1)
-    # the same frame in the reference's own arithmetic (glibc flavour): texel indices, step counts, escape codes and
-    # therefore pixels of EVERY ray identical (measured at full size, profiles/round2_libm_parity.txt)
-    libm_rgb, libm_dbg, libm_steps = oracle_full_frame(O.LIBM, om, oc, sp, sn, cap)
-    assert libm_steps == steps and np.array_equal(libm_rgb, want_rgb)
-    for f in ("steps", "code", "tx", "ty"):
-        assert np.array_equal(libm_dbg[f], want_dbg[f]), f
+    # the same frame in the reference's own arithmetic -- each of the three glibc flavours (sin/cos as separate libcalls,
+    # one sincos() per function, sincos() with update inlined; which one rustc emits is unknown): texel indices, step
+    # counts, escape codes and therefore pixels of EVERY ray identical (measured at full size,
+    # profiles/round3_libm_parity.txt)
+    for fl in O.GLIBC_FLAVOURS:
+        libm_rgb, libm_dbg, libm_steps = oracle_full_frame(fl, om, oc, sp, sn, cap)
+        assert libm_steps == steps and np.array_equal(libm_rgb, want_rgb), O.FLAVOUR_NAMES[fl]
+        for f in ("steps", "code", "tx", "ty"):
+            assert np.array_equal(libm_dbg[f], want_dbg[f]), (O.FLAVOUR_NAMES[fl], f)
 
 
 def test_config1_256x144_pixels(gpu_ctx):
     """BASELINE config 1 (256x144, all defaults, cap 40000): bit-exact vs oracle(cv) AND pixel-identical to
-    oracle(libm), the glibc arithmetic of the reference (measured: 36 864 of 36 864, profiles/round2_libm_parity.txt)."""
+    each of the oracle's three glibc arithmetics of the reference (measured: 36 864 of 36 864, profiles/round3_libm_parity.txt)."""
     sp, sn = common.make_skies(512, 256, "smooth")
     om, oc, pm, pc = common.scene("ellis", res=(256, 144))
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
@@ -205,17 +208,18 @@ def test_config1_256x144_pixels(gpu_ctx):
     want_cv, _, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05)
     assert np.array_equal(got, want_cv)
     assert sys_.last_stats.steps == st.steps
-    want_libm, _, _ = O.render_image(O.LIBM, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05)
-    diff = np.abs(got.astype(int) - want_libm.astype(int)).max(axis=2)
-    frac_exact = float((diff == 0).mean())
-    frac_le1 = float((diff <= 1).mean())
-    print("config1 vs libm oracle: exact %.5f, <=1 LSB %.5f, max %d" % (frac_exact, frac_le1, diff.max()))
-    assert frac_exact == 1.0 and diff.max() == 0, "rows with differing pixels: %s" % sorted(set(np.nonzero(diff)[0].tolist()))
-    # raw texel indices, step counts and escape codes of every ray as well (checkerboard-sky exactness)
-    _, dbg_libm, _ = O.render_image(O.LIBM, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05, debug=True)
     _, dbg = sys_.render_image_debug(40000, 100.0, 0.05)
-    for f in ("steps", "code", "tx", "ty"):
-        assert np.array_equal(dbg[f], dbg_libm[f]), f
+    for fl in O.GLIBC_FLAVOURS:  # all three glibc arithmetics (oracle/curvis_oracle.h)
+        want_libm, dbg_libm, _ = O.render_image(fl, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05, debug=True)
+        diff = np.abs(got.astype(int) - want_libm.astype(int)).max(axis=2)
+        frac_exact = float((diff == 0).mean())
+        frac_le1 = float((diff <= 1).mean())
+        print("config1 vs %s: exact %.5f, <=1 LSB %.5f, max %d" % (O.FLAVOUR_NAMES[fl], frac_exact, frac_le1, diff.max()))
+        assert frac_exact == 1.0 and diff.max() == 0, "%s: rows with differing pixels: %s" % (
+            O.FLAVOUR_NAMES[fl], sorted(set(np.nonzero(diff)[0].tolist())))
+        # raw texel indices, step counts and escape codes of every ray as well (checkerboard-sky exactness)
+        for f in ("steps", "code", "tx", "ty"):
+            assert np.array_equal(dbg[f], dbg_libm[f]), (O.FLAVOUR_NAMES[fl], f)
 
 
 def test_batch_equals_single_frames(gpu_ctx):
@@ -315,12 +319,13 @@ def test_efficient_default_960x540_vs_oracle(gpu_ctx):
                                          context=gpu_ctx)
     got = sys_.render_image_efficient(40000, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
     assert np.array_equal(got, want_rgb)
-    # against the glibc-libm flavour (what a Linux build of the reference computes): <= 1 LSB on the smooth sky
-    libm_rgb, _, _ = O.render_image_efficient(O.LIBM, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05, 100, 100, 1e-5,
-                                              1e-5)
-    d = np.abs(got.astype(int) - libm_rgb.astype(int)).max(axis=2)
-    print("efficient 960x540 vs libm oracle: exact %.5f, <=1 LSB %.5f, max %d" % ((d == 0).mean(), (d <= 1).mean(), d.max()))
-    assert d.max() == 0   # measured: 518 400 of 518 400 pixels identical (profiles/round2_libm_parity.txt)
+    # against the three glibc flavours (what a Linux build of the reference computes, with or without sincos merging)
+    for fl in O.GLIBC_FLAVOURS:
+        libm_rgb, _, _ = O.render_image_efficient(fl, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05, 100, 100, 1e-5,
+                                                  1e-5)
+        d = np.abs(got.astype(int) - libm_rgb.astype(int)).max(axis=2)
+        print("efficient 960x540 vs %s: exact %.5f, <=1 LSB %.5f, max %d" % (O.FLAVOUR_NAMES[fl], (d == 0).mean(), (d <= 1).mean(), d.max()))
+        assert d.max() == 0, O.FLAVOUR_NAMES[fl]  # measured: 518 400 of 518 400 pixels identical (profiles/round3_libm_parity.txt)
 
 
 def test_config3_full_size_4k_interstellar(gpu_ctx):

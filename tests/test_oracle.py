@@ -10,7 +10,7 @@ import oracle_lib as O
 
 L = O.lib()
 PI = math.pi
-FLS = [O.LIBM, O.CV]
+FLS = [O.LIBM, O.CV, O.LIBM_SINCOS, O.LIBM_SINCOS_INL]
 
 
 def v3(fl, theta, phi):
@@ -406,3 +406,61 @@ def test_total_angular_momentum_is_conserved_to_first_order(name):
             drifts.append(float(np.max(np.abs(b2 / b2[0] - 1.0))))
             assert (traj[-1, 1] > 8.0 and traj[:, 1].min() > 0.0) if ends == "turns around" else traj[-1, 1] < -8.0
         assert drifts[0] < 0.1 and 5.0 < drifts[0] / drifts[1] < 20.0, (direction, drifts)
+
+
+# ---------------------------------------------------------------- the three glibc arithmetics
+SINCOS_THETA = float.fromhex("0x1.5caf1e2fc24f6p+1")  # glibc 2.35: sincos(theta) sine != sin(theta) in the last bit
+
+
+def _glibc_sincos_differs():
+    import ctypes
+    m = ctypes.CDLL("libm.so.6")
+    m.sin.restype = ctypes.c_double
+    m.sin.argtypes = [ctypes.c_double]
+    m.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    s, c = ctypes.c_double(), ctypes.c_double()
+    m.sincos(SINCOS_THETA, ctypes.byref(s), ctypes.byref(c))
+    return s.value != m.sin(SINCOS_THETA)
+
+
+def test_sincos_flavours_really_call_sincos():
+    """CVO_LIBM_SINCOS / _INL are different arithmetics, not aliases: on an argument where glibc's sincos() sine
+    differs from sin() in the last bit the Euler step differs exactly where each flavour takes its sine from -- the
+    momentum update (both), the phi update through g33 (only the inlined variant)."""
+    if not _glibc_sincos_differs():
+        pytest.skip("this glibc returns the same sine from sin() and sincos() for the probe argument")
+    L = O.lib()
+    out = {}
+    for fl in O.GLIBC_FLAVOURS:
+        x = O.vec(0.0, 5.0, SINCOS_THETA, 0.0)   # zero phi, p_l, p_theta: the increments are not absorbed by roundings
+        p = O.vec(1.0, 0.0, 0.0, 1.3)
+        m = O.ellis()
+        L.cvo_update(fl, C.byref(m), O._dp(x), O._dp(p), 0.05)
+        out[fl] = (x.copy(), p.copy())
+    x0, p0 = out[O.LIBM]
+    x1, p1 = out[O.LIBM_SINCOS]
+    x2, p2 = out[O.LIBM_SINCOS_INL]
+    assert not np.array_equal(p0, p1)            # b^2 = p2^2 + p3^2/sin^2 uses the sincos sine
+    assert np.array_equal(x0, x1)                # g33 keeps its own sin() call
+    assert np.array_equal(p1, p2)
+    assert x2[3] != x1[3] and np.array_equal(x2[:3], x1[:3])  # ... unless update was inlined: phi moves by one ulp-ish
+
+
+@pytest.mark.parametrize("name", ["ellis", "interstellar"])
+def test_glibc_flavours_agree_on_every_pixel_of_a_small_frame(name):
+    """the three glibc arithmetics (sin/cos separate, merged per function, merged with update inlined) give the same
+    pixels, raw texel indices, step counts and escape codes on a 96x54 frame with a checkerboard sky; their final
+    states differ in the last bits for some rays (that is what makes them three arithmetics)."""
+    import common
+    sp, sn = common.make_skies(1024, 512, "check")
+    om, oc, _, _ = common.scene(name, res=(96, 54))
+    ref_rgb, ref, _ = O.render_image(O.LIBM, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05, debug=True)
+    moved = 0
+    for fl in (O.LIBM_SINCOS, O.LIBM_SINCOS_INL):
+        rgb, dbg, _ = O.render_image(fl, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05, debug=True)
+        assert np.array_equal(rgb, ref_rgb)
+        for f in ("steps", "code", "tx", "ty"):
+            assert np.array_equal(dbg[f], ref[f]), (fl, f)
+        moved += int((dbg["x"].view(np.uint64) != ref["x"].view(np.uint64)).any(axis=-1).sum())
+    if _glibc_sincos_differs():
+        assert moved > 0

@@ -1,7 +1,10 @@
-"""GPU (cv_math.h) against the oracle's glibc flavour -- the arithmetic a Linux build of the reference performs
+"""GPU (cv_math.h) against the oracle's glibc flavours -- the arithmetic a Linux build of the reference performs
 (Rust f64::sin/cos/atan/ln -> llvm intrinsics -> glibc libm, src/metrics.rs:68,257,262) -- at the FULL size of
 BASELINE configs[0..2], ray by ray, and the elementary functions themselves on the arguments the Euler loop
-produces, against glibc and against binary128 (libquadmath).  Writes profiles/round2_libm_parity.txt (run on the
+produces, against glibc and against binary128 (libquadmath).  ALL THREE glibc arithmetics are measured: sin and cos
+as separate libcalls (CVO_LIBM), merged into one sincos() per reference function (CVO_LIBM_SINCOS), and merged with
+update_relativistic_object fully inlined (CVO_LIBM_SINCOS_INL) -- which of them rustc/LLVM emits for the reference
+cannot be determined here (no Rust toolchain).  Writes profiles/round3_libm_parity.txt (run on the
 GPU box: python tools/gpu_libm_parity.py > gpurun_out/libm_parity.txt).  The numbers this prints are the ones the
 parity tests assert (tests/test_gpu_parity.py, tests/test_golden.py)."""
 import os
@@ -32,12 +35,22 @@ def compare_frame(ctx, name, metric, res, cap, sky_res):
     om, oc, pm, pc = common.scene(metric, res=res)
     sp, sn = skies.smooth(sky_res[0], sky_res[1], 128), skies.smooth(sky_res[0], sky_res[1], 32)
     cp, cn = skies.checker(sky_res[0], sky_res[1], seed=0xC0FFEE), skies.checker(sky_res[0], sky_res[1], seed=0xBADC0DE)
-    t0 = time.time()
-    want_rgb, want, _ = common.oracle_full_frame(O.LIBM, om, oc, sp, sn, cap, threads=THREADS)
-    t_or = time.time() - t0
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc, context=ctx)
     got_rgb, got = sys_.render_image_debug(cap, 100.0, 0.05)
     n = got.size
+    print("## %s: %s %dx%d cap %d, skies %dx%d, %d rays" % (name, metric, res[0], res[1], cap, sky_res[0], sky_res[1], n))
+    res_all = {}
+    for fl in O.GLIBC_FLAVOURS:
+        res_all[fl] = compare_with_flavour(fl, got_rgb, got, om, oc, sp, sn, cp, cn, cap)
+    print()
+    return res_all
+
+
+def compare_with_flavour(fl, got_rgb, got, om, oc, sp, sn, cp, cn, cap):
+    n = got.size
+    t0 = time.time()
+    want_rgb, want, _ = common.oracle_full_frame(fl, om, oc, sp, sn, cap, threads=THREADS)
+    t_or = time.time() - t0
     d = np.abs(got_rgb.astype(int) - want_rgb.astype(int)).max(axis=2)
     same_steps = got["steps"] == want["steps"]
     same_code = got["code"] == want["code"]
@@ -62,8 +75,7 @@ def compare_frame(ctx, name, metric, res, cap, sky_res):
             if sel.any():
                 worst = max(worst, int(ulp_diff(g[sel], w[sel]).max()))
     bad_rows = sorted(set(np.nonzero(~(d == 0))[0].tolist()))
-    print("## %s: %s %dx%d cap %d, skies %dx%d, %d rays (oracle libm flavour %.1f s on %d threads)" % (
-        name, metric, res[0], res[1], cap, sky_res[0], sky_res[1], n, t_or, THREADS))
+    print("### vs %s (oracle %.1f s on %d threads)" % (O.FLAVOUR_NAMES[fl], t_or, THREADS))
     print("pixels, smooth sky: identical %d of %d (%.6f), <= 1 LSB per channel %.6f, max difference %d" % (
         int((d == 0).sum()), n, (d == 0).mean(), (d <= 1).mean(), int(d.max())))
     print("pixels, checkerboard sky (exact texel needed): identical %d of %d (%.6f)" % (int(same_check.sum()), n, same_check.mean()))
@@ -74,7 +86,6 @@ def compare_frame(ctx, name, metric, res, cap, sky_res):
           "step count and code: %d ulp" % (int(state_same.sum()), n, state_same.mean(), worst))
     if bad_rows:
         print("rows with differing pixels: %s%s" % (bad_rows[:40], " ..." if len(bad_rows) > 40 else ""))
-    print()
     return dict(exact=(d == 0).mean(), le1=(d <= 1).mean(), texel=same_texel.mean(), steps=same_steps.mean(),
                 code=same_code.mean())
 
@@ -82,17 +93,19 @@ def compare_frame(ctx, name, metric, res, cap, sky_res):
 def compare_efficient(ctx):
     om, oc, pm, pc = common.scene("ellis", res=(960, 540))
     sp, sn = common.make_skies(2048, 1024, "smooth")
-    want, smp, _ = O.render_image_efficient(O.LIBM, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc, context=ctx)
     got = sys_.render_image_efficient(40000, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
     a, e, s = ctx.samples(0)
-    d = np.abs(got.astype(int) - want.astype(int)).max(axis=2)
     print("## render_image_efficient, default image 960x540 (cap 40000, n0 = 100, thr 1e-5), smooth 2048x1024 skies")
-    print("sample tables: %d vs %d points, alphas identical %s, escape spaces identical %s, max |escape angle difference| %.3g" % (
-        len(a), len(smp["a"]), bool(np.array_equal(a, smp["a"])), bool(np.array_equal(s, smp["s"])),
-        float(np.nanmax(np.abs(e - smp["e"]))) if len(a) == len(smp["a"]) else float("nan")))
-    print("pixels: identical %d of %d (%.6f), <= 1 LSB %.6f, max difference %d" % (
-        int((d == 0).sum()), d.size, (d == 0).mean(), (d <= 1).mean(), int(d.max())))
+    for fl in O.GLIBC_FLAVOURS:
+        want, smp, _ = O.render_image_efficient(fl, om, oc, O.sky(sp), O.sky(sn), 40000, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+        d = np.abs(got.astype(int) - want.astype(int)).max(axis=2)
+        print("### vs %s" % O.FLAVOUR_NAMES[fl])
+        print("sample tables: %d vs %d points, alphas identical %s, escape spaces identical %s, max |escape angle difference| %.3g" % (
+            len(a), len(smp["a"]), bool(np.array_equal(a, smp["a"])), bool(np.array_equal(s, smp["s"])),
+            float(np.nanmax(np.abs(e - smp["e"]))) if len(a) == len(smp["a"]) else float("nan")))
+        print("pixels: identical %d of %d (%.6f), <= 1 LSB %.6f, max difference %d" % (
+            int((d == 0).sum()), d.size, (d == 0).mean(), (d <= 1).mean(), int(d.max())))
     print()
 
 
@@ -155,7 +168,8 @@ def function_sweep(ctx):
 
 def main():
     ctx = curvis_amd.Context(0)
-    print("# GPU (fast step, cv_math.h) vs oracle CVO_LIBM (glibc %s) -- full-size BASELINE configurations" % (
+    print("# GPU (fast step, cv_math.h) vs the oracle's three glibc arithmetics (%s): sin/cos separate, one sincos() per "
+          "reference function, sincos() with update inlined -- full-size BASELINE configurations" % (
         os.confstr("CS_GNU_LIBC_VERSION")))
     print("device: %s; host threads used by the oracle: %d" % (ctx.device_info()["name"], THREADS))
     print()
