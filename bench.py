@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--multi-frame", type=int, default=6,
                     help="frames per launch of the secondary multi-frame measurement (value_multi_frame); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustained-seconds", type=float, default=3.0,
+                    help="length of the secondary back-to-back measurement behind `value_sustained` (clock and power "
+                         "sampled during it); 0 = skip")
     ap.add_argument("--cpu-row-step", type=int, default=8)
     return ap.parse_args()
 
@@ -156,6 +159,14 @@ def main():
         ctx.set_option("blocks_per_cu", args.blocks_per_cu)
     ctx.set_option("fast_math", args.fast_math)
     ctx.set_option("fuse_shade", args.fuse_shade)
+    pci_bus_id = ctx.device_status()["pci_bus_id"]
+    if use_dist and world > 1:
+        # one rank per PHYSICAL GPU: two ranks on one device would time-share it and the line would still say n_gpus = N
+        ids = [None] * world
+        dist.all_gather_object(ids, pci_bus_id)
+        if len(set(ids)) != world and not share_device:
+            raise SystemExit("bench.py: %d ranks on %d distinct GPU(s) %s; refusing (CURVIS_BENCH_SHARE_DEVICE=1 allows it "
+                             "for control-flow tests)" % (world, len(set(ids)), sorted(set(ids))))
 
     # ---- inputs resident in HBM before the timed region: two skies (rank 0 generates, RCCL broadcast)
     sw, sh = args.sky, args.sky // 2
@@ -262,8 +273,26 @@ def main():
                  "note": "same frame %d times per launch; not the contract's `value` (one frame per step)" % nf}
         ctx.render_brute(metric, cam, args.max_iter, R, DELTA, download=False)  # so that last_relay_launches below describes a single-frame launch
 
+    # secondary figure: >= `sustained_seconds` of back-to-back single-frame launches with the shader clock and the board
+    # power sampled from sysfs while they run -- the chip is power-limited under sustained FP64 load, and boxes differ
+    # by a few per cent in the clock they hold; this is where that shows.  Not the contract's `value`.
+    sustained = None
+    if args.sustained_seconds > 0:
+        sustained = sustained_run(ctx, step, args.sustained_seconds, torch)
+
+    own_elapsed = elapsed
+    per_rank = None
     if dist is not None:
         red_dev = "cuda" if backend == "nccl" else "cpu"
+        mine = {"rank": rank, "pci_bus_id": pci_bus_id, "device_index": device_index,
+                "ms_per_step": round(own_elapsed / args.steps * 1e3, 4),
+                "kernel_ms_avg": round(kernel_ms / args.steps, 4),
+                "value": round(steps_executed / own_elapsed / 1e6, 1),
+                "sclk_mhz": sustained["sclk_mhz_median"] if sustained else None,
+                "power_w": sustained["power_w_median"] if sustained else None,
+                "value_sustained": sustained["value"] if sustained else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -369,8 +398,22 @@ def main():
                         "note": "7 B/ray algorithmic; the loop is register-resident, HBM fraction is ~0 by construction"},
             },
         }
+        if sustained is not None:
+            out["value_sustained"] = sustained
         if comm_info is not None:
+            bms = comm_info["sky_broadcast_ms"]
+            comm_info["sky_broadcast_gbps"] = [round(comm_info["sky_bytes_each"] / (ms * 1e-3) / 1e9, 2) if ms > 0 else None for ms in bms]
             out["collective"] = comm_info
+        if per_rank is not None:
+            # who is the straggler: the timed region ends when the slowest rank does (max over ranks), so `value` is
+            # N x the slowest GPU's rate; the table says which GPU that was and at which clock it ran
+            per_rank.sort(key=lambda r: r["rank"])
+            out["per_rank"] = per_rank
+            out["value_per_gpu_min"] = min(r["value"] for r in per_rank)
+            out["value_per_gpu_max"] = max(r["value"] for r in per_rank)
+            out["distinct_gpus"] = len(set(r["pci_bus_id"] for r in per_rank))
+            if sustained is not None:
+                out["value_sustained"]["all_ranks"] = round(sum(r["value_sustained"] or 0.0 for r in per_rank), 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, host_skies)
 
@@ -387,6 +430,46 @@ def main():
     if rank == 0:
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
+
+
+def sustained_run(ctx, step, seconds, torch):
+    """back-to-back single-frame launches for at least `seconds`; a sampler thread reads the shader clock and the board
+    power from sysfs (curvis_ctx_device_status) every 100 ms meanwhile"""
+    import threading
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            st = ctx.device_status()
+            samples.append((st["sclk_mhz"], st["power_w"]))
+            stop.wait(0.1)
+    th = threading.Thread(target=sampler, daemon=True)
+    torch.cuda.synchronize()
+    th.start()
+    t0 = time.perf_counter()
+    n, n_steps, k_ms = 0, 0, 0.0
+    while True:
+        st = step()
+        n += 1
+        n_steps += st.steps
+        k_ms += st.integrate_ms
+        if time.perf_counter() - t0 >= seconds:
+            break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stop.set()
+    th.join()
+    sclk = sorted(v[0] for v in samples if v[0] > 0)
+    powr = sorted(v[1] for v in samples if v[1] > 0)
+
+    def med(v):
+        return v[len(v) // 2] if v else None
+    return {"value": round(n_steps / dt / 1e6, 1), "unit": "Mray-steps/s (executed), this rank", "launches": n,
+            "seconds": round(dt, 2), "ms_per_step": round(dt / n * 1e3, 4), "kernel_ms_avg": round(k_ms / n, 4),
+            "sclk_mhz_median": med(sclk), "sclk_mhz_min": sclk[0] if sclk else None, "sclk_mhz_max": sclk[-1] if sclk else None,
+            "power_w_median": med(powr), "power_w_max": powr[-1] if powr else None, "samples": len(samples),
+            "note": "back-to-back single-frame launches after the contract's timed region; clock and power from sysfs "
+                    "(pp_dpm_sclk, hwmon power1_average) every 100 ms; null where sysfs does not tell"}
 
 
 def pmc_traffic(args, kernel_name):
@@ -436,7 +519,7 @@ def live_traffic(args, kernel_name, steps_per_launch):
              "--width", str(args.width), "--height", str(args.height), "--max-iter", str(args.max_iter),
              "--metric", args.metric, "--sky", str(args.sky), "--variant", str(args.variant),
              "--fast-math", str(args.fast_math), "--fuse-shade", str(args.fuse_shade), "--multi-frame", "0",
-             "--no-traffic", "--no-live-traffic", "--no-cpu-baseline"]
+             "--sustained-seconds", "0", "--no-traffic", "--no-live-traffic", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CURVIS_BENCH_FORCE_DIST")}
     env["TMPDIR"] = "/tmp"
     SQ = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")

@@ -55,6 +55,7 @@ SYMBOLS = {
     "curvis_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "curvis_ctx_destroy": (None, [_vp]),
     "curvis_ctx_device_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "curvis_ctx_device_status": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "curvis_ctx_set_sky": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, C.c_uint32]),
     "curvis_ctx_set_sky_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_int]),
     "curvis_ctx_set_sky_orientation": (C.c_int, [_vp, C.c_int, _dp, _dp]),

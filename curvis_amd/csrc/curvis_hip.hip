@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -2045,6 +2046,46 @@ int curvis_ctx_device_info(const curvis_ctx *ctx, char *name, size_t name_cap, i
   }
   if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
   if (clock_mhz) *clock_mhz = ctx->prop.clockRate / 1000;
+  return CURVIS_OK;
+}
+
+/* first integer of a small sysfs file matched by `glob`-less path pieces; -1 when unreadable */
+static long read_sysfs_long(const std::string &path) {
+  FILE *f = std::fopen(path.c_str(), "r");
+  if (!f) return -1;
+  long v = -1;
+  if (std::fscanf(f, "%ld", &v) != 1) v = -1;
+  std::fclose(f);
+  return v;
+}
+
+int curvis_ctx_device_status(const curvis_ctx *ctx, char *pci_bus_id, size_t cap, int *sclk_mhz, int *power_w) {
+  if (!ctx) return CURVIS_E_INVALID;
+  char id[64] = {0};
+  if (hipDeviceGetPCIBusId(id, (int)sizeof id, ctx->device) != hipSuccess) id[0] = 0;
+  for (char *p = id; *p; ++p) *p = (char)std::tolower((unsigned char)*p); /* sysfs spells the address in lower case */
+  if (pci_bus_id && cap) std::snprintf(pci_bus_id, cap, "%s", id);
+  const std::string dev = std::string("/sys/bus/pci/devices/") + id;
+  if (sclk_mhz) { /* pp_dpm_sclk: one line per level, "1: 2100Mhz *" marks the current one */
+    *sclk_mhz = -1;
+    if (FILE *f = std::fopen((dev + "/pp_dpm_sclk").c_str(), "r")) {
+      char line[128];
+      while (std::fgets(line, sizeof line, f)) {
+        int level = 0, mhz = 0;
+        if (std::strchr(line, '*') && std::sscanf(line, "%d: %dMhz", &level, &mhz) == 2) *sclk_mhz = mhz;
+      }
+      std::fclose(f);
+    }
+  }
+  if (power_w) { /* hwmon/hwmonN/power1_average (or power1_input), microwatts */
+    *power_w = -1;
+    for (int n = 0; n < 16 && *power_w < 0; ++n) {
+      const std::string h = dev + "/hwmon/hwmon" + std::to_string(n);
+      long uw = read_sysfs_long(h + "/power1_average");
+      if (uw < 0) uw = read_sysfs_long(h + "/power1_input");
+      if (uw >= 0) *power_w = (int)(uw / 1000000);
+    }
+  }
   return CURVIS_OK;
 }
 

@@ -283,17 +283,28 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
     ray_step_core<KIND, PHI>(M, q, delta, s, c);
     return;
   }
-  double r, r2, rd, y_r;
+  double r, r2, rd, y_r, y_s;
   if (KIND == METRIC_ELLIS) {
     r2 = M.rho2 + q.l * q.l;
     sqrt_and_rsqrt(r2, r, y_r);
     rd = div_with_recip(q.l, r, y_r);
-  } else if (KIND == METRIC_INTERSTELLAR) {
-    interstellar_eval_x_ge2(M, q.l, x_i, r, r2, rd);
-    y_r = recip_refined(r);
+    y_s = recip_refined(s);
   } else {
-    metric_eval<KIND>(M, q.l, r, r2, rd);
-    y_r = recip_refined(r);
+    if (KIND == METRIC_INTERSTELLAR)
+      interstellar_eval_x_ge2(M, q.l, x_i, r, r2, rd);
+    else
+      metric_eval<KIND>(M, q.l, r, r2, rd);
+    /* no square root here, so 1/r would need a seed of its own: ONE v_rcp_f64 (a quarter-rate instruction) serves
+     * both reciprocals -- y ~ 1/(r s), 1/r ~ y s, 1/s ~ y r (each ~1.5 ulp; the quotients below stay correctly
+     * rounded, see div_with_recip).  r s cannot leave the normal range: 2^-90 < r < 2^91 and |s| > 2^-60. */
+    if (eq) {
+      y_r = recip_refined(r);
+      y_s = 1.0;
+    } else {
+      const double y_rs = recip_refined(r * s);
+      y_r = y_rs * s;
+      y_s = y_rs * r;
+    }
   }
   if (eq) { /* s == 1: see above; same operations as below with the factors that are exactly 1 left out */
     const double y_r2e = y_r * y_r;
@@ -316,7 +327,6 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
     q.p2 = q.p2 + dp2e * delta;
     return;
   }
-  const double y_s = recip_refined(s);
   const double y_r2 = y_r * y_r;
   const double y_ss = y_s * y_s;
   const double ss = s * s;

@@ -748,7 +748,7 @@ CV_HD double cv_acos(double x) {
 /* natural logarithm                                                          */
 /* ------------------------------------------------------------------------- */
 
-/* {invc, logc_hi - LN2_HI, logc_lo - LN2_LO} per 1/512-wide slice of [1, 2) (cv_log_table.h).  Host code reads the
+/* {2 invc, logc_hi - LN2_HI, logc_lo - LN2_LO} per 1/512-wide slice of [1, 2) (cv_log_table.h).  Host code reads the
  * static copy, device code the __constant__ copy unless the caller passes its own (the Interstellar kernels keep
  * one in LDS: 12 KiB per workgroup). */
 typedef const double (*cv_log_tab_t)[3];
@@ -764,42 +764,46 @@ CV_HD cv_log_tab_t cv_log_table(void) {
 #endif
 }
 
-/* log x, table-driven.  x = 2^k z, z in [1, 2); i = top 9 mantissa bits; c = 1/invc_i is close to z:
- *   r  = fma(z, invc, -1)             exact (invc is a multiple of 2^-10 and |r| <= 2^-9)
+/* log x, table-driven.  x = 2^e g with g in [1/2, 1) -- what v_frexp_exp_i32_f64 / v_frexp_mant_f64 deliver, one
+ * instruction each -- i.e. x = 2^k z, z = 2g in [1, 2), k = e - 1; i = top 9 mantissa bits; c = 1/invc_i is close to z:
+ *   r  = fma(g, 2 invc, -1)           = z invc - 1, exact (invc is a multiple of 2^-10 and |r| <= 2^-9); the table holds 2 invc
  *   w  = k*LN2_HI + logc_hi           exact (both multiples of 2^-32); computed as e*LN2_HI + (logc_hi - LN2_HI)
- *                                     with e = k + 1, the exponent v_frexp_exp_i32_f64 delivers in one instruction
  *                                     (the table holds logc_hi - LN2_HI, exactly, and logc_lo - LN2_LO)
  *   hi + lo = w + r                   Fast2Sum (w == 0 or |w| >= |r|, checked by the table generator)
  *   log x = hi + (lo + k*LN2_LO + logc_lo + r^2 (-1/2 + r/3 - ... + r^5/7))
  * Taylor truncation < 2^-59 relative even on the slice next to 1 (invc = 1, w = 0, log x = r + ...), so the
  * error is 0.5 ulp of the final addition plus ~0.02 ulp.
  * Arguments outside [1/2, 2) (k >= 1 or k <= -2) have |w| >= 0.69 while |r| <= 2^-9, so w needs no help from r:
- *   log x = w + fma(r^2, P3(r), r + (k*LN2_LO + logc_lo))        P3 = -1/2 + r/3 - r^2/4 + r^3/5
- * -- no Fast2Sum and two Taylor terms less (r^6/6 <= 2^-56.6 absolute against ulp(0.69) = 2^-53, on the two slices
- * next to 1 only; 2^-62.6 elsewhere): the result carries 0.5 ulp + 0.08.  Three additions and two fma fewer per Interstellar Euler step, whose
- * argument 1 + x^2 is >= 5 whenever x >= 2.  WHICH formula applies is a function of the argument alone (its
- * exponent), so cv_log stays one function with one value per argument on host and device. */
-/* log of the normal positive double with bits ux (hx = high word), plus k0 * ln 2 */
-CV_HD double cv_log_main(uint64_t ux, uint32_t hx, int k0, cv_log_tab_t T) {
+ *   log x = w + v,   v = t + r (1 + r (-1/2 + r (1/3 + r (-1/4 + r/5)))),   t = k*LN2_LO + logc_lo
+ * -- one Horner chain of five fmas ending in the small term (|v| < 2^-8: its own rounding and that of the inner
+ * factor ~1 are below 2^-61), no Fast2Sum and two Taylor terms less (r^6/6 <= 2^-56.6 absolute against ulp(0.69) =
+ * 2^-53, on the two slices next to 1 only; 2^-62.6 elsewhere): the result carries 0.5 ulp + 0.08.  This is the form
+ * every Interstellar Euler step takes (its argument 1 + x^2 is >= 5 whenever x >= 2): 16 instructions with the
+ * argument's construction (round 2: r^2 P3(r) + (r + t) and a bit-field insert for z, 18).  WHICH formula applies is
+ * a function of the argument alone (its exponent), so cv_log stays one function with one value per argument on host
+ * and device. */
+/* the k >= 1 / k <= -2 formula: e = k + 1 as a double, r, row of the table */
+CV_HD double cv_log_far(double kd, double r, double lch, double lcl) {
   const double LN2_HI = 6.93147180369123816490e-01, /* 0x3FE62E42FEE00000 */
       LN2_LO = 1.90821492927058770002e-10;          /* 0x3DEA39EF35793C76 */
+  const double t = CV_FMA(kd, LN2_LO, lcl);
+  const double w = CV_FMA(kd, LN2_HI, lch);
+  /* -0.5 and 1.0 are inline constants of the VOP3 encoding: plain fmas; the other two addends come from scalar pairs */
+  const double c1 = CV_FMA(r, CV_FMA(r, cv_fma_ks(r, cv_fma_ks(r, 0.2, -0.25), 3.33333333333333314830e-01), -0.5), 1.0);
+  return w + CV_FMA(r, c1, t);
+}
+/* log of the normal positive double with bits ux (hx = high word), plus k0 * ln 2 */
+CV_HD double cv_log_main(uint64_t ux, uint32_t hx, int k0, cv_log_tab_t T) {
+  const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
   const int e = k0 + (int)(hx >> 20) - 0x3fe; /* k + 1 */
   const unsigned i = (hx >> 11) & 0x1ffu;
-#if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t zh; /* (hx & 0xfffff) | 0x3ff00000 as ONE bit-field insert (the compiler emits and + or) */
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(zh) : "s"(0x000fffffu), "v"(hx), "v"(0x3ff00000u));
-#else
-  const uint32_t zh = (hx & 0x000fffffu) | 0x3ff00000u;
-#endif
-  const double z = cv_from_bits(((uint64_t)zh << 32) | (ux & 0xffffffffULL));
-  const double invc = T[i][0], lch = T[i][1], lcl = T[i][2];
-  const double r = CV_FMA(z, invc, -1.0);
+  const uint32_t gh = (hx & 0x000fffffu) | 0x3fe00000u;
+  const double g = cv_from_bits(((uint64_t)gh << 32) | (ux & 0xffffffffULL)); /* mantissa in [1/2, 1) */
+  const double invc2 = T[i][0], lch = T[i][1], lcl = T[i][2];
+  const double r = CV_FMA(g, invc2, -1.0);
   const double kd = (double)e;
+  if ((unsigned)e >= 2u) return cv_log_far(kd, r, lch, lcl); /* k >= 1 or k <= -2: |w| >= 0.69 */
   const double w = CV_FMA(kd, LN2_HI, lch);
-  if ((unsigned)e >= 2u) { /* k >= 1 or k <= -2: |w| >= 0.69 */
-    const double p3 = cv_fma_ks(r, cv_fma_ks(r, cv_fma_ks(r, 0.2, -0.25), 3.33333333333333314830e-01), -0.5);
-    return w + CV_FMA(r * r, p3, r + CV_FMA(kd, LN2_LO, lcl));
-  }
   const double hi = w + r;
   const double lo = ((w - hi) + r) + CV_FMA(kd, LN2_LO, lcl);
   const double r2 = r * r;
@@ -828,27 +832,19 @@ CV_HD double cv_log_t(double x, cv_log_tab_t T) {
 }
 
 /* the same value for a finite argument >= 2 (1 + x^2 with x >= 2: every Euler step outside |l| < a + pi m): only the
- * k >= 1 formula of cv_log_main, no test of k */
+ * k >= 1 formula of cv_log_main, no test of k; exponent and mantissa by v_frexp_exp_i32_f64 / v_frexp_mant_f64 */
 CV_HD double cv_log_ge2_t(double x, cv_log_tab_t T) {
-  const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-  const uint64_t ux = cv_bits(x);
-  const uint32_t hx = (uint32_t)(ux >> 32);
+  const uint32_t hx = cv_hi(x);
   const unsigned i = (hx >> 11) & 0x1ffu;
 #if defined(__HIP_DEVICE_COMPILE__)
-  const int e = __builtin_amdgcn_frexp_exp(x); /* v_frexp_exp_i32_f64: k + 1 for a normal number */
-  uint32_t zh;
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(zh) : "s"(0x000fffffu), "v"(hx), "v"(0x3ff00000u));
+  const int e = __builtin_amdgcn_frexp_exp(x); /* k + 1 for a normal number */
+  const double g = __builtin_amdgcn_frexp_mant(x);
 #else
   const int e = (int)(hx >> 20) - 0x3fe;
-  const uint32_t zh = (hx & 0x000fffffu) | 0x3ff00000u;
+  const double g = cv_from_bits((((uint64_t)((hx & 0x000fffffu) | 0x3fe00000u)) << 32) | (cv_bits(x) & 0xffffffffULL));
 #endif
-  const double z = cv_from_bits(((uint64_t)zh << 32) | (ux & 0xffffffffULL));
-  const double invc = T[i][0], lch = T[i][1], lcl = T[i][2];
-  const double r = CV_FMA(z, invc, -1.0);
-  const double kd = (double)e;
-  const double w = CV_FMA(kd, LN2_HI, lch);
-  const double p3 = cv_fma_ks(r, cv_fma_ks(r, cv_fma_ks(r, 0.2, -0.25), 3.33333333333333314830e-01), -0.5);
-  return w + CV_FMA(r * r, p3, r + CV_FMA(kd, LN2_LO, lcl));
+  const double r = CV_FMA(g, T[i][0], -1.0);
+  return cv_log_far((double)e, r, T[i][1], T[i][2]);
 }
 
 CV_HD double cv_log(double x) { return cv_log_t(x, cv_log_table()); }

@@ -4,17 +4,22 @@
  * expanded to RGBA8 the way the reference obtains texels (image 0.25.2: DynamicImage::get_pixel ->
  * Rgba<u8>; 16-bit samples are reduced with (v + 128) / 257, grey is replicated, missing alpha = 255)
  * -- src/images.rs:8, :107-111.
- * Writer: RGB8, one IDAT, filter type 0 (src/rendering.rs:110, :311 save an ImageRgb8 as PNG; the
- * compressed bytes differ from the image crate's encoder, the decoded pixels are identical).
+ * Writer: RGB8, one IDAT (src/rendering.rs:110, :311 save an ImageRgb8 as PNG; the compressed bytes differ from
+ * the image crate's encoder, the decoded pixels are identical): zlib at a chosen level with filter type 0, or the
+ * fast PNG-specific deflate below (the default of the curvis binary).
  */
 #ifndef CURVIS_PNG_IO_H
 #define CURVIS_PNG_IO_H
 #include <zlib.h>
 
+#include <time.h>
+
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace pngio {
@@ -262,7 +267,345 @@ inline void chunk(std::vector<uint8_t> &out, const char *type, const std::vector
   put_be32(out, crc);
 }
 
-inline bool save_rgb8(const std::string &path, const uint8_t *rgb, uint32_t w, uint32_t h, std::string &err, int level = 6) {
+/* ------------------------------------------------------------------------------------------------
+ * Fast PNG writer for the frame files of `curvis video` (src/rendering.rs:291-316 saves one PNG per frame).
+ * The reference's encoder (image 0.25 -> png 0.17, CompressionType::Fast) is a PNG-specific fast deflate; so is
+ * this one, written from the formats (RFC 1950/1951, PNG 1.2), not from that crate: filter Up (Sub on the first
+ * row), then ONE dynamic-Huffman deflate block over the filtered bytes in which the only matches are runs of zero
+ * bytes (distance 1, length 3..258) -- no hash chains, no lazy matching.  Two passes over the filtered frame
+ * (token histogram, then bit emission with a 64-bit accumulator): 0.3-1.5 GB/s per host thread depending on how
+ * much of the frame is zero runs, where zlib level 1 manages 0.1-0.25 GB/s (profiles/round3_cli_video.txt).
+ * The compressed bytes differ from the reference's; the decoded pixels are identical (tests decode the files with
+ * this header's reader AND with Python's zlib). */
+struct EncodeTimes { /* seconds, accumulated by the caller across frames (per-stage profile of `curvis video`) */
+  double filter = 0, deflate = 0, checksum = 0, write = 0;
+  size_t raw_bytes = 0, file_bytes = 0, frames = 0;
+};
+inline double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* code lengths (<= maxlen) of a Huffman code for freq[0..n): plain Huffman by repeated minimum extraction (n <= 286),
+ * frequencies halved and the tree rebuilt while it is too deep */
+inline void huffman_lengths(const uint32_t *freq_in, int n, int maxlen, uint8_t *len) {
+  std::vector<uint32_t> freq(freq_in, freq_in + n);
+  for (;;) {
+    struct Node { uint64_t f; int l, r; };
+    std::vector<Node> nodes;
+    std::vector<int> live;
+    for (int i = 0; i < n; ++i) {
+      len[i] = 0;
+      if (freq[i]) {
+        nodes.push_back({freq[i], -1 - i, -1 - i});
+        live.push_back((int)nodes.size() - 1);
+      }
+    }
+    if (live.empty()) return;
+    if (live.size() == 1) {
+      len[-1 - nodes[live[0]].l] = 1;
+      return;
+    }
+    while (live.size() > 1) {
+      size_t a = 0, b = 1; /* two smallest */
+      if (nodes[live[b]].f < nodes[live[a]].f) std::swap(a, b);
+      for (size_t k = 2; k < live.size(); ++k) {
+        if (nodes[live[k]].f < nodes[live[a]].f) { b = a; a = k; }
+        else if (nodes[live[k]].f < nodes[live[b]].f) b = k;
+      }
+      nodes.push_back({nodes[live[a]].f + nodes[live[b]].f, live[a], live[b]});
+      const int merged = (int)nodes.size() - 1;
+      if (a > b) std::swap(a, b);
+      live.erase(live.begin() + (long)b);
+      live[a] = merged;
+    }
+    /* depths */
+    int deepest = 0;
+    std::vector<std::pair<int, int>> stack = {{live[0], 0}};
+    while (!stack.empty()) {
+      const std::pair<int, int> t = stack.back();
+      stack.pop_back();
+      const Node &nd = nodes[(size_t)t.first];
+      if (nd.l < 0 && nd.l == nd.r) {
+        len[-1 - nd.l] = (uint8_t)std::min(t.second, 255);
+        if (t.second > deepest) deepest = t.second;
+      } else {
+        stack.push_back({nd.l, t.second + 1});
+        stack.push_back({nd.r, t.second + 1});
+      }
+    }
+    if (deepest <= maxlen) return;
+    for (int i = 0; i < n; ++i)
+      if (freq[i]) freq[i] = (freq[i] + 1) >> 1;
+  }
+}
+/* canonical codes (RFC 1951 3.2.2), bit-reversed for an LSB-first bit writer; entry = code | len << 16 */
+inline void canonical_codes(const uint8_t *len, int n, uint32_t *entry) {
+  uint32_t count[16] = {0}, next[16] = {0};
+  for (int i = 0; i < n; ++i) count[len[i]]++;
+  count[0] = 0;
+  uint32_t code = 0;
+  for (int b = 1; b < 16; ++b) {
+    code = (code + count[b - 1]) << 1;
+    next[b] = code;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int l = len[i];
+    uint32_t c = l ? next[l]++ : 0, r = 0;
+    for (int k = 0; k < l; ++k) r |= ((c >> k) & 1u) << (l - 1 - k);
+    entry[i] = r | ((uint32_t)l << 16);
+  }
+}
+
+struct BitWriter { /* LSB-first, branch-free: an unaligned 8-byte store per put, the pointer advances by whole bytes */
+  uint8_t *p;
+  uint64_t acc = 0;
+  unsigned nb = 0;
+  explicit BitWriter(uint8_t *dst) : p(dst) {}
+  inline void put(uint64_t bits, unsigned n) { /* nb <= 7 on entry, n <= 48 */
+    acc |= bits << nb;
+    nb += n;
+    std::memcpy(p, &acc, 8); /* little-endian host (x86-64); the buffer carries 8 spare bytes */
+    const unsigned adv = nb >> 3;
+    p += adv;
+    acc >>= adv * 8u;
+    nb &= 7u;
+  }
+  inline uint8_t *finish() {
+    if (nb) *p++ = (uint8_t)acc;
+    nb = 0;
+    acc = 0;
+    return p;
+  }
+};
+
+/* length -> (symbol 257.., extra bits, extra value) of RFC 1951 3.2.5 */
+inline void length_symbol(int length, int &sym, int &ebits, int &eval) {
+  static const int base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+  static const int extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+  int k = 28;
+  while (base[k] > length) --k;
+  sym = 257 + k;
+  ebits = extra[k];
+  eval = length - base[k];
+}
+
+inline uint32_t load32(const uint8_t *p) {
+  uint32_t v;
+  std::memcpy(&v, p, 4);
+  return v;
+}
+inline uint64_t load64(const uint8_t *p) {
+  uint64_t v;
+  std::memcpy(&v, p, 8);
+  return v;
+}
+/* end of the run of zero bytes that starts at d[i] (d[i..i+3] are known to be zero) */
+inline size_t zero_run_end(const uint8_t *d, size_t i, size_t n) {
+  size_t j = i + 4;
+  while (j + 8 <= n && load64(d + j) == 0) j += 8;
+  while (j < n && d[j] == 0) ++j;
+  return j;
+}
+/* tokens of the filtered stream: every byte a literal, except that a run of r >= 4 zero bytes is one literal 0
+ * followed by distance-1 matches covering the other r - 1 (pieces of 3..258).  `lit2` takes two literals at once
+ * (one store of the bit writer), the test for a run is one 32-bit load. */
+template <class Lit, class Lit2, class Match>
+inline void for_each_token(const uint8_t *d, size_t n, Lit lit, Lit2 lit2, Match match) {
+  size_t i = 0;
+  while (i + 4 <= n) {
+    if (load32(d + i) != 0) { /* no run of four starts here: two literals (a run that starts at i + 1 is found next time round) */
+      lit2(d[i], d[i + 1]);
+      i += 2;
+      continue;
+    }
+    const size_t j = zero_run_end(d, i, n);
+    size_t rem = j - i - 1; /* zeros after the first: >= 3 */
+    lit(0);
+    while (rem > 260) {
+      match(258);
+      rem -= 258;
+    }
+    if (rem > 258) {
+      match((int)rem - 3);
+      rem = 3;
+    }
+    match((int)rem);
+    i = j;
+  }
+  for (; i < n; ++i) lit(d[i]);
+}
+
+/* the whole PNG file of an RGB8 image into `out` */
+inline void encode_rgb8_fast(const uint8_t *rgb, uint32_t w, uint32_t h, std::vector<uint8_t> &out, EncodeTimes *tm = nullptr) {
+  const size_t stride = (size_t)w * 3, line = stride + 1, n = line * h;
+  double t0 = now_s();
+  /* per-thread scratch kept across frames: a fresh std::vector would zero-fill (and page-fault) 3x the frame size each time */
+  static thread_local std::vector<uint8_t> flt_buf;
+  if (flt_buf.size() < n) flt_buf.resize(n);
+  uint8_t *const fl = flt_buf.data();
+  for (uint32_t y = 0; y < h; ++y) {
+    const uint8_t *cur = rgb + (size_t)y * stride;
+    uint8_t *dst = fl + (size_t)y * line;
+    if (y == 0) { /* Sub: left neighbour (3 bytes back) */
+      dst[0] = 1;
+      for (size_t i = 0; i < stride; ++i) dst[1 + i] = (uint8_t)(cur[i] - (i >= 3 ? cur[i - 3] : 0));
+    } else { /* Up, eight bytes per operation: per-byte a - b = ((a | H) - (b & ~H)) ^ ((a ^ ~b) & H), H = 0x80 in every byte */
+      const uint8_t *prev = cur - stride;
+      dst[0] = 2;
+      const uint64_t H = 0x8080808080808080ULL;
+      size_t i = 0;
+      for (; i + 8 <= stride; i += 8) {
+        const uint64_t a = load64(cur + i), b = load64(prev + i);
+        const uint64_t r = ((a | H) - (b & ~H)) ^ ((a ^ ~b) & H);
+        std::memcpy(dst + 1 + i, &r, 8);
+      }
+      for (; i < stride; ++i) dst[1 + i] = (uint8_t)(cur[i] - prev[i]);
+    }
+  }
+  double t1 = now_s();
+  uLong ad = adler32(0L, Z_NULL, 0);
+  for (size_t off = 0; off < n;) { /* uInt-sized pieces */
+    const size_t piece = std::min<size_t>(n - off, (size_t)1 << 30);
+    ad = adler32(ad, fl + off, (uInt)piece);
+    off += piece;
+  }
+  double t2 = now_s();
+  /* pass 1: histogram */
+  uint32_t hist[286] = {0}, hist2[256] = {0}, hist_len[259] = {0};
+  hist[256] = 1;
+  for_each_token(fl, n, [&](uint8_t b) { hist[b]++; },
+                 [&](uint8_t b0, uint8_t b1) {
+                   hist[b0]++;
+                   hist2[b1]++; /* a second table: no store-to-load stall when b0 == b1 */
+                 },
+                 [&](int len) { hist_len[len]++; });
+  for (int i = 0; i < 256; ++i) hist[i] += hist2[i];
+  for (int len = 3; len <= 258; ++len)
+    if (hist_len[len]) {
+      int sym, eb, ev;
+      length_symbol(len, sym, eb, ev);
+      hist[sym] += hist_len[len];
+    }
+  uint8_t ll_len[286];
+  uint32_t ll[286];
+  huffman_lengths(hist, 286, 15, ll_len);
+  canonical_codes(ll_len, 286, ll);
+  /* matches of length 3..258: code, extra bits and the 1-bit distance code ('0') folded into one entry */
+  uint32_t m_bits[259];
+  uint8_t m_n[259];
+  for (int len = 3; len <= 258; ++len) {
+    int sym, eb, ev;
+    length_symbol(len, sym, eb, ev);
+    const int cl = (int)(ll[sym] >> 16);
+    m_bits[len] = (ll[sym] & 0xffffu) | ((uint32_t)ev << cl); /* + distance code 0 (one zero bit) */
+    m_n[len] = (uint8_t)(cl + eb + 1);
+  }
+  /* worst case: 15 bits per byte */
+  const size_t cap = 8 + 25 + 12 + 2 + 512 + n * 2 + 16 + 4 + 12;
+  if (out.size() < cap) out.resize(cap); /* callers that reuse `out` across frames pay the fill once */
+  uint8_t *o = out.data();
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  std::memcpy(o, sig, 8);
+  o += 8;
+  auto be = [](uint8_t *q, uint32_t v) {
+    q[0] = (uint8_t)(v >> 24);
+    q[1] = (uint8_t)(v >> 16);
+    q[2] = (uint8_t)(v >> 8);
+    q[3] = (uint8_t)v;
+  };
+  be(o, 13);
+  std::memcpy(o + 4, "IHDR", 4);
+  be(o + 8, w);
+  be(o + 12, h);
+  o[16] = 8;
+  o[17] = 2;
+  o[18] = o[19] = o[20] = 0;
+  be(o + 21, (uint32_t)crc32(0L, o + 4, 17));
+  o += 25;
+  uint8_t *idat = o; /* length filled in afterwards */
+  std::memcpy(o + 4, "IDAT", 4);
+  o += 8;
+  *o++ = 0x78;
+  *o++ = 0x01;
+  BitWriter bw(o);
+  bw.put(1, 1);  /* BFINAL */
+  bw.put(2, 2);  /* BTYPE = 10: dynamic Huffman */
+  bw.put(29, 5); /* HLIT: 286 literal/length codes */
+  bw.put(0, 5);  /* HDIST: 1 distance code */
+  bw.put(15, 4); /* HCLEN: all 19 code-length codes */
+  static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  for (int k = 0; k < 19; ++k) bw.put(order[k] < 16 ? 4u : 0u, 3u); /* lengths 0..15 written raw as 4-bit codes, no repeats */
+  auto rev4 = [](uint32_t v) { return ((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3); };
+  for (int i = 0; i < 286; ++i) bw.put(rev4(ll_len[i]), 4);
+  bw.put(rev4(1), 4); /* the one distance code: length 1 */
+  for_each_token(fl, n, [&](uint8_t b) { bw.put(ll[b] & 0xffffu, ll[b] >> 16); },
+                 [&](uint8_t b0, uint8_t b1) { /* two codes (<= 15 bits each) in one store */
+                   const uint32_t e0 = ll[b0], e1 = ll[b1];
+                   bw.put((uint64_t)(e0 & 0xffffu) | ((uint64_t)(e1 & 0xffffu) << (e0 >> 16)), (e0 >> 16) + (e1 >> 16));
+                 },
+                 [&](int len) { bw.put(m_bits[len], m_n[len]); });
+  bw.put(ll[256] & 0xffffu, ll[256] >> 16);
+  o = bw.finish();
+  be(o, (uint32_t)ad);
+  o += 4;
+  const size_t idat_len = (size_t)(o - (idat + 8));
+  be(idat, (uint32_t)idat_len);
+  double t3 = now_s();
+  uLong crc = crc32(0L, Z_NULL, 0);
+  for (size_t off = 0; off < idat_len + 4;) {
+    const size_t piece = std::min<size_t>(idat_len + 4 - off, (size_t)1 << 30);
+    crc = crc32(crc, idat + 4 + off, (uInt)piece);
+    off += piece;
+  }
+  be(o, (uint32_t)crc);
+  o += 4;
+  be(o, 0);
+  std::memcpy(o + 4, "IEND", 4);
+  be(o + 8, (uint32_t)crc32(0L, o + 4, 4));
+  o += 12;
+  out.resize((size_t)(o - out.data()));
+  double t4 = now_s();
+  if (tm) {
+    tm->filter += t1 - t0;
+    tm->checksum += (t2 - t1) + (t4 - t3);
+    tm->deflate += t3 - t2;
+    tm->raw_bytes += stride * h;
+    tm->file_bytes += out.size();
+    tm->frames += 1;
+  }
+}
+
+inline bool write_file(const std::string &path, const uint8_t *data, size_t n, std::string &err) {
+  FILE *f = std::fopen(path.c_str(), "wb");
+  if (!f) {
+    err = "could not open " + path + " for writing";
+    return false;
+  }
+  const bool ok = std::fwrite(data, 1, n, f) == n;
+  std::fclose(f);
+  if (!ok) err = "short write to " + path;
+  return ok;
+}
+
+/* level < 0: the fast writer above; 0..9: zlib at that level, filter type 0 */
+inline bool save_rgb8(const std::string &path, const uint8_t *rgb, uint32_t w, uint32_t h, std::string &err, int level = 6,
+                      EncodeTimes *tm = nullptr) {
+  if (level < 0) {
+    if ((uint64_t)w * 3 * h + h >= ((uint64_t)1 << 32) - 65536) { /* IDAT length is 32 bits: such a frame takes the zlib route */
+      level = 1;
+    } else {
+      static thread_local std::vector<uint8_t> file;
+      encode_rgb8_fast(rgb, w, h, file, tm);
+      const double t0 = now_s();
+      const bool ok = write_file(path, file.data(), file.size(), err);
+      if (tm) tm->write += now_s() - t0;
+      return ok;
+    }
+  }
+  const double ta = now_s();
+
   std::vector<uint8_t> raw((size_t)h * ((size_t)w * 3 + 1));
   for (uint32_t y = 0; y < h; ++y) {
     raw[(size_t)y * (w * 3 + 1)] = 0;
@@ -287,14 +630,15 @@ inline bool save_rgb8(const std::string &path, const uint8_t *rgb, uint32_t w, u
   chunk(out, "IHDR", ihdr);
   chunk(out, "IDAT", comp);
   chunk(out, "IEND", {});
-  FILE *f = std::fopen(path.c_str(), "wb");
-  if (!f) {
-    err = "could not open " + path + " for writing";
-    return false;
+  const double tb = now_s();
+  const bool ok = write_file(path, out.data(), out.size(), err);
+  if (tm) {
+    tm->deflate += tb - ta;
+    tm->write += now_s() - tb;
+    tm->raw_bytes += (size_t)w * 3 * h;
+    tm->file_bytes += out.size();
+    tm->frames += 1;
   }
-  const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
-  std::fclose(f);
-  if (!ok) err = "short write to " + path;
   return ok;
 }
 

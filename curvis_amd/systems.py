@@ -281,6 +281,13 @@ class Context:
         check(lib().curvis_ctx_device_info(self._h, name, 256, C.byref(cus), C.byref(mhz)), self._h)
         return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value}
 
+    def device_status(self):
+        """{"pci_bus_id", "sclk_mhz", "power_w"} of this context's GPU right now (-1 where sysfs does not tell)"""
+        buf = C.create_string_buffer(64)
+        sclk, power = C.c_int(-1), C.c_int(-1)
+        check(lib().curvis_ctx_device_status(self._h, buf, 64, C.byref(sclk), C.byref(power)), self._h)
+        return {"pci_bus_id": buf.value.decode(), "sclk_mhz": sclk.value, "power_w": power.value}
+
     def set_sky(self, which, image):
         check(lib().curvis_ctx_set_sky(self._h, which, image.rgba.ctypes.data, image.width_pixels,
                                        image.height_pixels), self._h)

@@ -102,6 +102,12 @@ int curvis_ctx_create(int device, curvis_ctx **out);
 void curvis_ctx_destroy(curvis_ctx *ctx);
 /* name of the device + number of CUs, for bench reports */
 int curvis_ctx_device_info(const curvis_ctx *ctx, char *name, size_t name_cap, int *compute_units, int *clock_mhz);
+/* which physical GPU this context sits on and what it is doing right now, for the per-device tables of multi-GPU runs
+ * (bench.py `per_rank`, `curvis video --stats`): PCI address "dddd:bb:dd.f" (hipDeviceGetPCIBusId), the current
+ * shader clock in MHz and the board power in W as the amdgpu driver reports them in sysfs (pp_dpm_sclk,
+ * hwmon power1_average / power1_input); a value that cannot be read comes back as -1, never as an error.  No
+ * reference counterpart (the reference is single-threaded CPU code). */
+int curvis_ctx_device_status(const curvis_ctx *ctx, char *pci_bus_id, size_t cap, int *sclk_mhz, int *power_w);
 
 /* SphericalImage (src/images.rs:51-56): which = 0 -> background_positive (+l), 1 -> background_negative.
  * `rgba` is the decoded image as Rgba8 (what DynamicImage::get_pixel returns, src/images.rs:107-111),

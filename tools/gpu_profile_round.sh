@@ -15,13 +15,13 @@ run_workload() { # name, bench arguments...
   cd "$ROOT"
   python bench.py "$@" --no-traffic --no-live-traffic > "$d/bench.json" 2> "$d/bench.err"
   cd /tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$d/stats" -o bench -- python "$ROOT/bench.py" "$@" --no-traffic --no-cpu-baseline --multi-frame 0 > "$d/stats.log" 2>&1
-  rocprofv3 --pmc $SQ --output-format csv -d "$d/pmc_sq" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 > "$d/pmc_sq.log" 2>&1
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/pmc_fetch" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 > "$d/pmc_fetch.log" 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/pmc_write" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 > "$d/pmc_write.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$d/stats" -o bench -- python "$ROOT/bench.py" "$@" --no-traffic --no-cpu-baseline --multi-frame 0 --sustained-seconds 0 > "$d/stats.log" 2>&1
+  rocprofv3 --pmc $SQ --output-format csv -d "$d/pmc_sq" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 --sustained-seconds 0 > "$d/pmc_sq.log" 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/pmc_fetch" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 --sustained-seconds 0 > "$d/pmc_fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/pmc_write" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 --sustained-seconds 0 > "$d/pmc_write.log" 2>&1
   # instruction mix of the FP64 pipe and LDS behaviour (two more passes; what the 83 / 116 VALU instructions are)
-  rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 --output-format csv -d "$d/pmc_mix1" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 > "$d/pmc_mix1.log" 2>&1
-  rocprofv3 --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d "$d/pmc_mix2" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 > "$d/pmc_mix2.log" 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 --output-format csv -d "$d/pmc_mix1" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 --sustained-seconds 0 > "$d/pmc_mix1.log" 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d "$d/pmc_mix2" -o pmc -- python "$ROOT/bench.py" "$@" --steps 3 --warmup 1 --no-traffic --no-cpu-baseline --multi-frame 0 --sustained-seconds 0 > "$d/pmc_mix2.log" 2>&1
   cd "$ROOT"
 }
 # configs[1] (the headline): the library's automatic kernel (relay) and the static kernel
