@@ -2533,6 +2533,14 @@ int curvis_image_save_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uin
   return CURVIS_OK;
 }
 
+int curvis_image_save_rgb8_level(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h, int level) {
+  if (!path || !rgb || w == 0 || h == 0) return fail(nullptr, CURVIS_E_INVALID, "null argument or empty image");
+  if (level < -1 || level > 9) return fail(nullptr, CURVIS_E_INVALID, "level must be -1 (fast writer) or 0..9 (zlib)");
+  std::string err;
+  if (!pngio::save_rgb8(path, rgb, w, h, err, level)) return fail(nullptr, CURVIS_E_IO, err);
+  return CURVIS_OK;
+}
+
 int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes) {
   if (!ctx) return CURVIS_E_INVALID;
   if (dev_ptr) *dev_ptr = ctx->d_fb;

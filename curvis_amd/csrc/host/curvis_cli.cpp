@@ -411,6 +411,8 @@ struct Args {
       sky_broadcast = "rccl";
   bool sky_broadcast_explicit = false, resume = false;
   int devices = 1, device = 0, batch = 8, writers = 0; /* writers 0 = automatic: a quarter of the host's threads, 4..64 */
+  int png_level = -1; /* -1 = the fast PNG writer (png_io.h; the reference's image crate also saves with its fast setting), 0..9 = zlib */
+  int encode_bench = 0; /* video, diagnostics: every rendered frame is encoded this many extra times into a scratch file */
 };
 [[noreturn]] void die(const std::string &msg, int code = 1) {
   std::fprintf(stderr, "%s\n", msg.c_str());
@@ -424,7 +426,7 @@ void usage() {
       "curvis video <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-v|--video-settings <TOML FILE>]\n"
       "  common: [-m|--metric-settings <TOML FILE>] [-c|--camera-settings <TOML FILE>] [-s|--simulation-settings <TOML FILE>]\n"
       "  extensions: [--mode efficient|brute] [--device N] [--devices N] [--batch B] [--stats FILE]\n"
-      "              [--sky-broadcast rccl|upload] [--writers T] [--resume]\n");
+      "              [--sky-broadcast rccl|upload] [--writers T] [--resume] [--png-level -1..9]\n");
 }
 Args parse_args(int argc, char **argv) {
   Args a;
@@ -464,6 +466,8 @@ Args parse_args(int argc, char **argv) {
     else if (key == "--device") { take(val); a.device = std::atoi(val.c_str()); }
     else if (key == "--batch") { take(val); a.batch = std::atoi(val.c_str()); }
     else if (key == "--writers") { take(val); a.writers = std::atoi(val.c_str()); }
+    else if (key == "--png-level") { take(val); a.png_level = std::max(-1, std::min(9, std::atoi(val.c_str()))); }
+    else if (key == "--encode-bench") { take(val); a.encode_bench = std::max(0, std::atoi(val.c_str())); }
     else if (key == "-h" || key == "--help") { usage(); std::exit(0); }
     else if (!s.empty() && s[0] == '-') die("error: unexpected argument '" + s + "' found", 2);
     else pos.push_back(s);
@@ -481,7 +485,7 @@ Args parse_args(int argc, char **argv) {
   if (a.sky_broadcast != "rccl" && a.sky_broadcast != "upload") die("error: --sky-broadcast must be rccl or upload", 2);
   if (a.devices < 1) a.devices = 1;
   if (a.batch < 1) a.batch = 1;
-  if (a.writers < 1) { /* zlib costs ~100 ms per 1080p frame and thread: the GPU renders a frame in 0.4-10 ms */
+  if (a.writers < 1) { /* encoding a 1080p frame costs 5-25 ms of a host thread (zlib: 20-230): the GPU renders one in 0.4-10 ms */
     unsigned hw = std::thread::hardware_concurrency();
     /* a container may see every CPU of the host behind a much smaller cgroup quota ("1600000 100000" = 16 CPUs) */
     if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -642,7 +646,7 @@ int image_main(const Args &a) {
   }
   /* PathBuf::join(image_name).with_extension("png") (src/rendering.rs:108): an existing extension is REPLACED */
   const std::string file = (std::filesystem::path(c.out) / std::filesystem::path(is.image_name).replace_extension("png")).string();
-  if (!pngio::save_rgb8(file, rgb.data(), cam.res_x, cam.res_y, err))
+  if (!pngio::save_rgb8(file, rgb.data(), cam.res_x, cam.res_y, err, a.png_level))
     die("Error in rendering image: Could not save image frame \"" + file + "\" due to error: " + err);
   if (!a.stats.empty()) {
     FILE *f = std::fopen(a.stats.c_str(), "w");
@@ -774,6 +778,19 @@ int video_main(const Args &a) {
   std::atomic<int> failed{0};
   FILE *stats_f = a.stats.empty() ? nullptr : std::fopen(a.stats.c_str(), "w");
   WriterPool writers(a.writers);
+  /* per-stage host profile (--stats): what the writer threads spent encoding and writing, what each device worker
+   * spent inside the render call (GPU kernels + D2H of the batch), waiting for work and handing frames over */
+  pngio::EncodeTimes enc_total;
+  pngio::EncodeTimes bench_total; /* --encode-bench: the extra encodes, kept apart */
+  struct DeviceSummary {
+    std::string pci_bus_id;
+    int sclk_mhz = -1, power_w = -1;
+    size_t frames = 0, batches = 0;
+    double render_s = 0, kernel_ms = 0, submit_s = 0, wait_s = 0, busy_s = 0;
+    unsigned long long steps = 0;
+  };
+  std::vector<DeviceSummary> dev_sum((size_t)a.devices);
+  const double t_video0 = pngio::now_s();
   /* sky distribution: rank 0 uploads the two textures once; with --sky-broadcast rccl (default for
    * --devices > 1) the other GPUs receive them with ncclBroadcast over xGMI (curvis_ctx_bcast_skies),
    * otherwise every GPU uploads from host memory. */
@@ -835,6 +852,13 @@ int video_main(const Args &a) {
   if (const char *fi = std::getenv("CURVIS_TEST_FAIL_BATCH")) std::sscanf(fi, "%d:%d", &fail_rank, &fail_call);
   auto worker = [&](int rank) {
     curvis_ctx *ctx = make_ctx_bare(share_device ? a.device : a.device + rank, "video");
+    DeviceSummary &ds = dev_sum[(size_t)rank];
+    {
+      char id[64] = {0};
+      (void)curvis_ctx_device_status(ctx, id, sizeof id, nullptr, nullptr);
+      ds.pci_bus_id = id;
+    }
+    const double t_worker0 = pngio::now_s();
     if (use_rccl) {
       if (rank == 0) upload_skies(ctx, c, "video");
       check(curvis_ctx_bcast_skies(ctx, comms[rank], 0), ctx, "video");
@@ -865,6 +889,8 @@ int video_main(const Args &a) {
         for (;;) {
           if (failed || batches_done == n_batches) {
             g.unlock();
+            q_cv.notify_all(); /* nobody may sleep on while the others leave */
+            ds.busy_s = pngio::now_s() - t_worker0;
             curvis_ctx_destroy(ctx);
             return;
           }
@@ -880,7 +906,9 @@ int video_main(const Args &a) {
             own[(size_t)rank].pop_front();
             break;
           }
-          q_cv.wait(g);
+          const double tw = pngio::now_s();
+          q_cv.wait_for(g, std::chrono::milliseconds(200)); /* re-checks `failed`: a writer thread sets it without this lock */
+          ds.wait_s += pngio::now_s() - tw;
         }
       }
       const size_t nb = b.frames.size();
@@ -889,7 +917,9 @@ int video_main(const Args &a) {
       rgb.resize(nb * fbytes);
       curvis_stats st;
       /* src/rendering.rs:305-306: threshold_1 is passed for both thresholds */
+      const double t_r0 = pngio::now_s();
       int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, rgb.data(), &st);
+      ds.render_s += pngio::now_s() - t_r0;
       const bool injected = rank == fail_rank && calls == fail_call;
       if (injected) rc = CURVIS_E_HIP;
       ++calls;
@@ -915,6 +945,17 @@ int video_main(const Args &a) {
       }
       /* hand the frames of this batch to the writer pool (each job owns a copy of its frame and ITS statistics:
        * the kernels keep one set of counters per frame of a launch) */
+      ds.frames += nb;
+      ds.batches += 1;
+      ds.kernel_ms += st.kernel_ms;
+      ds.steps += st.steps;
+      if (ds.batches % 8 == 1) { /* clock and power while the device is under load */
+        int sclk = -1, pw = -1;
+        (void)curvis_ctx_device_status(ctx, nullptr, 0, &sclk, &pw);
+        if (sclk > 0) ds.sclk_mhz = sclk;
+        if (pw > 0) ds.power_w = pw;
+      }
+      const double t_s0 = pngio::now_s();
       for (size_t j = 0; j < nb; ++j) {
         const size_t k = b.frames[j];
         auto frame = std::make_shared<std::vector<uint8_t>>(rgb.begin() + j * fbytes, rgb.begin() + (j + 1) * fbytes);
@@ -926,16 +967,32 @@ int video_main(const Args &a) {
           const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
           const std::string part = file + ".part"; /* written under another name, then renamed: --resume never sees half a file */
           std::string e;
-          bool ok = pngio::save_rgb8(part, frame->data(), c.cam.resolution_x, c.cam.resolution_y, e, 1);
+          pngio::EncodeTimes tm, tb;
+          bool ok = pngio::save_rgb8(part, frame->data(), c.cam.resolution_x, c.cam.resolution_y, e, a.png_level, &tm);
           if (ok && std::rename(part.c_str(), file.c_str()) != 0) {
             ok = false;
             e = std::strerror(errno);
           }
+          for (int rep = 0; ok && rep < a.encode_bench; ++rep) { /* diagnostics: the host's encode capacity with one GPU feeding it */
+            std::string e2;
+            (void)pngio::save_rgb8(part + ".bench", frame->data(), c.cam.resolution_x, c.cam.resolution_y, e2, a.png_level, &tb);
+          }
+          if (a.encode_bench) std::remove((part + ".bench").c_str());
           std::lock_guard<std::mutex> g(io_mu);
           if (!ok) {
             std::fprintf(stderr, "Error in rendering video: Could not save image frame \"%s\" due to error: %s\n", file.c_str(), e.c_str());
             failed = 1;
+            q_cv.notify_all(); /* device workers waiting for work must see it */
             return;
+          }
+          for (auto pr : {std::make_pair(&enc_total, &tm), std::make_pair(&bench_total, &tb)}) {
+            pr.first->filter += pr.second->filter;
+            pr.first->deflate += pr.second->deflate;
+            pr.first->checksum += pr.second->checksum;
+            pr.first->write += pr.second->write;
+            pr.first->raw_bytes += pr.second->raw_bytes;
+            pr.first->file_bytes += pr.second->file_bytes;
+            pr.first->frames += pr.second->frames;
           }
           std::printf("Rendering frame %zu/%zu...\n", k + 1, times.size());
           if (stats_f)
@@ -946,6 +1003,7 @@ int video_main(const Args &a) {
                          batch_ms);
         });
       }
+      ds.submit_s += pngio::now_s() - t_s0; /* frame copies + time blocked on a full writer queue */
       {
         std::lock_guard<std::mutex> g(q_mu);
         ++batches_done;
@@ -957,8 +1015,59 @@ int video_main(const Args &a) {
   for (int r = 0; r < a.devices; ++r) th.emplace_back(worker, r);
   for (auto &t : th) t.join();
   for (ncclComm_t cm : comms) ncclCommDestroy(cm);
+  const double t_workers_done = pngio::now_s();
   writers.finish();
+  const double t_video1 = pngio::now_s();
   if (stats_f) std::fclose(stats_f);
+  if (!a.stats.empty()) { /* <stats>.summary.json + a table: who rendered what at which clock, where the host's time went */
+    const double wall = t_video1 - t_video0;
+    size_t total_frames = 0;
+    for (const DeviceSummary &d : dev_sum) total_frames += d.frames;
+    std::string js = "{\"frames\": " + std::to_string(total_frames) + ", \"wall_s\": " + std::to_string(wall) +
+                     ", \"frames_per_s\": " + std::to_string(wall > 0 ? total_frames / wall : 0.0) +
+                     ", \"writers\": " + std::to_string(a.writers) + ", \"png_level\": " + std::to_string(a.png_level) +
+                     ", \"writer_drain_s\": " + std::to_string(t_video1 - t_workers_done) + ", \"devices\": [";
+    std::printf("device  pci_bus_id     frames  kernel ms/frame  render-call ms/frame  fps    sclk MHz  power W  wait s  hand-over s\n");
+    for (size_t r = 0; r < dev_sum.size(); ++r) {
+      const DeviceSummary &d = dev_sum[r];
+      const double kf = d.frames ? d.kernel_ms / d.frames : 0.0, rf = d.frames ? d.render_s * 1e3 / d.frames : 0.0;
+      std::printf("%-7zu %-14s %-7zu %-16.3f %-21.3f %-6.1f %-9d %-8d %-7.2f %.2f\n", (size_t)a.device + r, d.pci_bus_id.c_str(), d.frames, kf, rf,
+                  d.busy_s > 0 ? d.frames / d.busy_s : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s);
+      char buf[512];
+      std::snprintf(buf, sizeof buf,
+                    "%s{\"device\": %zu, \"pci_bus_id\": \"%s\", \"frames\": %zu, \"batches\": %zu, \"kernel_ms_per_frame\": %.4f, "
+                    "\"render_call_ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"mray_steps_per_s\": %.1f, \"sclk_mhz\": %d, \"power_w\": %d, "
+                    "\"wait_s\": %.3f, \"hand_over_s\": %.3f, \"busy_s\": %.3f}",
+                    r ? ", " : "", (size_t)a.device + r, d.pci_bus_id.c_str(), d.frames, d.batches, kf, rf, d.busy_s > 0 ? d.frames / d.busy_s : 0.0,
+                    d.kernel_ms > 0 ? (double)d.steps / d.kernel_ms / 1e3 : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s, d.busy_s);
+      js += buf;
+    }
+    js += "]";
+    for (auto pr : {std::make_pair("encode", &enc_total), std::make_pair("encode_bench", &bench_total)}) {
+      const pngio::EncodeTimes &t = *pr.second;
+      if (!t.frames) continue;
+      const double per = 1e3 / (double)t.frames, cpu = t.filter + t.deflate + t.checksum + t.write;
+      char buf[640];
+      std::snprintf(buf, sizeof buf,
+                    ", \"%s\": {\"frames\": %zu, \"filter_ms\": %.3f, \"deflate_ms\": %.3f, \"checksum_ms\": %.3f, \"write_ms\": %.3f, "
+                    "\"thread_ms_per_frame\": %.3f, \"raw_mb_per_frame\": %.3f, \"file_mb_per_frame\": %.3f, \"mb_per_s_per_thread\": %.1f, "
+                    "\"frames_per_s_per_thread\": %.1f}",
+                    pr.first, t.frames, t.filter * per, t.deflate * per, t.checksum * per, t.write * per, cpu * per, t.raw_bytes / 1e6 / t.frames,
+                    t.file_bytes / 1e6 / t.frames, cpu > 0 ? t.raw_bytes / 1e6 / cpu : 0.0, cpu > 0 ? t.frames / cpu : 0.0);
+      js += buf;
+      std::printf("%s: %zu frames, per frame and writer thread: filter %.2f + deflate %.2f + checksums %.2f + file write %.2f = %.2f ms "
+                  "(%.0f MB/s, %.1f frames/s per thread), %.2f -> %.2f MB\n",
+                  pr.first, t.frames, t.filter * per, t.deflate * per, t.checksum * per, t.write * per, cpu * per, cpu > 0 ? t.raw_bytes / 1e6 / cpu : 0.0,
+                  cpu > 0 ? t.frames / cpu : 0.0, t.raw_bytes / 1e6 / t.frames, t.file_bytes / 1e6 / t.frames);
+    }
+    js += "}\n";
+    std::printf("video: %zu frames in %.2f s wall = %.1f frames/s (%d writer threads, png level %d; writers still busy %.2f s after the last render)\n",
+                total_frames, wall, wall > 0 ? total_frames / wall : 0.0, a.writers, a.png_level, t_video1 - t_workers_done);
+    if (FILE *sf = std::fopen((a.stats + ".summary.json").c_str(), "w")) {
+      std::fputs(js.c_str(), sf);
+      std::fclose(sf);
+    }
+  }
   if (failed) return 1;
   if (!panic_msg.empty()) {
     std::fprintf(stderr, "thread 'main' panicked: %s (frame %zu of %zu)\n", panic_msg.c_str(), n_frames, times.size());

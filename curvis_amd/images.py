@@ -22,12 +22,16 @@ def load_image(path):
         lib().curvis_image_free(p)
 
 
-def save_image(path, rgb):
-    """DynamicImage::save as PNG for an H x W x 3 uint8 array"""
+def save_image(path, rgb, level=None):
+    """DynamicImage::save as PNG for an H x W x 3 uint8 array.  level: None = the library's default, -1 = its fast
+    writer (what `curvis video` uses), 0..9 = zlib; the decoded pixels are the same whatever the level."""
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     if rgb.ndim != 3 or rgb.shape[2] != 3:
         raise ValueError("rgb must be HxWx3 uint8")
-    rc = lib().curvis_image_save_rgb8(str(path).encode(), rgb.ctypes.data, rgb.shape[1], rgb.shape[0])
+    if level is None:
+        rc = lib().curvis_image_save_rgb8(str(path).encode(), rgb.ctypes.data, rgb.shape[1], rgb.shape[0])
+    else:
+        rc = lib().curvis_image_save_rgb8_level(str(path).encode(), rgb.ctypes.data, rgb.shape[1], rgb.shape[0], int(level))
     if rc != 0:
         raise CurvisError(rc, (lib().curvis_last_error(None) or b"").decode())
 

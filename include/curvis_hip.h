@@ -252,6 +252,10 @@ int curvis_image_load(const char *path, uint8_t **rgba_out, uint32_t *w, uint32_
 void curvis_image_free(uint8_t *rgba);
 /* DynamicImage::ImageRgb8(..).save(path) as PNG (8-bit RGB, non-interlaced) */
 int curvis_image_save_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h);
+/* same with the encoder chosen: level -1 = the library's fast PNG writer (filter Up + one dynamic-Huffman block whose
+ * only matches are zero runs: what `curvis video` writes its frames with; the reference's image crate also saves
+ * with its fast setting), 0..9 = zlib at that level.  Same decoded pixels whatever the level. */
+int curvis_image_save_rgb8_level(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h, int level);
 
 /* device framebuffer of the last render (RGB8, frames back to back) */
 int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes);

@@ -274,3 +274,49 @@ def test_library_image_codecs_equal_the_binarys(tmp_path):
     (tmp_path / "junk.png").write_bytes(b"not an image at all")
     with pytest.raises(curvis_amd.CurvisError):
         images.load_image(tmp_path / "junk.png")
+
+
+def _fast_png_cases():
+    rng = np.random.default_rng(11)
+    yield "one pixel", np.array([[[7, 0, 255]]], np.uint8)
+    yield "all zero", np.zeros((5, 300, 3), np.uint8)                       # one long zero run across rows of filter bytes
+    yield "constant", np.full((40, 33, 3), 200, np.uint8)
+    yield "noise", rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    g = np.zeros((64, 400, 3), np.uint8)
+    g[..., 0] = (np.arange(400) * 255 // 400)[None, :]
+    g[..., 1] = (np.arange(64) * 255 // 64)[:, None]
+    g[..., 2] = 128
+    yield "smooth sky gradient", g
+    # zero runs of every length around the piece boundaries of the run coder (3, 4, 258..262, 516..520)
+    for r in (1, 2, 3, 4, 5, 257, 258, 259, 260, 261, 262, 263, 516, 517, 518, 519, 520, 521, 777):
+        a = np.full((3, 300, 3), 9, np.uint8)
+        flat = a.reshape(3, -1)
+        flat[1, 10:10 + r] = flat[0, 10:10 + r]                            # Up-filtered row 1 holds a zero run of length r
+        flat[1, 10 + r] ^= 0x55
+        yield "zero run %d" % r, a
+    sparse = np.zeros((20, 64, 3), np.uint8)
+    sparse[rng.integers(0, 20, 40), rng.integers(0, 64, 40), rng.integers(0, 3, 40)] = 255
+    yield "sparse", sparse
+
+
+def test_fast_png_writer_round_trips(tmp_path):
+    """the fast PNG writer of `curvis video` (png_io.h: filter Up, one dynamic-Huffman block, zero-run matches only): its
+    files decode to the same pixels with TWO decoders that share nothing with it -- Python's zlib inflate + this repo's
+    test unfilter (pngio.read_png) and the library's own reader -- and the zlib levels give the same pixels too"""
+    from curvis_amd import images
+    for name, img in _fast_png_cases():
+        for level in (-1, 0, 1, 6):
+            p = tmp_path / "f.png"
+            images.save_image(p, img, level=level)
+            got = pngio.read_png(p)
+            assert got.shape == img.shape and np.array_equal(got, img), (name, level)
+            assert np.array_equal(images.load_image(p)[..., :3], img), (name, level)
+    big = np.random.default_rng(5).integers(0, 4, (270, 480, 3), dtype=np.uint8) * 60   # many short runs and literals
+    images.save_image(tmp_path / "b.png", big, level=-1)
+    assert np.array_equal(pngio.read_png(tmp_path / "b.png"), big)
+    smooth = next(a for n, a in _fast_png_cases() if n == "smooth sky gradient")
+    images.save_image(tmp_path / "s.png", smooth, level=-1)
+    assert (tmp_path / "s.png").stat().st_size < smooth.size // 4           # it does compress what a smooth sky looks like
+    import curvis_amd
+    with pytest.raises(curvis_amd.CurvisError):
+        images.save_image(tmp_path / "x.png", smooth, level=12)
