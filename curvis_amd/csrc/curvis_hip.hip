@@ -32,7 +32,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -462,6 +464,8 @@ struct RelayArgs {
   unsigned long long n_tiles;
   unsigned fresh_blocks; /* workgroups [0, fresh_blocks) start tiles, the rest relay parked ones */
   unsigned seg;          /* steps per segment */
+  unsigned corrupt_ticket; /* test hook (option "relay_test_corrupt"): the wave that takes ticket corrupt_ticket - 1 perturbs
+                              one reloaded ray, so that the first-launch check below has something to find; 0 = off */
 };
 
 /* Hand-over traffic of the relay kernel goes around the caches: system-scope relaxed atomics compile to
@@ -498,6 +502,7 @@ void geodesic_relay(const IntegrateParams P, const RelayArgs A) {
   load_math_tables<KIND>(s_tab, M);
   const unsigned lane = threadIdx.x & 63u;
   unsigned long long tile;
+  bool corrupt = false;
   if (fresh) {
     if (threadIdx.x == 0) atomicAdd(&Q->started, 1ull);
     tile = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -522,6 +527,7 @@ void geodesic_relay(const IntegrateParams P, const RelayArgs A) {
     if (lane == 0) st_sys(slot_p, 0u);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* order the state loads below after the ticket load */
     tile = (unsigned long long)(v - 1u);
+    corrupt = A.corrupt_ticket != 0u && __builtin_amdgcn_readfirstlane((unsigned)tk) == A.corrupt_ticket - 1u;
   }
   if (P.trace) t_work = wall_clock64();
   const unsigned long long id = tile * 64ull + lane;
@@ -545,6 +551,7 @@ void geodesic_relay(const IntegrateParams P, const RelayArgs A) {
     q.p2 = ld_sys(&P.store.p2[id]);
     q.p3 = ld_sys(&P.store.p3[id]);
     q.p3sq = q.p3 * q.p3;
+    if (corrupt) q.th = q.th + 0.25; /* what a hand-over that lost a store would look like: every ray of the tile lands elsewhere */
     steps = ld_sys(&P.store.steps[id]);
     const int c = ld_sys(&P.store.code[id]);
     active = (c & 4) != 0;
@@ -937,6 +944,12 @@ struct curvis_ctx {
   int relay_verify = 0;             /* debug option: every relay render is repeated with the static kernel and the two
                                        frames and statistics compared (CURVIS_E_HIP on a difference) */
   int relay_test_fault = 0;         /* test hook: pretend the next relay launch reported a wave that gave up */
+  int relay_test_corrupt = 0;       /* test hook: the next relay launch perturbs the first tile it hands over */
+  int relay_auto_verify = 1;        /* seat belt (default on): the FIRST relay launch of every launch shape (W, H, frames, metric,
+                                       step flavour) of this context is repeated by the static kernel and compared; on a
+                                       difference the context drops to the static kernel for good (relay_mismatches counts) */
+  uint32_t relay_mismatches = 0;
+  std::set<std::array<uint32_t, 5>> relay_verified; /* shapes whose first relay launch has been checked */
   uint32_t relay_fallbacks = 0;     /* renders that fell back from the relay to the static kernel */
   long long relay_min_blocks = -1;  /* smallest grid (fresh workgroups) the relay kernel is used for; -1 = automatic
                                        (4 per CU: with fewer workgroups than that nearly the whole grid is resident at
@@ -1116,6 +1129,8 @@ int launch_relay(curvis_ctx *ctx, const IntegrateParams &P, bool relay_only) {
     unsigned seg = (half >= 256.0 && half <= 65536.0) ? (unsigned)half : 1024u;
     A.seg = ctx->relay_segment > 0 ? (unsigned)ctx->relay_segment : seg;
   }
+  A.corrupt_ticket = ctx->relay_test_corrupt ? 1u : 0u;
+  ctx->relay_test_corrupt = 0;
   if (ctx->relay_resident_threads != (int)bt) {
     for (auto &row : ctx->relay_resident_blocks) row[0] = row[1] = 0;
     ctx->relay_resident_threads = (int)bt;
@@ -1444,13 +1459,23 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   }
   ctx->last_integrate_ms = integrate_ms;
   ctx->last_shade_ms = shade_ms;
-  if (relay && ctx->relay_verify) { /* debug: the same launch by the static kernel must give the same bytes and counters */
+  /* The relay kernel's hand-over rests on gfx950 facts (write-through sc0 sc1 stores, s_waitcnt vmcnt(0) before
+   * the ticket store) rather than on the HIP memory model, so it wears a seat belt: the first relay launch of every
+   * launch shape is repeated by the static kernel -- no inter-workgroup traffic at all -- and frames and counters are
+   * compared.  Option "relay_verify" = 1 checks EVERY launch and makes a difference an error (debugging); the automatic
+   * check (option "relay_auto_verify", default 1) costs one static launch per shape and context and, on a difference,
+   * reports it on stderr, counts it ("relay_mismatches"), switches the context to the static kernel and returns the
+   * static kernel's frame. */
+  const std::array<uint32_t, 5> shape = {W, H, n_frames, (uint32_t)metric->kind, (uint32_t)(fast ? 1 : 0)};
+  const bool auto_check = relay && !ctx->relay_verify && ctx->relay_auto_verify && !ctx->relay_verified.count(shape);
+  if (relay && (ctx->relay_verify || auto_check)) {
     std::vector<uint8_t> a(fb_bytes), b(fb_bytes);
     HIP_TRY(ctx, hipMemcpyAsync(a.data(), ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const std::vector<curvis_stats> fs = ctx->last_frame_stats;
     const uint32_t launches = ctx->last_relay_launches;
-    const uint64_t parks = ctx->last_relay_parks;
+    const uint64_t parks = ctx->last_relay_parks, waiters = ctx->last_relay_waiters;
+    const double keep_i = ctx->last_integrate_ms, keep_s = ctx->last_shade_ms;
     const int saved = ctx->variant;
     ctx->variant = 1;
     rc = render_impl(ctx, metric, cams, n_frames, max_iterations, max_radius, delta, b.data(), nullptr, nullptr, row_begin, row_count);
@@ -1461,9 +1486,25 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
       const curvis_stats &x = fs[f], &y = ctx->last_frame_stats[f];
       same = x.rays == y.rays && x.steps == y.steps && x.n_pos == y.n_pos && x.n_neg == y.n_neg && x.n_none == y.n_none && x.n_oob == y.n_oob;
     }
-    if (!same) return fail(ctx, CURVIS_E_HIP, "relay_verify: the relay kernel and the static kernel disagree on this launch");
+    if (!same) {
+      ctx->relay_mismatches++;
+      if (ctx->relay_verify) return fail(ctx, CURVIS_E_HIP, "relay_verify: the relay kernel and the static kernel disagree on this launch");
+      size_t n_diff = 0;
+      for (size_t i = 0; i < fb_bytes; ++i) n_diff += a[i] != b[i];
+      fprintf(stderr, "[curvis] relay kernel: first launch of shape %ux%u x %u frame(s) differs from the static kernel (%zu bytes of %zu); "
+                      "this context uses the static kernel from now on\n", W, H, n_frames, n_diff, fb_bytes);
+      ctx->relay_disabled = 1;
+      ctx->relay_fallbacks++;
+      return render_impl(ctx, metric, cams, n_frames, max_iterations, max_radius, delta, rgb_out, dbg_out, stats, row_begin, row_count);
+    }
+    ctx->relay_verified.insert(shape);
+    /* the launch that counts is the relay one: its frame is what d_fb holds again (same bytes), and so are its statistics */
+    ctx->last_frame_stats = fs;
     ctx->last_relay_launches = launches;
     ctx->last_relay_parks = parks;
+    ctx->last_relay_waiters = waiters;
+    ctx->last_integrate_ms = keep_i;
+    ctx->last_shade_ms = keep_s;
   }
   if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (dbg_out)
@@ -2582,6 +2623,11 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->relay_min_blocks = (long long)value;
   else if (k == "relay_verify")
     ctx->relay_verify = (int)value;
+  else if (k == "relay_auto_verify") {
+    ctx->relay_auto_verify = (int)value;
+    ctx->relay_verified.clear(); /* switching it (back) on checks every shape afresh */
+  } else if (k == "relay_test_corrupt")
+    ctx->relay_test_corrupt = (int)value;
   else if (k == "relay_disabled")
     ctx->relay_disabled = (int)value;
   else if (k == "relay_test_fault")
@@ -2623,6 +2669,12 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->relay_verify;
   else if (k == "relay_disabled")
     *value = ctx->relay_disabled;
+  else if (k == "relay_auto_verify")
+    *value = ctx->relay_auto_verify;
+  else if (k == "relay_mismatches")
+    *value = ctx->relay_mismatches;
+  else if (k == "relay_verified_shapes")
+    *value = (int64_t)ctx->relay_verified.size();
   else if (k == "relay_fallbacks")
     *value = ctx->relay_fallbacks;
   else if (k == "last_frames")

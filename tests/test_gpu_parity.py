@@ -679,6 +679,50 @@ def test_relay_safety_net_and_verify_option(gpu_ctx):
             gpu_ctx.set_option(k, v)
 
 
+def test_relay_seat_belt_checks_the_first_launch_of_every_shape(capfd):
+    """The relay kernel's hand-over is argued from gfx950 facts, not from the HIP memory model, so the first
+    relay launch of every launch shape of a context is repeated by the static kernel and compared.  Clean launches:
+    one check per shape, none afterwards.  A hand-over that delivers a wrong state (hook "relay_test_corrupt": the wave
+    that takes the first ticket perturbs the tile it reloads) is caught: the frame returned is the static kernel's,
+    the mismatch is counted and reported, and the context stays on the static kernel."""
+    sp, sn = common.make_skies(512, 256, "check")
+    om, oc, pm, pc = common.scene("ellis", res=(480, 270))
+    want, _, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
+    ctx = curvis_amd.Context(0)
+    try:
+        ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+        ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+        ctx.set_option("variant", 2)
+        ctx.set_option("relay_min_blocks", 0)
+        assert ctx.get_option("relay_auto_verify") == 1 and ctx.get_option("relay_verified_shapes") == 0
+        rgb, s = ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+        assert np.array_equal(rgb, want) and s.steps == st.steps
+        assert ctx.get_option("last_relay_launches") >= 1 and ctx.get_option("last_relay_parks") > 0   # statistics are the relay launch's
+        assert ctx.get_option("relay_verified_shapes") == 1 and ctx.get_option("relay_mismatches") == 0
+        rgb, _ = ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+        assert np.array_equal(rgb, want) and ctx.get_option("relay_verified_shapes") == 1               # checked once per shape
+        rgb2, s2 = ctx.render_brute(pm, [pc, pc], 4096, 100.0, 0.05)                                     # another shape: checked again
+        assert np.array_equal(rgb2[0], want) and np.array_equal(rgb2[1], want) and s2.steps == 2 * st.steps
+        assert ctx.get_option("relay_verified_shapes") == 2 and ctx.get_option("relay_disabled") == 0
+        # an unchecked launch with the hook shows that the hook does corrupt a frame ...
+        ctx.set_option("relay_auto_verify", 0)
+        ctx.set_option("relay_test_corrupt", 1)
+        bad, _ = ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+        assert not np.array_equal(bad, want)
+        # ... and with the seat belt on the same fault never reaches the caller
+        ctx.set_option("relay_auto_verify", 1)                                                          # forgets the checked shapes
+        ctx.set_option("relay_test_corrupt", 1)
+        capfd.readouterr()
+        rgb, s = ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+        assert np.array_equal(rgb, want) and (s.rays, s.steps, s.n_pos, s.n_neg, s.n_none) == (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none)
+        assert ctx.get_option("relay_mismatches") == 1 and ctx.get_option("relay_disabled") == 1
+        assert "differs from the static kernel" in capfd.readouterr().err
+        rgb, _ = ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+        assert np.array_equal(rgb, want) and ctx.get_option("last_relay_launches") == 0                  # static from now on
+    finally:
+        ctx.close()
+
+
 def test_batch_framebuffer_beyond_4_gib(gpu_ctx):
     """One launch whose frames fill more than 2^32 bytes of framebuffer (100 frames of 5120x2880, 4.4 GB): frame
     offsets, pixel indices and the per-frame counters must be 64-bit clean.  The escape radius is pulled in to 6 so
