@@ -221,8 +221,12 @@ def main():
                             args.width, args.height)
     R, DELTA = 100.0, 0.05
 
+    # --download: the frame is copied into page-locked host memory (one DMA transfer), as `curvis video` does it
+    host_frame = curvis_amd.HostBuffer(args.width * args.height * 3) if args.download else None
+
     def step():
-        _, st = ctx.render_brute(metric, cam, args.max_iter, R, DELTA, download=args.download)
+        _, st = ctx.render_brute(metric, cam, args.max_iter, R, DELTA, download=args.download,
+                                 out=host_frame.array if host_frame else None)
         return st
 
     for _ in range(args.warmup):

@@ -6,7 +6,7 @@ Python mirror of the reference's hot-path surface (src/lib.rs re-exports): `Came
 curvis_amd/lib/libcurvis_hip.so (include/curvis_hip.h); there is no CPU path.
 """
 from ._abi import CurvisError, LIB_PATH, lib  # noqa: F401
-from .systems import (Camera, Context, DiagonalSphericalMetric, EllisMetric, EscapeAngle,  # noqa: F401
+from .systems import (Camera, Context, HostBuffer, DiagonalSphericalMetric, EllisMetric, EscapeAngle,  # noqa: F401
                       FlatSphericalMetric, InterstellarMetric, RelativisticSystem, SphericalImage,
                       compute_escape_angle, compute_photon_trajectory)
 from .vectors import Covariance, CovarianceError, RelativisticObject, RelativisticVector  # noqa: F401
@@ -17,7 +17,7 @@ from . import images  # noqa: F401
 
 # the re-exports of src/lib.rs:28-37 (the rendering / settings types live in curvis_amd.rendering / .settings and are
 # re-exported lazily below: they import this package)
-__all__ = ["Camera", "Context", "EllisMetric", "InterstellarMetric", "FlatSphericalMetric", "DiagonalSphericalMetric",
+__all__ = ["Camera", "Context", "HostBuffer", "EllisMetric", "InterstellarMetric", "FlatSphericalMetric", "DiagonalSphericalMetric",
            "SphericalImage", "load_image_as_spherical_image", "RelativisticSystem", "RelativisticObject",
            "RelativisticVector", "Covariance", "CovarianceError", "Orientation", "EscapeAngle", "compute_escape_angle",
            "compute_photon_trajectory", "CurvisError", "skies", "images",

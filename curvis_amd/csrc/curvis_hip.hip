@@ -25,6 +25,7 @@
  * on five registers of state; HBM traffic is 3 B out + 4 B in per ~2000 steps (DESIGN.md sections 5-6).
  */
 #include <hip/hip_runtime.h>
+#include <dirent.h>
 
 #include <algorithm>
 #include <cctype>
@@ -171,14 +172,20 @@ struct alignas(16) MathTablesLds {
    * 0, so ds_read2_b64 (whose offset field is short) and ds_read_b64 share one address register; the 32- and
    * 64-byte rows of the other two tables are read with ds_read_b128, whose offset field reaches any LDS
    * address, so their base offsets cost no instruction either. */
-  /* 256-row form of the sin/cos table (cv_sincos_tw: no index mask) in every kernel: since only the reciprocal-branch
-   * rows of the atan table live in LDS (8 KiB; the direct-branch rows are read from __constant__ memory by the few
-   * steps next to the throat) the Interstellar kernels need 6 + 8 + 8 = 22 KiB per workgroup instead of 30 */
+  /* 256-row form of the sin/cos table (cv_sincos_tw: no index mask) in every kernel.  Footprint of the Interstellar
+   * kernels: 12 KiB log (512 rows x 24 B) + 8 KiB sin/cos + 8.06 KiB atan (the 129 reciprocal-branch rows x 64 B; the
+   * direct-branch rows are read from __constant__ memory by the few steps next to the throat) = 28.1 KiB per
+   * workgroup: five workgroups (= five waves per SIMD, what amdgpu_waves_per_eu(5) asks for) fit the CU's 160 KiB,
+   * six would not.  The static_assert below keeps a table change from silently costing that occupancy. */
   static constexpr bool WIDE_SC = true;
   double lg[LOG_ROWS][3]; /* only the Interstellar metric evaluates a logarithm and an arc tangent per step */
   double sc[WIDE_SC ? 256 : 128][4];
   double at[ATAN_ROWS][8];
 };
+
+static_assert(sizeof(MathTablesLds<cvk::METRIC_INTERSTELLAR>) * 5 <= 160 * 1024,
+              "five workgroups of the Interstellar kernels (5 waves per SIMD) must fit the CU's 160 KiB of LDS");
+static_assert(sizeof(MathTablesLds<cvk::METRIC_ELLIS>) * 8 <= 160 * 1024, "the Ellis / flat kernels run at up to 8 workgroups per CU");
 
 /* copy the elementary-function tables of cv_math.h into LDS and point the metric at them */
 template <int KIND>
@@ -2120,11 +2127,18 @@ int curvis_ctx_device_status(const curvis_ctx *ctx, char *pci_bus_id, size_t cap
   }
   if (power_w) { /* hwmon/hwmonN/power1_average (or power1_input), microwatts */
     *power_w = -1;
-    for (int n = 0; n < 16 && *power_w < 0; ++n) {
-      const std::string h = dev + "/hwmon/hwmon" + std::to_string(n);
-      long uw = read_sysfs_long(h + "/power1_average");
-      if (uw < 0) uw = read_sysfs_long(h + "/power1_input");
-      if (uw >= 0) *power_w = (int)(uw / 1000000);
+    if (DIR *dir = opendir((dev + "/hwmon").c_str())) {
+      while (struct dirent *e = readdir(dir)) {
+        if (std::strncmp(e->d_name, "hwmon", 5) != 0) continue;
+        const std::string h = dev + "/hwmon/" + e->d_name;
+        long uw = read_sysfs_long(h + "/power1_average");
+        if (uw < 0) uw = read_sysfs_long(h + "/power1_input");
+        if (uw >= 0) {
+          *power_w = (int)(uw / 1000000);
+          break;
+        }
+      }
+      closedir(dir);
     }
   }
   return CURVIS_OK;
@@ -2580,6 +2594,20 @@ int curvis_image_save_rgb8_level(const char *path, const uint8_t *rgb, uint32_t 
   std::string err;
   if (!pngio::save_rgb8(path, rgb, w, h, err, level)) return fail(nullptr, CURVIS_E_IO, err);
   return CURVIS_OK;
+}
+
+int curvis_host_alloc(size_t bytes, void **out) {
+  if (!out || bytes == 0) return fail(nullptr, CURVIS_E_INVALID, "curvis_host_alloc: null pointer or zero bytes");
+  *out = nullptr;
+  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return fail(nullptr, CURVIS_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  }
+  return CURVIS_OK;
+}
+void curvis_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes) {

@@ -715,6 +715,48 @@ class WriterPool {
   bool done_ = false;
 };
 
+/* Page-locked batch buffers of the video workers: the render call copies a batch of frames into one of them by DMA, the
+ * writer threads encode straight out of it, and the last frame written gives it back -- no pageable bounce copy (2 GB/s)
+ * and no per-frame memcpy between the render call and the encoder.  A worker that finds the pool empty waits: that is
+ * the back-pressure of a host that cannot keep up. */
+class PinnedPool {
+ public:
+  PinnedPool(size_t bytes_each, int n) : bytes_(bytes_each) {
+    for (int i = 0; i < n; ++i) {
+      void *p = nullptr;
+      if (curvis_host_alloc(bytes_each, &p) != CURVIS_OK || !p) break;
+      free_.push_back((uint8_t *)p);
+      all_.push_back((uint8_t *)p);
+    }
+  }
+  ~PinnedPool() {
+    for (uint8_t *p : all_) curvis_host_free(p);
+  }
+  size_t buffers() const { return all_.size(); }
+  /* a buffer that returns to the pool when the last holder lets go of it */
+  std::shared_ptr<uint8_t> take(double *waited_s) {
+    std::unique_lock<std::mutex> g(mu_);
+    const double t0 = pngio::now_s();
+    cv_.wait(g, [this] { return !free_.empty(); });
+    if (waited_s) *waited_s += pngio::now_s() - t0;
+    uint8_t *p = free_.back();
+    free_.pop_back();
+    return std::shared_ptr<uint8_t>(p, [this](uint8_t *q) {
+      {
+        std::lock_guard<std::mutex> g2(mu_);
+        free_.push_back(q);
+      }
+      cv_.notify_one();
+    });
+  }
+
+ private:
+  size_t bytes_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<uint8_t *> free_, all_;
+};
+
 int video_main(const Args &a) {
   std::printf("Video rendering\n");
   Common c;
@@ -786,7 +828,7 @@ int video_main(const Args &a) {
     std::string pci_bus_id;
     int sclk_mhz = -1, power_w = -1;
     size_t frames = 0, batches = 0;
-    double render_s = 0, kernel_ms = 0, submit_s = 0, wait_s = 0, busy_s = 0;
+    double render_s = 0, kernel_ms = 0, submit_s = 0, wait_s = 0, busy_s = 0, pool_wait_s = 0;
     unsigned long long steps = 0;
   };
   std::vector<DeviceSummary> dev_sum((size_t)a.devices);
@@ -880,7 +922,12 @@ int video_main(const Args &a) {
       upload_skies(ctx, c, "video");
     }
     std::vector<curvis_camera> bc;
-    std::vector<uint8_t> rgb;
+    std::vector<uint8_t> rgb_pageable; /* only if page-locked memory could not be had */
+    PinnedPool pool((size_t)a.batch * fbytes, 3); /* one being filled, up to two with the writers */
+    if (pool.buffers() < 2) {
+      std::lock_guard<std::mutex> gi(io_mu);
+      std::fprintf(stderr, "warning: device %d: no page-locked host memory for the frame buffers, using pageable memory\n", a.device + rank);
+    }
     int calls = 0;
     for (;;) {
       Batch b;
@@ -914,11 +961,19 @@ int video_main(const Args &a) {
       const size_t nb = b.frames.size();
       bc.clear();
       for (size_t j = 0; j < nb; ++j) bc.push_back(cams[b.frames[j]]);
-      rgb.resize(nb * fbytes);
+      std::shared_ptr<uint8_t> batch_buf;
+      uint8_t *rgb_ptr = nullptr;
+      if (pool.buffers() >= 2) {
+        batch_buf = pool.take(&ds.pool_wait_s);
+        rgb_ptr = batch_buf.get();
+      } else {
+        rgb_pageable.resize(nb * fbytes);
+        rgb_ptr = rgb_pageable.data();
+      }
       curvis_stats st;
       /* src/rendering.rs:305-306: threshold_1 is passed for both thresholds */
       const double t_r0 = pngio::now_s();
-      int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, rgb.data(), &st);
+      int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, rgb_ptr, &st);
       ds.render_s += pngio::now_s() - t_r0;
       const bool injected = rank == fail_rank && calls == fail_call;
       if (injected) rc = CURVIS_E_HIP;
@@ -958,24 +1013,27 @@ int video_main(const Args &a) {
       const double t_s0 = pngio::now_s();
       for (size_t j = 0; j < nb; ++j) {
         const size_t k = b.frames[j];
-        auto frame = std::make_shared<std::vector<uint8_t>>(rgb.begin() + j * fbytes, rgb.begin() + (j + 1) * fbytes);
+        /* the writer job keeps the batch buffer alive and reads its frame in place; with pageable memory it owns a copy */
+        std::shared_ptr<std::vector<uint8_t>> copy;
+        if (!batch_buf) copy = std::make_shared<std::vector<uint8_t>>(rgb_ptr + j * fbytes, rgb_ptr + (j + 1) * fbytes);
+        const uint8_t *frame = batch_buf ? batch_buf.get() + j * fbytes : copy->data();
         curvis_stats fs;
         std::memset(&fs, 0, sizeof fs);
         (void)curvis_ctx_frame_stats(ctx, (uint32_t)j, &fs);
         const double batch_ms = st.kernel_ms;
-        writers.submit([&, k, frame, fs, nb, rank, batch_ms] {
+        writers.submit([&, k, frame, batch_buf, copy, fs, nb, rank, batch_ms] {
           const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
           const std::string part = file + ".part"; /* written under another name, then renamed: --resume never sees half a file */
           std::string e;
           pngio::EncodeTimes tm, tb;
-          bool ok = pngio::save_rgb8(part, frame->data(), c.cam.resolution_x, c.cam.resolution_y, e, a.png_level, &tm);
+          bool ok = pngio::save_rgb8(part, frame, c.cam.resolution_x, c.cam.resolution_y, e, a.png_level, &tm);
           if (ok && std::rename(part.c_str(), file.c_str()) != 0) {
             ok = false;
             e = std::strerror(errno);
           }
           for (int rep = 0; ok && rep < a.encode_bench; ++rep) { /* diagnostics: the host's encode capacity with one GPU feeding it */
             std::string e2;
-            (void)pngio::save_rgb8(part + ".bench", frame->data(), c.cam.resolution_x, c.cam.resolution_y, e2, a.png_level, &tb);
+            (void)pngio::save_rgb8(part + ".bench", frame, c.cam.resolution_x, c.cam.resolution_y, e2, a.png_level, &tb);
           }
           if (a.encode_bench) std::remove((part + ".bench").c_str());
           std::lock_guard<std::mutex> g(io_mu);
@@ -1037,9 +1095,9 @@ int video_main(const Args &a) {
       std::snprintf(buf, sizeof buf,
                     "%s{\"device\": %zu, \"pci_bus_id\": \"%s\", \"frames\": %zu, \"batches\": %zu, \"kernel_ms_per_frame\": %.4f, "
                     "\"render_call_ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"mray_steps_per_s\": %.1f, \"sclk_mhz\": %d, \"power_w\": %d, "
-                    "\"wait_s\": %.3f, \"hand_over_s\": %.3f, \"busy_s\": %.3f}",
+                    "\"wait_s\": %.3f, \"hand_over_s\": %.3f, \"buffer_wait_s\": %.3f, \"busy_s\": %.3f}",
                     r ? ", " : "", (size_t)a.device + r, d.pci_bus_id.c_str(), d.frames, d.batches, kf, rf, d.busy_s > 0 ? d.frames / d.busy_s : 0.0,
-                    d.kernel_ms > 0 ? (double)d.steps / d.kernel_ms / 1e3 : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s, d.busy_s);
+                    d.kernel_ms > 0 ? (double)d.steps / d.kernel_ms / 1e3 : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s, d.pool_wait_s, d.busy_s);
       js += buf;
     }
     js += "]";

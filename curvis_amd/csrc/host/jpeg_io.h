@@ -23,6 +23,8 @@
 #include <string>
 #include <vector>
 
+#include <new>
+
 #include "png_io.h"
 
 namespace jpegio {
@@ -84,6 +86,7 @@ struct Component {
 
 struct Decoder {
   const uint8_t *p, *end;
+  size_t file_bytes = 0;
   std::string *err;
   uint16_t qt[4][64];
   bool qt_present[4] = {false, false, false, false};
@@ -301,7 +304,11 @@ struct Decoder {
     if (W == 0 || H == 0) return fail("empty JPEG frame");
     if (ncomp != 1 && ncomp != 3) return fail("only grey and three-component JPEG files are supported (no CMYK)");
     if (len < (size_t)6 + 3 * ncomp) return fail("truncated frame header");
-    if ((uint64_t)W * H > ((uint64_t)1 << 31)) return fail("JPEG dimensions out of range");
+    /* untrusted header: 2^28 pixels at most (a 16k x 16k sky; the coefficient arrays below cost 2 B per sample), and no
+     * more pixels than the file could possibly code (a progressive all-grey image still spends > 1 bit per 8x8 block
+     * and component): a few forged header bytes must not drive multi-GiB allocations */
+    if ((uint64_t)W * H > ((uint64_t)1 << 28)) return fail("JPEG dimensions out of range (more than 2^28 pixels)");
+    if ((uint64_t)W * H > (uint64_t)file_bytes * 4096u) return fail("JPEG dimensions are not plausible for a file of this size");
     for (int i = 0; i < ncomp; ++i) {
       Component &c = comp[i];
       c.id = d[6 + 3 * i];
@@ -399,15 +406,21 @@ struct Decoder {
   }
 
   /* ---- reconstruction ---- */
-  static uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+  static uint8_t clamp8(long long v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
   static void idct_block(uint8_t *out, int stride, const int16_t *coef, const uint16_t *q) {
-    int val[64], *v = val;
-    int d[64];
-    for (int i = 0; i < 64; ++i) d[i] = (int)coef[i] * (int)q[i];
-    const int *D = d;
+    /* 64-bit intermediates and dequantised coefficients held to +-2^15 (an 8-bit JPEG never exceeds that): a forged
+     * 16-bit quantisation table with extreme coefficients cannot overflow the butterflies (signed overflow is UB) */
+    typedef long long idct_t;
+    idct_t val[64], *v = val;
+    idct_t d[64];
+    for (int i = 0; i < 64; ++i) {
+      const idct_t x = (idct_t)coef[i] * (idct_t)q[i];
+      d[i] = x > 32767 ? 32767 : (x < -32768 ? -32768 : x);
+    }
+    const idct_t *D = d;
 #define CV_F2F(x) ((int)((x)*4096 + 0.5))
 #define CV_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                          \
-  int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                     \
+  idct_t t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                  \
   p2 = s2;                                                                                    \
   p3 = s6;                                                                                    \
   p1 = (p2 + p3) * CV_F2F(0.5411961f);                                                        \
@@ -444,7 +457,7 @@ struct Decoder {
   t0 += p1 + p3;
     for (int i = 0; i < 8; ++i, ++D, ++v) { /* columns */
       if (D[8] == 0 && D[16] == 0 && D[24] == 0 && D[32] == 0 && D[40] == 0 && D[48] == 0 && D[56] == 0) {
-        const int dc = D[0] * 4;
+        const idct_t dc = D[0] * 4;
         v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
       } else {
         CV_IDCT_1D(D[0], D[8], D[16], D[24], D[32], D[40], D[48], D[56])
@@ -618,9 +631,15 @@ inline bool decode(const std::vector<uint8_t> &file, pngio::Image &img, std::str
   Decoder *d = new Decoder();
   d->p = file.data();
   d->end = file.data() + file.size();
+  d->file_bytes = file.size();
   d->err = &err;
   std::memset(d->qt, 0, sizeof d->qt);
-  const bool ok = d->run(img);
+  bool ok = false;
+  try {
+    ok = d->run(img);
+  } catch (const std::bad_alloc &) { /* extern "C" callers and decoder threads must see an error, not std::terminate */
+    err = "out of memory while decoding the JPEG file";
+  }
   delete d;
   if (!ok && err.empty()) err = "corrupt JPEG";
   return ok;
@@ -634,7 +653,12 @@ inline bool load_image(const std::string &path, pngio::Image &img, std::string &
     return false;
   }
   if (file.size() >= 2 && file[0] == 0xFF && file[1] == 0xD8) return jpegio::decode(file, img, err);
-  return pngio::decode(file, img, err);
+  try {
+    return pngio::decode(file, img, err);
+  } catch (const std::bad_alloc &) {
+    err = "out of memory while decoding the PNG file";
+    return false;
+  }
 }
 
 }  // namespace jpegio

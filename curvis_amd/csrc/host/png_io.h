@@ -105,10 +105,16 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
       return false;
     }
     const uint8_t *data = &file[pos + 8];
-    /* every chunk carries a CRC-32 of type + data (the png crate rejects a mismatch for critical chunks) */
+    /* every chunk carries a CRC-32 of type + data.  Like the reference's png crate, a mismatch is fatal for CRITICAL
+     * chunks only (upper-case first letter: IHDR, PLTE, IDAT, IEND); an ancillary chunk with a damaged CRC (tEXt, iCCP,
+     * ... and tRNS) is skipped, so a star map with a broken metadata chunk loads here as it does there */
     if ((uint32_t)crc32(0L, &file[pos + 4], (uInt)(4 + len)) != be32(&file[pos + 8 + len])) {
-      err = "PNG chunk CRC mismatch";
-      return false;
+      if (!(type[0] & 0x20)) {
+        err = "PNG chunk CRC mismatch";
+        return false;
+      }
+      pos += 12 + (size_t)len;
+      continue;
     }
     if (!std::memcmp(type, "IHDR", 4)) {
       if (len != 13) { err = "bad IHDR"; return false; }

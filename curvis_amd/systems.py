@@ -255,6 +255,29 @@ class SphericalImage:
         return self.get_pixel(*self.pixel_index_from_vector3(v))
 
 
+class HostBuffer:
+    """page-locked host memory (curvis_host_alloc) as a uint8 numpy array `.array`: the device-to-host copy of a render
+    into it is one DMA transfer instead of a staged copy through pageable memory"""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(lib().curvis_host_alloc(int(nbytes), C.byref(p)))
+        self._p = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (int(nbytes),))
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().curvis_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One GPU: owns the HIP stream, the two sky textures in HBM and the device framebuffer."""
 
@@ -319,8 +342,9 @@ class Context:
         check(lib().curvis_ctx_framebuffer(self._h, C.byref(p), C.byref(n)), self._h)
         return p.value, n.value
 
-    def render_brute(self, metric, cameras, max_iterations, max_radius, delta, download=True, debug=False):
-        """cameras: one Camera or a list (one launch for the whole batch).  Returns (rgb, stats[, dbg])."""
+    def render_brute(self, metric, cameras, max_iterations, max_radius, delta, download=True, debug=False, out=None):
+        """cameras: one Camera or a list (one launch for the whole batch).  Returns (rgb, stats[, dbg]).
+        out: a uint8 array of n*H*W*3 bytes to receive the frames (e.g. a HostBuffer: page-locked, one DMA transfer)."""
         single = isinstance(cameras, Camera)
         cams = [cameras] if single else list(cameras)
         n = len(cams)
@@ -328,7 +352,13 @@ class Context:
         arr = (CameraC * n)(*[c._c for c in cams])
         m = metric._c()
         st = Stats()
-        rgb = np.empty((n, H, W, 3), dtype=np.uint8) if download else None
+        if out is not None:
+            if out.dtype != np.uint8 or out.size < n * H * W * 3 or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous uint8 array of at least n*H*W*3 bytes")
+            rgb = out.reshape(-1)[:n * H * W * 3].reshape(n, H, W, 3)
+            download = True
+        else:
+            rgb = np.empty((n, H, W, 3), dtype=np.uint8) if download else None
         out = rgb.ctypes.data if download else None
         if debug:
             if n != 1:

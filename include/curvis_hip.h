@@ -257,6 +257,13 @@ int curvis_image_save_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uin
  * with its fast setting), 0..9 = zlib at that level.  Same decoded pixels whatever the level. */
 int curvis_image_save_rgb8_level(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h, int level);
 
+/* Page-locked host memory for the `rgb_out` buffers of the render calls: into such a buffer the device-to-host copy of
+ * a frame is ONE DMA transfer (~25 GB/s over PCIe 5), into ordinary pageable memory the runtime stages it through
+ * bounce buffers (~2 GB/s measured: 12 ms of a 54 ms 4K frame).  `curvis video` keeps a small pool of these and hands
+ * them to its PNG writer threads without another copy.  Free with curvis_host_free; no reference counterpart. */
+int curvis_host_alloc(size_t bytes, void **out);
+void curvis_host_free(void *p);
+
 /* device framebuffer of the last render (RGB8, frames back to back) */
 int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes);
 int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);

@@ -175,6 +175,13 @@ def test_png_decoder_rejects_hostile_files(tmp_path):
     p = tmp_path / "good.png"
     p.write_bytes(good)
     assert _decode_with_binary(p, tmp_path).shape == (1, 4, 4)
+    # a damaged ANCILLARY chunk (lower-case first letter) is skipped, as the reference's png crate does; only critical ones are fatal
+    text = _png([(b"tEXt", b"Comment\x00star map")])[8:]
+    broken_text = text[:-1] + bytes([text[-1] ^ 0xFF])
+    with_meta = good[:33] + broken_text + good[33:]                     # signature (8) + IHDR chunk (25), then the tEXt chunk
+    p2 = tmp_path / "meta.png"
+    p2.write_bytes(with_meta)
+    assert np.array_equal(_decode_with_binary(p2, tmp_path), _decode_with_binary(p, tmp_path))
     for name, blob in cases.items():
         p = tmp_path / (name + ".png")
         p.write_bytes(blob)

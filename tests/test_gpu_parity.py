@@ -679,6 +679,27 @@ def test_relay_safety_net_and_verify_option(gpu_ctx):
             gpu_ctx.set_option(k, v)
 
 
+def test_render_into_page_locked_host_buffer(gpu_ctx):
+    """curvis_host_alloc: frames rendered straight into page-locked host memory (what `curvis video` hands to its PNG
+    writers) equal the frames returned through ordinary pageable memory"""
+    sp, sn = common.make_skies(256, 128, "check")
+    _, _, pm, pc = common.scene("ellis", res=(160, 90))
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    want, s0 = gpu_ctx.render_brute(pm, [pc, pc, pc], 4096, 100.0, 0.05)
+    buf = curvis_amd.HostBuffer(3 * 160 * 90 * 3 + 64)
+    try:
+        buf.array[:] = 7
+        got, s1 = gpu_ctx.render_brute(pm, [pc, pc, pc], 4096, 100.0, 0.05, out=buf.array)
+        assert np.array_equal(got, want) and s1.steps == s0.steps
+        assert got.ctypes.data == buf.array.ctypes.data and (buf.array[-64:] == 7).all()   # in place, nothing beyond the frames
+        with pytest.raises(ValueError):
+            gpu_ctx.render_brute(pm, [pc, pc, pc], 4096, 100.0, 0.05, out=buf.array[:100])
+    finally:
+        del got
+        buf.close()
+
+
 def test_relay_seat_belt_checks_the_first_launch_of_every_shape(capfd):
     """The relay kernel's hand-over is argued from gfx950 facts, not from the HIP memory model, so the first
     relay launch of every launch shape of a context is repeated by the static kernel and compared.  Clean launches:
@@ -694,6 +715,7 @@ def test_relay_seat_belt_checks_the_first_launch_of_every_shape(capfd):
         ctx.set_sky(1, curvis_amd.SphericalImage(sn))
         ctx.set_option("variant", 2)
         ctx.set_option("relay_min_blocks", 0)
+        ctx.set_option("relay_segment", 64)   # a hand-over point every 64 steps: every launch below passes tiles on
         assert ctx.get_option("relay_auto_verify") == 1 and ctx.get_option("relay_verified_shapes") == 0
         rgb, s = ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
         assert np.array_equal(rgb, want) and s.steps == st.steps
@@ -708,6 +730,7 @@ def test_relay_seat_belt_checks_the_first_launch_of_every_shape(capfd):
         ctx.set_option("relay_auto_verify", 0)
         ctx.set_option("relay_test_corrupt", 1)
         bad, _ = ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+        assert ctx.get_option("last_relay_parks") > 0
         assert not np.array_equal(bad, want)
         # ... and with the seat belt on the same fault never reaches the caller
         ctx.set_option("relay_auto_verify", 1)                                                          # forgets the checked shapes
