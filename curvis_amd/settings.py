@@ -78,14 +78,23 @@ class VideoSettings(_Settings):
     FIELDS = (("video_name", str, "output_video"), ("frame_rate", float, 30.0),
               ("filepath_to_camera_path", str, "paths/path_through.csv"))
 
-    def normalize(self):  # resolve_path (src/filepaths.rs:42-47): relative paths are package-relative
+    def normalize(self):
+        """resolve_path (src/filepaths.rs:42-47): an absolute path is kept, a relative one is joined to the package
+        folder -- subdirectories included.  The package folder here is curvis_amd/ and the bundled camera paths live
+        in curvis_amd/data/paths/, so the reference's default "paths/path_through.csv" is looked up as
+        <package>/paths/... and <package>/data/paths/...; a relative path that exists from the working directory is
+        accepted first (an extension shared with the `curvis` binary, host/curvis_cli.cpp resolve_path)."""
         p = self.filepath_to_camera_path
         if not os.path.isabs(p) and not os.path.exists(p):
-            cand = os.path.join(paths.DATA_DIR, os.path.basename(p))
-            if os.path.basename(p) in ("path_orbit.csv", "path_through.csv"):
-                paths.ensure_paths()
-            if os.path.exists(cand):
-                p = cand
+            root = os.path.dirname(os.path.abspath(__file__))
+            if os.path.basename(p) in ("path_orbit.csv", "path_through.csv") and os.path.normpath(p) == os.path.join("paths", os.path.basename(p)):
+                paths.ensure_paths()  # the two bundled paths are generated on demand
+            for cand in (os.path.join(root, p), os.path.join(root, "data", p)):
+                if os.path.exists(cand):
+                    p = cand
+                    break
+            else:
+                p = os.path.join(root, p)
         self.filepath_to_camera_path = p
 
     def validate(self):
@@ -179,7 +188,8 @@ def metric_settings_from_toml_file(path):
         try:
             return EllisMetricSettings.from_toml_file(path)
         except SettingsError:
-            raise first
+            # src/cli.rs:255-259: neither parse succeeded -> the reference's one message, not the first parser's
+            raise SettingsError("Could not read the metric configuration file.") from first
 
 
 def image_rendering_settings(background_1, background_2, output_folder, image=None, camera=None, simulation=None):
