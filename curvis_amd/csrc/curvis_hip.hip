@@ -2599,7 +2599,7 @@ int curvis_image_save_rgb8_level(const char *path, const uint8_t *rgb, uint32_t 
 int curvis_host_alloc(size_t bytes, void **out) {
   if (!out || bytes == 0) return fail(nullptr, CURVIS_E_INVALID, "curvis_host_alloc: null pointer or zero bytes");
   *out = nullptr;
-  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable); /* usable from every device's context */
   if (e != hipSuccess) {
     *out = nullptr;
     return fail(nullptr, CURVIS_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));

@@ -832,6 +832,7 @@ int video_main(const Args &a) {
     unsigned long long steps = 0;
   };
   std::vector<DeviceSummary> dev_sum((size_t)a.devices);
+  std::vector<std::unique_ptr<PinnedPool>> pools((size_t)a.devices); /* destroyed after writers.finish() below */
   const double t_video0 = pngio::now_s();
   /* sky distribution: rank 0 uploads the two textures once; with --sky-broadcast rccl (default for
    * --devices > 1) the other GPUs receive them with ncclBroadcast over xGMI (curvis_ctx_bcast_skies),
@@ -923,7 +924,10 @@ int video_main(const Args &a) {
     }
     std::vector<curvis_camera> bc;
     std::vector<uint8_t> rgb_pageable; /* only if page-locked memory could not be had */
-    PinnedPool pool((size_t)a.batch * fbytes, 3); /* one being filled, up to two with the writers */
+    /* one being filled, up to two with the writers.  The pool belongs to video_main's scope: writer jobs hold its
+     * buffers (and its mutex, through the deleter) after this worker has returned */
+    pools[(size_t)rank].reset(new PinnedPool((size_t)a.batch * fbytes, 3));
+    PinnedPool &pool = *pools[(size_t)rank];
     if (pool.buffers() < 2) {
       std::lock_guard<std::mutex> gi(io_mu);
       std::fprintf(stderr, "warning: device %d: no page-locked host memory for the frame buffers, using pageable memory\n", a.device + rank);
@@ -974,7 +978,8 @@ int video_main(const Args &a) {
       /* src/rendering.rs:305-306: threshold_1 is passed for both thresholds */
       const double t_r0 = pngio::now_s();
       int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, rgb_ptr, &st);
-      ds.render_s += pngio::now_s() - t_r0;
+      const double batch_call_ms = (pngio::now_s() - t_r0) * 1e3;
+      ds.render_s += batch_call_ms * 1e-3;
       const bool injected = rank == fail_rank && calls == fail_call;
       if (injected) rc = CURVIS_E_HIP;
       ++calls;
@@ -1021,7 +1026,7 @@ int video_main(const Args &a) {
         std::memset(&fs, 0, sizeof fs);
         (void)curvis_ctx_frame_stats(ctx, (uint32_t)j, &fs);
         const double batch_ms = st.kernel_ms;
-        writers.submit([&, k, frame, batch_buf, copy, fs, nb, rank, batch_ms] {
+        writers.submit([&, k, frame, batch_buf, copy, fs, nb, rank, batch_ms, batch_call_ms] {
           const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
           const std::string part = file + ".part"; /* written under another name, then renamed: --resume never sees half a file */
           std::string e;
@@ -1054,11 +1059,11 @@ int video_main(const Args &a) {
           }
           std::printf("Rendering frame %zu/%zu...\n", k + 1, times.size());
           if (stats_f)
-            std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"rays\": %llu, \"steps\": %llu, \"n_pos\": %llu, \"n_neg\": %llu, \"n_none\": %llu, \"n_oob\": %llu, \"kernel_ms\": %.4f, \"mray_steps_per_s\": %.1f, \"batch_frames\": %zu, \"batch_kernel_ms\": %.4f}\n",
+            std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"rays\": %llu, \"steps\": %llu, \"n_pos\": %llu, \"n_neg\": %llu, \"n_none\": %llu, \"n_oob\": %llu, \"kernel_ms\": %.4f, \"mray_steps_per_s\": %.1f, \"batch_frames\": %zu, \"batch_kernel_ms\": %.4f, \"batch_call_ms\": %.4f}\n",
                          k, times[k], a.device + rank, a.mode.c_str(), (unsigned long long)fs.rays, (unsigned long long)fs.steps,
                          (unsigned long long)fs.n_pos, (unsigned long long)fs.n_neg, (unsigned long long)fs.n_none,
                          (unsigned long long)fs.n_oob, fs.kernel_ms, fs.kernel_ms > 0.0 ? (double)fs.steps / fs.kernel_ms / 1e3 : 0.0, nb,
-                         batch_ms);
+                         batch_ms, batch_call_ms);
         });
       }
       ds.submit_s += pngio::now_s() - t_s0; /* frame copies + time blocked on a full writer queue */
@@ -1075,6 +1080,7 @@ int video_main(const Args &a) {
   for (ncclComm_t cm : comms) ncclCommDestroy(cm);
   const double t_workers_done = pngio::now_s();
   writers.finish();
+  pools.clear(); /* every writer job is done: the page-locked buffers can go */
   const double t_video1 = pngio::now_s();
   if (stats_f) std::fclose(stats_f);
   if (!a.stats.empty()) { /* <stats>.summary.json + a table: who rendered what at which clock, where the host's time went */

@@ -706,7 +706,7 @@ def test_relay_seat_belt_checks_the_first_launch_of_every_shape(capfd):
     one check per shape, none afterwards.  A hand-over that delivers a wrong state (hook "relay_test_corrupt": the wave
     that takes the first ticket perturbs the tile it reloads) is caught: the frame returned is the static kernel's,
     the mismatch is counted and reported, and the context stays on the static kernel."""
-    sp, sn = common.make_skies(512, 256, "check")
+    sp, sn = common.make_skies(2048, 1024, "smooth")   # smooth: every change of direction shows (a 64-texel checker cell would hide it)
     om, oc, pm, pc = common.scene("ellis", res=(480, 270))
     want, _, st = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
     ctx = curvis_amd.Context(0)
