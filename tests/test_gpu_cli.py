@@ -107,6 +107,30 @@ def test_video_orbit_frames_and_quirks(scene_files):
         assert np.array_equal(pngio.read_png(out / "tmp" / ("frame_%d.png" % k)), want), k
     lines = [json.loads(ln) for ln in (out / "st.jsonl").read_text().splitlines()]
     assert sorted(ln["frame"] for ln in lines) == list(range(15))
+    assert all(ln["batch_call_ms"] >= ln["batch_kernel_ms"] > 0 for ln in lines)
+    # --stats also writes the host profile: per-device table (PCI identity, frames, kernel / render-call time) and the
+    # writer threads' stage times
+    summ = json.loads((out / "st.jsonl.summary.json").read_text())
+    assert summ["frames"] == 15 and summ["png_level"] == -1 and len(summ["devices"]) == 1
+    dev = summ["devices"][0]
+    assert dev["frames"] == 15 and dev["kernel_ms_per_frame"] > 0 and len(dev["pci_bus_id"].split(":")) == 3
+    enc = summ["encode"]
+    assert enc["frames"] == 15 and enc["thread_ms_per_frame"] > 0 and enc["file_mb_per_frame"] < enc["raw_mb_per_frame"]
+    assert "pci_bus_id" in r.stdout and "writer thread" in r.stdout
+    # the frames are written by the fast PNG writer; zlib (--png-level 6) and a single slow writer thread that is kept
+    # busy long after the last render (--encode-bench) give the same pixels
+    out2 = d / "out_vid_z"
+    out2.mkdir()
+    r2 = run("video", d / "pos.png", d / "neg.png", out2, "-v", d / "vid.toml", "-s", d / "sim.toml", "-c", d / "cam.toml",
+             "--batch", "4", "--png-level", "6", "--writers", "1", "--encode-bench", "3")
+    assert r2.returncode == 0, r2.stderr
+    for k in range(15):
+        a = pngio.read_png(out / "tmp" / ("frame_%d.png" % k))
+        assert np.array_equal(a, pngio.read_png(out2 / "tmp" / ("frame_%d.png" % k))), k
+    r3 = run("video", d / "pos.png", d / "neg.png", out2, "-v", d / "vid.toml", "-s", d / "sim.toml", "-c", d / "cam.toml",
+             "--batch", "2", "--writers", "1", "--encode-bench", "5")   # fast writer, pool starved of writers: back-pressure, no crash
+    assert r3.returncode == 0, r3.stderr
+    assert np.array_equal(pngio.read_png(out2 / "tmp" / "frame_14.png"), pngio.read_png(out / "tmp" / "frame_14.png"))
 
 
 def test_video_off_by_one_panics_like_the_reference(scene_files):

@@ -106,16 +106,16 @@ def main():
     if s:
         line("fast writer, 16 thr, checker sky", s)
     print("\n### encode capacity of this host (one GPU feeding it, every frame encoded 1 + K times)")
-    for w, k in ((8, 31), (16, 31), (32, 31), (64, 31)):
+    for w, k in ((8, 63), (16, 95), (32, 95), (64, 95)):
         s = run(d, "c3_eb_w%d" % w, sky, vid, cam, sim, ["--batch", "8", "--writers", str(w), "--encode-bench", str(k)], 240)
         if s:
             line("fast writer, %2d threads, K = %d" % (w, k), s)
-    s = run(d, "c3_eb_ck", cks, vid, cam, sim, ["--batch", "8", "--writers", "16", "--encode-bench", "31"], 240)
+    s = run(d, "c3_eb_ck", cks, vid, cam, sim, ["--batch", "8", "--writers", "16", "--encode-bench", "95"], 240)
     if s:
-        line("fast, 16 thr, K = 31, checker sky", s)
-    s = run(d, "c3_eb_z1", sky, vid, cam, sim, ["--batch", "8", "--writers", "16", "--encode-bench", "7", "--png-level", "1"], 240)
+        line("fast, 16 thr, K = 95, checker sky", s)
+    s = run(d, "c3_eb_z1", sky, vid, cam, sim, ["--batch", "8", "--writers", "16", "--encode-bench", "31", "--png-level", "1"], 240)
     if s:
-        line("zlib level 1, 16 thr, K = 7", s)
+        line("zlib level 1, 16 thr, K = 31", s)
     # ---- configs[4]: a 24-frame shard of the 4K Interstellar video
     print("\n## configs[4], 24-frame shard: path_through.csv @ 24 fps (frames 0..23 of 480), 3840x2160, Interstellar, cap 8192 (24.9 MB raw per frame)")
     import numpy as np
@@ -135,7 +135,7 @@ def main():
     while t < t_last:
         cnt += 1
         t += 1.0 / 24.0
-    for w, k in ((16, 0), (16, 15), (32, 15)):
+    for w, k in ((16, 0), (16, 63), (32, 63)):
         s = run(d, "c4_w%d_k%d" % (w, k), sky, vid, cam, sim, ["-m", met, "--batch", "4", "--writers", str(w)] + (["--encode-bench", str(k)] if k else []), None)
         if s:
             line("fast writer, %2d threads, K = %d" % (w, k), s)
