@@ -827,6 +827,82 @@ __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPix
   flush_frame_counts(P.counters, f, valid, 0ull, 1u, pos, neg, none, oob);
 }
 
+/* "direct" mode (NOT in the reference; SURVEY 8f N1 names it as a quality option): what render_image_efficient
+ * approximates by sampling + interpolation, computed exactly -- compute_escape_angle(l_cam, alpha) for the alpha of
+ * EVERY pixel (src/systems.rs:203-261 on the result of :405-433), then step 5 (:498-523) with that escape angle and
+ * space.  One thread per pixel, 8x8 tiles per wave (neighbouring alphas: coherent step counts); every photon lives in
+ * the equatorial plane, so the loop is the sampling kernel's (phi integrated, equatorial step form). */
+struct DirectParams {
+  cvk::MetricParams metric;
+  cvk::SkyParams sky[2];
+  cvk::CameraParams cam;
+  cvk::EfficientFrame frame;
+  unsigned W, H, tiles_x, tiles_y;
+  unsigned long long total_rays; /* tiles_x * tiles_y * 64 */
+  unsigned max_iter;
+  double max_radius, delta;
+  int fast_ok;
+  unsigned char *fb;
+  FrameCounters counters;
+};
+
+template <int KIND, bool FAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == cvk::METRIC_INTERSTELLAR ? 4 : 6)))
+void direct_kernel(const DirectParams P) {
+  __shared__ MathTablesLds<KIND> s_tab;
+  cvk::MetricParams M = P.metric;
+  load_math_tables<KIND>(s_tab, M);
+  const unsigned long long id = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned tile = (unsigned)(id >> 6), k6 = (unsigned)id & 63u;
+  const unsigned tyi = tile / P.tiles_x, txi = tile - tyi * P.tiles_x;
+  const unsigned px = txi * 8u + (k6 & 7u), py = tyi * 8u + (k6 >> 3);
+  const bool valid = id < P.total_rays && px < P.W && py < P.H;
+  unsigned steps = 0, pos = 0, neg = 0, none = 0, oob = 0;
+  if (valid) {
+    double alpha, axis[3];
+    cvk::efficient_pixel_geometry(P.cam, P.frame, px, py, alpha, axis);
+    double sa, ca;
+    cv_sincos(alpha, &sa, &ca);
+    const double p4[4] = {0.0, P.cam.pos[1], CV_PI / 2.0, 0.0};
+    cvk::Ray q;
+    cvk::ray_init_dir<KIND>(M, p4, ca, 0.0, sa, q);
+    const bool lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
+    int code = cvk::CODE_NONE;
+    /* a per-lane loop (lanes outside the frame are idle from the start, so the counter is not wave-uniform) */
+    for (unsigned k = 0; k < P.max_iter; ++k) {
+      one_step<KIND, true, FAST, true>(M, P.delta, q, lane_ok);
+      ++steps;
+      if (ray_escaped(q.l, P.max_radius)) {
+        code = escape_code(q.l);
+        break;
+      }
+    }
+    unsigned texel = 0xFF000000u; /* NotEscaped / undefined tangent rotation: black */
+    double angle;
+    if (code != cvk::CODE_NONE && cvk::escape_angle_of<KIND>(M, q, angle)) {
+      cvk::efficient_pixel_geometry(P.cam, P.frame, px, py, alpha, axis); /* again: not kept live across the loop */
+      double fin[3];
+      cvk::efficient_final_direction(P.frame, axis, angle, fin);
+      const cvk::SkyParams &S = P.sky[code == cvk::CODE_POS ? 0 : 1];
+      unsigned tx, ty;
+      cvk::sky_indices(S, fin[0], fin[1], fin[2], tx, ty);
+      if (tx >= S.w || ty >= S.h) oob = 1;
+      if (tx >= S.w) tx = S.w - 1;
+      if (ty >= S.h) ty = S.h - 1;
+      texel = S.texels[(size_t)ty * S.w + tx];
+      pos = (code == cvk::CODE_POS);
+      neg = (code == cvk::CODE_NEG);
+    } else {
+      none = 1;
+    }
+    unsigned char *dst = P.fb + ((size_t)py * P.W + px) * 3;
+    dst[0] = (unsigned char)(texel & 0xFF);
+    dst[1] = (unsigned char)((texel >> 8) & 0xFF);
+    dst[2] = (unsigned char)((texel >> 16) & 0xFF);
+  }
+  flush_frame_counts(P.counters, 0u, valid, steps, 1u, pos, neg, none, oob);
+}
+
 /* compute_photon_trajectory (src/systems.rs:77-92): the state BEFORE each of `iterations` Euler steps,
  * all eight components (t and p_t included: x_t += (p_t * -1) * delta, p_t += 0 * delta), one thread per
  * photon.  Momentum is covariant on entry (what new_photon produces). */
@@ -2013,6 +2089,103 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   return CURVIS_OK;
 }
 
+template <int KIND>
+int launch_direct_kind(curvis_ctx *ctx, bool fast, const DirectParams &P) {
+  const unsigned blocks = (unsigned)((P.total_rays + 255ull) / 256ull);
+  if (fast)
+    hipLaunchKernelGGL((direct_kernel<KIND, true>), dim3(blocks), dim3(256), 0, ctx->stream, P);
+  else
+    hipLaunchKernelGGL((direct_kernel<KIND, false>), dim3(blocks), dim3(256), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  return CURVIS_OK;
+}
+
+int render_direct_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cam, uint32_t max_iter,
+                       double max_radius, double delta, uint8_t *rgb_out, curvis_stats *stats) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (!metric || !cam) return fail(ctx, CURVIS_E_INVALID, "null metric/camera");
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = curvis_metric_validate(metric);
+  if (rc != CURVIS_OK) return fail(ctx, rc, "invalid metric parameters (src/metrics.rs:409-456)");
+  const uint32_t W = cam->res_x, H = cam->res_y;
+  if (W == 0 || H == 0) return fail(ctx, CURVIS_E_INVALID, "resolution must be greater than 0 (src/cameras.rs:98)");
+  if (std::fabs(cam->pos[1]) > max_radius)
+    return fail(ctx, CURVIS_E_CAMERA_OUTSIDE, "Photon already beyond the maximum radius. Cannot evaluate escape. (src/systems.rs:122-124)");
+  if (!ctx->d_sky[0] || !ctx->d_sky[1]) return fail(ctx, CURVIS_E_NO_SKY, "both background images must be set");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DirectParams P;
+  P.metric = make_metric(*metric);
+  P.cam = make_camera(*cam);
+  cvk::vector3_from_theta_phi(cam->pos[2], cam->pos[3], P.frame.cam_bg); /* src/systems.rs:393-397 */
+  const double ex[3] = {1.0, 0.0, 0.0};
+  if (!cvk::rotation_from_two_vectors(ex, P.frame.cam_bg, P.frame.rot_bg))
+    return fail(ctx, CURVIS_E_PARALLEL, "v1 and v2 must not be parallel (src/algebra.rs:95-97, camera on the x axis)");
+  for (int k = 0; k < 2; ++k) {
+    P.sky[k].texels = (const unsigned *)ctx->d_sky[k];
+    P.sky[k].w = ctx->sky_w[k];
+    P.sky[k].h = ctx->sky_h[k];
+    for (int i = 0; i < 9; ++i) P.sky[k].inv_rot[i] = ctx->sky_inv_rot[k][i];
+  }
+  P.W = W;
+  P.H = H;
+  P.tiles_x = (W + 7) / 8;
+  P.tiles_y = (H + 7) / 8;
+  P.total_rays = (unsigned long long)P.tiles_x * P.tiles_y * 64ull;
+  if (P.total_rays / 64ull > 0xFFFFFFFFull) return fail(ctx, CURVIS_E_INVALID, "frame too large");
+  P.max_iter = max_iter;
+  P.max_radius = max_radius;
+  P.delta = delta;
+  P.fast_ok = cvk::metric_fast_ok(metric->kind, P.metric, max_radius) ? 1 : 0;
+  const size_t npix = (size_t)W * H, fb_bytes = npix * 3;
+  rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, fb_bytes);
+  if (rc) return rc;
+  ctx->fb_bytes = fb_bytes;
+  P.fb = ctx->d_fb;
+  FrameCounters FC;
+  rc = prepare_counters(ctx, 1, FC);
+  if (rc) return rc;
+  P.counters = FC;
+  const size_t cnt_words = counter_words(1, FC.slots);
+  const bool fast = ctx->fast_math != 0;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  switch (metric->kind) {
+    case CURVIS_METRIC_ELLIS:
+      rc = launch_direct_kind<cvk::METRIC_ELLIS>(ctx, fast, P);
+      break;
+    case CURVIS_METRIC_INTERSTELLAR:
+      rc = launch_direct_kind<cvk::METRIC_INTERSTELLAR>(ctx, fast, P);
+      break;
+    default:
+      rc = launch_direct_kind<cvk::METRIC_FLAT>(ctx, fast, P);
+      break;
+  }
+  if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words, hipMemcpyDeviceToHost, ctx->stream));
+  if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  uint64_t fc[FC_N];
+  sum_frame_counters(ctx->h_counters, FC.slots, 0, fc);
+  curvis_stats st;
+  std::memset(&st, 0, sizeof st);
+  st.rays = fc[FC_RAYS];
+  st.steps = fc[FC_STEPS];
+  st.n_pos = fc[FC_POS];
+  st.n_neg = fc[FC_NEG];
+  st.n_none = fc[FC_NONE];
+  st.n_oob = fc[FC_OOB];
+  st.kernel_ms = st.integrate_ms = ms;
+  st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  ctx->last_frame_stats.assign(1, st);
+  ctx->last_integrate_ms = ms;
+  ctx->last_shade_ms = 0.0;
+  ctx->last_relay_launches = 0;
+  if (stats) *stats = st;
+  return CURVIS_OK;
+}
+
 }  // namespace
 
 /* ------------------------------------------------------------------------------------------ ABI */
@@ -2445,6 +2618,11 @@ int curvis_render_efficient_batch(curvis_ctx *ctx, const curvis_metric *metric, 
   return render_efficient_impl(ctx, metric, cameras, n_frames, max_iterations_propagation, max_radius, delta,
                                alpha_nums, max_iterations_sampling, sampling_convergence_threshold_1,
                                sampling_convergence_threshold_2, rgb_out, stats);
+}
+
+int curvis_render_direct(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera, uint32_t max_iterations,
+                         double max_radius, double delta, uint8_t *rgb_out, curvis_stats *stats) {
+  return render_direct_impl(ctx, metric, camera, max_iterations, max_radius, delta, rgb_out, stats);
 }
 
 int curvis_ctx_sampling_info(const curvis_ctx *ctx, uint32_t frame, curvis_sampling_info *info) {

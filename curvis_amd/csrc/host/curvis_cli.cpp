@@ -425,7 +425,7 @@ void usage() {
       "curvis image <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-i|--image-settings <TOML FILE>]\n"
       "curvis video <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-v|--video-settings <TOML FILE>]\n"
       "  common: [-m|--metric-settings <TOML FILE>] [-c|--camera-settings <TOML FILE>] [-s|--simulation-settings <TOML FILE>]\n"
-      "  extensions: [--mode efficient|brute] [--device N] [--devices N] [--batch B] [--stats FILE]\n"
+      "  extensions: [--mode efficient|brute|direct] [--device N] [--devices N] [--batch B] [--stats FILE]\n"
       "              [--sky-broadcast rccl|upload] [--writers T] [--resume] [--png-level -1..9]\n");
 }
 Args parse_args(int argc, char **argv) {
@@ -481,7 +481,7 @@ Args parse_args(int argc, char **argv) {
     if (a.sub == "image" && !a.video_toml.empty()) die("error: unexpected argument '-v' found", 2);
     if (a.sub == "video" && !a.image_toml.empty()) die("error: unexpected argument '-i' found", 2);
   }
-  if (a.mode != "efficient" && a.mode != "brute") die("error: --mode must be efficient or brute", 2);
+  if (a.mode != "efficient" && a.mode != "brute" && a.mode != "direct") die("error: --mode must be efficient, brute or direct", 2);
   if (a.sky_broadcast != "rccl" && a.sky_broadcast != "upload") die("error: --sky-broadcast must be rccl or upload", 2);
   if (a.devices < 1) a.devices = 1;
   if (a.batch < 1) a.batch = 1;
@@ -573,11 +573,39 @@ curvis_ctx *make_ctx(int device, const Common &c, const char *what) {
   return ctx;
 }
 
+/* per-frame statistics of the last render_frames call of this thread in "direct" mode (one render call per frame there;
+ * the batch calls of the other modes keep theirs inside the context: curvis_ctx_frame_stats) */
+thread_local std::vector<curvis_stats> g_direct_frame_stats;
+
 int render_frames(curvis_ctx *ctx, const Args &a, const Common &c, const curvis_camera *cams, uint32_t n, double thr2,
                   uint8_t *rgb, curvis_stats *st) {
   if (a.mode == "brute")
     return curvis_render_brute_batch(ctx, &c.metric, cams, n, c.sim.ray_integration_max_itarations, c.sim.escape_radius,
                                      c.sim.ray_integration_step, rgb, st);
+  if (a.mode == "direct") { /* extension: compute_escape_angle for every pixel, no sampling / interpolation; frame by frame */
+    curvis_stats tot;
+    std::memset(&tot, 0, sizeof tot);
+    const size_t fbytes = (size_t)cams[0].res_x * cams[0].res_y * 3;
+    g_direct_frame_stats.clear();
+    for (uint32_t f = 0; f < n; ++f) {
+      curvis_stats one;
+      const int rc = curvis_render_direct(ctx, &c.metric, cams + f, c.sim.ray_integration_max_itarations, c.sim.escape_radius,
+                                          c.sim.ray_integration_step, rgb + (size_t)f * fbytes, &one);
+      if (rc != CURVIS_OK) return rc;
+      g_direct_frame_stats.push_back(one);
+      tot.rays += one.rays;
+      tot.steps += one.steps;
+      tot.n_pos += one.n_pos;
+      tot.n_neg += one.n_neg;
+      tot.n_none += one.n_none;
+      tot.n_oob += one.n_oob;
+      tot.kernel_ms += one.kernel_ms;
+      tot.integrate_ms += one.integrate_ms;
+      tot.total_ms += one.total_ms;
+    }
+    if (st) *st = tot;
+    return CURVIS_OK;
+  }
   /* src/main.rs:46-47 / :106-107: alphas_num AND max_iterations_sampling both take sampling_initial_nums */
   return curvis_render_efficient_batch(ctx, &c.metric, cams, n, c.sim.ray_integration_max_itarations, c.sim.escape_radius,
                                        c.sim.ray_integration_step, c.sim.sampling_initial_nums, c.sim.sampling_initial_nums,
@@ -1024,7 +1052,10 @@ int video_main(const Args &a) {
         const uint8_t *frame = batch_buf ? batch_buf.get() + j * fbytes : copy->data();
         curvis_stats fs;
         std::memset(&fs, 0, sizeof fs);
-        (void)curvis_ctx_frame_stats(ctx, (uint32_t)j, &fs);
+        if (a.mode == "direct" && j < g_direct_frame_stats.size())
+          fs = g_direct_frame_stats[j];
+        else
+          (void)curvis_ctx_frame_stats(ctx, (uint32_t)j, &fs);
         const double batch_ms = st.kernel_ms;
         writers.submit([&, k, frame, batch_buf, copy, fs, nb, rank, batch_ms, batch_call_ms] {
           const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";

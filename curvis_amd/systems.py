@@ -402,6 +402,17 @@ class Context:
             rgb = rgb[0]
         return rgb, st
 
+    def render_direct(self, metric, camera, max_iterations, max_radius, delta, download=True):
+        """"direct" mode (not in the reference): compute_escape_angle for the alpha of every pixel instead of sampling and
+        interpolating (curvis_render_direct).  Returns (rgb or None, stats)."""
+        W, H = camera.resolution_width, camera.resolution_height
+        m = metric._c()
+        st = Stats()
+        rgb = np.empty((H, W, 3), dtype=np.uint8) if download else None
+        check(lib().curvis_render_direct(self._h, C.byref(m), C.byref(camera._c), max_iterations, max_radius, delta,
+                                         rgb.ctypes.data if download else None, C.byref(st)), self._h)
+        return rgb, st
+
     def frame_stats(self, frame=None):
         """Statistics of one frame (or the list for all frames) of the last render call: the per-frame
         early-termination counters (rays, executed steps, escaped +l / -l, capped, out-of-range texels)."""
@@ -558,6 +569,14 @@ class RelativisticSystem:
         rgb, st = self.context.render_efficient(self.metric, self.camera, max_iterations_propagation, max_radius, delta,
                                                 alpha_nums, max_iterations_sampling, sampling_convergence_threshold_1,
                                                 sampling_convergence_threshold_2)
+        self.last_stats = st
+        return rgb
+
+    def render_image_direct(self, max_iterations_propagation, max_radius, delta):
+        """NOT in the reference: the image render_image_efficient approximates, with compute_escape_angle evaluated
+        for every pixel instead of sampled and interpolated (a quality option; Context.render_direct)."""
+        self._bind_skies()
+        rgb, st = self.context.render_direct(self.metric, self.camera, max_iterations_propagation, max_radius, delta)
         self.last_stats = st
         return rgb
 

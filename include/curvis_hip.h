@@ -206,6 +206,14 @@ int curvis_render_efficient_batch(curvis_ctx *ctx, const curvis_metric *metric, 
                                   double delta, uint32_t alpha_nums, uint32_t max_iterations_sampling,
                                   double sampling_convergence_threshold_1, double sampling_convergence_threshold_2,
                                   uint8_t *rgb_out, curvis_stats *stats);
+/* "direct" mode -- NOT a function of the reference (SURVEY.md 8f N1 names it as an option): the image that
+ * render_image_efficient approximates by adaptive sampling + linear interpolation, computed without either:
+ * compute_escape_angle (src/systems.rs:203-261) is evaluated for the alpha of EVERY pixel (:405-433) and step 5
+ * (:498-523) applied to its result.  A not-escaped photon, or one whose tangent rotation is undefined, gives a black
+ * pixel (counted in n_none).  Parity: bit-exact against this repository's oracle (cvo_render_image_direct); against the
+ * reference only through what it approximates (its efficient image differs where the interpolation does). */
+int curvis_render_direct(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera, uint32_t max_iterations,
+                         double max_radius, double delta, uint8_t *rgb_out, curvis_stats *stats);
 /* sampler bookkeeping of the last efficient render (per frame): final table size, refinement rounds,
  * integrator calls, Euler steps, and whether the "maximum number of iterations" warning fired. */
 typedef struct curvis_sampling_info {

@@ -371,6 +371,11 @@ int cvo_render_image_efficient(int fl, const cvo_metric *m, const cvo_camera *c,
                   max_iterations_sampling, thr1, thr2, rgb, samples_out, stats);
 }
 
+int cvo_render_image_direct(int fl, const cvo_metric *m, const cvo_camera *c, const cvo_sky *pos, const cvo_sky *neg,
+                            uint32_t max_iter, double max_radius, double delta, uint8_t *rgb, cvo_stats *stats) {
+  return DISPATCH(fl, render_image_direct, m, c, pos, neg, max_iter, max_radius, delta, rgb, stats);
+}
+
 /* ------------------------------------------------------------------ src/csv.rs:24-62 load_path */
 static int parse_rust_f64(const char *s, size_t len, double *out) {
   /* str::parse::<f64>: no surrounding whitespace allowed, whole token must be consumed */

@@ -144,6 +144,10 @@ int cvo_render_image_efficient(int fl, const cvo_metric *m, const cvo_camera *c,
                                const cvo_sky *neg, uint32_t max_iter, double max_radius, double delta,
                                uint32_t alpha_nums, uint32_t max_iterations_sampling, double thr1, double thr2,
                                uint8_t *rgb, cvo_samples *samples_out /*nullable*/, cvo_stats *stats);
+/* "direct" mode (not a reference function): compute_escape_angle at the alpha of every pixel instead of sampling and
+ * interpolating; counterpart of curvis_render_direct */
+int cvo_render_image_direct(int fl, const cvo_metric *m, const cvo_camera *c, const cvo_sky *pos, const cvo_sky *neg,
+                            uint32_t max_iter, double max_radius, double delta, uint8_t *rgb, cvo_stats *stats);
 
 /* --- camera path (src/csv.rs, src/interpolation.rs, src/rendering.rs:224-238) --- */
 typedef struct {

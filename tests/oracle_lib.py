@@ -103,6 +103,7 @@ def lib():
     sig("cvo_interp_slice", None, [dp, dp, C.c_size_t, dp, C.c_size_t, dp])
     sig("cvo_render_image_efficient", i32, [i32, MP, CP, SP, SP, u32, d, d, u32, u32, d, d, vp,
                                             C.POINTER(Samples), C.POINTER(Stats)])
+    sig("cvo_render_image_direct", i32, [i32, MP, CP, SP, SP, u32, d, d, vp, C.POINTER(Stats)])
     sig("cvo_load_path", i32, [C.c_char_p, C.POINTER(Path)])
     sig("cvo_path_free", None, [C.POINTER(Path)])
     sig("cvo_path_camera", i32, [C.POINTER(Path), d, dp, dp, dp])
@@ -186,6 +187,18 @@ def render_image_efficient(fl, metric, cam, sky_pos, sky_neg, max_iter, max_radi
                    rounds=smp.rounds)
     lib().cvo_samples_free(C.byref(smp))
     return rgb, samples, st
+
+
+def render_image_direct(fl, metric, cam, sky_pos, sky_neg, max_iter, max_radius, delta):
+    """"direct" mode (not a reference function): compute_escape_angle for the alpha of every pixel"""
+    W, H = cam.res_x, cam.res_y
+    rgb = np.zeros((H, W, 3), dtype=np.uint8)
+    st = Stats()
+    rc = lib().cvo_render_image_direct(fl, C.byref(metric), C.byref(cam), C.byref(sky_pos), C.byref(sky_neg), max_iter,
+                                       max_radius, delta, rgb.ctypes.data, C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle panic: %d" % rc)
+    return rgb, st
 
 
 def escape_photon(fl, metric, pos, direction, delta, max_iter, max_radius):

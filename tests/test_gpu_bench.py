@@ -61,3 +61,18 @@ def test_single_rank_line_carries_sustained_figure_and_device_identity(gpu_ctx):
     s = out["value_sustained"]
     assert s["seconds"] >= 1.0 and s["launches"] >= 50 and s["value"] > 0.5 * out["value"]
     assert s["samples"] >= 5                              # the sampler ran; the clock itself may be unreadable in a container
+
+
+def test_single_rank_over_rccl_takes_the_multi_gpu_code_path():
+    """CURVIS_BENCH_FORCE_DIST=1: process group on RCCL (torch `nccl`), all-reduce span check, object gathers of the
+    per-rank records, device-to-device sky broadcast, barriers and reductions -- the N > 1 code path with the real
+    collective library, on the one GPU a test box has"""
+    r = run_bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--no-live-traffic", "--multi-frame", "0",
+                   "--sustained-seconds", "0.5"], {"CURVIS_BENCH_FORCE_DIST": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                      # RCCL's banner went to stderr
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["collective"]["backend"].startswith("rccl") and out["collective"]["ranks"] == 1
+    assert len(out["collective"]["sky_broadcast_gbps"]) == 2 and all(v is None or v > 0 for v in out["collective"]["sky_broadcast_gbps"])
+    assert len(out["per_rank"]) == 1 and out["per_rank"][0]["pci_bus_id"] and out["distinct_gpus"] == 1

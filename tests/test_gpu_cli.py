@@ -59,6 +59,14 @@ def test_image_default_pose_efficient_and_brute(scene_files):
     om, oc, _, _ = common.scene("interstellar", res=(96, 54))
     want, _, _ = O.render_image(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
     assert np.array_equal(got, want)
+    # "direct" mode (an extension): compute_escape_angle for every pixel, no sampling / interpolation
+    r = run("image", d / "pos.png", d / "neg.png", out, "-s", d / "sim.toml", "-c", d / "cam.toml", "-m", d / "met.toml",
+            "--mode", "direct", "--stats", out / "st_direct.json")
+    assert r.returncode == 0, r.stderr
+    want, st_d = O.render_image_direct(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
+    assert np.array_equal(pngio.read_png(out / "output_image.png"), want)
+    st = json.loads((out / "st_direct.json").read_text())
+    assert st["steps"] == st_d.steps and st["mode"] == "direct"
 
 
 def test_image_rows_split_over_devices(scene_files):

@@ -679,6 +679,43 @@ def test_relay_safety_net_and_verify_option(gpu_ctx):
             gpu_ctx.set_option(k, v)
 
 
+@pytest.mark.parametrize("metric,res,pos", [("ellis", (160, 90), None), ("interstellar", (96, 54), (0.0, -2.0, 1.1, 0.7)),
+                                            ("flat", (61, 35), (0.0, 4.0, 1.3, 0.2))])
+def test_direct_mode_bit_exact_vs_oracle(gpu_ctx, metric, res, pos):
+    """curvis_render_direct ("direct" mode, not a reference function): compute_escape_angle for the alpha of every pixel,
+    then step 5 -- pixels and counters bit-exact against the oracle's counterpart; fast and strict step; ragged
+    frame sizes (tiles padded)."""
+    sp, sn = common.make_skies(1024, 512, "smooth")
+    kw = {} if pos is None else {"pos": pos}
+    om, oc, pm, pc = common.scene(metric, res=res, **kw)
+    want, st = O.render_image_direct(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc, context=gpu_ctx)
+    try:
+        for fast in (1, 0):
+            gpu_ctx.set_option("fast_math", fast)
+            got = sys_.render_image_direct(4096, 100.0, 0.05)
+            s = sys_.last_stats
+            assert np.array_equal(got, want), (metric, fast, int((got != want).any(axis=2).sum()))
+            assert (s.rays, s.steps, s.n_pos, s.n_neg, s.n_none, s.n_oob) == (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none, st.n_oob)
+    finally:
+        gpu_ctx.set_option("fast_math", 1)
+
+
+def test_direct_mode_1080p_against_efficient(gpu_ctx):
+    """a 1080p frame: the direct image and the efficient image (the reference's CLI renderer) differ only where the
+    interpolation error moves a texel; the cap binds nowhere, so every ray escapes"""
+    sp, sn = common.make_skies(2048, 1024, "smooth")
+    _, _, pm, pc = common.scene("ellis", res=(1920, 1080))
+    sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc, context=gpu_ctx)
+    d = sys_.render_image_direct(40000, 100.0, 0.05)
+    sd = sys_.last_stats
+    e = sys_.render_image_efficient(40000, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+    diff = np.abs(d.astype(int) - e.astype(int)).max(axis=2)
+    print("direct vs efficient 1080p: identical %.5f, <= 1 LSB %.5f, max %d; direct kernel %.2f ms, %d steps" % (
+        (diff == 0).mean(), (diff <= 1).mean(), diff.max(), sd.kernel_ms, sd.steps))
+    assert sd.rays == 1920 * 1080 and sd.n_none == 0 and (diff <= 1).mean() > 0.99
+
+
 def test_render_into_page_locked_host_buffer(gpu_ctx):
     """curvis_host_alloc: frames rendered straight into page-locked host memory (what `curvis video` hands to its PNG
     writers) equal the frames returned through ordinary pageable memory"""

@@ -464,3 +464,22 @@ def test_glibc_flavours_agree_on_every_pixel_of_a_small_frame(name):
         moved += int((dbg["x"].view(np.uint64) != ref["x"].view(np.uint64)).any(axis=-1).sum())
     if _glibc_sincos_differs():
         assert moved > 0
+
+
+@pytest.mark.parametrize("name", ["ellis", "interstellar"])
+def test_direct_mode_is_what_the_efficient_renderer_approximates(name):
+    """"direct" mode (not a reference function): compute_escape_angle at the alpha of every pixel.  The
+    reference's efficient image interpolates that function between adaptive samples, so the two images agree except
+    where the interpolation error moves a texel: measured here, bounded loosely (a smooth sky: <= 1 LSB nearly everywhere)."""
+    import common
+    sp, sn = common.make_skies(1024, 512, "smooth")
+    om, oc, _, _ = common.scene(name, res=(64, 36))
+    d, st = O.render_image_direct(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
+    e, _, _ = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+    assert st.rays == 64 * 36 and st.n_pos + st.n_neg + st.n_none == st.rays and st.n_pos > 0
+    diff = np.abs(d.astype(int) - e.astype(int)).max(axis=2)
+    assert (diff <= 1).mean() > 0.98 and (diff == 0).mean() > 0.9, ((diff <= 1).mean(), (diff == 0).mean())
+    # the three glibc flavours give the same direct image as cv_math.h on this frame
+    for fl in O.GLIBC_FLAVOURS:
+        g, _ = O.render_image_direct(fl, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
+        assert np.abs(d.astype(int) - g.astype(int)).max() <= 1
