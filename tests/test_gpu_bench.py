@@ -44,8 +44,10 @@ def test_two_ranks_sharing_the_device():
 
 def test_two_ranks_on_one_gpu_are_refused_without_the_hook():
     """without the hook a 2-rank run on a 1-GPU box must not produce a line (it would claim n_gpus = 2 for one GPU)"""
-    import torch
-    if torch.cuda.device_count() >= 2:
+    # NOT `import torch` here: torch brings its own copies of the HIP runtime and RCCL into the pytest process, after which
+    # tests that open librccl.so / libamdhip64.so through ctypes find "no ROCm-capable device"
+    from curvis_amd import _abi
+    if _abi.lib().curvis_device_count() >= 2:
         pytest.skip("this box has two GPUs")
     r = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-traffic", "--no-live-traffic"], {})
     assert r.returncode != 0 and r.stdout.strip() == "" and "refusing" in r.stderr
