@@ -471,8 +471,8 @@ struct RelayArgs {
   unsigned long long n_tiles;
   unsigned fresh_blocks; /* workgroups [0, fresh_blocks) start tiles, the rest relay parked ones */
   unsigned seg;          /* steps per segment */
-  unsigned corrupt_ticket; /* test hook (option "relay_test_corrupt"): the wave that takes ticket corrupt_ticket - 1 perturbs
-                              one reloaded ray, so that the first-launch check below has something to find; 0 = off */
+  unsigned corrupt_ticket; /* test hook (option "relay_test_corrupt"): non-zero = every relay wave of this launch perturbs the
+                              state it reloads, so that the first-launch check below has something to find; 0 = off */
 };
 
 /* Hand-over traffic of the relay kernel goes around the caches: system-scope relaxed atomics compile to
@@ -534,7 +534,7 @@ void geodesic_relay(const IntegrateParams P, const RelayArgs A) {
     if (lane == 0) st_sys(slot_p, 0u);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); /* order the state loads below after the ticket load */
     tile = (unsigned long long)(v - 1u);
-    corrupt = A.corrupt_ticket != 0u && __builtin_amdgcn_readfirstlane((unsigned)tk) == A.corrupt_ticket - 1u;
+    corrupt = A.corrupt_ticket != 0u; /* test hook: every tile this launch hands over arrives perturbed */
   }
   if (P.trace) t_work = wall_clock64();
   const unsigned long long id = tile * 64ull + lane;
@@ -558,7 +558,10 @@ void geodesic_relay(const IntegrateParams P, const RelayArgs A) {
     q.p2 = ld_sys(&P.store.p2[id]);
     q.p3 = ld_sys(&P.store.p3[id]);
     q.p3sq = q.p3 * q.p3;
-    if (corrupt) q.th = q.th + 0.25; /* what a hand-over that lost a store would look like: every ray of the tile lands elsewhere */
+    if (corrupt) { /* what a hand-over that lost stores would look like: the rays of the tile land elsewhere */
+      q.th = q.th + 0.25;
+      q.p1 = -q.p1;
+    }
     steps = ld_sys(&P.store.steps[id]);
     const int c = ld_sys(&P.store.code[id]);
     active = (c & 4) != 0;
@@ -652,6 +655,18 @@ void geodesic_relay(const IntegrateParams P, const RelayArgs A) {
              ((unsigned long long)(parked ? 1 : 0) << 41) | ((unsigned long long)(k0 & 0xffff) << 44);
     rec[3] = t_work;
   }
+}
+
+/* seat belt of the relay kernel: number of differing 8-byte words of two framebuffers (one atomic per wave that saw one) */
+__global__ __launch_bounds__(256) void compare_kernel(const unsigned long long *a, const unsigned long long *b, size_t n_words,
+                                                      unsigned long long *n_diff) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned mine = 0;
+  for (; i < n_words; i += stride) mine += a[i] != b[i];
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(mine != 0);
+  if (mine) atomicAdd(n_diff, (unsigned long long)mine);
+  (void)m;
 }
 
 /* K2: final photon -> tangent direction -> nearest sky texel -> RGB8 (rows R9-R10 of SURVEY.md 8a).
@@ -1017,6 +1032,8 @@ struct curvis_ctx {
   size_t dbg_cap = 0;
   unsigned char *d_store = nullptr; /* RayStore arrays, carved from one allocation */
   unsigned char *d_rq = nullptr;    /* RelayQueue + ticket ring of the relay kernel */
+  unsigned char *d_verify = nullptr; /* copy of the relay kernel's frame while the static kernel re-renders it (seat belt) */
+  size_t verify_cap = 0;
   int relay_segment = 0;            /* steps between two hand-over points; 0 = automatic */
   int relay_max_frames = 8;         /* largest launch (frames) the relay kernel is used for: the end-game it repairs is
                                        ~5 % of a one-frame launch and 1-2 % of a launch of three to six frames;
@@ -1552,19 +1569,38 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
   const std::array<uint32_t, 5> shape = {W, H, n_frames, (uint32_t)metric->kind, (uint32_t)(fast ? 1 : 0)};
   const bool auto_check = relay && !ctx->relay_verify && ctx->relay_auto_verify && !ctx->relay_verified.count(shape);
   if (relay && (ctx->relay_verify || auto_check)) {
-    std::vector<uint8_t> a(fb_bytes), b(fb_bytes);
-    HIP_TRY(ctx, hipMemcpyAsync(a.data(), ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    /* the relay frame is kept in a second device buffer and compared there: no host copies (two pageable D2H copies of a
+     * batch cost more than the static re-render and left the NEXT render call 20 ms slower) */
+    const size_t padded = (fb_bytes + 7) & ~(size_t)7;
+    rc = ensure_device(ctx, ctx->d_verify, ctx->verify_cap, padded + 8);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_verify + (padded - 8), 0, 16, ctx->stream)); /* tail padding + the counter */
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_verify, ctx->d_fb, fb_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (ctx->fb_cap < padded) { /* room for the zeroed tail the word-wise compare reads (the frame is re-rendered below anyway) */
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, padded);
+      if (rc) return rc;
+    }
     const std::vector<curvis_stats> fs = ctx->last_frame_stats;
     const uint32_t launches = ctx->last_relay_launches;
     const uint64_t parks = ctx->last_relay_parks, waiters = ctx->last_relay_waiters;
     const double keep_i = ctx->last_integrate_ms, keep_s = ctx->last_shade_ms;
     const int saved = ctx->variant;
     ctx->variant = 1;
-    rc = render_impl(ctx, metric, cams, n_frames, max_iterations, max_radius, delta, b.data(), nullptr, nullptr, row_begin, row_count);
+    rc = render_impl(ctx, metric, cams, n_frames, max_iterations, max_radius, delta, nullptr, nullptr, nullptr, row_begin, row_count);
     ctx->variant = saved;
     if (rc) return rc;
-    bool same = a == b && fs.size() == ctx->last_frame_stats.size();
+    /* d_fb holds the static kernel's frame now */
+    if (padded != fb_bytes) HIP_TRY(ctx, hipMemsetAsync(ctx->d_fb + fb_bytes, 0, padded - fb_bytes, ctx->stream));
+    unsigned long long *d_cnt = (unsigned long long *)(ctx->d_verify + padded);
+    const size_t n_words = padded / 8;
+    hipLaunchKernelGGL(compare_kernel, dim3((unsigned)std::min<size_t>((n_words + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
+                       (const unsigned long long *)ctx->d_verify, (const unsigned long long *)ctx->d_fb, n_words, d_cnt);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long n_diff_words = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_diff_words, d_cnt, sizeof n_diff_words, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    bool same = n_diff_words == 0 && fs.size() == ctx->last_frame_stats.size();
     for (size_t f = 0; same && f < fs.size(); ++f) {
       const curvis_stats &x = fs[f], &y = ctx->last_frame_stats[f];
       same = x.rays == y.rays && x.steps == y.steps && x.n_pos == y.n_pos && x.n_neg == y.n_neg && x.n_none == y.n_none && x.n_oob == y.n_oob;
@@ -1572,10 +1608,8 @@ int render_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camer
     if (!same) {
       ctx->relay_mismatches++;
       if (ctx->relay_verify) return fail(ctx, CURVIS_E_HIP, "relay_verify: the relay kernel and the static kernel disagree on this launch");
-      size_t n_diff = 0;
-      for (size_t i = 0; i < fb_bytes; ++i) n_diff += a[i] != b[i];
-      fprintf(stderr, "[curvis] relay kernel: first launch of shape %ux%u x %u frame(s) differs from the static kernel (%zu bytes of %zu); "
-                      "this context uses the static kernel from now on\n", W, H, n_frames, n_diff, fb_bytes);
+      fprintf(stderr, "[curvis] relay kernel: first launch of shape %ux%u x %u frame(s) differs from the static kernel (%llu of %zu 8-byte words%s); "
+                      "this context uses the static kernel from now on\n", W, H, n_frames, n_diff_words, n_words, n_diff_words ? "" : ", counters only");
       ctx->relay_disabled = 1;
       ctx->relay_fallbacks++;
       return render_impl(ctx, metric, cams, n_frames, max_iterations, max_radius, delta, rgb_out, dbg_out, stats, row_begin, row_count);
@@ -2247,6 +2281,7 @@ void curvis_ctx_destroy(curvis_ctx *ctx) {
   if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
   if (ctx->d_store) (void)hipFree(ctx->d_store);
   if (ctx->d_rq) (void)hipFree(ctx->d_rq);
+  if (ctx->d_verify) (void)hipFree(ctx->d_verify);
   if (ctx->d_eff) (void)hipFree(ctx->d_eff);
   if (ctx->h_eff) (void)hipHostFree(ctx->h_eff);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);

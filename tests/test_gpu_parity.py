@@ -740,8 +740,8 @@ def test_render_into_page_locked_host_buffer(gpu_ctx):
 def test_relay_seat_belt_checks_the_first_launch_of_every_shape(capfd):
     """The relay kernel's hand-over is argued from gfx950 facts, not from the HIP memory model, so the first
     relay launch of every launch shape of a context is repeated by the static kernel and compared.  Clean launches:
-    one check per shape, none afterwards.  A hand-over that delivers a wrong state (hook "relay_test_corrupt": the wave
-    that takes the first ticket perturbs the tile it reloads) is caught: the frame returned is the static kernel's,
+    one check per shape, none afterwards.  A hand-over that delivers a wrong state (hook "relay_test_corrupt": every relay wave
+    of that launch perturbs the tile it reloads) is caught: the frame returned is the static kernel's,
     the mismatch is counted and reported, and the context stays on the static kernel."""
     sp, sn = common.make_skies(2048, 1024, "smooth")   # smooth: every change of direction shows (a 64-texel checker cell would hide it)
     om, oc, pm, pc = common.scene("ellis", res=(480, 270))
