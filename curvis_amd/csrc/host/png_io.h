@@ -601,7 +601,7 @@ inline bool write_file(const std::string &path, const uint8_t *data, size_t n, s
 inline bool save_rgb8(const std::string &path, const uint8_t *rgb, uint32_t w, uint32_t h, std::string &err, int level = 6,
                       EncodeTimes *tm = nullptr) {
   if (level < 0) {
-    if ((uint64_t)w * 3 * h + h >= ((uint64_t)1 << 32) - 65536) { /* IDAT length is 32 bits: such a frame takes the zlib route */
+    if ((uint64_t)w * 3 * h + h >= ((uint64_t)1 << 31) - 65536) { /* IDAT length is 32 bits and the worst case is 15 bits per byte: a 2 GiB frame takes the zlib route */
       level = 1;
     } else {
       static thread_local std::vector<uint8_t> file;

@@ -56,3 +56,14 @@ def test_image_decoders_are_clean_under_asan_and_ubsan_on_hostile_files(tmp_path
     r = subprocess.run([os.path.join(D, "san_images")] + files, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "decoded" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
+def test_fast_png_writer_is_clean_under_asan_and_ubsan():
+    """the fast PNG writer of `curvis video` (png_io.h) on 400 small images of awkward shapes and contents (all zero, noise,
+    long runs, gradients, short runs), each decoded again and compared, under ASan + UBSan: its bit writer stores eight
+    bytes at a time and its run coder splits runs at 258 -- the places an off-by-one would hide"""
+    subprocess.run(["make", "-s", "-C", D, "san_images"], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(D, "san_images"), "--encode"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert "encoded and decoded 400 images" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
