@@ -30,12 +30,12 @@ def cpu_quota():
         return None
 
 
-def run(d, tag, sky, vid, cam, sim, extra, expect_frames):
+def run(d, tag, sky, vid, cam, sim, extra, expect_frames, mode="brute"):
     out = os.path.join(d, "out_" + tag)
     os.mkdir(out)
     st = os.path.join(out, "st.jsonl")
     t0 = time.perf_counter()
-    r = subprocess.run([BIN, "video", sky[0], sky[1], out, "-v", vid, "-c", cam, "-s", sim, "--mode", "brute", "--stats", st] + extra,
+    r = subprocess.run([BIN, "video", sky[0], sky[1], out, "-v", vid, "-c", cam, "-s", sim, "--mode", mode, "--stats", st] + extra,
                        capture_output=True, text=True)
     dt = time.perf_counter() - t0
     if r.returncode not in (0, 101):  # 101 = the reference's own panic in the last segment of a path (frames before it are written)
@@ -105,6 +105,11 @@ def main():
     s = run(d, "c3_ck", cks, vid, cam, sim, ["--batch", "8", "--writers", "16"], 240)
     if s:
         line("fast writer, 16 thr, checker sky", s)
+    print("\n### the reference's default renderer (`--mode efficient`: ~0.4 ms of GPU per frame) -- here the HOST is the limit")
+    for w in (4, 16, 32):
+        s = run(d, "c3_eff_w%d" % w, sky, vid, cam, sim, ["--batch", "16", "--writers", str(w)], 240, mode="efficient")
+        if s:
+            line("efficient mode, %2d writer threads" % w, s)
     print("\n### encode capacity of this host (one GPU feeding it, every frame encoded 1 + K times)")
     for w, k in ((8, 63), (16, 95), (32, 95), (64, 95)):
         s = run(d, "c3_eb_w%d" % w, sky, vid, cam, sim, ["--batch", "8", "--writers", str(w), "--encode-bench", str(k)], 240)
