@@ -146,8 +146,36 @@ def main():
         sys.stdout.flush()
         saved_stdout_fd = os.dup(1)
         os.dup2(2, 1)
+        backend_fallback = None
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            # RCCL first.  If the communicator cannot be brought up on this node (init or the first collective raises), the
+            # run is NOT lost: every rank falls back to gloo for the control collectives and the skies go through host
+            # memory; the line then says so (`collective.fallback_from`), loudly -- a scaling curve with a flagged
+            # broadcast is worth more than no curve.  (A hang inside RCCL cannot be caught this way.)
+            try:
+                if os.environ.get("CURVIS_BENCH_TEST_RCCL_FAIL") == "1":  # test hook: take the fallback branch
+                    raise RuntimeError("injected RCCL failure (CURVIS_BENCH_TEST_RCCL_FAIL)")
+                import datetime
+                # a collective that cannot complete aborts after 3 minutes instead of the default 10
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, dtype=torch.float64, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                ok_local = int(probe.item()) == world
+            except Exception as exc:  # noqa: BLE001 -- whatever RCCL / torch raise here
+                backend_fallback = "%s: %s" % (type(exc).__name__, str(exc).splitlines()[0][:200] if str(exc) else "")
+                ok_local = False
+            if not ok_local:
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + 1)
+                dist.init_process_group("gloo")
+                backend = "gloo"
+                backend_fallback = backend_fallback or "all-reduce of ones did not span the ranks"
+                sys.stderr.write("bench.py: rank %d: RCCL unavailable (%s); continuing over gloo\n" % (rank, backend_fallback))
         else:
             dist.init_process_group(backend)
 
@@ -182,6 +210,8 @@ def main():
         dist.all_reduce(one)
         comm_info = {"backend": "rccl (torch nccl)" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
                      "allreduce_of_ones": int(one.item()), "sky_bytes_each": sw * sh * 4, "sky_broadcast_ms": []}
+        if backend_fallback:
+            comm_info["fallback_from"] = "rccl (torch nccl) -> gloo: " + backend_fallback
         if comm_info["allreduce_of_ones"] != world:
             raise SystemExit("bench.py: the %s communicator spans %d ranks, not %d" % (backend, comm_info["allreduce_of_ones"], world))
         flush_c_stdio()

@@ -78,3 +78,14 @@ def test_single_rank_over_rccl_takes_the_multi_gpu_code_path():
     assert out["n_gpus"] == 1 and out["collective"]["backend"].startswith("rccl") and out["collective"]["ranks"] == 1
     assert len(out["collective"]["sky_broadcast_gbps"]) == 2 and all(v is None or v > 0 for v in out["collective"]["sky_broadcast_gbps"])
     assert len(out["per_rank"]) == 1 and out["per_rank"][0]["pci_bus_id"] and out["distinct_gpus"] == 1
+
+
+def test_rccl_failure_falls_back_to_gloo_and_says_so():
+    """a node on which RCCL cannot be brought up must still produce a (flagged) line: control collectives over gloo, skies
+    staged through host memory, `collective.fallback_from` set"""
+    r = run_bench(["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-traffic", "--no-live-traffic", "--multi-frame", "0",
+                   "--sustained-seconds", "0"], {"CURVIS_BENCH_FORCE_DIST": "1", "CURVIS_BENCH_TEST_RCCL_FAIL": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["collective"]["backend"] == "gloo" and "injected RCCL failure" in out["collective"]["fallback_from"]
+    assert "RCCL unavailable" in r.stderr and out["value"] > 0
