@@ -415,15 +415,17 @@ inline size_t zero_run_end(const uint8_t *d, size_t i, size_t n) {
   return j;
 }
 /* tokens of the filtered stream: every byte a literal, except that a run of r >= 4 zero bytes is one literal 0
- * followed by distance-1 matches covering the other r - 1 (pieces of 3..258).  `lit2` takes two literals at once
- * (one store of the bit writer), the test for a run is one 32-bit load. */
-template <class Lit, class Lit2, class Match>
-inline void for_each_token(const uint8_t *d, size_t n, Lit lit, Lit2 lit2, Match match) {
+ * followed by distance-1 matches covering the other r - 1 (pieces of 3..258).  `lit4` takes four literals at once
+ * (one store of the bit writer: the code is limited to 12 bits per symbol), the test for a run is one 32-bit load. */
+template <class Lit, class Lit4, class Match>
+inline void for_each_token(const uint8_t *d, size_t n, Lit lit, Lit4 lit4, Match match) {
   size_t i = 0;
   while (i + 4 <= n) {
-    if (load32(d + i) != 0) { /* no run of four starts here: two literals (a run that starts at i + 1 is found next time round) */
-      lit2(d[i], d[i + 1]);
-      i += 2;
+    const uint32_t w4 = load32(d + i);
+    if (w4 != 0) { /* no run of four starts here: four literals (a run that starts inside them is picked up next time round,
+                      up to three of its zeros having gone out as literals) */
+      lit4(w4);
+      i += 4;
       continue;
     }
     const size_t j = zero_run_end(d, i, n);
@@ -480,16 +482,18 @@ inline void encode_rgb8_fast(const uint8_t *rgb, uint32_t w, uint32_t h, std::ve
   double t2 = now_s();
   /* pass 1: token histogram of every 4th row (each taken as a stream of its own); every symbol gets a count of at
    * least one so that the code covers whatever the other rows hold -- a quarter of the work for ~1 % of file size */
-  uint32_t hist[286], hist2[256] = {0}, hist_len[259] = {0};
+  uint32_t hist[286], hist2[256] = {0}, hist3[256] = {0}, hist4[256] = {0}, hist_len[259] = {0};
   for (int i = 0; i < 286; ++i) hist[i] = 1;
   for (uint32_t y = 0; y < h; y += 4)
     for_each_token(fl + (size_t)y * line, line, [&](uint8_t b) { hist[b]++; },
-                   [&](uint8_t b0, uint8_t b1) {
-                     hist[b0]++;
-                     hist2[b1]++; /* a second table: no store-to-load stall when b0 == b1 */
+                   [&](uint32_t w4) { /* four tables: no store-to-load stall when neighbours are equal */
+                     hist[w4 & 0xffu]++;
+                     hist2[(w4 >> 8) & 0xffu]++;
+                     hist3[(w4 >> 16) & 0xffu]++;
+                     hist4[w4 >> 24]++;
                    },
                    [&](int len) { hist_len[len]++; });
-  for (int i = 0; i < 256; ++i) hist[i] += hist2[i];
+  for (int i = 0; i < 256; ++i) hist[i] += hist2[i] + hist3[i] + hist4[i];
   for (int len = 3; len <= 258; ++len)
     if (hist_len[len]) {
       int sym, eb, ev;
@@ -498,7 +502,7 @@ inline void encode_rgb8_fast(const uint8_t *rgb, uint32_t w, uint32_t h, std::ve
     }
   uint8_t ll_len[286];
   uint32_t ll[286];
-  huffman_lengths(hist, 286, 15, ll_len);
+  huffman_lengths(hist, 286, 12, ll_len); /* <= 12 bits per code: four literals fit one 64-bit put (48 + 7 pending bits) */
   canonical_codes(ll_len, 286, ll);
   /* matches of length 3..258: code, extra bits and the 1-bit distance code ('0') folded into one entry */
   uint32_t m_bits[259];
@@ -510,7 +514,7 @@ inline void encode_rgb8_fast(const uint8_t *rgb, uint32_t w, uint32_t h, std::ve
     m_bits[len] = (ll[sym] & 0xffffu) | ((uint32_t)ev << cl); /* + distance code 0 (one zero bit) */
     m_n[len] = (uint8_t)(cl + eb + 1);
   }
-  /* worst case: 15 bits per byte */
+  /* worst case: 12 bits per byte; the buffer is sized for 16 */
   const size_t cap = 8 + 25 + 12 + 2 + 512 + n * 2 + 16 + 4 + 12;
   if (out.size() < cap) out.resize(cap); /* callers that reuse `out` across frames pay the fill once */
   uint8_t *o = out.data();
@@ -549,9 +553,12 @@ inline void encode_rgb8_fast(const uint8_t *rgb, uint32_t w, uint32_t h, std::ve
   for (int i = 0; i < 286; ++i) bw.put(rev4(ll_len[i]), 4);
   bw.put(rev4(1), 4); /* the one distance code: length 1 */
   for_each_token(fl, n, [&](uint8_t b) { bw.put(ll[b] & 0xffffu, ll[b] >> 16); },
-                 [&](uint8_t b0, uint8_t b1) { /* two codes (<= 15 bits each) in one store */
-                   const uint32_t e0 = ll[b0], e1 = ll[b1];
-                   bw.put((uint64_t)(e0 & 0xffffu) | ((uint64_t)(e1 & 0xffffu) << (e0 >> 16)), (e0 >> 16) + (e1 >> 16));
+                 [&](uint32_t w4) { /* four codes (<= 12 bits each) in one store */
+                   const uint32_t e0 = ll[w4 & 0xffu], e1 = ll[(w4 >> 8) & 0xffu], e2 = ll[(w4 >> 16) & 0xffu], e3 = ll[w4 >> 24];
+                   const unsigned l0 = e0 >> 16, l1 = e1 >> 16, l2 = e2 >> 16, l3 = e3 >> 16;
+                   const uint64_t lo = (uint64_t)(e0 & 0xffffu) | ((uint64_t)(e1 & 0xffffu) << l0);
+                   const uint64_t hi = (uint64_t)(e2 & 0xffffu) | ((uint64_t)(e3 & 0xffffu) << l2);
+                   bw.put(lo | (hi << (l0 + l1)), l0 + l1 + l2 + l3);
                  },
                  [&](int len) { bw.put(m_bits[len], m_n[len]); });
   bw.put(ll[256] & 0xffffu, ll[256] >> 16);
