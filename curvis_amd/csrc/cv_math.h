@@ -836,12 +836,7 @@ CV_HD double cv_log_t(double x, cv_log_tab_t T) {
 CV_HD double cv_log_ge2_t(double x, cv_log_tab_t T) {
   const uint32_t hx = cv_hi(x);
   const unsigned i = (hx >> 11) & 0x1ffu;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(CV_LOG_BFI) /* A/B experiment: mantissa by bit-field insert on the high word */
-  const int e = __builtin_amdgcn_frexp_exp(x);
-  uint32_t gh;
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(gh) : "s"(0x000fffffu), "v"(hx), "v"(0x3fe00000u));
-  const double g = cv_from_bits(((uint64_t)gh << 32) | (cv_bits(x) & 0xffffffffULL));
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
   const int e = __builtin_amdgcn_frexp_exp(x); /* k + 1 for a normal number */
   const double g = __builtin_amdgcn_frexp_mant(x);
 #else
