@@ -2,6 +2,7 @@
 known-answer values of the survey.  CPU only."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -483,3 +484,20 @@ def test_direct_mode_is_what_the_efficient_renderer_approximates(name):
     for fl in O.GLIBC_FLAVOURS:
         g, _ = O.render_image_direct(fl, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05)
         assert np.abs(d.astype(int) - g.astype(int)).max() <= 1
+
+
+def test_llvm_merges_sin_and_cos_of_the_update_shape_into_sincos():
+    """evidence for the sincos flavours: the LLVM of this image compiles the shape of update_relativistic_object
+    (llvm.sin.f64 / llvm.cos.f64 without errno, as rustc emits them) to ONE sincos() call per function on
+    x86_64-unknown-linux-gnu -- inlined or not (oracle/llvm_sincos_probe.c)"""
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no clang in this image")
+    r = subprocess.run(["make", "-s", "-C", O.ORACLE_DIR, "sincos-probe"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    body = r.stdout.split("update_all_inlined:")[1]
+    inl, sep = body.split("momentum_not_inlined:")
+    for part in (inl, sep):
+        calls = [ln.split()[-1] for ln in part.splitlines() if "call" in ln]
+        assert calls == ["sincos@PLT"], calls
