@@ -25,10 +25,11 @@
  *   CVO_LIBM_SINCOS (2), CVO_LIBM_SINCOS_INL (3): the same, with sin and cos of one
  *                 value taken inside one function coming from ONE glibc sincos()
  *                 call -- what LLVM's FSIN+FCOS -> sincos combine emits on
- *                 *-linux-gnu.  Whether rustc's build of the reference merges them
- *                 (and how far update_relativistic_object is inlined first: flavour
- *                 3 also takes g33's sine from that call) cannot be seen here, so
- *                 all three glibc arithmetics are carried and measured.
+ *                 *-linux-gnu.  rustc cannot be run here; the LLVM of this image does merge them
+ *                 for the shape of update_relativistic_object (llvm_sincos_probe.c,
+ *                 `make sincos-probe`), g33's sine included once inlined (flavour 3).
+ *                 Another LLVM version may decide differently, so all three glibc
+ *                 arithmetics are carried and measured.
  *   CVO_CV   (1): curvis_amd/csrc/cv_math.h -- the deterministic, fma-explicit
  *                 functions the gfx950 kernels use; the GPU must match this
  *                 flavour BIT FOR BIT.  Only elementary functions are shared
