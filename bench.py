@@ -15,8 +15,15 @@ run when the node has fewer than N GPUs or when the rank count it ends up with i
 reports fewer GPUs than it was asked for.
 
 With N > 1 every rank renders its own K frames (video frames are independent: weak scaling, no
-data-path collective); the only communication is the RCCL broadcast of the two sky textures from
-rank 0 before the timed region.  Rank 0 prints ONE JSON line.
+data-path collective); the only communication on the data path is the RCCL broadcast of the two sky
+textures from rank 0 before the timed region, made by the PRODUCT's entry point (curvis_ctx_bcast_skies
+on a communicator from curvis_ctx_rccl_comm_init; the ncclUniqueId travels over the control plane).
+The control plane (barriers, the max-over-ranks reduction, the per-rank table) is a gloo process group
+on the launcher's store: it comes up wherever torchrun does, and it is what the ranks use to AGREE on a
+fall-back (torch's nccl broadcast, then host-staged gloo) should RCCL fail on any of them -- the line
+then says so in `collective.via` / `collective.fallback_from`.  Rank 0 prints ONE JSON line; for N > 1
+it also carries `cpu_baseline`, `value_single_image_rows` (ONE configs[1] image split by rows over the
+N GPUs) and `video_e2e` (`curvis video --mode brute --devices N` on a 16N-frame rendition of configs[3]).
 """
 import argparse
 import json
@@ -65,7 +72,12 @@ def parse():
     ap.add_argument("--multi-frame", type=int, default=6,
                     help="frames per launch of the secondary multi-frame measurement (value_multi_frame); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sustained-seconds", type=float, default=3.0,
+    ap.add_argument("--no-video-e2e", action="store_true",
+                    help="N > 1: skip the `curvis video --mode brute --devices N` end-to-end figure (video_e2e)")
+    ap.add_argument("--video-e2e-frames-per-gpu", type=int, default=16)
+    ap.add_argument("--no-rows-split", action="store_true",
+                    help="N > 1: skip value_single_image_rows (one image split by rows over the ranks)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0,
                     help="length of the secondary back-to-back measurement behind `value_sustained` (clock and power "
                          "sampled during it); 0 = skip")
     ap.add_argument("--cpu-row-step", type=int, default=8)
@@ -114,6 +126,13 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the JSON line would not describe the run that was "
                          "asked for" % (args.gpus, world))
 
+    # The job's stdout carries the JSON line and nothing else: gloo ("[Gloo] Rank 0 is connected to ..."), RCCL (version
+    # banner) and whatever else writes to the C stdout go to stderr -- file descriptor 1 points there until the line is due.
+    flush_c_stdio()
+    sys.stdout.flush()
+    job_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch  # device memory / streams / torch.distributed plumbing only
     import curvis_amd
     from curvis_amd import skies
@@ -122,62 +141,33 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if os.environ.get("CURVIS_BENCH_SHARE_DEVICE") != "1" and torch.cuda.device_count() < world:
         raise SystemExit("bench.py: %d ranks but %d GPU(s) visible" % (world, torch.cuda.device_count()))
-    # test hooks (1-GPU boxes): CURVIS_BENCH_SHARE_DEVICE=1 maps every rank to GPU 0 and
-    # CURVIS_BENCH_BACKEND=gloo replaces RCCL, so the N>1 control flow can be exercised on one GPU.
+    # test hooks (1-GPU boxes): CURVIS_BENCH_SHARE_DEVICE=1 maps every rank to GPU 0; RCCL refuses two ranks on one GPU
+    # ("Duplicate GPU detected"), so with it RCCL is only attempted when CURVIS_BENCH_TRY_RCCL=1 (which then exercises
+    # the agreed fall-back with two real ranks); CURVIS_BENCH_BACKEND=gloo skips RCCL altogether.
     share_device = os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1"
     device_index = 0 if share_device else local_rank
-    # RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so the share-device hook implies gloo
-    backend = os.environ.get("CURVIS_BENCH_BACKEND", "gloo" if share_device else "nccl")
+    try_rccl = os.environ.get("CURVIS_BENCH_BACKEND", "nccl") != "gloo" and (
+        not share_device or os.environ.get("CURVIS_BENCH_TRY_RCCL") == "1")
     torch.cuda.set_device(device_index)
     dist = None
-    # test hook (1-GPU boxes): CURVIS_BENCH_FORCE_DIST=1 takes the N > 1 code path -- process group on RCCL, all-reduce
-    # check, sky broadcast, barriers, reductions -- with a single rank
+    # test hook (1-GPU boxes): CURVIS_BENCH_FORCE_DIST=1 takes the N > 1 code path -- control plane, RCCL communicator,
+    # sky broadcast through the product's entry point, barriers, reductions -- with a single rank
     use_dist = world > 1 or os.environ.get("CURVIS_BENCH_FORCE_DIST") == "1"
     if use_dist:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if world == 1:
-            os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        # RCCL writes a version banner to the C stdout when a communicator comes up: while that happens (process group,
-        # first collective below) file descriptor 1 points at stderr, so the job's stdout carries the JSON line only
-        flush_c_stdio()
-        sys.stdout.flush()
-        saved_stdout_fd = os.dup(1)
-        os.dup2(2, 1)
-        backend_fallback = None
-        if backend == "nccl":
-            # RCCL first.  If the communicator cannot be brought up on this node (init or the first collective raises), the
-            # run is NOT lost: every rank falls back to gloo for the control collectives and the skies go through host
-            # memory; the line then says so (`collective.fallback_from`), loudly -- a scaling curve with a flagged
-            # broadcast is worth more than no curve.  (A hang inside RCCL cannot be caught this way.)
-            try:
-                if os.environ.get("CURVIS_BENCH_TEST_RCCL_FAIL") == "1":  # test hook: take the fallback branch
-                    raise RuntimeError("injected RCCL failure (CURVIS_BENCH_TEST_RCCL_FAIL)")
-                import datetime
-                # a collective that cannot complete aborts after 3 minutes instead of the default 10
-                dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=180))
-                probe = torch.ones(1, dtype=torch.float64, device="cuda")
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                ok_local = int(probe.item()) == world
-            except Exception as exc:  # noqa: BLE001 -- whatever RCCL / torch raise here
-                backend_fallback = "%s: %s" % (type(exc).__name__, str(exc).splitlines()[0][:200] if str(exc) else "")
-                ok_local = False
-            if not ok_local:
-                try:
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + 1)
-                dist.init_process_group("gloo")
-                backend = "gloo"
-                backend_fallback = backend_fallback or "all-reduce of ones did not span the ranks"
-                sys.stderr.write("bench.py: rank %d: RCCL unavailable (%s); continuing over gloo\n" % (rank, backend_fallback))
-        else:
-            dist.init_process_group(backend)
+        # Control plane: gloo on the launcher's store (under torchrun every rank is a client of the agent's TCPStore, so
+        # nothing here may move MASTER_PORT or re-initialise the default group).  The long timeout covers rank 0's
+        # CPU baseline and the video end-to-end run, during which the other ranks wait at a barrier.
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=1800))
 
     ctx = curvis_amd.Context(device_index)
     ctx.set_option("variant", args.variant)
@@ -204,43 +194,9 @@ def main():
     sky_dev = []
     comm_info = None
     if use_dist:
-        # how many ranks the collective backend really spans (an all-reduce of ones on the device), before it is
-        # trusted with the skies
-        one = torch.ones(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(one)
-        comm_info = {"backend": "rccl (torch nccl)" if backend == "nccl" else backend, "ranks": dist.get_world_size(),
-                     "allreduce_of_ones": int(one.item()), "sky_bytes_each": sw * sh * 4, "sky_broadcast_ms": []}
-        if backend_fallback:
-            comm_info["fallback_from"] = "rccl (torch nccl) -> gloo: " + backend_fallback
-        if comm_info["allreduce_of_ones"] != world:
-            raise SystemExit("bench.py: the %s communicator spans %d ranks, not %d" % (backend, comm_info["allreduce_of_ones"], world))
-        flush_c_stdio()
-        os.dup2(saved_stdout_fd, 1)  # banner written (to stderr); stdout is the job's again
-        os.close(saved_stdout_fd)
-    for which in range(2):
-        if use_dist:
-            t = torch.empty((sh, sw, 4), dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                t.copy_(torch.from_numpy(host_skies[which]))
-            torch.cuda.synchronize()
-            dist.barrier()
-            tb = time.perf_counter()
-            if backend == "nccl":
-                dist.broadcast(t, src=0)  # RCCL over xGMI, w*h*4 bytes
-            else:  # test hook: stage through host memory
-                h = t.cpu()
-                dist.broadcast(h, src=0)
-                t.copy_(h)
-            torch.cuda.synchronize()
-            comm_info["sky_broadcast_ms"].append(round((time.perf_counter() - tb) * 1e3, 3))
-            if rank != 0:  # the texture really arrived: same closed form as rank 0 generated (first and last row)
-                want = skies.smooth(sw, sh, 128 if which == 0 else 32)
-                got0, got1 = t[0].cpu().numpy(), t[sh - 1].cpu().numpy()
-                if not (np.array_equal(got0, want[0]) and np.array_equal(got1, want[sh - 1])):
-                    raise SystemExit("bench.py: rank %d received a corrupted sky texture" % rank)
-            ctx.set_sky_device(which, t.data_ptr(), sw, sh, copy=False)
-            sky_dev.append(t)  # keep alive
-        else:
+        comm_info = distribute_skies(ctx, dist, torch, world, rank, host_skies, sw, sh, try_rccl, sky_dev)
+    else:
+        for which in range(2):
             ctx.set_sky(which, curvis_amd.SphericalImage(host_skies[which]))
 
     if args.metric == "ellis":
@@ -272,6 +228,7 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    clock = ClockSampler(ctx, 0.02)  # shader clock / board power OF THE TIMED REGION (sysfs reads on a helper thread)
     t0 = time.perf_counter()
     steps_executed = 0
     rays = 0
@@ -285,6 +242,7 @@ def main():
         shade_ms += st.shade_ms
     fence()
     elapsed = time.perf_counter() - t0
+    timed_clock = clock.stop()
 
     # secondary figure, outside the contract's timed region: launches of several frames amortise the ramp and the
     # end-game of a launch (~5 % of a single 1080p frame), which is what a video shard runs as
@@ -317,24 +275,30 @@ def main():
     if args.sustained_seconds > 0:
         sustained = sustained_run(ctx, step, args.sustained_seconds, torch)
 
+    # secondary figure, N > 1: ONE image of the same workload split by rows over the ranks (curvis_render_brute_rows, bit
+    # for bit the rows of the whole frame) -- strong scaling of a single image, next to the weak scaling of `value`
+    rows_split = None
+    if dist is not None and (world > 1 or os.environ.get("CURVIS_BENCH_FORCE_DIST") == "1") and not args.no_rows_split:
+        rows_split = rows_split_run(ctx, dist, torch, world, rank, metric, cam, args, R, DELTA, fence)
+
     own_elapsed = elapsed
     per_rank = None
     if dist is not None:
-        red_dev = "cuda" if backend == "nccl" else "cpu"
         mine = {"rank": rank, "pci_bus_id": pci_bus_id, "device_index": device_index,
                 "ms_per_step": round(own_elapsed / args.steps * 1e3, 4),
                 "kernel_ms_avg": round(kernel_ms / args.steps, 4),
                 "value": round(steps_executed / own_elapsed / 1e6, 1),
+                "sclk_mhz_timed_region": timed_clock["sclk_mhz_median"],
+                "power_w_timed_region": timed_clock["power_w_median"],
                 "sclk_mhz": sustained["sclk_mhz_median"] if sustained else None,
                 "power_w": sustained["power_w_median"] if sustained else None,
                 "value_sustained": sustained["value"] if sustained else None}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        agg = torch.tensor([float(steps_executed), float(rays), kernel_ms, shade_ms], dtype=torch.float64,
-                           device=red_dev)
+        agg = torch.tensor([float(steps_executed), float(rays), kernel_ms, shade_ms], dtype=torch.float64)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         total_steps, total_rays, total_kernel_ms, total_shade_ms = [float(v) for v in agg.tolist()]
     else:
@@ -383,6 +347,11 @@ def main():
             "unit": "Mray-steps/s (executed Euler steps, all GPUs)",
             "value_nominal_cap": round(nominal, 1),
             "value_note": "single-frame launches (one frame per step): each carries the ramp and end-game tail of a launch",
+            # shader clock and board power while the timed region ran (rank 0's GPU; every rank's in per_rank): boxes differ by
+            # 2-6 % in the clock they hold under this load, and a short region runs at boost clock -- see value_sustained
+            "sclk_mhz": timed_clock["sclk_mhz_median"],
+            "power_w": timed_clock["power_w_median"],
+            "clock_samples": timed_clock["samples"],
             "value_multi_frame": multi,
             "n_gpus": world,
             "steps": args.steps,
@@ -438,9 +407,9 @@ def main():
         if sustained is not None:
             out["value_sustained"] = sustained
         if comm_info is not None:
-            bms = comm_info["sky_broadcast_ms"]
-            comm_info["sky_broadcast_gbps"] = [round(comm_info["sky_bytes_each"] / (ms * 1e-3) / 1e9, 2) if ms > 0 else None for ms in bms]
             out["collective"] = comm_info
+        if rows_split is not None:
+            out["value_single_image_rows"] = rows_split
         if per_rank is not None:
             # who is the straggler: the timed region ends when the slowest rank does (max over ranks), so `value` is
             # N x the slowest GPU's rate; the table says which GPU that was and at which clock it ran
@@ -451,38 +420,345 @@ def main():
             out["distinct_gpus"] = len(set(r["pci_bus_id"] for r in per_rank))
             if sustained is not None:
                 out["value_sustained"]["all_ranks"] = round(sum(r["value_sustained"] or 0.0 for r in per_rank), 1)
-        if world == 1 and not args.no_cpu_baseline:
+        # the reference's CPU path beside EVERY line (north_star: "timed on the node's own host cores in the same run"):
+        # rank 0 runs it after the timed region while the other ranks wait at the barrier below
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, host_skies)
 
     # The JSON line must be the LAST thing on the job's stdout: libraries (RCCL's banner) write to the C stdout, which is
     # block-buffered when redirected and would otherwise be flushed at exit, after the line.  So: tear everything down,
     # flush the C streams on every rank, meet once more, and only then rank 0 prints.
     ctx.close()
+    sky_dev.clear()
+    if dist is not None and not args.no_video_e2e and (world > 1 or os.environ.get("CURVIS_BENCH_FORCE_DIST") == "1"):
+        # the product's own multi-GPU design -- ONE process, N device threads, ncclCommInitAll + curvis_ctx_bcast_skies, shared
+        # retry queue, page-locked batch buffers, PNG writer pool -- end to end on a 16N-frame rendition of configs[3]; every
+        # rank has released its context, the others wait at the barrier while rank 0 runs the binary over all N GPUs
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            try:
+                out["video_e2e"] = video_e2e(args, world, host_skies, os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1")
+            except Exception as exc:  # noqa: BLE001 -- an extra must never cost the bench line
+                out["video_e2e"] = {"failed": short(exc)}
     if dist is not None:
         dist.barrier()
         flush_c_stdio()
         dist.barrier()
         dist.destroy_process_group()
     flush_c_stdio()
+    sys.stdout.flush()
+    os.dup2(job_stdout_fd, 1)
+    os.close(job_stdout_fd)
     if rank == 0:
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
 
 
+def agree(dist, world, ok, why=None):
+    """every rank contributes (ok, reason) over the control plane; all get (everybody ok?, the first reason why not)"""
+    flags = [None] * world
+    dist.all_gather_object(flags, (bool(ok), why))
+    bad = ["rank %d: %s" % (r, w) for r, (o, w) in enumerate(flags) if not o]
+    return not bad, (bad[0] if bad else None)
+
+
+def short(exc):
+    t = str(exc).splitlines()
+    return "%s: %s" % (type(exc).__name__, t[0][:200] if t else "")
+
+
+def product_comm(ctx, dist, world, rank, timeout_s=150.0):
+    """An RCCL communicator over the ranks' contexts, made by the product's entry points: rank 0 draws the ncclUniqueId
+    (curvis_rccl_unique_id), it travels over the control plane, every rank joins with curvis_ctx_rccl_comm_init.  The
+    join runs on a helper thread with a time limit (ncclCommInitRank waits for all ranks: a rank that failed early would
+    leave the others inside it for ever), and the ranks agree on the outcome.  (comm, None) on every rank or
+    (None, reason) on every rank."""
+    import threading
+    import curvis_amd
+    uid, why = [None], None
+    if rank == 0:
+        try:
+            if os.environ.get("CURVIS_BENCH_TEST_RCCL_FAIL") == "id":  # test hook
+                raise RuntimeError("injected RCCL failure (CURVIS_BENCH_TEST_RCCL_FAIL=id)")
+            uid[0] = curvis_amd.Context.rccl_unique_id()
+        except Exception as exc:  # noqa: BLE001
+            why = short(exc)
+    dist.broadcast_object_list(uid, src=0)
+    if uid[0] is None:
+        return None, agree(dist, world, rank != 0, why)[1]
+    res = {}
+
+    def join():
+        try:
+            # test hook: the LAST rank never reaches ncclCommInitRank -- the others must get out by the time limit / error
+            if os.environ.get("CURVIS_BENCH_TEST_RCCL_FAIL") == "1" and rank == world - 1:
+                raise RuntimeError("injected RCCL failure (CURVIS_BENCH_TEST_RCCL_FAIL)")
+            res["comm"] = ctx.rccl_comm_init(uid[0], world, rank)
+        except Exception as exc:  # noqa: BLE001
+            res["why"] = short(exc)
+    th = threading.Thread(target=join, daemon=True)
+    th.start()
+    th.join(float(os.environ.get("CURVIS_BENCH_RCCL_INIT_TIMEOUT", timeout_s)))
+    mine_ok = "comm" in res
+    ok, why = agree(dist, world, mine_ok, res.get("why") or ("ncclCommInitRank did not return within the time limit" if th.is_alive() else None))
+    if ok:
+        return res["comm"], None
+    if mine_ok and world == 1:  # with peers missing, destroying a half-connected communicator may block: leave it
+        curvis_amd.Context.rccl_comm_destroy(res["comm"])
+    return None, why
+
+
+def distribute_skies(ctx, dist, torch, world, rank, host_skies, sw, sh, try_rccl, keep_alive):
+    """Both sky textures from rank 0 into every rank's context.  First choice: the PRODUCT's path (curvis_ctx_bcast_skies =
+    ncclBroadcast on the context's stream, textures allocated on the receiving ranks from the broadcast shapes).  If any
+    rank cannot take it, ALL ranks fall back together -- to torch's nccl broadcast into borrowed tensors, then to a
+    host-staged gloo broadcast -- and the line says so.  Every rank then reads head, middle and tail of both textures
+    back from ITS context and compares them with the closed form rank 0 generated from."""
+    import datetime
+    import curvis_amd
+    from curvis_amd import skies
+    nbytes = sw * sh * 4
+    one = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(one)
+    info = {"control_plane": "gloo (torch.distributed on the launcher's store)", "ranks": dist.get_world_size(),
+            "allreduce_of_ones": int(one.item()), "sky_bytes_each": nbytes}
+    if info["allreduce_of_ones"] != world:
+        raise SystemExit("bench.py: the control plane spans %d ranks, not %d" % (info["allreduce_of_ones"], world))
+    fell = []
+    done = False
+    fail3 = os.environ.get("CURVIS_BENCH_TEST_RCCL_FAIL") == "all"  # test hook: no RCCL at all
+
+    def timed_ms(t0):
+        t = torch.tensor([(time.perf_counter() - t0) * 1e3], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return round(float(t.item()), 3)
+
+    if fail3:
+        fell.append("injected RCCL failure (CURVIS_BENCH_TEST_RCCL_FAIL=all): no RCCL on this node")
+    if try_rccl and not fail3:
+        comm, why = product_comm(ctx, dist, world, rank)
+        if comm is None:
+            fell.append("curvis_ctx_rccl_comm_init: " + str(why))
+        else:
+            ok, why, t0 = True, None, time.perf_counter()
+            try:
+                if rank == 0:
+                    for which in range(2):
+                        ctx.set_sky(which, curvis_amd.SphericalImage(host_skies[which]))
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                ctx.bcast_skies(comm, 0)  # header + 2 x ncclBroadcast on the context's stream, synchronised inside
+            except Exception as exc:  # noqa: BLE001
+                ok, why = False, short(exc)
+            ms = timed_ms(t0)
+            ok, why = agree(dist, world, ok, why)
+            try:
+                curvis_amd.Context.rccl_comm_destroy(comm)
+            except Exception:  # noqa: BLE001
+                pass
+            if ok:
+                done = True
+                info.update({"backend": "rccl (product ABI)",
+                             "via": "curvis_ctx_bcast_skies on a communicator from curvis_ctx_rccl_comm_init "
+                                    "(ncclUniqueId from curvis_rccl_unique_id, shipped over the control plane)",
+                             "sky_broadcast_ms": ms, "sky_broadcast_gbps": round(2 * nbytes / (ms * 1e-3) / 1e9, 2) if ms > 0 else None})
+            else:
+                fell.append("curvis_ctx_bcast_skies: " + str(why))
+    group = None
+    if not done and try_rccl and not fail3:  # second choice: torch's RCCL
+        ok, why = True, None
+        try:
+            group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+            probe = torch.ones(1, dtype=torch.float64, device="cuda")
+            dist.all_reduce(probe, group=group)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                ok, why = False, "all-reduce of ones over torch's nccl group gave %d" % int(probe.item())
+        except Exception as exc:  # noqa: BLE001
+            ok, why = False, short(exc)
+        ok, why = agree(dist, world, ok, why)
+        if not ok:
+            fell.append("torch nccl group: " + str(why))
+            group = None
+    if not done:
+        ms_all = 0.0
+        for which in range(2):
+            t = torch.empty((sh, sw, 4), dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                t.copy_(torch.from_numpy(host_skies[which]))
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            if group is not None:
+                dist.broadcast(t, src=0, group=group)
+            else:  # last resort: through host memory over the control plane
+                h = t.cpu()
+                dist.broadcast(h, src=0)
+                t.copy_(h)
+            torch.cuda.synchronize()
+            ms_all += timed_ms(t0)
+            ctx.set_sky_device(which, t.data_ptr(), sw, sh, copy=False)
+            keep_alive.append(t)
+        info.update({"backend": "rccl (torch nccl)" if group is not None else "gloo",
+                     "via": "torch.distributed.broadcast into borrowed device tensors (curvis_ctx_set_sky_device)" +
+                            ("" if group is not None else ", staged through host memory"),
+                     "sky_broadcast_ms": round(ms_all, 3),
+                     "sky_broadcast_gbps": round(2 * nbytes / (ms_all * 1e-3) / 1e9, 2) if ms_all > 0 else None})
+    if fell:
+        info["fallback_from"] = fell
+        sys.stderr.write("bench.py: rank %d: sky broadcast fell back (%s); continuing via %s\n" % (rank, "; ".join(fell), info["backend"]))
+    elif not try_rccl:
+        info["fallback_from"] = ["RCCL not attempted (CURVIS_BENCH_SHARE_DEVICE / CURVIS_BENCH_BACKEND test hook)"]
+    # what sits in THIS rank's HBM now, against the closed form (head, middle, tail of both textures)
+    ok, why = True, None
+    piece = min(nbytes, 1 << 16)
+    for which in range(2):
+        want = skies.smooth(sw, sh, 128 if which == 0 else 32).reshape(-1)
+        for off in (0, (nbytes - piece) // 2 // 4 * 4, nbytes - piece):
+            got = ctx.read_sky(which, off, piece)
+            if not np.array_equal(got, want[off:off + piece]):
+                ok, why = False, "sky %d differs at byte offset %d" % (which, off)
+    ok, why = agree(dist, world, ok, why)
+    if not ok:
+        raise SystemExit("bench.py: a sky texture arrived corrupted (%s)" % why)
+    info["readback_verified_on_every_rank"] = True
+    return info
+
+
+class ClockSampler:
+    """shader clock and board power of a context's GPU, read from sysfs (curvis_ctx_device_status) on a helper thread
+    every `period` seconds between construction and stop()"""
+
+    def __init__(self, ctx, period):
+        import threading
+        self.samples, self._stop, self._ctx, self._period = [], threading.Event(), ctx, period
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+
+    def _run(self):
+        while True:
+            st = self._ctx.device_status()
+            self.samples.append((st["sclk_mhz"], st["power_w"]))
+            if self._stop.wait(self._period):
+                break
+
+    def stop(self):
+        self._stop.set()
+        self._th.join()
+        sclk = sorted(v[0] for v in self.samples if v[0] > 0)
+        powr = sorted(v[1] for v in self.samples if v[1] > 0)
+
+        def med(v):
+            return v[len(v) // 2] if v else None
+        return {"sclk_mhz_median": med(sclk), "sclk_mhz_min": sclk[0] if sclk else None, "sclk_mhz_max": sclk[-1] if sclk else None,
+                "power_w_median": med(powr), "power_w_max": powr[-1] if powr else None, "samples": len(self.samples)}
+
+
+def rows_split_run(ctx, dist, torch, world, rank, metric, cam, args, R, DELTA, fence):
+    """ONE frame of the workload, rows [rank*H/N, (rank+1)*H/N) on each rank (curvis_render_brute_rows), repeated
+    args.steps times between barriers; time = max over ranks.  Rows near the image centre need more steps than rows at
+    the edge, so the split is not perfectly balanced -- the per-rank times say by how much."""
+    H = args.height
+    r0, r1 = rank * H // world, (rank + 1) * H // world
+    ctx.render_brute_rows(metric, cam, r0, r1 - r0, args.max_iter, R, DELTA, download=False)  # shape priming
+    fence()
+    t0 = time.perf_counter()
+    n_steps, k_ms = 0, 0.0
+    for _ in range(args.steps):
+        _, st = ctx.render_brute_rows(metric, cam, r0, r1 - r0, args.max_iter, R, DELTA, download=False)
+        n_steps += st.steps
+        k_ms += st.integrate_ms
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    agg = torch.tensor([float(n_steps)], dtype=torch.float64)
+    dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+    parts = [None] * world
+    dist.all_gather_object(parts, {"rank": rank, "rows": [r0, r1], "ms_per_image": round(own / args.steps * 1e3, 4),
+                                   "kernel_ms_avg": round(k_ms / args.steps, 4), "steps_per_image": n_steps // max(1, args.steps)})
+    return {"value": round(float(agg.item()) / float(tt.item()) / 1e6, 1), "unit": "Mray-steps/s (executed), ONE image over all GPUs",
+            "scaling": "strong", "images": args.steps, "ms_per_image": round(float(tt.item()) / args.steps * 1e3, 4),
+            "per_rank": parts,
+            "note": "one %dx%d image per step, split by rows over the %d ranks with curvis_render_brute_rows; the frame "
+                    "stays in HBM (a host would gather the bands: %d bytes per image); not the contract's `value`" % (
+                        args.width, args.height, world, args.width * args.height * 3)}
+
+
+def video_e2e(args, world, host_skies, share_device):
+    """`curvis video --mode brute --devices N --stats` on a 16N-frame rendition of configs[3] (Ellis, path_orbit.csv,
+    1920x1080, cap 4096): files in, PNG frames out, the binary's own per-device table back."""
+    import shutil
+    import subprocess
+    import tempfile
+    from curvis_amd import paths
+    exe = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
+    d = tempfile.mkdtemp(prefix="curvis_e2e_")
+    try:
+        t_files = time.perf_counter()
+        from curvis_amd import _abi
+        for name, sky in (("pos.png", host_skies[0]), ("neg.png", host_skies[1])):  # alpha is 255 throughout: RGB8 decodes to the same RGBA8
+            rgb = np.ascontiguousarray(sky[..., :3])
+            _abi.check(_abi.lib().curvis_image_save_rgb8(os.path.join(d, name).encode(), rgb.ctypes.data, sky.shape[1], sky.shape[0]))
+        n_frames = max(1, args.video_e2e_frames_per_gpu) * world
+        # path_orbit.csv runs for 60 s; times_of_frames pushes t = 0, 1/fps, ... while t < 60 (src/rendering.rs:224-238)
+        fps = n_frames / 60.0
+        with open(os.path.join(d, "vid.toml"), "w") as f:
+            f.write('video_name = "e2e"\nframe_rate = %r\nfilepath_to_camera_path = "%s"\n' % (fps, paths.path_file("path_orbit.csv")))
+        with open(os.path.join(d, "sim.toml"), "w") as f:
+            f.write("escape_radius = 100.0\nray_integration_max_itarations = %d\nray_integration_step = 0.05\n"
+                    "sampling_initial_nums = 100\nsampling_max_iterations = 50\n"
+                    "sampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 2e-5\n" % args.max_iter)
+        with open(os.path.join(d, "cam.toml"), "w") as f:
+            f.write("resolution_x = %d\nresolution_y = %d\ndiagonal = 43.0\nfocal_length = 15.0\n" % (args.width, args.height))
+        t_files = time.perf_counter() - t_files
+        cmd = [exe, "video", os.path.join(d, "pos.png"), os.path.join(d, "neg.png"), os.path.join(d, "out"),
+               "-v", os.path.join(d, "vid.toml"), "-s", os.path.join(d, "sim.toml"), "-c", os.path.join(d, "cam.toml"),
+               "--mode", "brute", "--devices", str(world), "--batch", "4", "--stats", os.path.join(d, "st.jsonl")]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        if share_device:
+            env["CURVIS_TEST_SHARE_DEVICE"] = "1"
+        elif world == 1:
+            env["CURVIS_FORCE_RCCL"] = "1"  # single-rank communicator: the broadcast entry point still runs
+        os.makedirs(os.path.join(d, "out"), exist_ok=True)
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"failed": "curvis video exited with %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else "")}
+        with open(os.path.join(d, "st.jsonl.summary.json")) as f:
+            summ = json.load(f)
+        with open(os.path.join(d, "st.jsonl")) as f:
+            recs = [json.loads(ln) for ln in f if ln.strip()]
+        frames_on_disk = len([n for n in os.listdir(os.path.join(d, "out", "tmp")) if n.endswith(".png")])
+        steps = sum(rc["steps"] for rc in recs)
+        return {"command": "curvis video --mode brute --devices %d --batch 4 --stats (configs[3]: Ellis, path_orbit.csv at %.4g fps, %dx%d, cap %d)" % (
+                    world, fps, args.width, args.height, args.max_iter),
+                "frames": summ["frames"], "frames_on_disk": frames_on_disk,
+                "frames_per_s": round(summ["frames_per_s"], 2), "wall_s": round(summ["wall_s"], 3),
+                "process_wall_s": round(wall, 3),
+                "value": round(steps / summ["wall_s"] / 1e6, 1), "unit": "Mray-steps/s (executed), files in -> PNG frames out",
+                "sky_distribution": summ.get("sky_distribution"),
+                "writer_drain_s": round(summ["writer_drain_s"], 3), "writers": summ["writers"],
+                "per_device": summ["devices"], "encode": summ.get("encode"),
+                "distinct_gpus": len(set(dv["pci_bus_id"] for dv in summ["devices"])),
+                "input_files_s": round(t_files, 2),
+                "note": "one process, one host thread + context per GPU, frames k mod N, skies decoded once and broadcast from "
+                        "device 0 (ncclCommInitAll + curvis_ctx_bcast_skies), PNG frames written by the writer pool; wall_s "
+                        "includes context creation, sky decode/upload/broadcast and the first-launch check of the relay kernel"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def sustained_run(ctx, step, seconds, torch):
     """back-to-back single-frame launches for at least `seconds`; a sampler thread reads the shader clock and the board
     power from sysfs (curvis_ctx_device_status) every 100 ms meanwhile"""
-    import threading
-    samples, stop = [], threading.Event()
-
-    def sampler():
-        while not stop.is_set():
-            st = ctx.device_status()
-            samples.append((st["sclk_mhz"], st["power_w"]))
-            stop.wait(0.1)
-    th = threading.Thread(target=sampler, daemon=True)
     torch.cuda.synchronize()
-    th.start()
+    clock = ClockSampler(ctx, 0.1)
     t0 = time.perf_counter()
     n, n_steps, k_ms = 0, 0, 0.0
     while True:
@@ -494,19 +770,17 @@ def sustained_run(ctx, step, seconds, torch):
             break
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    stop.set()
-    th.join()
-    sclk = sorted(v[0] for v in samples if v[0] > 0)
-    powr = sorted(v[1] for v in samples if v[1] > 0)
-
-    def med(v):
-        return v[len(v) // 2] if v else None
-    return {"value": round(n_steps / dt / 1e6, 1), "unit": "Mray-steps/s (executed), this rank", "launches": n,
-            "seconds": round(dt, 2), "ms_per_step": round(dt / n * 1e3, 4), "kernel_ms_avg": round(k_ms / n, 4),
-            "sclk_mhz_median": med(sclk), "sclk_mhz_min": sclk[0] if sclk else None, "sclk_mhz_max": sclk[-1] if sclk else None,
-            "power_w_median": med(powr), "power_w_max": powr[-1] if powr else None, "samples": len(samples),
-            "note": "back-to-back single-frame launches after the contract's timed region; clock and power from sysfs "
-                    "(pp_dpm_sclk, hwmon power1_average) every 100 ms; null where sysfs does not tell"}
+    ck = clock.stop()
+    # the second half alone: what the chip holds once the boost budget of the first seconds is spent
+    half = clock.samples[len(clock.samples) // 2:]
+    late = sorted(v[0] for v in half if v[0] > 0)
+    out = {"value": round(n_steps / dt / 1e6, 1), "unit": "Mray-steps/s (executed), this rank", "launches": n,
+           "seconds": round(dt, 2), "ms_per_step": round(dt / n * 1e3, 4), "kernel_ms_avg": round(k_ms / n, 4)}
+    out.update(ck)
+    out["sclk_mhz_median_second_half"] = late[len(late) // 2] if late else None
+    out["note"] = ("back-to-back single-frame launches after the contract's timed region; clock and power from sysfs "
+                   "(pp_dpm_sclk, hwmon power1_average) every 100 ms; null where sysfs does not tell")
+    return out
 
 
 def pmc_traffic(args, kernel_name):

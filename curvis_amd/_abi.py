@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcurvis_hip.so")
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_CAMERA_OUTSIDE, E_NO_SKY, E_PARALLEL, E_METRIC, E_RCCL, E_SAMPLING, E_IO = range(-1, -11, -1)
 METRIC_ELLIS, METRIC_INTERSTELLAR, METRIC_FLAT = 0, 1, 2
+RCCL_ID_BYTES = 128
 
 
 class CurvisError(RuntimeError):
@@ -60,6 +61,9 @@ SYMBOLS = {
     "curvis_ctx_set_sky_device": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_int]),
     "curvis_ctx_set_sky_orientation": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "curvis_ctx_bcast_skies": (C.c_int, [_vp, _vp, C.c_int]),
+    "curvis_rccl_unique_id": (C.c_int, [_vp]),
+    "curvis_ctx_rccl_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "curvis_rccl_comm_destroy": (C.c_int, [_vp]),
     "curvis_ctx_read_sky": (C.c_int, [_vp, C.c_int, C.c_size_t, C.c_size_t, _vp]),
     "curvis_camera_init": (C.c_int, [C.POINTER(CameraC), _dp, _dp, _dp, C.c_double, C.c_double, C.c_uint32, C.c_uint32]),
     "curvis_orientation_init": (C.c_int, [_dp, _dp, _dp, _dp, _dp]),

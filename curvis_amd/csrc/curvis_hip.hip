@@ -2445,6 +2445,37 @@ int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root) {
   return CURVIS_OK;
 }
 
+static_assert(sizeof(ncclUniqueId) == CURVIS_RCCL_ID_BYTES, "ncclUniqueId is 128 bytes in RCCL");
+
+int curvis_rccl_unique_id(uint8_t id[CURVIS_RCCL_ID_BYTES]) {
+  if (!id) return fail(nullptr, CURVIS_E_INVALID, "null id");
+  ncclUniqueId u;
+  const ncclResult_t rc = ncclGetUniqueId(&u);
+  if (rc != ncclSuccess) return fail(nullptr, CURVIS_E_RCCL, std::string("ncclGetUniqueId: ") + ncclGetErrorString(rc));
+  std::memcpy(id, &u, sizeof u);
+  return CURVIS_OK;
+}
+
+int curvis_ctx_rccl_comm_init(curvis_ctx *ctx, const uint8_t id[CURVIS_RCCL_ID_BYTES], int n_ranks, int rank,
+                              void **comm_out) {
+  if (!ctx || !id || !comm_out || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+    return fail(ctx, CURVIS_E_INVALID, "bad argument");
+  *comm_out = nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t rc = ncclCommInitRank(&comm, n_ranks, u, rank);
+  if (rc != ncclSuccess) return fail(ctx, CURVIS_E_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(rc));
+  *comm_out = (void *)comm;
+  return CURVIS_OK;
+}
+
+int curvis_rccl_comm_destroy(void *nccl_comm) {
+  if (!nccl_comm) return CURVIS_OK;
+  return ncclCommDestroy((ncclComm_t)nccl_comm) == ncclSuccess ? CURVIS_OK : CURVIS_E_RCCL;
+}
+
 int curvis_ctx_read_sky(curvis_ctx *ctx, int which, size_t offset, size_t bytes, uint8_t *out) {
   if (!ctx || !out || which < 0 || which > 1) return fail(ctx, CURVIS_E_INVALID, "bad argument");
   if (!ctx->d_sky[which]) return fail(ctx, CURVIS_E_NO_SKY, "sky not set");

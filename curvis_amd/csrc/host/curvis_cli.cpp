@@ -857,6 +857,7 @@ int video_main(const Args &a) {
     int sclk_mhz = -1, power_w = -1;
     size_t frames = 0, batches = 0;
     double render_s = 0, kernel_ms = 0, submit_s = 0, wait_s = 0, busy_s = 0, pool_wait_s = 0;
+    double sky_s = 0, sky_bcast_s = 0; /* skies into this device's HBM: all of it / the curvis_ctx_bcast_skies call alone */
     unsigned long long steps = 0;
   };
   std::vector<DeviceSummary> dev_sum((size_t)a.devices);
@@ -932,7 +933,9 @@ int video_main(const Args &a) {
     const double t_worker0 = pngio::now_s();
     if (use_rccl) {
       if (rank == 0) upload_skies(ctx, c, "video");
+      const double t_b0 = pngio::now_s();
       check(curvis_ctx_bcast_skies(ctx, comms[rank], 0), ctx, "video");
+      ds.sky_bcast_s = pngio::now_s() - t_b0;
       /* every GPU checks what arrived over xGMI against the decoded files (head, middle and tail of both textures):
        * a broken broadcast must stop the run, not colour its frames */
       const pngio::Image *sk[2] = {&c.sky1, &c.sky2};
@@ -950,6 +953,7 @@ int video_main(const Args &a) {
     } else {
       upload_skies(ctx, c, "video");
     }
+    ds.sky_s = pngio::now_s() - t_worker0;
     std::vector<curvis_camera> bc;
     std::vector<uint8_t> rgb_pageable; /* only if page-locked memory could not be had */
     /* one being filled, up to two with the writers.  The pool belongs to video_main's scope: writer jobs hold its
@@ -1121,7 +1125,24 @@ int video_main(const Args &a) {
     std::string js = "{\"frames\": " + std::to_string(total_frames) + ", \"wall_s\": " + std::to_string(wall) +
                      ", \"frames_per_s\": " + std::to_string(wall > 0 ? total_frames / wall : 0.0) +
                      ", \"writers\": " + std::to_string(a.writers) + ", \"png_level\": " + std::to_string(a.png_level) +
-                     ", \"writer_drain_s\": " + std::to_string(t_video1 - t_workers_done) + ", \"devices\": [";
+                     ", \"writer_drain_s\": " + std::to_string(t_video1 - t_workers_done);
+    { /* how the two textures reached the devices: the slowest device's time; for RCCL the broadcast call alone as well
+       * (root: upload first, then header + 2 x ncclBroadcast; the first collective of a communicator carries its set-up) */
+      double sky_max = 0, bcast_max = 0;
+      for (const DeviceSummary &d : dev_sum) {
+        sky_max = std::max(sky_max, d.sky_s);
+        bcast_max = std::max(bcast_max, d.sky_bcast_s);
+      }
+      const double sky_bytes = (double)c.sky1.rgba.size() + (double)c.sky2.rgba.size();
+      char buf[384];
+      std::snprintf(buf, sizeof buf,
+                    ", \"sky_distribution\": {\"via\": \"%s\", \"bytes\": %.0f, \"seconds\": %.4f, \"broadcast_call_s\": %.4f, "
+                    "\"sky_broadcast_gbps\": %.2f}",
+                    use_rccl ? "rccl: ncclCommInitAll + curvis_ctx_bcast_skies" : "upload to every device", sky_bytes, sky_max, bcast_max,
+                    bcast_max > 0 ? sky_bytes / bcast_max / 1e9 : 0.0);
+      js += buf;
+    }
+    js += ", \"devices\": [";
     std::printf("device  pci_bus_id     frames  kernel ms/frame  render-call ms/frame  fps    sclk MHz  power W  wait s  hand-over s\n");
     for (size_t r = 0; r < dev_sum.size(); ++r) {
       const DeviceSummary &d = dev_sum[r];

@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import CameraC, Metric, Stats, check, dptr, lib
+from ._abi import RCCL_ID_BYTES, CameraC, Metric, Stats, check, dptr, lib
 from .vectors import Covariance, CovarianceError, RelativisticObject, RelativisticVector
 
 
@@ -322,6 +322,32 @@ class Context:
         check(lib().curvis_ctx_set_sky_orientation(self._h, which, dptr(_vec(forward, 3)), dptr(_vec(up, 3))),
               self._h)
         self._sky_objs[which] = None
+
+    @staticmethod
+    def rccl_unique_id():
+        """ncclGetUniqueId as bytes: rank 0 draws it and ships it to the other processes out of band"""
+        buf = (C.c_uint8 * RCCL_ID_BYTES)()
+        check(lib().curvis_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def rccl_comm_init(self, unique_id, n_ranks, rank):
+        """ncclCommInitRank on this context's GPU; returns the communicator handle (destroy with rccl_comm_destroy)"""
+        if len(unique_id) != RCCL_ID_BYTES:
+            raise ValueError("an RCCL unique id has %d bytes" % RCCL_ID_BYTES)
+        buf = (C.c_uint8 * RCCL_ID_BYTES).from_buffer_copy(unique_id)
+        comm = C.c_void_p()
+        check(lib().curvis_ctx_rccl_comm_init(self._h, buf, int(n_ranks), int(rank), C.byref(comm)), self._h)
+        return comm
+
+    @staticmethod
+    def rccl_comm_destroy(comm):
+        check(lib().curvis_rccl_comm_destroy(comm))
+
+    def bcast_skies(self, comm, root=0):
+        """curvis_ctx_bcast_skies: both textures from rank `root` over the communicator (RCCL over xGMI); ranks other
+        than the root need no skies beforehand"""
+        check(lib().curvis_ctx_bcast_skies(self._h, comm, int(root)), self._h)
+        self._sky_objs = [None, None]
 
     def read_sky(self, which, offset, nbytes):
         """bytes [offset, offset + nbytes) of sky texture `which` as it sits in HBM (RGBA8, row-major)"""

@@ -123,6 +123,18 @@ int curvis_ctx_set_sky_orientation(curvis_ctx *ctx, int which, const double forw
  * Non-root ranks need no prior set_sky: their textures are allocated from the broadcast shapes. */
 int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root);
 
+/* RCCL plumbing for a host that has no RCCL binding of its own (one process per GPU -- a Rust host, `bench.py`):
+ * rank 0 draws an id (ncclGetUniqueId) and ships its CURVIS_RCCL_ID_BYTES bytes to the other processes by whatever
+ * out-of-band channel it has; every process then joins with its own context (ncclCommInitRank on the context's
+ * device) and passes the returned communicator to curvis_ctx_bcast_skies.  The communicator is the caller's:
+ * curvis_rccl_comm_destroy it after the broadcast.  A one-process / N-thread host (`curvis video --devices N`) needs
+ * none of this: it calls ncclCommInitAll itself.  No reference counterpart (single-threaded CPU code). */
+#define CURVIS_RCCL_ID_BYTES 128
+int curvis_rccl_unique_id(uint8_t id[CURVIS_RCCL_ID_BYTES]);
+int curvis_ctx_rccl_comm_init(curvis_ctx *ctx, const uint8_t id[CURVIS_RCCL_ID_BYTES], int n_ranks, int rank,
+                              void **comm_out);
+int curvis_rccl_comm_destroy(void *nccl_comm);
+
 /* Read back `bytes` bytes at byte offset `offset` of sky texture `which` from HBM (e.g. to verify on every rank that
  * a broadcast texture equals the root's file). */
 int curvis_ctx_read_sky(curvis_ctx *ctx, int which, size_t offset, size_t bytes, uint8_t *out);

@@ -113,6 +113,22 @@ def twin_render_efficient(pm, pc, sky_pos, sky_neg, max_iter, max_radius, delta,
     return rgb, dict(a=a[:k].copy(), e=e[:k].copy(), s=s[:k].copy(), calls=calls.value, steps=steps.value)
 
 
+def device_count():
+    """GPUs the product sees (curvis_device_count; not torch -- importing torch here would bring a second HIP runtime
+    into the pytest process)"""
+    return int(_abi.lib().curvis_device_count())
+
+
+def share_env(n_devices, **extra):
+    """environment for a `curvis ... --devices n` run: the devices themselves when the box has them, the
+    CURVIS_TEST_SHARE_DEVICE hook (every worker on GPU 0) ONLY when it has fewer"""
+    env = dict(os.environ, **extra)
+    env.pop("CURVIS_TEST_SHARE_DEVICE", None)
+    if device_count() < n_devices:
+        env["CURVIS_TEST_SHARE_DEVICE"] = "1"
+    return env
+
+
 def host_threads(cap=128):
     """threads worth starting for the striped oracle renders: the container's CPU quota when the cgroup sets one (the
     GPU boxes show 256 logical CPUs behind a 16-CPU quota; more threads than that only add throttling), else the CPUs

@@ -70,16 +70,16 @@ def test_image_default_pose_efficient_and_brute(scene_files):
 
 
 def test_image_rows_split_over_devices(scene_files):
-    """image --mode brute --devices 3: three contexts render row bands of the one frame (all on this GPU through
-    the CURVIS_TEST_SHARE_DEVICE hook; on a multi-GPU node one band per GPU); file and statistics equal the
-    single-device run."""
+    """image --mode brute --devices 3: three contexts render row bands of the one frame (one band per GPU when the box
+    has three; all on GPU 0 through the CURVIS_TEST_SHARE_DEVICE hook only when it has fewer); file and statistics equal
+    the single-device run."""
     d, sp, sn = scene_files
     outs = []
     for n in (1, 3):
         out = d / ("out_rows%d" % n)
         out.mkdir()
         r = run("image", d / "pos.png", d / "neg.png", out, "-s", d / "sim.toml", "-c", d / "cam.toml", "--mode", "brute",
-                "--devices", n, "--stats", out / "st.json", env=dict(os.environ, CURVIS_TEST_SHARE_DEVICE="1"))
+                "--devices", n, "--stats", out / "st.json", env=common.share_env(n))
         assert r.returncode == 0, r.stderr
         st = json.loads((out / "st.json").read_text())
         outs.append((pngio.read_png(out / "output_image.png"), st["rays"], st["steps"], st["n_pos"], st["n_neg"], st["n_none"]))

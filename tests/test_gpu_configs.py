@@ -156,7 +156,7 @@ SIM = ("escape_radius = 100.0\nray_integration_max_itarations = %d\nray_integrat
 @pytest.mark.parametrize("video", ["orbit", "through"])
 def test_video_config_through_the_binary(tmp_path, video):
     """`curvis video --mode brute --stats`: all frames of the config's video at reduced resolution, PNG frames and the
-    per-frame JSON statistics against the oracle; two devices' worth of workers on the one GPU, one of whose render
+    per-frame JSON statistics against the oracle; two device workers (two GPUs when the box has them, else both on the one GPU), one of whose render
     calls is made to fail once (the batch is re-queued on the other worker), then --resume after deleting frames."""
     metric, csv, fps, n_frames, res, _, cap = VIDEOS[video]
     times, poses = video_poses(csv, fps)
@@ -175,7 +175,7 @@ def test_video_config_through_the_binary(tmp_path, video):
     if metric == "interstellar":
         (d / "met.toml").write_text("m = 0.1\na = 0.0001\nrho = 1.0\n")
         args += ["-m", d / "met.toml"]
-    env = dict(os.environ, CURVIS_TEST_SHARE_DEVICE="1", CURVIS_TEST_FAIL_BATCH="1:2")
+    env = common.share_env(2, CURVIS_TEST_FAIL_BATCH="1:2")   # two real GPUs when the box has them
     r = subprocess.run([str(a) for a in args], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "injected test fault" in r.stderr and "re-queued" in r.stderr
@@ -199,7 +199,7 @@ def test_video_config_through_the_binary(tmp_path, video):
     keep = d / "out" / "tmp" / "frame_5.png"
     stamp = os.stat(keep).st_mtime_ns
     r = subprocess.run([str(a) for a in args] + ["--resume"], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, CURVIS_TEST_SHARE_DEVICE="1"))
+                       env=common.share_env(2))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Resuming: %d of %d frames already present" % (n_frames - len(gone), n_frames) in r.stdout
     assert os.stat(keep).st_mtime_ns == stamp
