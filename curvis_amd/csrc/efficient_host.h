@@ -1,0 +1,567 @@
+/* efficient_host.h -- host side of render_image_efficient (E1-E4): batched escape-angle evaluation, the adaptive sampler
+ * driver with speculation, per-pixel launch; direct mode; trajectories.
+ * Part of the ONE translation unit curvis_hip.hip (included there, nowhere else). */
+#pragma once
+
+namespace {
+
+/* ---- efficient mode ------------------------------------------------------------------------- */
+
+template <int KIND>
+int launch_escape_kind(curvis_ctx *ctx, bool fast, const EscapeAngleParams &P) {
+  const unsigned blocks = (P.n + 63u) / 64u;
+  if (fast)
+    hipLaunchKernelGGL((escape_angle_kernel<KIND, true>), dim3(blocks), dim3(64), 0, ctx->stream, P);
+  else
+    hipLaunchKernelGGL((escape_angle_kernel<KIND, false>), dim3(blocks), dim3(64), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  return CURVIS_OK;
+}
+
+/* evaluate compute_escape_angle for a batch on the GPU */
+int eval_escape_batch(curvis_ctx *ctx, const curvis_metric *metric, const cvk::MetricParams &MP,
+                      const std::vector<double> &alpha, const std::vector<double> &lcam, uint32_t max_iter,
+                      double max_radius, double delta, std::vector<double> &angle, std::vector<double> &space,
+                      std::vector<uint32_t> &steps, std::vector<int> &status, double *ms_acc) {
+  const size_t n = alpha.size();
+  angle.resize(n);
+  space.resize(n);
+  steps.resize(n);
+  status.resize(n);
+  if (n == 0) return CURVIS_OK;
+  /* layout: alpha | l | angle | space (f64) | steps (u32) | status (i32) */
+  const size_t bytes = n * (4 * sizeof(double) + sizeof(unsigned) + sizeof(int));
+  int rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, bytes);
+  if (rc) return rc;
+  double *d_alpha = (double *)ctx->d_eff, *d_l = d_alpha + n, *d_angle = d_l + n, *d_space = d_angle + n;
+  unsigned *d_steps = (unsigned *)(d_space + n);
+  int *d_status = (int *)(d_steps + n);
+  /* one pinned staging buffer, one copy in and one copy out per launch: pageable hipMemcpyAsync of more than
+   * 1 MiB takes a path that costs ~10 ms per array on this stack (a 262 144-point launch took 20-30 ms instead of
+   * 3), and six small pageable copies per launch cost more host time than the kernel of a small launch */
+  if (ctx->h_eff_cap < bytes) {
+    if (ctx->h_eff) HIP_TRY(ctx, hipHostFree(ctx->h_eff));
+    ctx->h_eff = nullptr;
+    ctx->h_eff_cap = 0;
+    const size_t cap = bytes + bytes / 2;
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_eff, cap));
+    ctx->h_eff_cap = cap;
+  }
+  double *h_alpha = (double *)ctx->h_eff, *h_l = h_alpha + n;
+  std::memcpy(h_alpha, alpha.data(), n * sizeof(double));
+  std::memcpy(h_l, lcam.data(), n * sizeof(double));
+  HIP_TRY(ctx, hipMemcpyAsync(d_alpha, h_alpha, 2 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  EscapeAngleParams P;
+  P.metric = MP;
+  P.alpha = d_alpha;
+  P.l_cam = d_l;
+  P.angle = d_angle;
+  P.space = d_space;
+  P.steps = d_steps;
+  P.status = d_status;
+  P.n = (unsigned)n;
+  P.max_iter = max_iter;
+  P.max_radius = max_radius;
+  P.delta = delta;
+  P.fast_ok = cvk::metric_fast_ok(metric->kind, MP, max_radius) ? 1 : 0;
+  const bool fast = ctx->fast_math != 0;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  switch (metric->kind) {
+    case CURVIS_METRIC_ELLIS:
+      rc = launch_escape_kind<cvk::METRIC_ELLIS>(ctx, fast, P);
+      break;
+    case CURVIS_METRIC_INTERSTELLAR:
+      rc = launch_escape_kind<cvk::METRIC_INTERSTELLAR>(ctx, fast, P);
+      break;
+    default:
+      rc = launch_escape_kind<cvk::METRIC_FLAT>(ctx, fast, P);
+      break;
+  }
+  if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  const size_t out_bytes = n * (2 * sizeof(double) + sizeof(unsigned) + sizeof(int));
+  unsigned char *h_out = ctx->h_eff + 2 * n * sizeof(double);
+  HIP_TRY(ctx, hipMemcpyAsync(h_out, d_angle, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(angle.data(), h_out, n * sizeof(double));
+  std::memcpy(space.data(), h_out + n * sizeof(double), n * sizeof(double));
+  std::memcpy(steps.data(), h_out + 2 * n * sizeof(double), n * sizeof(unsigned));
+  std::memcpy(status.data(), h_out + 2 * n * sizeof(double) + n * sizeof(unsigned), n * sizeof(int));
+  float ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (ms_acc) *ms_acc += ms;
+  return CURVIS_OK;
+}
+
+int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cams, uint32_t n_frames,
+                          uint32_t max_iter, double max_radius, double delta, uint32_t alpha_nums,
+                          uint32_t max_iterations_sampling, double thr1, double thr2, uint8_t *rgb_out,
+                          curvis_stats *stats) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (!metric || !cams || n_frames == 0) return fail(ctx, CURVIS_E_INVALID, "null metric/camera or zero frames");
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = curvis_metric_validate(metric);
+  if (rc != CURVIS_OK) return fail(ctx, rc, "invalid metric parameters (src/metrics.rs:409-456)");
+  const uint32_t W = cams[0].res_x, H = cams[0].res_y;
+  if (W == 0 || H == 0) return fail(ctx, CURVIS_E_INVALID, "resolution must be greater than 0 (src/cameras.rs:98)");
+  if (alpha_nums < 3) return fail(ctx, CURVIS_E_SAMPLING, "alpha_nums < 3: the sampler panics (src/sampling.rs:155-157)");
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    if (cams[f].res_x != W || cams[f].res_y != H)
+      return fail(ctx, CURVIS_E_INVALID, "all cameras of a batch must share one resolution");
+    if (std::fabs(cams[f].pos[1]) > max_radius)
+      return fail(ctx, CURVIS_E_CAMERA_OUTSIDE,
+                  "Photon already beyond the maximum radius. Cannot evaluate escape. (src/systems.rs:122-124)");
+  }
+  if (!ctx->d_sky[0] || !ctx->d_sky[1]) return fail(ctx, CURVIS_E_NO_SKY, "both background images must be set");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const cvk::MetricParams MP = make_metric(*metric);
+
+  /* step 1 (host): camera direction on the background space and the tangent->background rotation */
+  std::vector<cvk::EfficientFrame> eframes(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    cvk::vector3_from_theta_phi(cams[f].pos[2], cams[f].pos[3], eframes[f].cam_bg);
+    const double ex[3] = {1.0, 0.0, 0.0};
+    if (!cvk::rotation_from_two_vectors(ex, eframes[f].cam_bg, eframes[f].rot_bg))
+      return fail(ctx, CURVIS_E_PARALLEL, "v1 and v2 must not be parallel (src/algebra.rs:95-97, camera on the x axis)");
+  }
+
+  /* step 3: one sampler per frame, advanced in lock step; every round is ONE kernel launch */
+  std::vector<cvs::Sampler> smp(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    smp[f].a_min = -0.1 * CV_PI; /* src/systems.rs:437-438 */
+    smp[f].a_max = 1.1 * CV_PI;
+    smp[f].n0 = alpha_nums;
+    smp[f].max_iterations = max_iterations_sampling;
+    smp[f].thr1 = thr1;
+    smp[f].thr2 = thr2;
+  }
+  /* Evaluation cache + speculation.  Every point the sampler will ever ask for is the midpoint of two
+   * samples that are adjacent at that time, i.e. a node of the dyadic tree below an interval of the current
+   * table, computed by the same (lo + hi) / 2.0.  So whenever some requested alpha is not cached yet, the
+   * launch also evaluates the whole subtree of depth `spec` below the interval it comes from (and, on the
+   * first launch, below every interval of the uniform grid): the GPU is idle anyway -- a round is a single
+   * wave's 2000-step dependency chain -- and the following rounds are then served from the cache without
+   * a launch.  The sampler consumes exactly the values the sequential algorithm would compute; calls and
+   * steps are counted at consumption, so the bookkeeping equals the reference's. */
+  /* open-addressing table keyed by the bit pattern of alpha; state 0 = empty, 1 = queued for the next launch,
+   * 2 = evaluated (a node-based std::unordered_map cost more host time per batch than the kernels) */
+  struct Cached {
+    uint64_t key;
+    double e, s;
+    uint32_t steps;
+    int status;
+    uint32_t state;
+  };
+  struct EvalCache {
+    std::vector<Cached> slots;
+    size_t used = 0;
+    explicit EvalCache(size_t capacity = 4096) : slots(capacity, Cached{0, 0.0, 0.0, 0, 0, 0}) {}
+    static size_t hash(uint64_t k) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20); }
+    Cached *find(uint64_t k) { /* the slot holding k, or the empty slot where it would go */
+      const size_t mask = slots.size() - 1;
+      size_t i = hash(k) & mask;
+      while (slots[i].state != 0 && slots[i].key != k) i = (i + 1) & mask;
+      return &slots[i];
+    }
+    Cached *claim(uint64_t k) { /* find, inserting an empty (state 0) entry for a new key */
+      if (2 * (used + 1) > slots.size()) {
+        std::vector<Cached> old;
+        old.swap(slots);
+        slots.assign(old.size() * 2, Cached{0, 0.0, 0.0, 0, 0, 0});
+        for (const Cached &c : old)
+          if (c.state != 0) *find(c.key) = c;
+      }
+      Cached *c = find(k);
+      if (c->state == 0) c->key = k;
+      return c;
+    }
+  };
+  auto key_of = [](double a) {
+    uint64_t u;
+    std::memcpy(&u, &a, sizeof u);
+    return u;
+  };
+  /* automatic depths: about 30-50 k points per launch (tools/gpu_eff_two_launch.py, tools/gpu_eff_batch_spec.py) */
+  const int spec = ctx->sampling_speculation < 0 ? (n_frames <= 2 ? 10 : n_frames <= 5 ? 6 : 4)
+                                                 : (ctx->sampling_speculation > 11 ? 11 : ctx->sampling_speculation);
+  /* depth of the subtrees evaluated below the intervals of the initial uniform grid (first launch) */
+  const int first_cap = ctx->sampling_speculation_first < 0 ? (n_frames <= 2 ? 8 : n_frames <= 5 ? 4 : 3)
+                                                            : (ctx->sampling_speculation_first > 11 ? 11 : ctx->sampling_speculation_first);
+  /* sized for the first launch (grid x subtree) plus as much again, so that the table is not rebuilt four times on
+   * the way up from a small default (a quarter of the host time of a single image) */
+  size_t cache_cap = 4096;
+  {
+    const size_t first = (size_t)alpha_nums << (spec > 0 ? (spec > first_cap ? first_cap : spec) : 0);
+    while (cache_cap < 4 * first && cache_cap < ((size_t)1 << 22)) cache_cap *= 2;
+  }
+  std::vector<EvalCache> cache;
+  cache.reserve(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) cache.emplace_back(cache_cap);
+  std::vector<char> planned(n_frames, 0);
+  double sample_ms = 0.0;
+  uint64_t evaluated = 0;
+  uint32_t launches = 0;
+  std::vector<double> b_alpha, b_l, r_angle, r_space, ce, cs;
+  std::vector<uint32_t> r_steps, cst;
+  std::vector<int> r_status;
+  std::vector<uint32_t> b_frame;
+  bool panic = false;
+  const bool dbg_timing = getenv("CURVIS_DEBUG_TIMING") != nullptr;
+  double t_adv = 0.0, t_build = 0.0, t_eval = 0.0, t_ins = 0.0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  for (;;) {
+    const auto tp0 = now();
+    /* advance every sampler as far as the cache allows */
+    bool any_waiting = false;
+    for (uint32_t f = 0; f < n_frames; ++f) {
+      for (;;) {
+        if (!planned[f]) {
+          if (!smp[f].plan()) break; /* finished */
+          planned[f] = 1;
+        }
+        bool all_cached = true;
+        for (double a : smp[f].pending)
+          if (cache[f].find(key_of(a))->state != 2) {
+            all_cached = false;
+            break;
+          }
+        if (!all_cached) {
+          any_waiting = true;
+          break;
+        }
+        const size_t n = smp[f].pending.size();
+        ce.resize(n);
+        cs.resize(n);
+        cst.resize(n);
+        for (size_t k = 0; k < n; ++k) {
+          const Cached &c = *cache[f].find(key_of(smp[f].pending[k]));
+          ce[k] = c.e;
+          cs[k] = c.s;
+          cst[k] = c.steps;
+          if (c.status == cvk::ESC_PANIC) panic = true;
+        }
+        smp[f].consume(ce.data(), cs.data(), cst.data());
+        planned[f] = 0;
+      }
+    }
+    const auto tp1 = now();
+    t_adv += secs(tp0, tp1);
+    if (!any_waiting) break;
+    /* one launch: the missing points of every waiting frame plus their speculative subtrees */
+    b_alpha.clear();
+    b_l.clear();
+    b_frame.clear();
+    for (uint32_t f = 0; f < n_frames; ++f) {
+      if (!planned[f]) continue;
+      auto want = [&](double a) {
+        Cached *c = cache[f].claim(key_of(a));
+        if (c->state != 0) return; /* evaluated, or already queued for this launch */
+        c->state = 1;
+        cache[f].used++;
+        b_alpha.push_back(a);
+        b_l.push_back(cams[f].pos[1]);
+        b_frame.push_back(f);
+      };
+      struct Node {
+        double lo, hi;
+        int depth;
+      };
+      std::vector<Node> stack;
+      const cvs::Sampler &S = smp[f];
+      for (size_t k = 0; k < S.pending.size(); ++k) {
+        want(S.pending[k]);
+        if (spec <= 0) continue;
+        if (S.pend_lo[k] == S.pend_lo[k]) {
+          stack.push_back(Node{S.pend_lo[k], S.pend_hi[k], spec});
+        } else if (k + 1 < S.pending.size()) { /* uniform grid: subtree below [x_k, x_{k+1}] */
+          stack.push_back(Node{S.pending[k], S.pending[k + 1], spec > first_cap ? first_cap : spec});
+        }
+        while (!stack.empty()) {
+          const Node nd = stack.back();
+          stack.pop_back();
+          const double mid = (nd.lo + nd.hi) / 2.0;
+          if (!(mid > nd.lo && mid < nd.hi)) continue; /* interval exhausted in double precision */
+          want(mid);
+          if (nd.depth > 1) {
+            stack.push_back(Node{nd.lo, mid, nd.depth - 1});
+            stack.push_back(Node{mid, nd.hi, nd.depth - 1});
+          }
+        }
+      }
+    }
+    const auto tp2 = now();
+    t_build += secs(tp1, tp2);
+    rc = eval_escape_batch(ctx, metric, MP, b_alpha, b_l, max_iter, max_radius, delta, r_angle, r_space, r_steps,
+                           r_status, &sample_ms);
+    if (rc) return rc;
+    const auto tp3 = now();
+    t_eval += secs(tp2, tp3);
+    ++launches;
+    evaluated += b_alpha.size();
+    for (size_t k = 0; k < b_alpha.size(); ++k) {
+      Cached *c = cache[b_frame[k]].find(key_of(b_alpha[k]));
+      c->e = r_angle[k];
+      c->s = r_space[k];
+      c->steps = r_steps[k];
+      c->status = r_status[k];
+      c->state = 2;
+    }
+    t_ins += secs(tp3, now());
+  }
+  if (dbg_timing)
+    fprintf(stderr, "[curvis] sampling host phases (ms): advance %.3f, build %.3f, evaluate (copies+kernel+sync) %.3f of which kernels %.3f, cache insert %.3f; launches %u, points %llu\n",
+            t_adv, t_build, t_eval, sample_ms, t_ins, launches, (unsigned long long)evaluated);
+  ctx->last_sampling_launches = launches;
+  ctx->last_sampling_evaluated = evaluated;
+  ctx->last_samples.assign(n_frames, {});
+  ctx->last_sampling_info.assign(n_frames, curvis_sampling_info{});
+  uint64_t total_steps = 0;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    if (smp[f].panicked) panic = true;
+    ctx->last_samples[f] = smp[f].pts;
+    curvis_sampling_info &si = ctx->last_sampling_info[f];
+    si.n_samples = (uint32_t)smp[f].pts.size();
+    si.rounds = smp[f].rounds;
+    si.calls = smp[f].calls;
+    si.steps = smp[f].steps;
+    si.warned_max_iterations = smp[f].warned ? 1 : 0;
+    total_steps += smp[f].steps;
+  }
+  if (panic)
+    return fail(ctx, CURVIS_E_SAMPLING,
+                "sampler panic: fewer than 3 finite samples (src/sampling.rs:155-157) or undefined tangent rotation "
+                "(src/algebra.rs:95-97)");
+
+  /* step 4 tables (interp 1.0.3) */
+  std::vector<double> sx, m_e, c_e, m_s, c_s, x, ye, ys, m, c;
+  std::vector<unsigned> tab_off(n_frames), tab_n(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const auto &pts = smp[f].pts;
+    x.clear();
+    ye.clear();
+    ys.clear();
+    for (const auto &b : pts) {
+      x.push_back(b.a);
+      ye.push_back(b.e);
+      ys.push_back(b.s);
+    }
+    tab_off[f] = (unsigned)sx.size();
+    tab_n[f] = (unsigned)pts.size();
+    const size_t slots = std::max<size_t>(pts.size(), 1);
+    cvs::interp_tables(x, ye, m, c);
+    m.resize(slots, 0.0);
+    c.resize(slots, 0.0);
+    m_e.insert(m_e.end(), m.begin(), m.end());
+    c_e.insert(c_e.end(), c.begin(), c.end());
+    cvs::interp_tables(x, ys, m, c);
+    m.resize(slots, 0.0);
+    c.resize(slots, 0.0);
+    m_s.insert(m_s.end(), m.begin(), m.end());
+    c_s.insert(c_s.end(), c.begin(), c.end());
+    x.resize(slots, 0.0);
+    sx.insert(sx.end(), x.begin(), x.end());
+  }
+
+  /* device buffers for K3 */
+  const size_t npix = (size_t)W * H;
+  const size_t fb_bytes = npix * 3 * n_frames;
+  rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, fb_bytes);
+  if (rc) return rc;
+  ctx->fb_bytes = fb_bytes;
+  const size_t T = sx.size();
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 15) & ~(size_t)15;
+    return o;
+  };
+  const size_t o_cams = carve(sizeof(cvk::CameraParams) * n_frames), o_fr = carve(sizeof(cvk::EfficientFrame) * n_frames),
+               o_to = carve(sizeof(unsigned) * n_frames), o_tn = carve(sizeof(unsigned) * n_frames),
+               o_sx = carve(sizeof(double) * T), o_me = carve(sizeof(double) * T), o_ce = carve(sizeof(double) * T),
+               o_ms = carve(sizeof(double) * T), o_cs = carve(sizeof(double) * T);
+  rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, off);
+  if (rc) return rc;
+  std::vector<unsigned char> stage(off);
+  std::vector<cvk::CameraParams> cp(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) cp[f] = make_camera(cams[f]);
+  std::memcpy(stage.data() + o_cams, cp.data(), sizeof(cvk::CameraParams) * n_frames);
+  std::memcpy(stage.data() + o_fr, eframes.data(), sizeof(cvk::EfficientFrame) * n_frames);
+  std::memcpy(stage.data() + o_to, tab_off.data(), sizeof(unsigned) * n_frames);
+  std::memcpy(stage.data() + o_tn, tab_n.data(), sizeof(unsigned) * n_frames);
+  std::memcpy(stage.data() + o_sx, sx.data(), sizeof(double) * T);
+  std::memcpy(stage.data() + o_me, m_e.data(), sizeof(double) * T);
+  std::memcpy(stage.data() + o_ce, c_e.data(), sizeof(double) * T);
+  std::memcpy(stage.data() + o_ms, m_s.data(), sizeof(double) * T);
+  std::memcpy(stage.data() + o_cs, c_s.data(), sizeof(double) * T);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eff, stage.data(), off, hipMemcpyHostToDevice, ctx->stream));
+  FrameCounters FC;
+  rc = prepare_counters(ctx, n_frames, FC);
+  if (rc) return rc;
+  const size_t cnt_words = counter_words(n_frames, FC.slots);
+  EfficientPixelParams Q;
+  for (int k = 0; k < 2; ++k) {
+    Q.sky[k].texels = (const unsigned *)ctx->d_sky[k];
+    Q.sky[k].w = ctx->sky_w[k];
+    Q.sky[k].h = ctx->sky_h[k];
+    for (int i = 0; i < 9; ++i) Q.sky[k].inv_rot[i] = ctx->sky_inv_rot[k][i];
+  }
+  Q.cams = (const cvk::CameraParams *)(ctx->d_eff + o_cams);
+  Q.frames = (const cvk::EfficientFrame *)(ctx->d_eff + o_fr);
+  Q.tab_off = (const unsigned *)(ctx->d_eff + o_to);
+  Q.tab_n = (const unsigned *)(ctx->d_eff + o_tn);
+  Q.sx = (const double *)(ctx->d_eff + o_sx);
+  Q.m_e = (const double *)(ctx->d_eff + o_me);
+  Q.c_e = (const double *)(ctx->d_eff + o_ce);
+  Q.m_s = (const double *)(ctx->d_eff + o_ms);
+  Q.c_s = (const double *)(ctx->d_eff + o_cs);
+  Q.n_frames = n_frames;
+  Q.W = W;
+  Q.H = H;
+  Q.fb = ctx->d_fb;
+  Q.counters = FC;
+  const unsigned long long blocks = ((unsigned long long)npix * n_frames + 255ull) / 256ull;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, Q);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words,
+                              hipMemcpyDeviceToHost, ctx->stream));
+  if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  uint64_t tot[FC_N] = {0};
+  ctx->last_frame_stats.assign(n_frames, curvis_stats{});
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    uint64_t fc[FC_N];
+    sum_frame_counters(ctx->h_counters, FC.slots, f, fc);
+    for (int k = 0; k < FC_N; ++k) tot[k] += fc[k];
+    curvis_stats &fs = ctx->last_frame_stats[f];
+    fs.rays = (uint64_t)npix; /* pixels; the integrator calls of the frame's sampler are in curvis_ctx_sampling_info */
+    fs.steps = smp[f].steps;
+    fs.n_pos = fc[FC_POS];
+    fs.n_neg = fc[FC_NEG];
+    fs.n_none = fc[FC_NONE];
+    fs.n_oob = fc[FC_OOB];
+    /* the samplers of a batch share their launches: times are the batch's, shared out evenly */
+    fs.integrate_ms = sample_ms / n_frames;
+    fs.shade_ms = ms / n_frames;
+    fs.kernel_ms = fs.integrate_ms + fs.shade_ms;
+    fs.total_ms = fs.kernel_ms;
+  }
+  if (stats) {
+    stats->rays = (uint64_t)npix * n_frames;
+    stats->steps = total_steps;
+    stats->n_pos = tot[FC_POS];
+    stats->n_neg = tot[FC_NEG];
+    stats->n_none = tot[FC_NONE];
+    stats->n_oob = tot[FC_OOB];
+    stats->integrate_ms = sample_ms;
+    stats->shade_ms = ms;
+    stats->kernel_ms = sample_ms + ms;
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return CURVIS_OK;
+}
+
+template <int KIND>
+int launch_direct_kind(curvis_ctx *ctx, bool fast, const DirectParams &P) {
+  const unsigned blocks = (unsigned)((P.total_rays + 255ull) / 256ull);
+  if (fast)
+    hipLaunchKernelGGL((direct_kernel<KIND, true>), dim3(blocks), dim3(256), 0, ctx->stream, P);
+  else
+    hipLaunchKernelGGL((direct_kernel<KIND, false>), dim3(blocks), dim3(256), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  return CURVIS_OK;
+}
+
+int render_direct_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cam, uint32_t max_iter,
+                       double max_radius, double delta, uint8_t *rgb_out, curvis_stats *stats) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (!metric || !cam) return fail(ctx, CURVIS_E_INVALID, "null metric/camera");
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = curvis_metric_validate(metric);
+  if (rc != CURVIS_OK) return fail(ctx, rc, "invalid metric parameters (src/metrics.rs:409-456)");
+  const uint32_t W = cam->res_x, H = cam->res_y;
+  if (W == 0 || H == 0) return fail(ctx, CURVIS_E_INVALID, "resolution must be greater than 0 (src/cameras.rs:98)");
+  if (std::fabs(cam->pos[1]) > max_radius)
+    return fail(ctx, CURVIS_E_CAMERA_OUTSIDE, "Photon already beyond the maximum radius. Cannot evaluate escape. (src/systems.rs:122-124)");
+  if (!ctx->d_sky[0] || !ctx->d_sky[1]) return fail(ctx, CURVIS_E_NO_SKY, "both background images must be set");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DirectParams P;
+  P.metric = make_metric(*metric);
+  P.cam = make_camera(*cam);
+  cvk::vector3_from_theta_phi(cam->pos[2], cam->pos[3], P.frame.cam_bg); /* src/systems.rs:393-397 */
+  const double ex[3] = {1.0, 0.0, 0.0};
+  if (!cvk::rotation_from_two_vectors(ex, P.frame.cam_bg, P.frame.rot_bg))
+    return fail(ctx, CURVIS_E_PARALLEL, "v1 and v2 must not be parallel (src/algebra.rs:95-97, camera on the x axis)");
+  for (int k = 0; k < 2; ++k) {
+    P.sky[k].texels = (const unsigned *)ctx->d_sky[k];
+    P.sky[k].w = ctx->sky_w[k];
+    P.sky[k].h = ctx->sky_h[k];
+    for (int i = 0; i < 9; ++i) P.sky[k].inv_rot[i] = ctx->sky_inv_rot[k][i];
+  }
+  P.W = W;
+  P.H = H;
+  P.tiles_x = (W + 7) / 8;
+  P.tiles_y = (H + 7) / 8;
+  P.total_rays = (unsigned long long)P.tiles_x * P.tiles_y * 64ull;
+  if (P.total_rays / 64ull > 0xFFFFFFFFull) return fail(ctx, CURVIS_E_INVALID, "frame too large");
+  P.max_iter = max_iter;
+  P.max_radius = max_radius;
+  P.delta = delta;
+  P.fast_ok = cvk::metric_fast_ok(metric->kind, P.metric, max_radius) ? 1 : 0;
+  const size_t npix = (size_t)W * H, fb_bytes = npix * 3;
+  rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, fb_bytes);
+  if (rc) return rc;
+  ctx->fb_bytes = fb_bytes;
+  P.fb = ctx->d_fb;
+  FrameCounters FC;
+  rc = prepare_counters(ctx, 1, FC);
+  if (rc) return rc;
+  P.counters = FC;
+  const size_t cnt_words = counter_words(1, FC.slots);
+  const bool fast = ctx->fast_math != 0;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  switch (metric->kind) {
+    case CURVIS_METRIC_ELLIS:
+      rc = launch_direct_kind<cvk::METRIC_ELLIS>(ctx, fast, P);
+      break;
+    case CURVIS_METRIC_INTERSTELLAR:
+      rc = launch_direct_kind<cvk::METRIC_INTERSTELLAR>(ctx, fast, P);
+      break;
+    default:
+      rc = launch_direct_kind<cvk::METRIC_FLAT>(ctx, fast, P);
+      break;
+  }
+  if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words, hipMemcpyDeviceToHost, ctx->stream));
+  if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  uint64_t fc[FC_N];
+  sum_frame_counters(ctx->h_counters, FC.slots, 0, fc);
+  curvis_stats st;
+  std::memset(&st, 0, sizeof st);
+  st.rays = fc[FC_RAYS];
+  st.steps = fc[FC_STEPS];
+  st.n_pos = fc[FC_POS];
+  st.n_neg = fc[FC_NEG];
+  st.n_none = fc[FC_NONE];
+  st.n_oob = fc[FC_OOB];
+  st.kernel_ms = st.integrate_ms = ms;
+  st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  ctx->last_frame_stats.assign(1, st);
+  ctx->last_integrate_ms = ms;
+  ctx->last_shade_ms = 0.0;
+  ctx->last_relay_launches = 0;
+  if (stats) *stats = st;
+  return CURVIS_OK;
+}
+
+}  // namespace

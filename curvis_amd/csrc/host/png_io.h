@@ -446,7 +446,9 @@ inline void for_each_token(const uint8_t *d, size_t n, Lit lit, Lit4 lit4, Match
 }
 
 /* the whole PNG file of an RGB8 image into `out` */
-inline void encode_rgb8_fast(const uint8_t *rgb, uint32_t w, uint32_t h, std::vector<uint8_t> &out, EncodeTimes *tm = nullptr) {
+/* Returns the length of the PNG file now at the start of `out`.  `out` is scratch that is only ever GROWN (to the worst-case
+ * size of this frame): a caller that reuses it across frames pays the allocation and its zero fill once, not per frame. */
+inline size_t encode_rgb8_fast(const uint8_t *rgb, uint32_t w, uint32_t h, std::vector<uint8_t> &out, EncodeTimes *tm = nullptr) {
   const size_t stride = (size_t)w * 3, line = stride + 1, n = line * h;
   double t0 = now_s();
   /* per-thread scratch kept across frames: a fresh std::vector would zero-fill (and page-fault) 3x the frame size each time */
@@ -516,7 +518,7 @@ inline void encode_rgb8_fast(const uint8_t *rgb, uint32_t w, uint32_t h, std::ve
   }
   /* worst case: 12 bits per byte; the buffer is sized for 16 */
   const size_t cap = 8 + 25 + 12 + 2 + 512 + n * 2 + 16 + 4 + 12;
-  if (out.size() < cap) out.resize(cap); /* callers that reuse `out` across frames pay the fill once */
+  if (out.size() < cap) out.resize(cap);
   uint8_t *o = out.data();
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   std::memcpy(o, sig, 8);
@@ -580,16 +582,17 @@ inline void encode_rgb8_fast(const uint8_t *rgb, uint32_t w, uint32_t h, std::ve
   std::memcpy(o + 4, "IEND", 4);
   be(o + 8, (uint32_t)crc32(0L, o + 4, 4));
   o += 12;
-  out.resize((size_t)(o - out.data()));
+  const size_t file_len = (size_t)(o - out.data());
   double t4 = now_s();
   if (tm) {
     tm->filter += t1 - t0;
     tm->checksum += (t2 - t1) + (t4 - t3);
     tm->deflate += t3 - t2;
     tm->raw_bytes += stride * h;
-    tm->file_bytes += out.size();
+    tm->file_bytes += file_len;
     tm->frames += 1;
   }
+  return file_len;
 }
 
 inline bool write_file(const std::string &path, const uint8_t *data, size_t n, std::string &err) {
@@ -608,13 +611,16 @@ inline bool write_file(const std::string &path, const uint8_t *data, size_t n, s
 inline bool save_rgb8(const std::string &path, const uint8_t *rgb, uint32_t w, uint32_t h, std::string &err, int level = 6,
                       EncodeTimes *tm = nullptr) {
   if (level < 0) {
-    if ((uint64_t)w * 3 * h + h >= ((uint64_t)1 << 31) - 65536) { /* IDAT length is 32 bits and the worst case is 15 bits per byte: a 2 GiB frame takes the zlib route */
+    /* A chunk length must stay below 2^31 (PNG spec; libpng and the `png` crate reject longer ones) and the fast deflate's
+     * worst case is 12 bits per byte: frames whose WORST-CASE stream would not fit one IDAT take the zlib route, which
+     * splits its stream into several IDAT chunks below. */
+    if (((uint64_t)w * 3 * h + h) * 3 / 2 + 1024 >= ((uint64_t)1 << 31)) {
       level = 1;
     } else {
       static thread_local std::vector<uint8_t> file;
-      encode_rgb8_fast(rgb, w, h, file, tm);
+      const size_t file_len = encode_rgb8_fast(rgb, w, h, file, tm);
       const double t0 = now_s();
-      const bool ok = write_file(path, file.data(), file.size(), err);
+      const bool ok = write_file(path, file.data(), file_len, err);
       if (tm) tm->write += now_s() - t0;
       return ok;
     }
@@ -643,7 +649,13 @@ inline bool save_rgb8(const std::string &path, const uint8_t *rgb, uint32_t w, u
   ihdr.push_back(0);
   ihdr.push_back(0);
   chunk(out, "IHDR", ihdr);
-  chunk(out, "IDAT", comp);
+  /* several IDAT chunks when the stream is long: a single chunk must stay below 2^31 bytes */
+  const size_t kIdatMax = (size_t)1 << 30;
+  for (size_t off = 0; off < comp.size() || off == 0; off += kIdatMax) {
+    const size_t piece = std::min(kIdatMax, comp.size() - off);
+    chunk(out, "IDAT", std::vector<uint8_t>(comp.begin() + (ptrdiff_t)off, comp.begin() + (ptrdiff_t)(off + piece)));
+    if (comp.empty()) break;
+  }
   chunk(out, "IEND", {});
   const double tb = now_s();
   const bool ok = write_file(path, out.data(), out.size(), err);

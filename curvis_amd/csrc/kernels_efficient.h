@@ -1,0 +1,295 @@
+/* kernels_efficient.h -- device side of render_image_efficient (E1-E3), direct mode, trajectories and the math self-test.
+ * Part of the ONE translation unit curvis_hip.hip (included there, nowhere else). */
+#pragma once
+
+namespace {
+
+/* ------------------------------------------------------------------------------------------------
+ * Efficient renderer (render_image_efficient, src/systems.rs:333-527): the CLI's variant. */
+
+struct EscapeAngleParams {
+  cvk::MetricParams metric;
+  const double *alpha; /* n */
+  const double *l_cam; /* n: radial coordinate of the camera the sample belongs to */
+  double *angle;       /* n: escape angle, NaN when not escaped */
+  double *space;       /* n: +1 / -1, NaN when not escaped */
+  unsigned *steps;     /* n */
+  int *status;         /* n: escape code, or ESC_PANIC */
+  unsigned n;
+  unsigned max_iter;
+  double max_radius, delta;
+  int fast_ok;
+};
+
+/* K2: compute_escape_angle (src/systems.rs:203-261) for a batch of alphas: photon at (0, l, pi/2, 0)
+ * with tangent direction (cos a, 0, sin a), Euler loop WITH phi, world direction, angle. */
+template <int KIND, bool FAST>
+__global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParams P) {
+  __shared__ MathTablesLds<KIND> s_tab;
+  cvk::MetricParams M = P.metric;
+  load_math_tables<KIND>(s_tab, M);
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const double alpha = P.alpha[i];
+  double sa, ca;
+  cv_sincos(alpha, &sa, &ca);
+  const double pos[4] = {0.0, P.l_cam[i], CV_PI / 2.0, 0.0};
+  cvk::Ray q;
+  cvk::ray_init_dir<KIND>(M, pos, ca, 0.0, sa, q);
+  const bool lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
+  /* same loop shape as geodesic_static: wave-uniform step counter (all lanes start together), one escape compare,
+   * the per-lane step count captured under a scalar branch in the iterations in which some lane escapes */
+  unsigned steps = P.max_iter;
+  int code = cvk::CODE_NONE;
+  if (P.max_iter != 0) {
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned k = 0;
+    for (;;) {
+      ++k;
+      one_step<KIND, true, FAST, true>(M, P.delta, q, lane_ok); /* equatorial photons: see ray_step_fast */
+      const bool esc = ray_escaped(q.l, P.max_radius);
+      const unsigned long long em = __builtin_amdgcn_ballot_w64(esc);
+      if (em) {
+        unsigned kv;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kv) : "s"(k));
+        if ((em >> lane) & 1ull) steps = kv;
+      }
+      if (esc) break;
+      if (k >= P.max_iter) break;
+    }
+    if (ray_escaped(q.l, P.max_radius)) code = escape_code(q.l);
+  } else {
+    steps = 0;
+  }
+  const double nan = __builtin_nan("");
+  double angle = nan, space = nan;
+  int status = code;
+  if (code != cvk::CODE_NONE) {
+    if (cvk::escape_angle_of<KIND>(M, q, angle)) {
+      space = (code == cvk::CODE_POS) ? 1.0 : -1.0;
+    } else {
+      angle = nan;
+      status = cvk::ESC_PANIC;
+    }
+  }
+  P.angle[i] = angle;
+  P.space[i] = space;
+  P.steps[i] = steps;
+  P.status[i] = status;
+}
+
+struct EfficientPixelParams {
+  cvk::SkyParams sky[2];
+  const cvk::CameraParams *cams;      /* n_frames */
+  const cvk::EfficientFrame *frames;  /* n_frames */
+  const unsigned *tab_off;            /* n_frames: offset of the frame's tables in sx/m/c */
+  const unsigned *tab_n;              /* n_frames: number of samples */
+  const double *sx, *m_e, *c_e, *m_s, *c_s;
+  unsigned n_frames, W, H;
+  unsigned char *fb;
+  FrameCounters counters;
+};
+
+/* K3: steps 2, 4, 5 of render_image_efficient + sky lookup, one thread per pixel. */
+__global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPixelParams P) {
+  const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long npix = (unsigned long long)P.W * P.H;
+  unsigned pos = 0, neg = 0, none = 0, oob = 0;
+  const bool valid = o < npix * P.n_frames;
+  const unsigned f = valid ? (unsigned)(o / npix) : 0u;
+  if (valid) {
+    const unsigned pix = (unsigned)(o - (unsigned long long)f * npix);
+    const unsigned py = pix / P.W, px = pix - py * P.W;
+    const unsigned off = P.tab_off[f], n = P.tab_n[f];
+    double fin[3], space;
+    cvk::efficient_pixel(P.cams[f], P.frames[f], px, py, P.sx + off, P.m_e + off, P.c_e + off, P.m_s + off,
+                         P.c_s + off, n, fin, space);
+    unsigned texel = 0xFF000000u;
+    if (space == 1.0 || space == -1.0) { /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black } */
+      const cvk::SkyParams &S = P.sky[space == 1.0 ? 0 : 1];
+      unsigned tx, ty;
+      cvk::sky_indices(S, fin[0], fin[1], fin[2], tx, ty);
+      if (tx >= S.w || ty >= S.h) oob = 1;
+      if (tx >= S.w) tx = S.w - 1;
+      if (ty >= S.h) ty = S.h - 1;
+      texel = S.texels[(size_t)ty * S.w + tx];
+      pos = (space == 1.0);
+      neg = (space == -1.0);
+    } else {
+      none = 1;
+    }
+    unsigned char *dst = P.fb + o * 3;
+    dst[0] = (unsigned char)(texel & 0xFF);
+    dst[1] = (unsigned char)((texel >> 8) & 0xFF);
+    dst[2] = (unsigned char)((texel >> 16) & 0xFF);
+  }
+  flush_frame_counts(P.counters, f, valid, 0ull, 1u, pos, neg, none, oob);
+}
+
+/* "direct" mode (NOT in the reference; SURVEY 8f N1 names it as a quality option): what render_image_efficient
+ * approximates by sampling + interpolation, computed exactly -- compute_escape_angle(l_cam, alpha) for the alpha of
+ * EVERY pixel (src/systems.rs:203-261 on the result of :405-433), then step 5 (:498-523) with that escape angle and
+ * space.  One thread per pixel, 8x8 tiles per wave (neighbouring alphas: coherent step counts); every photon lives in
+ * the equatorial plane, so the loop is the sampling kernel's (phi integrated, equatorial step form). */
+struct DirectParams {
+  cvk::MetricParams metric;
+  cvk::SkyParams sky[2];
+  cvk::CameraParams cam;
+  cvk::EfficientFrame frame;
+  unsigned W, H, tiles_x, tiles_y;
+  unsigned long long total_rays; /* tiles_x * tiles_y * 64 */
+  unsigned max_iter;
+  double max_radius, delta;
+  int fast_ok;
+  unsigned char *fb;
+  FrameCounters counters;
+};
+
+template <int KIND, bool FAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KIND == cvk::METRIC_INTERSTELLAR ? 4 : 6)))
+void direct_kernel(const DirectParams P) {
+  __shared__ MathTablesLds<KIND> s_tab;
+  cvk::MetricParams M = P.metric;
+  load_math_tables<KIND>(s_tab, M);
+  const unsigned long long id = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned tile = (unsigned)(id >> 6), k6 = (unsigned)id & 63u;
+  const unsigned tyi = tile / P.tiles_x, txi = tile - tyi * P.tiles_x;
+  const unsigned px = txi * 8u + (k6 & 7u), py = tyi * 8u + (k6 >> 3);
+  const bool valid = id < P.total_rays && px < P.W && py < P.H;
+  unsigned steps = 0, pos = 0, neg = 0, none = 0, oob = 0;
+  if (valid) {
+    double alpha, axis[3];
+    cvk::efficient_pixel_geometry(P.cam, P.frame, px, py, alpha, axis);
+    double sa, ca;
+    cv_sincos(alpha, &sa, &ca);
+    const double p4[4] = {0.0, P.cam.pos[1], CV_PI / 2.0, 0.0};
+    cvk::Ray q;
+    cvk::ray_init_dir<KIND>(M, p4, ca, 0.0, sa, q);
+    const bool lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
+    int code = cvk::CODE_NONE;
+    /* a per-lane loop (lanes outside the frame are idle from the start, so the counter is not wave-uniform) */
+    for (unsigned k = 0; k < P.max_iter; ++k) {
+      one_step<KIND, true, FAST, true>(M, P.delta, q, lane_ok);
+      ++steps;
+      if (ray_escaped(q.l, P.max_radius)) {
+        code = escape_code(q.l);
+        break;
+      }
+    }
+    unsigned texel = 0xFF000000u; /* NotEscaped / undefined tangent rotation: black */
+    double angle;
+    if (code != cvk::CODE_NONE && cvk::escape_angle_of<KIND>(M, q, angle)) {
+      cvk::efficient_pixel_geometry(P.cam, P.frame, px, py, alpha, axis); /* again: not kept live across the loop */
+      double fin[3];
+      cvk::efficient_final_direction(P.frame, axis, angle, fin);
+      const cvk::SkyParams &S = P.sky[code == cvk::CODE_POS ? 0 : 1];
+      unsigned tx, ty;
+      cvk::sky_indices(S, fin[0], fin[1], fin[2], tx, ty);
+      if (tx >= S.w || ty >= S.h) oob = 1;
+      if (tx >= S.w) tx = S.w - 1;
+      if (ty >= S.h) ty = S.h - 1;
+      texel = S.texels[(size_t)ty * S.w + tx];
+      pos = (code == cvk::CODE_POS);
+      neg = (code == cvk::CODE_NEG);
+    } else {
+      none = 1;
+    }
+    unsigned char *dst = P.fb + ((size_t)py * P.W + px) * 3;
+    dst[0] = (unsigned char)(texel & 0xFF);
+    dst[1] = (unsigned char)((texel >> 8) & 0xFF);
+    dst[2] = (unsigned char)((texel >> 16) & 0xFF);
+  }
+  flush_frame_counts(P.counters, 0u, valid, steps, 1u, pos, neg, none, oob);
+}
+
+/* compute_photon_trajectory (src/systems.rs:77-92): the state BEFORE each of `iterations` Euler steps,
+ * all eight components (t and p_t included: x_t += (p_t * -1) * delta, p_t += 0 * delta), one thread per
+ * photon.  Momentum is covariant on entry (what new_photon produces). */
+struct TrajectoryParams {
+  cvk::MetricParams metric;
+  const double *x0, *p0; /* n*4 each */
+  double *out;           /* n * iterations * 8: [photon][iteration][x0..x3, p0..p3] */
+  unsigned n, iterations;
+  double delta;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(64) void trajectory_kernel(const TrajectoryParams P) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  cvk::MetricParams M = P.metric;
+  M.T = cv_sc_table();
+  M.LT = cv_log_table();
+  M.AT = cv_atan_table();
+  double t = P.x0[4 * i], pt = P.p0[4 * i];
+  cvk::Ray q;
+  q.l = P.x0[4 * i + 1];
+  q.th = P.x0[4 * i + 2];
+  q.ph = P.x0[4 * i + 3];
+  q.p1 = P.p0[4 * i + 1];
+  q.p2 = P.p0[4 * i + 2];
+  q.p3 = P.p0[4 * i + 3];
+  q.p3sq = q.p3 * q.p3;
+  double p3 = q.p3;
+  double *o = P.out + (size_t)i * P.iterations * 8;
+  for (unsigned k = 0; k < P.iterations; ++k) {
+    o[0] = t;
+    o[1] = q.l;
+    o[2] = q.th;
+    o[3] = q.ph;
+    o[4] = pt;
+    o[5] = q.p1;
+    o[6] = q.p2;
+    o[7] = p3;
+    o += 8;
+    cvk::ray_step<KIND, true>(M, q, P.delta);
+    t = t + (pt * (1.0 / -1.0)) * P.delta; /* dx0 = p0 * g00.powi(-1) */
+    pt = pt + 0.0 * P.delta;
+    p3 = p3 + 0.0 * P.delta;
+  }
+}
+
+__global__ void selftest_math_kernel(int op, const double *a, const double *b, double *out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b ? b[i] : 0.0;
+  double r;
+  switch (op) {
+    case 0:
+      r = cv_sin(x);
+      break;
+    case 1:
+      r = cv_cos(x);
+      break;
+    case 2:
+      r = cv_atan(x);
+      break;
+    case 3:
+      r = cv_acos(x);
+      break;
+    case 4:
+      r = cv_log(x);
+      break;
+    case 5:
+      r = cv_atan2(x, y);
+      break;
+    case 6:
+      r = x / y;
+      break;
+    case 7:
+      r = CV_SQRT(x);
+      break;
+    case 9:
+      r = __builtin_amdgcn_rcp(x); /* raw v_rcp_f64 seed */
+      break;
+    case 10:
+      r = __builtin_amdgcn_rsq(x); /* raw v_rsq_f64 seed */
+      break;
+    default:
+      r = CV_FMA(x, y, x);
+      break;
+  }
+  out[i] = r;
+}
+
+}  // namespace

@@ -33,10 +33,11 @@ static int encode_round_trips() {
       }
     }
     file.clear();
-    pngio::encode_rgb8_fast(rgb.data(), w, h, file);
+    const size_t file_len = pngio::encode_rgb8_fast(rgb.data(), w, h, file); /* `file` is scratch, kept at capacity across frames */
+    const std::vector<uint8_t> png(file.begin(), file.begin() + (ptrdiff_t)file_len);
     pngio::Image img;
     std::string err;
-    if (!pngio::decode(file, img, err) || img.w != w || img.h != h) {
+    if (!pngio::decode(png, img, err) || img.w != w || img.h != h) {
       std::printf("encode round trip %d (%ux%u kind %d): decode failed: %s\n", it, w, h, kind, err.c_str());
       return 1;
     }

@@ -346,6 +346,33 @@ def test_config3_full_size_4k_interstellar(gpu_ctx):
     assert s.steps == steps
     assert (s.n_pos, s.n_neg, s.n_none) == (int((want_dbg["code"] == 1).sum()), int((want_dbg["code"] == -1).sum()),
                                            int((want_dbg["code"] == 0).sum()))
+    # The same frame in the reference's own (glibc) arithmetic -- the one check that shares no code with the product's
+    # cv_math.h: every 8th row (1 036 800 rays, 2.0e9 Euler steps: sized for the 16-CPU quota of a GPU box) in the
+    # flavour LLVM's own lowering points at (one sincos() per update with g33's sine taken from it,
+    # profiles/round3_llvm_sincos_probe.txt): pixel, raw texel index, step count and escape code of every ray identical.
+    # All three flavours over the full frame: tools/gpu_libm_parity.py -> profiles/round3_libm_parity.txt.
+    from concurrent.futures import ThreadPoolExecutor
+    _, got_dbg = sys_.render_image_debug(8192, 100.0, 0.05)
+    assert np.array_equal(got_dbg["steps"], want_dbg["steps"]) and np.array_equal(got_dbg["code"], want_dbg["code"])
+    T = common.host_threads(64)
+    osp, osn = O.sky(sp), O.sky(sn)
+    H = 2160
+    libm_rgb = np.zeros_like(want_rgb)
+    libm_dbg = np.zeros((H, 3840), O.RAY_DEBUG)
+
+    def work(i):
+        r, d, st = O.render_image(O.LIBM_SINCOS_INL, om, oc, osp, osn, 8192, 100.0, 0.05, row_begin=8 * i, row_step=8 * T, debug=True)
+        libm_rgb[8 * i::8 * T] = r[8 * i::8 * T]
+        libm_dbg[8 * i::8 * T] = d[8 * i::8 * T]
+        return st.rays, st.steps
+    with ThreadPoolExecutor(T) as ex:
+        parts = list(ex.map(work, range(T)))
+    assert sum(p[0] for p in parts) == 3840 * (H // 8) and sum(p[1] for p in parts) == int(got_dbg["steps"][::8].sum())
+    assert np.array_equal(got[::8], libm_rgb[::8])
+    for f in ("steps", "code", "tx", "ty"):
+        assert np.array_equal(got_dbg[f][::8], libm_dbg[f][::8]), f
+    # ... while the trajectories themselves DO differ in their last bits on some rays (else this would prove nothing)
+    assert (got_dbg["x"][::8] != libm_dbg["x"][::8]).any()
 
 
 def test_rotated_skies_and_random_cameras(gpu_ctx):
