@@ -126,6 +126,7 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the JSON line would not describe the run that was "
                          "asked for" % (args.gpus, world))
 
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap needs no network interface (torch's nccl group included)
     # The job's stdout carries the JSON line and nothing else: gloo ("[Gloo] Rank 0 is connected to ..."), RCCL (version
     # banner) and whatever else writes to the C stdout go to stderr -- file descriptor 1 points there until the line is due.
     flush_c_stdio()

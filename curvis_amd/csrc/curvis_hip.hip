@@ -5,6 +5,7 @@
  *   kernels_efficient.h  device side of render_image_efficient (src/systems.rs:333-527), direct mode, trajectories, math self-test
  *   render_host.h        struct curvis_ctx, kernel selection, render_impl, per-frame statistics, the relay seat belt
  *   efficient_host.h     the adaptive sampler's driver (src/sampling.rs) over batched escape-angle launches, per-pixel launch
+ *   kernels_png.h, png_host.h   PNG front end on the device: the frames in HBM -> one zlib stream per frame (src/rendering.rs:110, :311)
  *   (this file)          the extern "C" entry points
  *   per-ray arithmetic: cv_device.h / cv_efficient.h / cv_sampler.h / cv_math.h (shared with the host twin of the tests)
  *
@@ -64,6 +65,8 @@
 #include "kernels_efficient.h"
 #include "render_host.h"
 #include "efficient_host.h"
+#include "kernels_png.h"
+#include "png_host.h"
 
 /* ------------------------------------------------------------------------------------------ ABI */
 extern "C" {
@@ -125,6 +128,7 @@ void curvis_ctx_destroy(curvis_ctx *ctx) {
   if (ctx->d_store) (void)hipFree(ctx->d_store);
   if (ctx->d_rq) (void)hipFree(ctx->d_rq);
   if (ctx->d_verify) (void)hipFree(ctx->d_verify);
+  if (ctx->d_png) (void)hipFree(ctx->d_png);
   if (ctx->d_eff) (void)hipFree(ctx->d_eff);
   if (ctx->h_eff) (void)hipHostFree(ctx->h_eff);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
@@ -290,8 +294,14 @@ int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root) {
 
 static_assert(sizeof(ncclUniqueId) == CURVIS_RCCL_ID_BYTES, "ncclUniqueId is 128 bytes in RCCL");
 
+/* the ranks of these communicators sit on ONE node (frames of a video shard over the GPUs of a node): RCCL's bootstrap goes
+ * over the loopback interface unless the user has chosen one -- on hosts whose first interface is slow or unroutable the
+ * default choice was seen to cost 6 s to ~80 s of communicator set-up */
+static void rccl_single_node_defaults() { ::setenv("NCCL_SOCKET_IFNAME", "lo", 0); }
+
 int curvis_rccl_unique_id(uint8_t id[CURVIS_RCCL_ID_BYTES]) {
   if (!id) return fail(nullptr, CURVIS_E_INVALID, "null id");
+  rccl_single_node_defaults();
   ncclUniqueId u;
   const ncclResult_t rc = ncclGetUniqueId(&u);
   if (rc != ncclSuccess) return fail(nullptr, CURVIS_E_RCCL, std::string("ncclGetUniqueId: ") + ncclGetErrorString(rc));
@@ -305,6 +315,7 @@ int curvis_ctx_rccl_comm_init(curvis_ctx *ctx, const uint8_t id[CURVIS_RCCL_ID_B
     return fail(ctx, CURVIS_E_INVALID, "bad argument");
   *comm_out = nullptr;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  rccl_single_node_defaults();
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof u);
   ncclComm_t comm = nullptr;
@@ -680,6 +691,18 @@ int curvis_image_save_rgb8_level(const char *path, const uint8_t *rgb, uint32_t 
   if (level < -1 || level > 9) return fail(nullptr, CURVIS_E_INVALID, "level must be -1 (fast writer) or 0..9 (zlib)");
   std::string err;
   if (!pngio::save_rgb8(path, rgb, w, h, err, level)) return fail(nullptr, CURVIS_E_IO, err);
+  return CURVIS_OK;
+}
+
+int curvis_ctx_deflate_frames(curvis_ctx *ctx, uint32_t res_x, uint32_t res_y, uint32_t n_frames, uint8_t *zlib_out, size_t out_cap,
+                              size_t *offsets, double *kernel_ms) {
+  return deflate_frames_impl(ctx, res_x, res_y, n_frames, zlib_out, out_cap, offsets, kernel_ms);
+}
+
+int curvis_image_save_zlib_rgb8(const char *path, const uint8_t *zlib_stream, size_t len, uint32_t w, uint32_t h) {
+  if (!path || !zlib_stream || len < 6 || w == 0 || h == 0) return fail(nullptr, CURVIS_E_INVALID, "null argument or empty stream");
+  std::string err;
+  if (!pngio::save_zlib_stream_rgb8(path, zlib_stream, len, w, h, err)) return fail(nullptr, CURVIS_E_IO, err);
   return CURVIS_OK;
 }
 

@@ -20,7 +20,9 @@
  * --writers T (PNG encoder threads; default: a quarter of the host threads, 4..64), --stats FILE (JSON lines, one per
  * frame, with that frame's own early-termination counters: rays, executed Euler steps, escaped +l / -l, capped),
  * --resume (video: keep <out>/tmp and skip the frames whose frame_{k}.png is already there; default off = the
- * reference's behaviour of deleting and recreating tmp, src/rendering.rs:276-287).  A batch of frames whose render
+ * reference's behaviour of deleting and recreating tmp, src/rendering.rs:276-287), --gpu-png auto|on|off (video: filter + Huffman
+ * coding + Adler-32 of every frame on the GPU, curvis_ctx_deflate_frames -- the frames never cross PCIe as pixels and a writer
+ * thread only wraps the stream into a PNG file; auto = with the fast writer, in modes brute and efficient).  A batch of frames whose render
  * call fails is re-queued on another GPU (frames are independent) before the run is declared failed.
  * Backgrounds: PNG (any colour type / bit depth) or JPEG (8-bit Huffman, baseline / progressive, grey or YCbCr; own
  * decoder in jpeg_io.h -- JPEG input is outside the pixel-parity claims, see there).
@@ -413,6 +415,7 @@ struct Args {
   int devices = 1, device = 0, batch = 8, writers = 0; /* writers 0 = automatic: a quarter of the host's threads, 4..64 */
   int png_level = -1; /* -1 = the fast PNG writer (png_io.h; the reference's image crate also saves with its fast setting), 0..9 = zlib */
   int encode_bench = 0; /* video, diagnostics: every rendered frame is encoded this many extra times into a scratch file */
+  std::string gpu_png = "auto"; /* video: PNG front end on the device (curvis_ctx_deflate_frames): auto = with the fast writer, on, off */
 };
 [[noreturn]] void die(const std::string &msg, int code = 1) {
   std::fprintf(stderr, "%s\n", msg.c_str());
@@ -426,7 +429,7 @@ void usage() {
       "curvis video <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-v|--video-settings <TOML FILE>]\n"
       "  common: [-m|--metric-settings <TOML FILE>] [-c|--camera-settings <TOML FILE>] [-s|--simulation-settings <TOML FILE>]\n"
       "  extensions: [--mode efficient|brute|direct] [--device N] [--devices N] [--batch B] [--stats FILE]\n"
-      "              [--sky-broadcast rccl|upload] [--writers T] [--resume] [--png-level -1..9]\n");
+      "              [--sky-broadcast rccl|upload] [--writers T] [--resume] [--png-level -1..9] [--gpu-png auto|on|off]\n");
 }
 Args parse_args(int argc, char **argv) {
   Args a;
@@ -468,6 +471,7 @@ Args parse_args(int argc, char **argv) {
     else if (key == "--writers") { take(val); a.writers = std::atoi(val.c_str()); }
     else if (key == "--png-level") { take(val); a.png_level = std::max(-1, std::min(9, std::atoi(val.c_str()))); }
     else if (key == "--encode-bench") { take(val); a.encode_bench = std::max(0, std::atoi(val.c_str())); }
+    else if (key == "--gpu-png") take(a.gpu_png);
     else if (key == "-h" || key == "--help") { usage(); std::exit(0); }
     else if (!s.empty() && s[0] == '-') die("error: unexpected argument '" + s + "' found", 2);
     else pos.push_back(s);
@@ -483,6 +487,7 @@ Args parse_args(int argc, char **argv) {
   }
   if (a.mode != "efficient" && a.mode != "brute" && a.mode != "direct") die("error: --mode must be efficient, brute or direct", 2);
   if (a.sky_broadcast != "rccl" && a.sky_broadcast != "upload") die("error: --sky-broadcast must be rccl or upload", 2);
+  if (a.gpu_png != "auto" && a.gpu_png != "on" && a.gpu_png != "off") die("error: --gpu-png must be auto, on or off", 2);
   if (a.devices < 1) a.devices = 1;
   if (a.batch < 1) a.batch = 1;
   if (a.writers < 1) { /* encoding a 1080p frame costs 5-25 ms of a host thread (zlib: 20-230): the GPU renders one in 0.4-10 ms */
@@ -857,6 +862,8 @@ int video_main(const Args &a) {
     int sclk_mhz = -1, power_w = -1;
     size_t frames = 0, batches = 0;
     double render_s = 0, kernel_ms = 0, submit_s = 0, wait_s = 0, busy_s = 0, pool_wait_s = 0;
+    double png_ms = 0; /* device PNG front end: HIP-event time of its kernels */
+    size_t png_frames = 0, png_fallback_frames = 0;
     double sky_s = 0, sky_bcast_s = 0; /* skies into this device's HBM: all of it / the curvis_ctx_bcast_skies call alone */
     unsigned long long steps = 0;
   };
@@ -873,6 +880,9 @@ int video_main(const Args &a) {
     std::vector<int> devs;
     for (int r = 0; r < a.devices; ++r) devs.push_back(a.device + r);
     comms.resize(a.devices);
+    /* one node, one process: RCCL's bootstrap needs no network.  Left to itself it picks the first "real" interface, and on
+     * hosts where that one is slow or unroutable communicator set-up was seen to take 6 s (lo: 2.7 s) up to ~80 s */
+    ::setenv("NCCL_SOCKET_IFNAME", "lo", 0 /* a value the user has set stays */);
     const ncclResult_t nrc = ncclCommInitAll(comms.data(), a.devices, devs.data());
     if (nrc != ncclSuccess) {
       /* asked for explicitly: a broken xGMI broadcast must not hide behind a silent fallback */
@@ -914,6 +924,10 @@ int video_main(const Args &a) {
     n_batches += own[(size_t)r].size();
   }
   if (a.resume) std::printf("Resuming: %zu of %zu frames already present in \"%s\"\n", n_skipped, n_frames, tmp.c_str());
+  /* PNG front end on the device: with the fast writer (the default) in the modes whose frames of a batch sit together in the
+   * context's framebuffer; --encode-bench measures the HOST encoder and therefore keeps it */
+  const bool gpu_png = a.gpu_png == "on" ? (a.mode != "direct")
+                       : a.gpu_png == "auto" ? (a.png_level < 0 && a.mode != "direct" && a.encode_bench == 0) : false;
   std::mutex q_mu;
   std::condition_variable q_cv;
   std::deque<Batch> retry;
@@ -1009,7 +1023,26 @@ int video_main(const Args &a) {
       curvis_stats st;
       /* src/rendering.rs:305-306: threshold_1 is passed for both thresholds */
       const double t_r0 = pngio::now_s();
-      int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, rgb_ptr, &st);
+      /* with the device PNG front end the pixels stay in HBM (rgb_out = NULL) and the batch buffer receives the frames' zlib
+       * streams instead; should they not fit (frames that do not compress: > 1 byte per byte) the raw frames are fetched after
+       * all and the host encoder takes them */
+      std::vector<size_t> zoff;
+      bool streams = false;
+      int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, gpu_png ? nullptr : rgb_ptr, &st);
+      if (rc == CURVIS_OK && gpu_png) {
+        zoff.resize(nb + 1);
+        double pms = 0.0;
+        const int zrc = curvis_ctx_deflate_frames(ctx, c.cam.resolution_x, c.cam.resolution_y, (uint32_t)nb, rgb_ptr,
+                                                  batch_buf ? (size_t)a.batch * fbytes : nb * fbytes, zoff.data(), &pms);
+        if (zrc == CURVIS_OK) {
+          streams = true;
+          ds.png_ms += pms;
+          ds.png_frames += nb;
+        } else {
+          rc = curvis_ctx_download(ctx, rgb_ptr, nb * fbytes);
+          ds.png_fallback_frames += nb;
+        }
+      }
       const double batch_call_ms = (pngio::now_s() - t_r0) * 1e3;
       ds.render_s += batch_call_ms * 1e-3;
       const bool injected = rank == fail_rank && calls == fail_call;
@@ -1052,8 +1085,9 @@ int video_main(const Args &a) {
         const size_t k = b.frames[j];
         /* the writer job keeps the batch buffer alive and reads its frame in place; with pageable memory it owns a copy */
         std::shared_ptr<std::vector<uint8_t>> copy;
-        if (!batch_buf) copy = std::make_shared<std::vector<uint8_t>>(rgb_ptr + j * fbytes, rgb_ptr + (j + 1) * fbytes);
-        const uint8_t *frame = batch_buf ? batch_buf.get() + j * fbytes : copy->data();
+        const size_t f_off = streams ? zoff[j] : j * fbytes, f_len = streams ? zoff[j + 1] - zoff[j] : fbytes;
+        if (!batch_buf) copy = std::make_shared<std::vector<uint8_t>>(rgb_ptr + f_off, rgb_ptr + f_off + f_len);
+        const uint8_t *frame = batch_buf ? batch_buf.get() + f_off : copy->data();
         curvis_stats fs;
         std::memset(&fs, 0, sizeof fs);
         if (a.mode == "direct" && j < g_direct_frame_stats.size())
@@ -1061,17 +1095,18 @@ int video_main(const Args &a) {
         else
           (void)curvis_ctx_frame_stats(ctx, (uint32_t)j, &fs);
         const double batch_ms = st.kernel_ms;
-        writers.submit([&, k, frame, batch_buf, copy, fs, nb, rank, batch_ms, batch_call_ms] {
+        writers.submit([&, k, frame, f_len, streams, batch_buf, copy, fs, nb, rank, batch_ms, batch_call_ms] {
           const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
           const std::string part = file + ".part"; /* written under another name, then renamed: --resume never sees half a file */
           std::string e;
           pngio::EncodeTimes tm, tb;
-          bool ok = pngio::save_rgb8(part, frame, c.cam.resolution_x, c.cam.resolution_y, e, a.png_level, &tm);
+          bool ok = streams ? pngio::save_zlib_stream_rgb8(part, frame, f_len, c.cam.resolution_x, c.cam.resolution_y, e, &tm)
+                            : pngio::save_rgb8(part, frame, c.cam.resolution_x, c.cam.resolution_y, e, a.png_level, &tm);
           if (ok && std::rename(part.c_str(), file.c_str()) != 0) {
             ok = false;
             e = std::strerror(errno);
           }
-          for (int rep = 0; ok && rep < a.encode_bench; ++rep) { /* diagnostics: the host's encode capacity with one GPU feeding it */
+          for (int rep = 0; ok && !streams && rep < a.encode_bench; ++rep) { /* diagnostics: the host's encode capacity with one GPU feeding it */
             std::string e2;
             (void)pngio::save_rgb8(part + ".bench", frame, c.cam.resolution_x, c.cam.resolution_y, e2, a.png_level, &tb);
           }
@@ -1125,6 +1160,7 @@ int video_main(const Args &a) {
     std::string js = "{\"frames\": " + std::to_string(total_frames) + ", \"wall_s\": " + std::to_string(wall) +
                      ", \"frames_per_s\": " + std::to_string(wall > 0 ? total_frames / wall : 0.0) +
                      ", \"writers\": " + std::to_string(a.writers) + ", \"png_level\": " + std::to_string(a.png_level) +
+                     ", \"gpu_png\": " + (gpu_png ? "true" : "false") +
                      ", \"writer_drain_s\": " + std::to_string(t_video1 - t_workers_done);
     { /* how the two textures reached the devices: the slowest device's time; for RCCL the broadcast call alone as well
        * (root: upload first, then header + 2 x ncclBroadcast; the first collective of a communicator carries its set-up) */
@@ -1149,13 +1185,15 @@ int video_main(const Args &a) {
       const double kf = d.frames ? d.kernel_ms / d.frames : 0.0, rf = d.frames ? d.render_s * 1e3 / d.frames : 0.0;
       std::printf("%-7zu %-14s %-7zu %-16.3f %-21.3f %-6.1f %-9d %-8d %-7.2f %.2f\n", (size_t)a.device + r, d.pci_bus_id.c_str(), d.frames, kf, rf,
                   d.busy_s > 0 ? d.frames / d.busy_s : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s);
-      char buf[512];
+      char buf[768];
       std::snprintf(buf, sizeof buf,
                     "%s{\"device\": %zu, \"pci_bus_id\": \"%s\", \"frames\": %zu, \"batches\": %zu, \"kernel_ms_per_frame\": %.4f, "
                     "\"render_call_ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"mray_steps_per_s\": %.1f, \"sclk_mhz\": %d, \"power_w\": %d, "
-                    "\"wait_s\": %.3f, \"hand_over_s\": %.3f, \"buffer_wait_s\": %.3f, \"busy_s\": %.3f}",
+                    "\"wait_s\": %.3f, \"hand_over_s\": %.3f, \"buffer_wait_s\": %.3f, \"busy_s\": %.3f, \"gpu_png_frames\": %zu, "
+                    "\"gpu_png_kernel_ms_per_frame\": %.4f, \"gpu_png_fallback_frames\": %zu}",
                     r ? ", " : "", (size_t)a.device + r, d.pci_bus_id.c_str(), d.frames, d.batches, kf, rf, d.busy_s > 0 ? d.frames / d.busy_s : 0.0,
-                    d.kernel_ms > 0 ? (double)d.steps / d.kernel_ms / 1e3 : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s, d.pool_wait_s, d.busy_s);
+                    d.kernel_ms > 0 ? (double)d.steps / d.kernel_ms / 1e3 : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s, d.pool_wait_s, d.busy_s,
+                    d.png_frames, d.png_frames ? d.png_ms / d.png_frames : 0.0, d.png_fallback_frames);
       js += buf;
     }
     js += "]";

@@ -445,6 +445,22 @@ inline void for_each_token(const uint8_t *d, size_t n, Lit lit, Lit4 lit4, Match
   for (; i < n; ++i) lit(d[i]);
 }
 
+/* header of the ONE dynamic-Huffman block a frame is written as: final block, 286 literal/length codes of the given lengths
+ * (all non-zero), one distance code of length 1; the code lengths themselves go out raw, as 4-bit code-length codes.
+ * 1222 bits. */
+inline void put_dynamic_block_header(BitWriter &bw, const uint8_t ll_len[286]) {
+  bw.put(1, 1);  /* BFINAL */
+  bw.put(2, 2);  /* BTYPE = 10: dynamic Huffman */
+  bw.put(29, 5); /* HLIT: 286 literal/length codes */
+  bw.put(0, 5);  /* HDIST: 1 distance code */
+  bw.put(15, 4); /* HCLEN: all 19 code-length codes */
+  static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  for (int k = 0; k < 19; ++k) bw.put(order[k] < 16 ? 4u : 0u, 3u); /* lengths 0..15 written raw as 4-bit codes, no repeats */
+  auto rev4 = [](uint32_t v) { return ((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3); };
+  for (int i = 0; i < 286; ++i) bw.put(rev4(ll_len[i]), 4);
+  bw.put(rev4(1), 4); /* the one distance code: length 1 */
+}
+
 /* the whole PNG file of an RGB8 image into `out` */
 /* Returns the length of the PNG file now at the start of `out`.  `out` is scratch that is only ever GROWN (to the worst-case
  * size of this frame): a caller that reuses it across frames pays the allocation and its zero fill once, not per frame. */
@@ -544,16 +560,7 @@ inline size_t encode_rgb8_fast(const uint8_t *rgb, uint32_t w, uint32_t h, std::
   *o++ = 0x78;
   *o++ = 0x01;
   BitWriter bw(o);
-  bw.put(1, 1);  /* BFINAL */
-  bw.put(2, 2);  /* BTYPE = 10: dynamic Huffman */
-  bw.put(29, 5); /* HLIT: 286 literal/length codes */
-  bw.put(0, 5);  /* HDIST: 1 distance code */
-  bw.put(15, 4); /* HCLEN: all 19 code-length codes */
-  static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-  for (int k = 0; k < 19; ++k) bw.put(order[k] < 16 ? 4u : 0u, 3u); /* lengths 0..15 written raw as 4-bit codes, no repeats */
-  auto rev4 = [](uint32_t v) { return ((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3); };
-  for (int i = 0; i < 286; ++i) bw.put(rev4(ll_len[i]), 4);
-  bw.put(rev4(1), 4); /* the one distance code: length 1 */
+  put_dynamic_block_header(bw, ll_len);
   for_each_token(fl, n, [&](uint8_t b) { bw.put(ll[b] & 0xffffu, ll[b] >> 16); },
                  [&](uint32_t w4) { /* four codes (<= 12 bits each) in one store */
                    const uint32_t e0 = ll[w4 & 0xffu], e1 = ll[(w4 >> 8) & 0xffu], e2 = ll[(w4 >> 16) & 0xffu], e3 = ll[w4 >> 24];
@@ -604,6 +611,65 @@ inline bool write_file(const std::string &path, const uint8_t *data, size_t n, s
   const bool ok = std::fwrite(data, 1, n, f) == n;
   std::fclose(f);
   if (!ok) err = "short write to " + path;
+  return ok;
+}
+
+/* A PNG file around a finished zlib stream of the filtered scanlines (what curvis_ctx_deflate_frames hands back: filtering,
+ * Huffman coding and Adler-32 were done on the GPU): signature, IHDR, IDAT chunk(s) with their CRC-32, IEND. */
+inline bool save_zlib_stream_rgb8(const std::string &path, const uint8_t *z, size_t len, uint32_t w, uint32_t h, std::string &err,
+                                  EncodeTimes *tm = nullptr) {
+  const double t0 = now_s();
+  FILE *f = std::fopen(path.c_str(), "wb");
+  if (!f) {
+    err = "could not open " + path + " for writing";
+    return false;
+  }
+  auto be = [](uint8_t *q, uint32_t v) {
+    q[0] = (uint8_t)(v >> 24);
+    q[1] = (uint8_t)(v >> 16);
+    q[2] = (uint8_t)(v >> 8);
+    q[3] = (uint8_t)v;
+  };
+  uint8_t head[8 + 25 + 8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  uint8_t *o = head + 8;
+  be(o, 13);
+  std::memcpy(o + 4, "IHDR", 4);
+  be(o + 8, w);
+  be(o + 12, h);
+  o[16] = 8;
+  o[17] = 2;
+  o[18] = o[19] = o[20] = 0;
+  be(o + 21, (uint32_t)crc32(0L, o + 4, 17));
+  bool ok = std::fwrite(head, 1, 8 + 25, f) == 8 + 25;
+  double t_crc = 0.0;
+  const size_t kIdatMax = (size_t)1 << 30; /* a chunk stays below 2^31 bytes */
+  for (size_t off = 0; ok && (off < len || off == 0); off += kIdatMax) {
+    const size_t piece = std::min(kIdatMax, len - off);
+    uint8_t ch[8], tail[4];
+    be(ch, (uint32_t)piece);
+    std::memcpy(ch + 4, "IDAT", 4);
+    const double tc = now_s();
+    uLong crc = crc32(0L, ch + 4, 4);
+    crc = crc32(crc, z + off, (uInt)piece);
+    t_crc += now_s() - tc;
+    be(tail, (uint32_t)crc);
+    ok = std::fwrite(ch, 1, 8, f) == 8 && std::fwrite(z + off, 1, piece, f) == piece && std::fwrite(tail, 1, 4, f) == 4;
+    if (len == 0) break;
+  }
+  uint8_t end[12];
+  be(end, 0);
+  std::memcpy(end + 4, "IEND", 4);
+  be(end + 8, (uint32_t)crc32(0L, end + 4, 4));
+  ok = ok && std::fwrite(end, 1, 12, f) == 12;
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok) err = "short write to " + path;
+  if (tm) {
+    tm->checksum += t_crc;
+    tm->write += (now_s() - t0) - t_crc;
+    tm->raw_bytes += (size_t)w * 3 * h;
+    tm->file_bytes += 8 + 25 + 12 + len + 12 * ((len + kIdatMax - 1) / kIdatMax);
+    tm->frames += 1;
+  }
   return ok;
 }
 

@@ -1,0 +1,164 @@
+/* png_host.h -- host side of the device PNG front end (kernels_png.h): scratch layout, the two launches around the host's
+ * Huffman-code construction, assembly of one zlib stream per frame in the caller's buffer.
+ * Part of the ONE translation unit curvis_hip.hip (included there, nowhere else). */
+#pragma once
+
+namespace {
+
+struct PngScratch { /* one allocation, carved */
+  size_t hist, adler, codes, block_bits, start_bit, frame_bits, out, total;
+  size_t out_words;
+};
+
+PngScratch png_scratch_layout(const PngParams &P) {
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  PngScratch L{};
+  const size_t n = (size_t)P.H * (P.row_bytes + 1);
+  /* zlib header (16 bits) + block header (1222) + 12 bits per filtered byte + end of block, rounded up generously */
+  L.out_words = (((n * kPngCodeBits + 16 + 1222 + 64) / 32 + 8) + 3) & ~(size_t)3;
+  size_t off = 0;
+  L.hist = off;
+  off = up(off + (size_t)P.n_frames * kPngBins * sizeof(unsigned));
+  L.adler = off;
+  off = up(off + (size_t)P.n_frames * 2 * sizeof(unsigned long long));
+  L.codes = off;
+  off = up(off + (size_t)P.n_frames * kPngCodes * sizeof(unsigned));
+  L.block_bits = off;
+  off = up(off + (size_t)P.n_frames * P.blocks_per_frame * sizeof(unsigned long long));
+  L.start_bit = off;
+  off = up(off + (size_t)P.n_frames * sizeof(unsigned));
+  L.frame_bits = off;
+  off = up(off + (size_t)P.n_frames * sizeof(unsigned long long));
+  L.out = off;
+  off = up(off + (size_t)P.n_frames * L.out_words * sizeof(unsigned));
+  L.total = off;
+  return L;
+}
+
+/* frames [0, n_frames) of W x H RGB8 in ctx->d_fb -> zlib streams, back to back in `out`; offsets[f] .. offsets[f + 1] is
+ * frame f's stream.  kernel_ms: HIP-event time of the five launches (the host's code construction between them excluded). */
+int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_frames, uint8_t *out, size_t out_cap, size_t *offsets,
+                        double *kernel_ms) {
+  if (!ctx || !out || !offsets || W == 0 || H == 0 || n_frames == 0) return fail(ctx, CURVIS_E_INVALID, "bad argument");
+  const size_t frame_bytes = (size_t)W * 3 * H;
+  if (!ctx->d_fb || frame_bytes * n_frames > ctx->fb_bytes)
+    return fail(ctx, CURVIS_E_INVALID, "the context's framebuffer does not hold that many frames of that size (render first)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  PngParams P{};
+  P.fb = ctx->d_fb;
+  P.frame_bytes = frame_bytes;
+  P.W = W;
+  P.H = H;
+  P.row_bytes = W * 3;
+  P.chunks_per_row = (P.row_bytes + kPngChunk - 1) / kPngChunk;
+  const uint64_t cpf = (uint64_t)P.chunks_per_row * H;
+  if (cpf > 0x7fffffffull) return fail(ctx, CURVIS_E_INVALID, "frame too large for the device PNG front end");
+  P.chunks_per_frame = (unsigned)cpf;
+  P.blocks_per_frame = (P.chunks_per_frame + kPngBlock - 1) / kPngBlock;
+  P.n_frames = n_frames;
+  P.aligned = (P.row_bytes % 16u) == 0u ? 1 : 0;
+  const PngScratch L = png_scratch_layout(P);
+  int rc = ensure_device(ctx, ctx->d_png, ctx->png_cap, L.total);
+  if (rc) return rc;
+  unsigned char *base = ctx->d_png;
+  P.hist = (unsigned *)(base + L.hist);
+  P.adler = (unsigned long long *)(base + L.adler);
+  P.codes = (const unsigned *)(base + L.codes);
+  P.block_bits = (unsigned long long *)(base + L.block_bits);
+  P.start_bit = (const unsigned *)(base + L.start_bit);
+  P.frame_bits = (unsigned long long *)(base + L.frame_bits);
+  P.out = (unsigned *)(base + L.out);
+  P.out_words = L.out_words;
+  const dim3 grid(P.blocks_per_frame, n_frames), block(kPngBlock);
+  float ms_a = 0.f, ms_b = 0.f;
+
+  /* pass 1: histograms + Adler sums */
+  HIP_TRY(ctx, hipMemsetAsync(base + L.hist, 0, L.codes - L.hist, ctx->stream)); /* hist and adler are adjacent */
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(png_hist_kernel, grid, block, 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  std::vector<unsigned> hist((size_t)n_frames * kPngBins);
+  std::vector<unsigned long long> adler((size_t)n_frames * 2);
+  HIP_TRY(ctx, hipMemcpyAsync(hist.data(), base + L.hist, hist.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(adler.data(), base + L.adler, adler.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipEventElapsedTime(&ms_a, ctx->ev0, ctx->ev1));
+
+  /* the frames' codes: lengths <= 12 bits over the 286 literal/length symbols (every symbol keeps a code: +1 on each count,
+   * which also makes the block header the host writer's), one distance code */
+  std::vector<unsigned> codes((size_t)n_frames * kPngCodes, 0u), start_bit(n_frames);
+  std::vector<std::array<uint8_t, 176>> header(n_frames); /* zlib header + block header: 16 + 1222 bits, + BitWriter slack */
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    uint32_t freq[286];
+    for (int i = 0; i < 286; ++i) freq[i] = hist[(size_t)f * kPngBins + i] + 1u;
+    freq[256] += 1u; /* the end-of-block symbol */
+    uint8_t ll_len[286];
+    uint32_t ll[286];
+    pngio::huffman_lengths(freq, 286, (int)kPngCodeBits, ll_len);
+    pngio::canonical_codes(ll_len, 286, ll);
+    unsigned *c = codes.data() + (size_t)f * kPngCodes;
+    for (int v = 0; v < 256; ++v) c[v] = (ll[v] & 0xffffu) | ((ll[v] >> 16) << 24);
+    c[256] = (ll[256] & 0xffffu) | ((ll[256] >> 16) << 24); /* end of block, in the slot of the impossible "match of length 0" */
+    for (int len = 3; len < (int)kPngChunk; ++len) {
+      int sym, eb, ev;
+      pngio::length_symbol(len, sym, eb, ev);
+      const unsigned cl = ll[sym] >> 16;
+      const unsigned bits = (ll[sym] & 0xffffu) | ((unsigned)ev << cl); /* + the distance code: one zero bit */
+      c[256 + len] = bits | ((cl + (unsigned)eb + 1u) << 24);
+    }
+    header[f].fill(0);
+    header[f][0] = 0x78;
+    header[f][1] = 0x01;
+    pngio::BitWriter bw(header[f].data() + 2);
+    pngio::put_dynamic_block_header(bw, ll_len);
+    start_bit[f] = (unsigned)((bw.p - header[f].data()) * 8 + bw.nb);
+    bw.finish();
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(base + L.codes, codes.data(), codes.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(base + L.start_bit, start_bit.data(), start_bit.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+
+  /* passes 2 and 3 */
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(png_count_kernel, grid, block, 0, ctx->stream, P);
+  hipLaunchKernelGGL(png_scan_kernel, dim3(n_frames), block, 0, ctx->stream, P);
+  hipLaunchKernelGGL(png_zero_kernel, dim3(64, n_frames), block, 0, ctx->stream, P);
+  hipLaunchKernelGGL(png_emit_kernel, grid, block, 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  std::vector<unsigned long long> frame_bits(n_frames);
+  HIP_TRY(ctx, hipMemcpyAsync(frame_bits.data(), base + L.frame_bits, frame_bits.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipEventElapsedTime(&ms_b, ctx->ev0, ctx->ev1));
+
+  /* streams to the host: deflate bytes, then the Adler-32 of the filtered scanlines */
+  size_t off = 0;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const size_t bytes = (size_t)((frame_bits[f] + 7) / 8);
+    if (bytes > L.out_words * 4 || off + bytes + 4 > out_cap)
+      return fail(ctx, CURVIS_E_INVALID, "output buffer too small for the compressed frames");
+    offsets[f] = off;
+    HIP_TRY(ctx, hipMemcpyAsync(out + off, (const uint8_t *)(P.out + (size_t)f * L.out_words), bytes, hipMemcpyDeviceToHost, ctx->stream));
+    off += bytes + 4;
+  }
+  offsets[n_frames] = off;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const unsigned long long n = (unsigned long long)H * ((unsigned long long)W * 3 + 1);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    uint8_t *z = out + offsets[f];
+    const size_t hb = (start_bit[f] + 7) / 8;
+    for (size_t k = 0; k < hb; ++k) z[k] |= header[f][k]; /* the device wrote from bit start_bit on, into zeroed words */
+    const unsigned long long s1 = (1ull + adler[(size_t)f * 2]) % 65521ull, s2 = (n % 65521ull + adler[(size_t)f * 2 + 1]) % 65521ull;
+    uint8_t *a = out + offsets[f + 1] - 4;
+    a[0] = (uint8_t)(s2 >> 8);
+    a[1] = (uint8_t)s2;
+    a[2] = (uint8_t)(s1 >> 8);
+    a[3] = (uint8_t)s1;
+  }
+  if (kernel_ms) *kernel_ms = (double)ms_a + (double)ms_b;
+  ctx->last_png_ms = (double)ms_a + (double)ms_b;
+  return CURVIS_OK;
+}
+
+}  // namespace

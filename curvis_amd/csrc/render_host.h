@@ -31,6 +31,9 @@ struct curvis_ctx {
   unsigned char *d_rq = nullptr;    /* RelayQueue + ticket ring of the relay kernel */
   unsigned char *d_verify = nullptr; /* copy of the relay kernel's frame while the static kernel re-renders it (seat belt) */
   size_t verify_cap = 0;
+  unsigned char *d_png = nullptr;    /* scratch of the device PNG front end (kernels_png.h): histograms, codes, offsets, streams */
+  size_t png_cap = 0;
+  double last_png_ms = 0.0;          /* HIP-event time of the last curvis_ctx_deflate_frames */
   int relay_segment = 0;            /* steps between two hand-over points; 0 = automatic */
   int relay_max_hops = 0;           /* hand-overs per tile at most; 0 = no limit */
   int relay_max_frames = 8;         /* largest launch (frames) the relay kernel is used for: the end-game it repairs is

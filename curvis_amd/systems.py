@@ -355,6 +355,18 @@ class Context:
         check(lib().curvis_ctx_read_sky(self._h, int(which), int(offset), int(nbytes), out.ctypes.data), self._h)
         return out
 
+    def deflate_frames(self, width, height, n_frames=1, out=None):
+        """curvis_ctx_deflate_frames: the frames the last render call left in HBM -> [zlib stream of frame 0, ...] (bytes
+        objects) and the HIP-event time of the kernels in ms.  `out`: a uint8 array to receive the streams (a HostBuffer's
+        array: page-locked); default: a fresh array of the worst-case size."""
+        if out is None:
+            out = np.empty(int(n_frames) * ((height * (width * 3 + 1)) * 3 // 2 + 512), dtype=np.uint8)
+        offs = (C.c_size_t * (int(n_frames) + 1))()
+        ms = C.c_double(0.0)
+        check(lib().curvis_ctx_deflate_frames(self._h, int(width), int(height), int(n_frames), out.ctypes.data, out.size, offs,
+                                              C.byref(ms)), self._h)
+        return [out[offs[k]:offs[k + 1]].tobytes() for k in range(int(n_frames))], ms.value
+
     def set_option(self, key, value):
         check(lib().curvis_ctx_set_option(self._h, key.encode(), int(value)), self._h)
 

@@ -128,7 +128,9 @@ int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root);
  * out-of-band channel it has; every process then joins with its own context (ncclCommInitRank on the context's
  * device) and passes the returned communicator to curvis_ctx_bcast_skies.  The communicator is the caller's:
  * curvis_rccl_comm_destroy it after the broadcast.  A one-process / N-thread host (`curvis video --devices N`) needs
- * none of this: it calls ncclCommInitAll itself.  No reference counterpart (single-threaded CPU code). */
+ * none of this: it calls ncclCommInitAll itself.  Single node by design (frames shard over the GPUs of ONE node): unless
+ * NCCL_SOCKET_IFNAME is set these two calls set it to "lo", so RCCL's bootstrap does not wait on an unroutable interface.
+ * No reference counterpart (single-threaded CPU code). */
 #define CURVIS_RCCL_ID_BYTES 128
 int curvis_rccl_unique_id(uint8_t id[CURVIS_RCCL_ID_BYTES]);
 int curvis_ctx_rccl_comm_init(curvis_ctx *ctx, const uint8_t id[CURVIS_RCCL_ID_BYTES], int n_ranks, int rank,
@@ -276,6 +278,19 @@ int curvis_image_save_rgb8(const char *path, const uint8_t *rgb, uint32_t w, uin
  * only matches are zero runs: what `curvis video` writes its frames with; the reference's image crate also saves
  * with its fast setting), 0..9 = zlib at that level.  Same decoded pixels whatever the level. */
 int curvis_image_save_rgb8_level(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h, int level);
+
+/* PNG front end ON THE DEVICE, for hosts that save every frame (src/rendering.rs:110, :311): the `n_frames` RGB8 frames of
+ * res_x x res_y pixels that the last render call left in the context's framebuffer (call it with rgb_out = NULL: the pixels
+ * then never cross PCIe) are filtered (type 2, Up), Huffman-coded (one dynamic block per frame, distance-1 matches for zero
+ * runs) and check-summed (Adler-32) by HIP kernels; what comes back is one finished zlib stream per frame, back to back in
+ * `zlib_out` (host memory, preferably from curvis_host_alloc), frame f at [offsets[f], offsets[f + 1]) -- `offsets` has
+ * n_frames + 1 entries.  curvis_image_save_zlib_rgb8 wraps such a stream into a PNG file (signature, IHDR, IDAT + CRC-32,
+ * IEND: ~0.1 ms of a host thread per MB of stream instead of 4-7 ms per 1080p frame for filtering and coding on the
+ * host).  CURVIS_E_INVALID with "output buffer too small" when out_cap does not suffice (worst case: 1.5 x the raw
+ * frames + 200 bytes each; typical frames compress 10-100 x).  kernel_ms (may be NULL): HIP-event time of the launches. */
+int curvis_ctx_deflate_frames(curvis_ctx *ctx, uint32_t res_x, uint32_t res_y, uint32_t n_frames, uint8_t *zlib_out, size_t out_cap,
+                              size_t *offsets, double *kernel_ms);
+int curvis_image_save_zlib_rgb8(const char *path, const uint8_t *zlib_stream, size_t len, uint32_t w, uint32_t h);
 
 /* Page-locked host memory for the `rgb_out` buffers of the render calls: into such a buffer the device-to-host copy of
  * a frame is ONE DMA transfer (~25 GB/s over PCIe 5), into ordinary pageable memory the runtime stages it through

@@ -122,6 +122,10 @@ def test_video_orbit_frames_and_quirks(scene_files):
     assert summ["frames"] == 15 and summ["png_level"] == -1 and len(summ["devices"]) == 1
     dev = summ["devices"][0]
     assert dev["frames"] == 15 and dev["kernel_ms_per_frame"] > 0 and len(dev["pci_bus_id"].split(":")) == 3
+    # the default writer: PNG front end on the device (filter, Huffman coding, Adler-32 in HIP kernels; the frames checked above
+    # against the oracle were decoded from ITS streams), a writer thread only wraps the stream and adds the CRC
+    assert summ["gpu_png"] is True and dev["gpu_png_frames"] == 15 and dev["gpu_png_fallback_frames"] == 0
+    assert dev["gpu_png_kernel_ms_per_frame"] > 0 and summ["encode"]["filter_ms"] == 0 and summ["encode"]["deflate_ms"] == 0
     enc = summ["encode"]
     assert enc["frames"] == 15 and enc["thread_ms_per_frame"] > 0 and enc["file_mb_per_frame"] < enc["raw_mb_per_frame"]
     assert "pci_bus_id" in r.stdout and "writer thread" in r.stdout
@@ -136,8 +140,14 @@ def test_video_orbit_frames_and_quirks(scene_files):
         a = pngio.read_png(out / "tmp" / ("frame_%d.png" % k))
         assert np.array_equal(a, pngio.read_png(out2 / "tmp" / ("frame_%d.png" % k))), k
     r3 = run("video", d / "pos.png", d / "neg.png", out2, "-v", d / "vid.toml", "-s", d / "sim.toml", "-c", d / "cam.toml",
-             "--batch", "2", "--writers", "1", "--encode-bench", "5")   # fast writer, pool starved of writers: back-pressure, no crash
+             "--batch", "2", "--writers", "1", "--encode-bench", "5", "--stats", out2 / "st3.jsonl")   # HOST fast writer, pool starved of writers: back-pressure, no crash
     assert r3.returncode == 0, r3.stderr
+    s3 = json.loads((out2 / "st3.jsonl.summary.json").read_text())
+    assert s3["gpu_png"] is False and s3["encode"]["deflate_ms"] > 0          # --encode-bench measures the host encoder
+    for k in range(15):   # host fast writer == device front end == zlib, pixel for pixel
+        assert np.array_equal(pngio.read_png(out2 / "tmp" / ("frame_%d.png" % k)), pngio.read_png(out / "tmp" / ("frame_%d.png" % k))), k
+    r4 = run("video", d / "pos.png", d / "neg.png", out2, "-v", d / "vid.toml", "-s", d / "sim.toml", "-c", d / "cam.toml", "--gpu-png", "off")
+    assert r4.returncode == 0, r4.stderr
     assert np.array_equal(pngio.read_png(out2 / "tmp" / "frame_14.png"), pngio.read_png(out / "tmp" / "frame_14.png"))
 
 

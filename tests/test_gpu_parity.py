@@ -766,8 +766,8 @@ def test_render_into_page_locked_host_buffer(gpu_ctx):
 
 def test_relay_seat_belt_checks_the_first_launch_of_every_shape(capfd):
     """The relay kernel's hand-over is argued from gfx950 facts, not from the HIP memory model, so the first
-    relay launch of every launch shape of a context is repeated by the static kernel and compared.  Clean launches:
-    one check per shape, none afterwards.  A hand-over that delivers a wrong state (hook "relay_test_corrupt": every relay wave
+    relay launch of every launch shape of a context -- and every 1024th after it -- is repeated by the static kernel and
+    compared.  Clean launches: one check per shape, the next one 1024 launches later.  A hand-over that delivers a wrong state (hook "relay_test_corrupt": every relay wave
     of that launch perturbs the tile it reloads) is caught: the frame returned is the static kernel's,
     the mismatch is counted and reported, and the context stays on the static kernel."""
     sp, sn = common.make_skies(2048, 1024, "smooth")   # smooth: every change of direction shows (a 64-texel checker cell would hide it)
@@ -790,6 +790,21 @@ def test_relay_seat_belt_checks_the_first_launch_of_every_shape(capfd):
         rgb2, s2 = ctx.render_brute(pm, [pc, pc], 4096, 100.0, 0.05)                                     # another shape: checked again
         assert np.array_equal(rgb2[0], want) and np.array_equal(rgb2[1], want) and s2.steps == 2 * st.steps
         assert ctx.get_option("relay_verified_shapes") == 2 and ctx.get_option("relay_disabled") == 0
+        # the check comes back every `relay_recheck_every`-th relay launch of a shape (default 1024: ~0.1 % overhead), so a
+        # hand-over that starts to fail LATER in a context's life is caught too: with 3, launches 0, 3, 6 of a shape are checked
+        assert ctx.get_option("relay_recheck_every") == 1024
+        ctx.set_option("relay_recheck_every", 3)
+        base = ctx.get_option("relay_checks")
+        assert base == 2                                                                                 # the two first launches above
+        for k in range(5):                                                                               # launches 2..6 of the one-frame shape
+            rgb, _ = ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+            assert np.array_equal(rgb, want)
+        assert ctx.get_option("relay_checks") == base + 2 and ctx.get_option("relay_mismatches") == 0   # launches 3 and 6
+        # a band of the frame or another step cap is another shape (they change the hand-over pattern)
+        ctx.render_brute_rows(pm, pc, 0, 136, 4096, 100.0, 0.05)
+        ctx.render_brute(pm, pc, 3000, 100.0, 0.05)
+        assert ctx.get_option("relay_verified_shapes") == 4
+        ctx.set_option("relay_recheck_every", 1024)
         # an unchecked launch with the hook shows that the hook does corrupt a frame ...
         ctx.set_option("relay_auto_verify", 0)
         ctx.set_option("relay_test_corrupt", 1)

@@ -1,0 +1,109 @@
+"""PNG front end on the device (curvis_ctx_deflate_frames, kernels_png.h): the frames a render call left in HBM come back as
+finished zlib streams; wrapped into PNG files they must decode -- with Python's zlib (which also checks the Adler-32 the
+device computed), with this repository's two PNG decoders -- to exactly the pixels the same render call downloads.
+Reference seam: `image::DynamicImage::save` after every frame (src/rendering.rs:110, :311)."""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import common
+import curvis_amd
+from curvis_amd import _abi, pngio
+
+pytestmark = pytest.mark.gpu
+
+
+def unfilter_up(raw, w, h):
+    rows = np.frombuffer(raw, np.uint8).reshape(h, w * 3 + 1)
+    assert (rows[:, 0] == 2).all()                                   # filter type Up on every row
+    return np.cumsum(rows[:, 1:].astype(np.uint32), axis=0).astype(np.uint8).reshape(h, w, 3)   # Up: running sum mod 256
+
+
+def product_decode(path):
+    p, w, h = C.POINTER(C.c_uint8)(), C.c_uint32(), C.c_uint32()
+    _abi.check(_abi.lib().curvis_image_load(str(path).encode(), C.byref(p), C.byref(w), C.byref(h)))
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
+    finally:
+        _abi.lib().curvis_image_free(p)
+
+
+def check_streams(ctx, tmp_path, frames, w, h, tag):
+    streams, ms = ctx.deflate_frames(w, h, len(frames))
+    assert ms > 0 and len(streams) == len(frames)
+    for k, (z, want) in enumerate(zip(streams, frames)):
+        assert z[:2] == b"\x78\x01"
+        raw = zlib.decompress(z)                                      # raises on a wrong Adler-32 or a malformed block
+        assert len(raw) == h * (w * 3 + 1)
+        assert np.array_equal(unfilter_up(raw, w, h), want), (tag, k)
+        path = tmp_path / ("%s_%d.png" % (tag, k))
+        buf = np.frombuffer(z, np.uint8)
+        _abi.check(_abi.lib().curvis_image_save_zlib_rgb8(str(path).encode(), buf.ctypes.data, buf.size, w, h))
+        assert np.array_equal(pngio.read_png(path), want), (tag, k)              # decoder 1: tests' own (zlib + unfilter)
+        got = product_decode(path)                                               # decoder 2: the product's (host/png_io.h)
+        assert np.array_equal(got[..., :3], want) and (got[..., 3] == 255).all(), (tag, k)
+    return streams, ms
+
+
+@pytest.mark.parametrize("metric,res", [("ellis", (96, 54)), ("interstellar", (64, 36)), ("ellis", (50, 31)), ("ellis", (7, 3)), ("ellis", (341, 17))])
+def test_brute_frames_round_trip(gpu_ctx, tmp_path, metric, res):
+    """aligned rows (16-byte loads) and ragged ones (50, 7, 341 pixels: byte loads, a last chunk of 22 / 21 / 63 bytes)"""
+    sp, sn = common.make_skies(512, 256, "check")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    _, _, pm, pc = common.scene(metric, res=res)
+    rgb, _ = gpu_ctx.render_brute(pm, pc, 4096, 100.0, 0.05)
+    check_streams(gpu_ctx, tmp_path, [rgb], res[0], res[1], "brute")
+
+
+def test_batch_of_frames_and_black_frame(gpu_ctx, tmp_path):
+    """a multi-frame launch (every frame its own code and stream) and an all-black frame (cap 0: nothing but zero runs,
+    cut into matches of 63 at the 64-byte chunk boundaries)"""
+    sp, sn = common.make_skies(512, 256, "smooth")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    cams = []
+    for k in range(5):
+        _, _, pm, pc = common.scene("ellis", res=(128, 72), pos=(0.0, 3.0 + k, common.HALF_PI, 0.5 * k))
+        cams.append(pc)
+    rgb, _ = gpu_ctx.render_brute(pm, cams, 4096, 100.0, 0.05)
+    streams, _ = check_streams(gpu_ctx, tmp_path, list(rgb), 128, 72, "batch")
+    assert len(set(streams)) == 5
+    black, _ = gpu_ctx.render_brute(pm, cams[0], 0, 100.0, 0.05)
+    assert not black.any()
+    (z,), _ = check_streams(gpu_ctx, tmp_path, [black], 128, 72, "black")
+    assert len(z) < 128 * 72 * 3 // 30                                 # 72 rows x (1 literal + 6 x (literal + match)) + header
+
+
+def test_efficient_frames_and_full_hd(gpu_ctx, tmp_path):
+    """what `curvis video` (default mode) saves: render_image_efficient frames, 1920x1080, left in HBM (download=False) and
+    compressed there; the stream is a small fraction of the 6.2 MB frame and decodes to the frame a download gives"""
+    sp, sn = common.make_skies(2048, 1024, "smooth")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    cams = []
+    for k in range(3):
+        _, _, pm, pc = common.scene("ellis", res=(1920, 1080), pos=(0.0, 4.0 + k, common.HALF_PI, 0.3 * k))
+        cams.append(pc)
+    want, _ = gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+    gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
+    streams, ms = check_streams(gpu_ctx, tmp_path, list(want), 1920, 1080, "eff")
+    assert all(len(z) < 1920 * 1080 * 3 // 4 for z in streams)
+    print("device PNG front end: 3 x 1080p in %.3f ms, streams %s bytes" % (ms, [len(z) for z in streams]))
+
+
+def test_errors(gpu_ctx):
+    sp, sn = common.make_skies(64, 32, "check")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    _, _, pm, pc = common.scene("ellis", res=(32, 18))
+    gpu_ctx.render_brute(pm, pc, 100, 100.0, 0.05)
+    with pytest.raises(curvis_amd.CurvisError) as e:
+        gpu_ctx.deflate_frames(32, 18, 2)                              # only one frame of that size is there
+    assert e.value.code == _abi.E_INVALID
+    with pytest.raises(curvis_amd.CurvisError) as e:
+        gpu_ctx.deflate_frames(32, 18, 1, out=np.empty(64, np.uint8))
+    assert e.value.code == _abi.E_INVALID and "too small" in str(e.value)
