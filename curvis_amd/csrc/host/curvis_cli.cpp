@@ -22,7 +22,9 @@
  * --resume (video: keep <out>/tmp and skip the frames whose frame_{k}.png is already there; default off = the
  * reference's behaviour of deleting and recreating tmp, src/rendering.rs:276-287), --gpu-png auto|on|off (video: filter + Huffman
  * coding + Adler-32 of every frame on the GPU, curvis_ctx_deflate_frames -- the frames never cross PCIe as pixels and a writer
- * thread only wraps the stream into a PNG file; auto = with the fast writer, in modes brute and efficient).  A batch of frames whose render
+ * thread only wraps the stream into a PNG file; auto = with the fast writer, in modes brute and efficient),
+ * --contexts-per-device C (video: C worker threads with a context each per GPU, frames k mod (N*C); default 2 in --mode
+ * efficient, whose render call is half host work, else 1).  A batch of frames whose render
  * call fails is re-queued on another GPU (frames are independent) before the run is declared failed.
  * Backgrounds: PNG (any colour type / bit depth) or JPEG (8-bit Huffman, baseline / progressive, grey or YCbCr; own
  * decoder in jpeg_io.h -- JPEG input is outside the pixel-parity claims, see there).
@@ -412,6 +414,7 @@ struct Args {
   std::string sub, bg1, bg2, out, image_toml, video_toml, metric_toml, camera_toml, sim_toml, mode = "efficient", stats,
       sky_broadcast = "rccl";
   bool sky_broadcast_explicit = false, resume = false;
+  int contexts = 0; /* 0 = automatic (2 in --mode efficient, else 1); video: contexts (= host worker threads) per device: while one waits on the host-side sampler or the D2H copy another's kernels run */
   int devices = 1, device = 0, batch = 8, writers = 0; /* writers 0 = automatic: a quarter of the host's threads, 4..64 */
   int png_level = -1; /* -1 = the fast PNG writer (png_io.h; the reference's image crate also saves with its fast setting), 0..9 = zlib */
   int encode_bench = 0; /* video, diagnostics: every rendered frame is encoded this many extra times into a scratch file */
@@ -429,7 +432,8 @@ void usage() {
       "curvis video <IMAGE FILE 1> <IMAGE FILE 2> [OUTPUT FOLDER] [-v|--video-settings <TOML FILE>]\n"
       "  common: [-m|--metric-settings <TOML FILE>] [-c|--camera-settings <TOML FILE>] [-s|--simulation-settings <TOML FILE>]\n"
       "  extensions: [--mode efficient|brute|direct] [--device N] [--devices N] [--batch B] [--stats FILE]\n"
-      "              [--sky-broadcast rccl|upload] [--writers T] [--resume] [--png-level -1..9] [--gpu-png auto|on|off]\n");
+      "              [--sky-broadcast rccl|upload] [--writers T] [--resume] [--png-level -1..9] [--gpu-png auto|on|off]\n"
+      "              [--contexts-per-device C]\n");
 }
 Args parse_args(int argc, char **argv) {
   Args a;
@@ -466,6 +470,7 @@ Args parse_args(int argc, char **argv) {
     else if (key == "--sky-broadcast") { take(a.sky_broadcast); a.sky_broadcast_explicit = true; }
     else if (key == "--resume") a.resume = true;
     else if (key == "--devices") { take(val); a.devices = std::atoi(val.c_str()); }
+    else if (key == "--contexts-per-device") { take(val); a.contexts = std::max(0, std::min(8, std::atoi(val.c_str()))); }
     else if (key == "--device") { take(val); a.device = std::atoi(val.c_str()); }
     else if (key == "--batch") { take(val); a.batch = std::atoi(val.c_str()); }
     else if (key == "--writers") { take(val); a.writers = std::atoi(val.c_str()); }
@@ -489,6 +494,10 @@ Args parse_args(int argc, char **argv) {
   if (a.sky_broadcast != "rccl" && a.sky_broadcast != "upload") die("error: --sky-broadcast must be rccl or upload", 2);
   if (a.gpu_png != "auto" && a.gpu_png != "on" && a.gpu_png != "off") die("error: --gpu-png must be auto, on or off", 2);
   if (a.devices < 1) a.devices = 1;
+  /* --mode efficient spends about half of a frame's render call on the host (the adaptive sampler between its launches of
+   * lone waves): two contexts per GPU overlap that with each other's kernels (measured: 1830 -> 2500 1080p frames/s on one
+   * MI355X, three or four contexts are slower again).  The per-pixel modes keep the GPU busy by themselves. */
+  if (a.contexts == 0) a.contexts = a.mode == "efficient" ? 2 : 1;
   if (a.batch < 1) a.batch = 1;
   if (a.writers < 1) { /* encoding a 1080p frame costs 5-25 ms of a host thread (zlib: 20-230): the GPU renders one in 0.4-10 ms */
     unsigned hw = std::thread::hardware_concurrency();
@@ -867,8 +876,13 @@ int video_main(const Args &a) {
     double sky_s = 0, sky_bcast_s = 0; /* skies into this device's HBM: all of it / the curvis_ctx_bcast_skies call alone */
     unsigned long long steps = 0;
   };
-  std::vector<DeviceSummary> dev_sum((size_t)a.devices);
-  std::vector<std::unique_ptr<PinnedPool>> pools((size_t)a.devices); /* destroyed after writers.finish() below */
+  /* workers = devices x contexts-per-device; worker r drives device r / contexts with a context of its own (`--mode efficient`
+   * spends half of a frame's render call on the host -- the adaptive sampler between its launches --, so a second context
+   * on the same GPU fills the gaps) */
+  const int n_workers = a.devices * a.contexts;
+  auto device_of = [&](int rank) { return a.device + rank / a.contexts; };
+  std::vector<DeviceSummary> dev_sum((size_t)n_workers);
+  std::vector<std::unique_ptr<PinnedPool>> pools((size_t)n_workers); /* destroyed after writers.finish() below */
   const double t_video0 = pngio::now_s();
   /* sky distribution: rank 0 uploads the two textures once; with --sky-broadcast rccl (default for
    * --devices > 1) the other GPUs receive them with ncclBroadcast over xGMI (curvis_ctx_bcast_skies),
@@ -901,11 +915,11 @@ int video_main(const Args &a) {
     std::vector<size_t> frames;
     int attempts = 0, last_device = -1;
   };
-  std::vector<std::deque<Batch>> own((size_t)a.devices);
+  std::vector<std::deque<Batch>> own((size_t)n_workers);
   size_t n_skipped = 0, n_batches = 0;
-  for (int r = 0; r < a.devices; ++r) {
+  for (int r = 0; r < n_workers; ++r) {
     Batch cur;
-    for (size_t k = (size_t)r; k < n_frames; k += (size_t)a.devices) {
+    for (size_t k = (size_t)r; k < n_frames; k += (size_t)n_workers) {
       if (a.resume) {
         struct stat sb;
         const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
@@ -932,12 +946,12 @@ int video_main(const Args &a) {
   std::condition_variable q_cv;
   std::deque<Batch> retry;
   size_t batches_done = 0;
-  const int max_attempts = std::max(2, a.devices);
+  const int max_attempts = std::max(2, n_workers);
   /* fault injection for the tests: "rank:n" makes the n-th render call of that worker fail once */
   int fail_rank = -1, fail_call = -1;
   if (const char *fi = std::getenv("CURVIS_TEST_FAIL_BATCH")) std::sscanf(fi, "%d:%d", &fail_rank, &fail_call);
   auto worker = [&](int rank) {
-    curvis_ctx *ctx = make_ctx_bare(share_device ? a.device : a.device + rank, "video");
+    curvis_ctx *ctx = make_ctx_bare(share_device ? a.device : device_of(rank), "video");
     DeviceSummary &ds = dev_sum[(size_t)rank];
     {
       char id[64] = {0};
@@ -945,10 +959,10 @@ int video_main(const Args &a) {
       ds.pci_bus_id = id;
     }
     const double t_worker0 = pngio::now_s();
-    if (use_rccl) {
+    if (use_rccl && rank % a.contexts == 0) { /* one context per device takes part in the broadcast; its siblings upload */
       if (rank == 0) upload_skies(ctx, c, "video");
       const double t_b0 = pngio::now_s();
-      check(curvis_ctx_bcast_skies(ctx, comms[rank], 0), ctx, "video");
+      check(curvis_ctx_bcast_skies(ctx, comms[rank / a.contexts], 0), ctx, "video");
       ds.sky_bcast_s = pngio::now_s() - t_b0;
       /* every GPU checks what arrived over xGMI against the decoded files (head, middle and tail of both textures):
        * a broken broadcast must stop the run, not colour its frames */
@@ -961,7 +975,7 @@ int video_main(const Args &a) {
           if (std::getenv("CURVIS_TEST_CORRUPT_BCAST")) got[piece / 2] ^= 0x10;  /* test hook: pretend a flipped bit */
           if (std::memcmp(got.data(), sk[w]->rgba.data() + off, piece) != 0)
             die("Error in rendering video: background " + std::to_string(w + 1) + " arrived corrupted on device " +
-                std::to_string(a.device + rank) + " after the RCCL broadcast");
+                std::to_string(device_of(rank)) + " after the RCCL broadcast");
         }
       }
     } else {
@@ -976,7 +990,7 @@ int video_main(const Args &a) {
     PinnedPool &pool = *pools[(size_t)rank];
     if (pool.buffers() < 2) {
       std::lock_guard<std::mutex> gi(io_mu);
-      std::fprintf(stderr, "warning: device %d: no page-locked host memory for the frame buffers, using pageable memory\n", a.device + rank);
+      std::fprintf(stderr, "warning: device %d: no page-locked host memory for the frame buffers, using pageable memory\n", device_of(rank));
     }
     int calls = 0;
     for (;;) {
@@ -992,7 +1006,7 @@ int video_main(const Args &a) {
             return;
           }
           auto it = retry.begin();
-          while (it != retry.end() && it->last_device == rank && a.devices > 1) ++it;
+          while (it != retry.end() && it->last_device == rank && n_workers > 1) ++it;
           if (it != retry.end()) {
             b = *it;
             retry.erase(it);
@@ -1053,7 +1067,7 @@ int video_main(const Args &a) {
         {
           std::lock_guard<std::mutex> gi(io_mu);
           std::fprintf(stderr, "warning: device %d: rendering frames %zu.. failed: %s (code %d), attempt %d of %d%s\n",
-                       a.device + rank, b.frames[0], injected ? "injected test fault" : curvis_last_error(ctx), rc,
+                       device_of(rank), b.frames[0], injected ? "injected test fault" : curvis_last_error(ctx), rc,
                        b.attempts + 1, max_attempts, b.attempts + 1 < max_attempts ? "; re-queued" : "");
         }
         b.attempts++;
@@ -1106,9 +1120,12 @@ int video_main(const Args &a) {
             ok = false;
             e = std::strerror(errno);
           }
-          for (int rep = 0; ok && !streams && rep < a.encode_bench; ++rep) { /* diagnostics: the host's encode capacity with one GPU feeding it */
+          for (int rep = 0; ok && rep < a.encode_bench; ++rep) { /* diagnostics: the host's encode capacity with one GPU feeding it */
             std::string e2;
-            (void)pngio::save_rgb8(part + ".bench", frame, c.cam.resolution_x, c.cam.resolution_y, e2, a.png_level, &tb);
+            if (streams)
+              (void)pngio::save_zlib_stream_rgb8(part + ".bench", frame, f_len, c.cam.resolution_x, c.cam.resolution_y, e2, &tb);
+            else
+              (void)pngio::save_rgb8(part + ".bench", frame, c.cam.resolution_x, c.cam.resolution_y, e2, a.png_level, &tb);
           }
           if (a.encode_bench) std::remove((part + ".bench").c_str());
           std::lock_guard<std::mutex> g(io_mu);
@@ -1130,7 +1147,7 @@ int video_main(const Args &a) {
           std::printf("Rendering frame %zu/%zu...\n", k + 1, times.size());
           if (stats_f)
             std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"rays\": %llu, \"steps\": %llu, \"n_pos\": %llu, \"n_neg\": %llu, \"n_none\": %llu, \"n_oob\": %llu, \"kernel_ms\": %.4f, \"mray_steps_per_s\": %.1f, \"batch_frames\": %zu, \"batch_kernel_ms\": %.4f, \"batch_call_ms\": %.4f}\n",
-                         k, times[k], a.device + rank, a.mode.c_str(), (unsigned long long)fs.rays, (unsigned long long)fs.steps,
+                         k, times[k], device_of(rank), a.mode.c_str(), (unsigned long long)fs.rays, (unsigned long long)fs.steps,
                          (unsigned long long)fs.n_pos, (unsigned long long)fs.n_neg, (unsigned long long)fs.n_none,
                          (unsigned long long)fs.n_oob, fs.kernel_ms, fs.kernel_ms > 0.0 ? (double)fs.steps / fs.kernel_ms / 1e3 : 0.0, nb,
                          batch_ms, batch_call_ms);
@@ -1145,7 +1162,7 @@ int video_main(const Args &a) {
     }
   };
   std::vector<std::thread> th;
-  for (int r = 0; r < a.devices; ++r) th.emplace_back(worker, r);
+  for (int r = 0; r < n_workers; ++r) th.emplace_back(worker, r);
   for (auto &t : th) t.join();
   for (ncclComm_t cm : comms) ncclCommDestroy(cm);
   const double t_workers_done = pngio::now_s();
@@ -1183,7 +1200,7 @@ int video_main(const Args &a) {
     for (size_t r = 0; r < dev_sum.size(); ++r) {
       const DeviceSummary &d = dev_sum[r];
       const double kf = d.frames ? d.kernel_ms / d.frames : 0.0, rf = d.frames ? d.render_s * 1e3 / d.frames : 0.0;
-      std::printf("%-7zu %-14s %-7zu %-16.3f %-21.3f %-6.1f %-9d %-8d %-7.2f %.2f\n", (size_t)a.device + r, d.pci_bus_id.c_str(), d.frames, kf, rf,
+      std::printf("%-7zu %-14s %-7zu %-16.3f %-21.3f %-6.1f %-9d %-8d %-7.2f %.2f\n", (size_t)device_of((int)r), d.pci_bus_id.c_str(), d.frames, kf, rf,
                   d.busy_s > 0 ? d.frames / d.busy_s : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s);
       char buf[768];
       std::snprintf(buf, sizeof buf,
@@ -1191,7 +1208,7 @@ int video_main(const Args &a) {
                     "\"render_call_ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"mray_steps_per_s\": %.1f, \"sclk_mhz\": %d, \"power_w\": %d, "
                     "\"wait_s\": %.3f, \"hand_over_s\": %.3f, \"buffer_wait_s\": %.3f, \"busy_s\": %.3f, \"gpu_png_frames\": %zu, "
                     "\"gpu_png_kernel_ms_per_frame\": %.4f, \"gpu_png_fallback_frames\": %zu}",
-                    r ? ", " : "", (size_t)a.device + r, d.pci_bus_id.c_str(), d.frames, d.batches, kf, rf, d.busy_s > 0 ? d.frames / d.busy_s : 0.0,
+                    r ? ", " : "", (size_t)device_of((int)r), d.pci_bus_id.c_str(), d.frames, d.batches, kf, rf, d.busy_s > 0 ? d.frames / d.busy_s : 0.0,
                     d.kernel_ms > 0 ? (double)d.steps / d.kernel_ms / 1e3 : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s, d.pool_wait_s, d.busy_s,
                     d.png_frames, d.png_frames ? d.png_ms / d.png_frames : 0.0, d.png_fallback_frames);
       js += buf;

@@ -296,49 +296,47 @@ inline double now_s() {
 /* code lengths (<= maxlen) of a Huffman code for freq[0..n): plain Huffman by repeated minimum extraction (n <= 286),
  * frequencies halved and the tree rebuilt while it is too deep */
 inline void huffman_lengths(const uint32_t *freq_in, int n, int maxlen, uint8_t *len) {
+  /* Huffman by the two-queue method: leaves sorted once, merged nodes come out in non-decreasing weight, so the two smallest
+   * are always at the heads of the two queues -- O(n log n) for the sort, O(n) for the tree (this runs once per frame on the
+   * thread that feeds a GPU).  Too deep for `maxlen`: weights halved (rounding up) and again, as zlib's fast strategies do. */
   std::vector<uint32_t> freq(freq_in, freq_in + n);
+  std::vector<int> order, parent, depth;
+  std::vector<uint64_t> w;
   for (;;) {
-    struct Node { uint64_t f; int l, r; };
-    std::vector<Node> nodes;
-    std::vector<int> live;
+    order.clear();
     for (int i = 0; i < n; ++i) {
       len[i] = 0;
-      if (freq[i]) {
-        nodes.push_back({freq[i], -1 - i, -1 - i});
-        live.push_back((int)nodes.size() - 1);
-      }
+      if (freq[i]) order.push_back(i);
     }
-    if (live.empty()) return;
-    if (live.size() == 1) {
-      len[-1 - nodes[live[0]].l] = 1;
+    const int m = (int)order.size();
+    if (m == 0) return;
+    if (m == 1) {
+      len[order[0]] = 1;
       return;
     }
-    while (live.size() > 1) {
-      size_t a = 0, b = 1; /* two smallest */
-      if (nodes[live[b]].f < nodes[live[a]].f) std::swap(a, b);
-      for (size_t k = 2; k < live.size(); ++k) {
-        if (nodes[live[k]].f < nodes[live[a]].f) { b = a; a = k; }
-        else if (nodes[live[k]].f < nodes[live[b]].f) b = k;
-      }
-      nodes.push_back({nodes[live[a]].f + nodes[live[b]].f, live[a], live[b]});
-      const int merged = (int)nodes.size() - 1;
-      if (a > b) std::swap(a, b);
-      live.erase(live.begin() + (long)b);
-      live[a] = merged;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return freq[a] < freq[b]; });
+    /* nodes [0, m): leaves in weight order; [m, 2m - 1): internal nodes in creation order */
+    w.assign((size_t)2 * m - 1, 0);
+    parent.assign((size_t)2 * m - 1, -1);
+    for (int k = 0; k < m; ++k) w[(size_t)k] = freq[order[(size_t)k]];
+    int leaf = 0, inner = m, next = m;
+    auto take = [&]() {
+      if (leaf < m && (inner >= next || w[(size_t)leaf] <= w[(size_t)inner])) return leaf++;
+      return inner++;
+    };
+    while (next < 2 * m - 1) {
+      const int a = take(), b = take();
+      w[(size_t)next] = w[(size_t)a] + w[(size_t)b];
+      parent[(size_t)a] = parent[(size_t)b] = next;
+      ++next;
     }
-    /* depths */
+    depth.assign((size_t)2 * m - 1, 0);
     int deepest = 0;
-    std::vector<std::pair<int, int>> stack = {{live[0], 0}};
-    while (!stack.empty()) {
-      const std::pair<int, int> t = stack.back();
-      stack.pop_back();
-      const Node &nd = nodes[(size_t)t.first];
-      if (nd.l < 0 && nd.l == nd.r) {
-        len[-1 - nd.l] = (uint8_t)std::min(t.second, 255);
-        if (t.second > deepest) deepest = t.second;
-      } else {
-        stack.push_back({nd.l, t.second + 1});
-        stack.push_back({nd.r, t.second + 1});
+    for (int k = 2 * m - 3; k >= 0; --k) { /* a parent is created after its children: one backward pass */
+      depth[(size_t)k] = depth[(size_t)parent[(size_t)k]] + 1;
+      if (k < m) {
+        len[order[(size_t)k]] = (uint8_t)std::min(depth[(size_t)k], 255);
+        deepest = std::max(deepest, depth[(size_t)k]);
       }
     }
     if (deepest <= maxlen) return;
@@ -346,6 +344,7 @@ inline void huffman_lengths(const uint32_t *freq_in, int n, int maxlen, uint8_t 
       if (freq[i]) freq[i] = (freq[i] + 1) >> 1;
   }
 }
+
 /* canonical codes (RFC 1951 3.2.2), bit-reversed for an LSB-first bit writer; entry = code | len << 16 */
 inline void canonical_codes(const uint8_t *len, int n, uint32_t *entry) {
   uint32_t count[16] = {0}, next[16] = {0};

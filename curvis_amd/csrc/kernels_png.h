@@ -40,6 +40,7 @@ struct PngParams {
   unsigned long long *adler;      /* [n_frames][2]: sum of the filtered bytes; sum of (n - i) * byte_i; both mod 65521 per workgroup */
   const unsigned *codes;          /* [n_frames][kPngCodes]: bits | n_bits << 24 */
   unsigned long long *block_bits; /* [n_frames][blocks_per_frame]: bits per workgroup, then (in place) exclusive prefix */
+  unsigned short *thread_bits;    /* [n_frames][blocks_per_frame * 256]: bits per thread (<= 798), pass 2 -> pass 3 */
   const unsigned *start_bit;      /* [n_frames]: where the token stream starts (after the zlib and the block header) */
   unsigned long long *frame_bits; /* [n_frames]: end of the stream in bits (start offset, tokens, end-of-block code) */
   unsigned *out;                  /* [n_frames][out_words] */
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(kPngBlock) void png_count_kernel(const PngParams P)
   if (threadIdx.x == 0u) s_total = 0u;
   __syncthreads();
   unsigned bits = png_thread_bits(P, s_codes, frame, g);
+  P.thread_bits[((size_t)frame * P.blocks_per_frame + blockIdx.x) * kPngBlock + threadIdx.x] = (unsigned short)bits;
   for (int off = 32; off > 0; off >>= 1) bits += __shfl_down(bits, off, 64);
   if ((threadIdx.x & 63u) == 0u) atomicAdd(&s_total, bits);
   __syncthreads();
@@ -213,9 +215,7 @@ __global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) 
   __shared__ unsigned s_out[kPngLdsWords];
   const unsigned frame = blockIdx.y, g = blockIdx.x * kPngBlock + threadIdx.x;
   for (unsigned k = threadIdx.x; k < kPngCodes; k += kPngBlock) s_codes[k] = P.codes[(size_t)frame * kPngCodes + k];
-  for (unsigned k = threadIdx.x; k < kPngLdsWords; k += kPngBlock) s_out[k] = 0u;
-  __syncthreads();
-  const unsigned mine = png_thread_bits(P, s_codes, frame, g);
+  const unsigned mine = P.thread_bits[((size_t)frame * P.blocks_per_frame + blockIdx.x) * kPngBlock + threadIdx.x]; /* counted by pass 2 */
   /* exclusive scan over the workgroup: inside the wave by shuffles, across the four waves through LDS */
   unsigned incl = mine;
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -232,6 +232,9 @@ __global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) 
   }
   const unsigned long long base = (unsigned long long)P.start_bit[frame] + P.block_bits[(size_t)frame * P.blocks_per_frame + blockIdx.x];
   const unsigned shift = (unsigned)(base & 31ull);
+  const unsigned words = (shift + total + 31u) >> 5; /* what this workgroup's codes occupy: typically a tenth of s_out */
+  for (unsigned k = threadIdx.x; k < words; k += kPngBlock) s_out[k] = 0u;
+  __syncthreads(); /* also: s_codes complete */
   unsigned pos = shift + before + (incl - mine); /* bit position of this thread's first code in s_out */
   if (g < P.chunks_per_frame) {
     unsigned w = pos >> 5, fill = pos & 31u;
@@ -252,7 +255,6 @@ __global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) 
     if (fill) atomicOr(&s_out[w], (unsigned)acc);
   }
   __syncthreads();
-  const unsigned words = (shift + total + 31u) >> 5;
   unsigned *dst = P.out + (size_t)frame * P.out_words + (size_t)(base >> 5);
   for (unsigned k = threadIdx.x; k < words; k += kPngBlock) {
     const unsigned v = s_out[k];

@@ -6,7 +6,7 @@
 namespace {
 
 struct PngScratch { /* one allocation, carved */
-  size_t hist, adler, codes, block_bits, start_bit, frame_bits, out, total;
+  size_t hist, adler, codes, block_bits, thread_bits, start_bit, frame_bits, out, total;
   size_t out_words;
 };
 
@@ -25,6 +25,8 @@ PngScratch png_scratch_layout(const PngParams &P) {
   off = up(off + (size_t)P.n_frames * kPngCodes * sizeof(unsigned));
   L.block_bits = off;
   off = up(off + (size_t)P.n_frames * P.blocks_per_frame * sizeof(unsigned long long));
+  L.thread_bits = off;
+  off = up(off + (size_t)P.n_frames * P.blocks_per_frame * kPngBlock * sizeof(unsigned short));
   L.start_bit = off;
   off = up(off + (size_t)P.n_frames * sizeof(unsigned));
   L.frame_bits = off;
@@ -65,6 +67,7 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   P.adler = (unsigned long long *)(base + L.adler);
   P.codes = (const unsigned *)(base + L.codes);
   P.block_bits = (unsigned long long *)(base + L.block_bits);
+  P.thread_bits = (unsigned short *)(base + L.thread_bits);
   P.start_bit = (const unsigned *)(base + L.start_bit);
   P.frame_bits = (unsigned long long *)(base + L.frame_bits);
   P.out = (unsigned *)(base + L.out);

@@ -119,13 +119,15 @@ def test_video_orbit_frames_and_quirks(scene_files):
     # --stats also writes the host profile: per-device table (PCI identity, frames, kernel / render-call time) and the
     # writer threads' stage times
     summ = json.loads((out / "st.jsonl.summary.json").read_text())
-    assert summ["frames"] == 15 and summ["png_level"] == -1 and len(summ["devices"]) == 1
-    dev = summ["devices"][0]
-    assert dev["frames"] == 15 and dev["kernel_ms_per_frame"] > 0 and len(dev["pci_bus_id"].split(":")) == 3
+    # --mode efficient runs two contexts (two host threads) on the one GPU by default: half of its render call is host work
+    assert summ["frames"] == 15 and summ["png_level"] == -1 and len(summ["devices"]) == 2
+    devs = summ["devices"]
+    assert devs[0]["device"] == devs[1]["device"] == 0 and devs[0]["pci_bus_id"] == devs[1]["pci_bus_id"] and len(devs[0]["pci_bus_id"].split(":")) == 3
+    assert sum(dv["frames"] for dv in devs) == 15 and all(dv["kernel_ms_per_frame"] > 0 for dv in devs)
     # the default writer: PNG front end on the device (filter, Huffman coding, Adler-32 in HIP kernels; the frames checked above
     # against the oracle were decoded from ITS streams), a writer thread only wraps the stream and adds the CRC
-    assert summ["gpu_png"] is True and dev["gpu_png_frames"] == 15 and dev["gpu_png_fallback_frames"] == 0
-    assert dev["gpu_png_kernel_ms_per_frame"] > 0 and summ["encode"]["filter_ms"] == 0 and summ["encode"]["deflate_ms"] == 0
+    assert summ["gpu_png"] is True and sum(dv["gpu_png_frames"] for dv in devs) == 15 and all(dv["gpu_png_fallback_frames"] == 0 for dv in devs)
+    assert all(dv["gpu_png_kernel_ms_per_frame"] > 0 for dv in devs) and summ["encode"]["filter_ms"] == 0 and summ["encode"]["deflate_ms"] == 0
     enc = summ["encode"]
     assert enc["frames"] == 15 and enc["thread_ms_per_frame"] > 0 and enc["file_mb_per_frame"] < enc["raw_mb_per_frame"]
     assert "pci_bus_id" in r.stdout and "writer thread" in r.stdout

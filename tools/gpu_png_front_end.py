@@ -18,7 +18,9 @@ def scene(kind, res, sky):
     m = curvis_amd.EllisMetric(1.0) if kind != "interstellar" else curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0)
     return m
 CASES = [("efficient", "ellis", (1920, 1080), "smooth", (1, 8, 32)), ("efficient", "ellis", (1920, 1080), "check", (8,)),
-         ("brute", "ellis", (1920, 1080), "smooth", (1, 8)), ("brute", "interstellar", (3840, 2160), "smooth", (1, 4))]
+         ("brute", "ellis", (1920, 1080), "smooth", (1, 8)), ("brute", "interstellar", (3840, 2160), "smooth", (1, 4)),
+         # how far the kernels go when a launch has enough bytes to fill the chip: 64 4K frames = 1.6 GB of pixels per call
+         ("efficient", "ellis", (3840, 2160), "check", (64,))]
 if only == "profile":   # a short fixed workload for rocprofv3
     CASES = [("efficient", "ellis", (1920, 1080), "smooth", (8,))]
 for mode, kind, res, sky, batches in CASES:
