@@ -821,6 +821,8 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = (int64_t)ctx->relay_verified.size();
   else if (k == "relay_checks")
     *value = (int64_t)ctx->relay_checks;
+  else if (k == "last_png_direct_blocks")
+    *value = (int64_t)ctx->last_png_direct_blocks;
   else if (k == "relay_recheck_every")
     *value = ctx->relay_recheck_every;
   else if (k == "relay_fallbacks")

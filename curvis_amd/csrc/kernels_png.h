@@ -15,8 +15,10 @@
  *   png_emit_kernel   pass 3: every thread writes its codes at its bit offset -- assembled in LDS per workgroup (ds_or), written
  *                     out as whole words (the first and last word of a workgroup's span are shared with its neighbours: atomicOr)
  *
- * This is byte work bound by HBM / L2 traffic, not by FP64 issue: each pass reads the frame (current row + row above) once,
- * pass 3 writes the stream.  Algorithmic bytes per frame: W*H*3 read + stream written.
+ * Byte work, no floating point.  Each pass reads the frame once -- current row and row above, the latter out of the XCD's own
+ * L2 thanks to the workgroup order (png_logical_block) --, stages the filtered bytes in LDS with coalesced 16-byte loads
+ * (png_stage) and then tokenises 64 bytes per thread; pass 3 writes the stream.  Algorithmic bytes per frame: W*H*3 read +
+ * stream written.  What bounds the passes is the byte-serial tokeniser (divergent branches per byte), not HBM: DESIGN.md 8.
  * Part of the ONE translation unit curvis_hip.hip (included there, nowhere else). */
 #pragma once
 
@@ -27,15 +29,17 @@ constexpr unsigned kPngBlock = 256;  /* threads per workgroup */
 constexpr unsigned kPngBins = 288;   /* 286 literal/length symbols, padded */
 constexpr unsigned kPngCodes = 256 + 64; /* per frame: literal entries [0, 256), match entries for lengths [0, 64) */
 constexpr unsigned kPngCodeBits = 12;    /* longest literal/length code */
-/* a thread emits at most 65 literals of <= 12 bits (a match replaces >= 3 of them by <= 12 + 3 + 1 bits) = 780 bits */
-constexpr unsigned kPngWordsPerThread = 25;
-constexpr unsigned kPngLdsWords = kPngBlock * kPngWordsPerThread + 2;
+/* LDS image of a workgroup's piece of the stream: 8 KiB = 256 bits per thread on average, i.e. frames that compress at least
+ * 2 x; a workgroup whose codes need more (at most 65 literals of 12 bits per thread = 780 bits) ORs them into global memory */
+constexpr unsigned kPngLdsWords = 2048;
 
 struct PngParams {
   const unsigned char *fb;        /* n_frames frames of H rows of row_bytes bytes, back to back */
   size_t frame_bytes;
   unsigned W, H, row_bytes, chunks_per_row, chunks_per_frame, blocks_per_frame, n_frames;
   int aligned;                    /* row_bytes % 16 == 0: 16-byte loads */
+  int staged;                     /* row_bytes % 64 == 0: every chunk is full; workgroups stage their filtered bytes in LDS */
+  unsigned grid_x;                /* 8 * ceil(blocks_per_frame / 8): see png_logical_block */
   unsigned *hist;                 /* [n_frames][kPngBins] */
   unsigned long long *adler;      /* [n_frames][2]: sum of the filtered bytes; sum of (n - i) * byte_i; both mod 65521 per workgroup */
   const unsigned *codes;          /* [n_frames][kPngCodes]: bits | n_bits << 24 */
@@ -43,6 +47,7 @@ struct PngParams {
   unsigned short *thread_bits;    /* [n_frames][blocks_per_frame * 256]: bits per thread (<= 798), pass 2 -> pass 3 */
   const unsigned *start_bit;      /* [n_frames]: where the token stream starts (after the zlib and the block header) */
   unsigned long long *frame_bits; /* [n_frames]: end of the stream in bits (start offset, tokens, end-of-block code) */
+  unsigned *direct_blocks;        /* [1]: workgroups of pass 3 whose codes did not fit their LDS image (diagnostics, tests) */
   unsigned *out;                  /* [n_frames][out_words] */
   size_t out_words;
 };
@@ -60,82 +65,164 @@ __device__ __forceinline__ unsigned png_sub4(unsigned c, unsigned u) {
   return ((c | 0x80808080u) - (u & 0x7f7f7f7fu)) ^ ((c ^ ~u) & 0x80808080u);
 }
 
-/* The tokens of chunk `chunk` of row `row` of frame `frame`, in stream order: lit(value) for a literal byte, match(len) for
- * `len` (3..63) further zero bytes after a literal zero.  Chunk 0 of a row starts with the row's filter-type byte (2 = Up). */
-template <typename Lit, typename Match>
-__device__ __forceinline__ void png_tokens(const PngParams &P, unsigned frame, unsigned row, unsigned chunk, Lit &&lit, Match &&match) {
+/* XCD-aware order of the workgroups.  The dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with an L2 of
+ * its own; a workgroup reads the image rows of its chunks AND the row above them (filter Up), i.e. the rows of its
+ * predecessor.  Workgroup b therefore takes the LOGICAL span (b mod 8) * ceil(n / 8) + b div 8: every XCD walks one contiguous
+ * eighth of the frame and finds the row above in its own L2 (measured: FETCH_SIZE of a pass 3.1 x -> see profiles).  The grid
+ * is 8 * ceil(n / 8) wide; spans >= n are idle. */
+__device__ __forceinline__ unsigned png_logical_block(unsigned b, unsigned n_blocks) {
+  const unsigned per = (n_blocks + 7u) >> 3;
+  return (b & 7u) * per + (b >> 3);
+}
+
+/* Staging (frames whose rows are a multiple of 64 bytes, i.e. every chunk is full and the 256 chunks of a workgroup are 16 KiB
+ * of consecutive image bytes): the workgroup loads its span and the span one row above with fully coalesced 16-byte loads
+ * (lane i reads bytes [16 i, 16 i + 16) of a 4 KiB piece), subtracts, and leaves the FILTERED bytes in LDS, chunk c at
+ * c * 80: with that stride the four ds_read_b128 of a thread's chunk are bank-conflict free (16 lanes x 20 banks apart). */
+constexpr unsigned kPngLdsStride = 80;
+__device__ __forceinline__ void png_stage(const PngParams &P, unsigned frame, unsigned block, unsigned char *s_f) {
+  const unsigned char *f = P.fb + (size_t)frame * P.frame_bytes;
+  const size_t base = (size_t)block * (kPngBlock * kPngChunk);
+#pragma unroll
+  for (unsigned k = 0; k < 4u; ++k) {
+    const unsigned j = threadIdx.x + kPngBlock * k; /* 16-byte piece of the span */
+    const size_t off = base + (size_t)j * 16u;
+    uint4 d = make_uint4(0u, 0u, 0u, 0u);
+    if (off < P.frame_bytes) {
+      const uint4 c = *reinterpret_cast<const uint4 *>(f + off);
+      uint4 u = make_uint4(0u, 0u, 0u, 0u);
+      if (off >= P.row_bytes) u = *reinterpret_cast<const uint4 *>(f + off - P.row_bytes);
+      d = make_uint4(png_sub4(c.x, u.x), png_sub4(c.y, u.y), png_sub4(c.z, u.z), png_sub4(c.w, u.w));
+    }
+    *reinterpret_cast<uint4 *>(s_f + (j >> 2) * kPngLdsStride + (j & 3u) * 16u) = d;
+  }
+}
+
+/* The tokens of chunk `chunk` of row `row` of frame `frame`, in stream order: sink.lit(value) for a literal byte,
+ * sink.match(len) for `len` (3..63) further zero bytes after a literal zero.  Chunk 0 of a row starts with the row's
+ * filter-type byte (2 = Up).  s_chunk: this thread's 64 filtered bytes in LDS (staged frames), or NULL: read and filter from
+ * global memory.  Written as ONE rolled loop over the words of the chunk with two small emission sites: the sinks' state has to
+ * stay in registers (an earlier version with a lambda call per byte, 64 sites, was not inlined and ran out of scratch memory). */
+template <typename Sink>
+__device__ __forceinline__ void png_tokens(const PngParams &P, const unsigned char *s_chunk, unsigned frame, unsigned row, unsigned chunk, Sink &sink) {
   const unsigned x0 = chunk * kPngChunk;
   const unsigned nb = min(kPngChunk, P.row_bytes - x0);
   const unsigned char *cur = P.fb + (size_t)frame * P.frame_bytes + (size_t)row * P.row_bytes + x0;
   const unsigned char *up = cur - P.row_bytes; /* row 0: treated as zeros, never read */
-  if (chunk == 0u) lit(2u);
+  if (chunk == 0u) sink.lit(2u);
   unsigned run = 0;
-  auto flush = [&]() {
-    if (run == 0u) return;
-    if (run <= 3u) {
-      for (unsigned k = 0; k < run; ++k) lit(0u);
+#define PNG_FLUSH_RUN()                                \
+  do {                                                 \
+    if (run) {                                         \
+      const unsigned n_lit = run <= 3u ? run : 1u;     \
+      for (unsigned k_ = 0; k_ < n_lit; ++k_) sink.lit(0u); \
+      if (run > 3u) sink.match(run - 1u);              \
+      run = 0u;                                        \
+    }                                                  \
+  } while (0)
+  const unsigned n_words = (nb + 3u) >> 2;
+#pragma unroll 1
+  for (unsigned w = 0; w < n_words; ++w) {
+    unsigned d;
+    if (s_chunk) {
+      d = *reinterpret_cast<const unsigned *>(s_chunk + 4u * w);
+    } else if (P.aligned) {
+      const unsigned c = *reinterpret_cast<const unsigned *>(cur + 4u * w);
+      d = png_sub4(c, row != 0u ? *reinterpret_cast<const unsigned *>(up + 4u * w) : 0u);
     } else {
-      lit(0u);
-      match(run - 1u);
+      d = 0u;
+      for (unsigned b = 0; b < 4u && 4u * w + b < nb; ++b)
+        d |= (((unsigned)cur[4u * w + b] - (row != 0u ? (unsigned)up[4u * w + b] : 0u)) & 0xffu) << (8u * b);
     }
-    run = 0u;
-  };
-  auto byte = [&](unsigned v) {
-    if (v == 0u) {
-      ++run;
-    } else {
-      flush();
-      lit(v);
+    const unsigned in_word = min(4u, nb - 4u * w);
+    if (d == 0u) { /* four zero bytes at once (fewer in the ragged last word) */
+      run += in_word;
+      continue;
     }
-  };
-  if (P.aligned) {
-    for (unsigned q = 0; q < nb; q += 16u) {
-      const uint4 c = *reinterpret_cast<const uint4 *>(cur + q);
-      uint4 u = make_uint4(0u, 0u, 0u, 0u);
-      if (row != 0u) u = *reinterpret_cast<const uint4 *>(up + q);
-      const unsigned d[4] = {png_sub4(c.x, u.x), png_sub4(c.y, u.y), png_sub4(c.z, u.z), png_sub4(c.w, u.w)};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (d[k] == 0u) { /* four zero bytes at once */
-          run += 4u;
-        } else {
-          byte(d[k] & 0xffu);
-          byte((d[k] >> 8) & 0xffu);
-          byte((d[k] >> 16) & 0xffu);
-          byte(d[k] >> 24);
-        }
+#pragma unroll 1
+    for (unsigned b = 0; b < in_word; ++b) {
+      const unsigned v = d & 0xffu;
+      d >>= 8;
+      if (v == 0u) {
+        ++run;
+        continue;
       }
+      PNG_FLUSH_RUN();
+      sink.lit(v);
     }
-  } else {
-    for (unsigned j = 0; j < nb; ++j) byte(((unsigned)cur[j] - (row != 0u ? (unsigned)up[j] : 0u)) & 0xffu);
   }
-  flush();
+  PNG_FLUSH_RUN();
+#undef PNG_FLUSH_RUN
 }
+
+struct PngHistSink { /* pass 1 */
+  unsigned *hist; /* LDS */
+  unsigned k;     /* index of the next filtered byte, counted from the thread's first (<= 65) */
+  unsigned a, kv; /* Adler-32 partial sums in 32 bits: sum of bytes (<= 65 * 255), sum of k * byte_k (<= 65 * 65 * 255) */
+  unsigned zeros; /* literal zeros are the hottest bin by far: counted in a register, added once */
+  __device__ __forceinline__ void lit(unsigned v) {
+    if (v == 0u) {
+      ++zeros;
+    } else {
+      atomicAdd(&hist[v], 1u);
+      a += v;
+      kv += k * v;
+    }
+    ++k;
+  }
+  __device__ __forceinline__ void match(unsigned len) {
+    atomicAdd(&hist[png_len_symbol(len)], 1u);
+    k += len;
+  }
+};
+
+struct PngCountSink { /* pass 2 */
+  const unsigned *codes; /* LDS */
+  unsigned bits;
+  __device__ __forceinline__ void lit(unsigned v) { bits += codes[v] >> 24; }
+  __device__ __forceinline__ void match(unsigned len) { bits += codes[256u + len] >> 24; }
+};
+
+struct PngEmitSink { /* pass 3: codes ORed into the workgroup's LDS image of the stream */
+  const unsigned *codes; /* LDS */
+  unsigned *out;         /* LDS */
+  unsigned w, fill;
+  unsigned long long acc;
+  __device__ __forceinline__ void put(unsigned e) {
+    acc |= (unsigned long long)(e & 0xffffffu) << fill;
+    fill += e >> 24;
+    if (fill >= 32u) {
+      atomicOr(&out[w], (unsigned)acc);
+      ++w;
+      acc >>= 32;
+      fill -= 32u;
+    }
+  }
+  __device__ __forceinline__ void lit(unsigned v) { put(codes[v]); }
+  __device__ __forceinline__ void match(unsigned len) { put(codes[256u + len]); }
+};
 
 __global__ __launch_bounds__(kPngBlock) void png_hist_kernel(const PngParams P) {
   __shared__ unsigned s_hist[kPngBins];
   __shared__ unsigned long long s_sum[2];
-  const unsigned frame = blockIdx.y, g = blockIdx.x * kPngBlock + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
+  const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
+  if (block >= P.blocks_per_frame) return; /* the whole workgroup */
+  const unsigned g = block * kPngBlock + threadIdx.x;
   for (unsigned k = threadIdx.x; k < kPngBins; k += kPngBlock) s_hist[k] = 0u;
   if (threadIdx.x < 2u) s_sum[threadIdx.x] = 0ull;
+  if (P.staged) png_stage(P, frame, block, s_f);
   __syncthreads();
   if (g < P.chunks_per_frame) {
     const unsigned row = g / P.chunks_per_row, chunk = g - row * P.chunks_per_row;
     const unsigned long long n = (unsigned long long)P.H * (P.row_bytes + 1u);
     /* index of this thread's first filtered byte in the frame's stream (the filter-type byte leads every row) */
-    unsigned long long i = (unsigned long long)row * (P.row_bytes + 1u) + (chunk == 0u ? 0u : 1u + chunk * kPngChunk);
-    unsigned long long a = 0ull, b = 0ull;
-    png_tokens(P, frame, row, chunk,
-               [&](unsigned v) {
-                 atomicAdd(&s_hist[v], 1u);
-                 a += v;
-                 b += (n - i) * v; /* Adler-32: s2 = n + sum (n - i) * byte_i */
-                 ++i;
-               },
-               [&](unsigned len) {
-                 atomicAdd(&s_hist[png_len_symbol(len)], 1u);
-                 i += len;
-               });
+    const unsigned long long i0 = (unsigned long long)row * (P.row_bytes + 1u) + (chunk == 0u ? 0u : 1u + chunk * kPngChunk);
+    PngHistSink sink{s_hist, 0u, 0u, 0u, 0u};
+    png_tokens(P, P.staged ? s_f + threadIdx.x * kPngLdsStride : nullptr, frame, row, chunk, sink);
+    if (sink.zeros) atomicAdd(&s_hist[0], sink.zeros);
+    /* Adler-32: s2 = n + sum over the stream of (n - i) * byte_i; this thread's bytes sit at i = i0 + k */
+    const unsigned long long a = sink.a, b = (n - i0) * a - sink.kv;
     atomicAdd(&s_sum[0], a % 65521ull);
     atomicAdd(&s_sum[1], b % 65521ull);
   }
@@ -146,11 +233,13 @@ __global__ __launch_bounds__(kPngBlock) void png_hist_kernel(const PngParams P) 
 }
 
 /* bits this thread's tokens take with the frame's code (+ the end-of-block code after the last chunk of the frame) */
-__device__ __forceinline__ unsigned png_thread_bits(const PngParams &P, const unsigned *s_codes, unsigned frame, unsigned g) {
+__device__ __forceinline__ unsigned png_thread_bits(const PngParams &P, const unsigned *s_codes, const unsigned char *s_chunk, unsigned frame, unsigned g) {
   unsigned bits = 0;
   if (g < P.chunks_per_frame) {
     const unsigned row = g / P.chunks_per_row, chunk = g - row * P.chunks_per_row;
-    png_tokens(P, frame, row, chunk, [&](unsigned v) { bits += s_codes[v] >> 24; }, [&](unsigned len) { bits += s_codes[256u + len] >> 24; });
+    PngCountSink sink{s_codes, 0u};
+    png_tokens(P, s_chunk, frame, row, chunk, sink);
+    bits = sink.bits;
     if (g == P.chunks_per_frame - 1u) bits += s_codes[256u] >> 24; /* end of block: stored in the unused slot "match of length 0" */
   }
   return bits;
@@ -159,16 +248,20 @@ __device__ __forceinline__ unsigned png_thread_bits(const PngParams &P, const un
 __global__ __launch_bounds__(kPngBlock) void png_count_kernel(const PngParams P) {
   __shared__ unsigned s_codes[kPngCodes];
   __shared__ unsigned s_total;
-  const unsigned frame = blockIdx.y, g = blockIdx.x * kPngBlock + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
+  const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
+  if (block >= P.blocks_per_frame) return;
+  const unsigned g = block * kPngBlock + threadIdx.x;
   for (unsigned k = threadIdx.x; k < kPngCodes; k += kPngBlock) s_codes[k] = P.codes[(size_t)frame * kPngCodes + k];
   if (threadIdx.x == 0u) s_total = 0u;
+  if (P.staged) png_stage(P, frame, block, s_f);
   __syncthreads();
-  unsigned bits = png_thread_bits(P, s_codes, frame, g);
-  P.thread_bits[((size_t)frame * P.blocks_per_frame + blockIdx.x) * kPngBlock + threadIdx.x] = (unsigned short)bits;
+  unsigned bits = png_thread_bits(P, s_codes, P.staged ? s_f + threadIdx.x * kPngLdsStride : nullptr, frame, g);
+  P.thread_bits[((size_t)frame * P.blocks_per_frame + block) * kPngBlock + threadIdx.x] = (unsigned short)bits;
   for (int off = 32; off > 0; off >>= 1) bits += __shfl_down(bits, off, 64);
   if ((threadIdx.x & 63u) == 0u) atomicAdd(&s_total, bits);
   __syncthreads();
-  if (threadIdx.x == 0u) P.block_bits[(size_t)frame * P.blocks_per_frame + blockIdx.x] = s_total;
+  if (threadIdx.x == 0u) P.block_bits[(size_t)frame * P.blocks_per_frame + block] = s_total;
 }
 
 /* one workgroup per frame: block_bits -> exclusive prefix (in place), frame_bits = start + total */
@@ -213,9 +306,13 @@ __global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) 
   __shared__ unsigned s_codes[kPngCodes];
   __shared__ unsigned s_wave[kPngBlock / 64];
   __shared__ unsigned s_out[kPngLdsWords];
-  const unsigned frame = blockIdx.y, g = blockIdx.x * kPngBlock + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
+  const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
+  if (block >= P.blocks_per_frame) return;
+  const unsigned g = block * kPngBlock + threadIdx.x;
   for (unsigned k = threadIdx.x; k < kPngCodes; k += kPngBlock) s_codes[k] = P.codes[(size_t)frame * kPngCodes + k];
-  const unsigned mine = P.thread_bits[((size_t)frame * P.blocks_per_frame + blockIdx.x) * kPngBlock + threadIdx.x]; /* counted by pass 2 */
+  if (P.staged) png_stage(P, frame, block, s_f);
+  const unsigned mine = P.thread_bits[((size_t)frame * P.blocks_per_frame + block) * kPngBlock + threadIdx.x]; /* counted by pass 2 */
   /* exclusive scan over the workgroup: inside the wave by shuffles, across the four waves through LDS */
   unsigned incl = mine;
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -230,32 +327,35 @@ __global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) 
     if (w < wave) before += s_wave[w];
     total += s_wave[w];
   }
-  const unsigned long long base = (unsigned long long)P.start_bit[frame] + P.block_bits[(size_t)frame * P.blocks_per_frame + blockIdx.x];
+  const unsigned long long base = (unsigned long long)P.start_bit[frame] + P.block_bits[(size_t)frame * P.blocks_per_frame + block];
   const unsigned shift = (unsigned)(base & 31ull);
-  const unsigned words = (shift + total + 31u) >> 5; /* what this workgroup's codes occupy: typically a tenth of s_out */
-  for (unsigned k = threadIdx.x; k < words; k += kPngBlock) s_out[k] = 0u;
-  __syncthreads(); /* also: s_codes complete */
-  unsigned pos = shift + before + (incl - mine); /* bit position of this thread's first code in s_out */
+  const unsigned words = (shift + total + 31u) >> 5; /* what this workgroup's codes occupy */
+  unsigned *dst = P.out + (size_t)frame * P.out_words + (size_t)(base >> 5);
+  const bool in_lds = words <= kPngLdsWords; /* the same for the whole workgroup */
+  if (in_lds)
+    for (unsigned k = threadIdx.x; k < words; k += kPngBlock) s_out[k] = 0u;
+  __syncthreads();
+  const unsigned pos = shift + before + (incl - mine); /* bit position of this thread's first code in the workgroup's piece */
   if (g < P.chunks_per_frame) {
-    unsigned w = pos >> 5, fill = pos & 31u;
-    unsigned long long acc = 0ull;
-    auto put = [&](unsigned e) {
-      acc |= (unsigned long long)(e & 0xffffffu) << fill;
-      fill += e >> 24;
-      if (fill >= 32u) {
-        atomicOr(&s_out[w], (unsigned)acc);
-        ++w;
-        acc >>= 32;
-        fill -= 32u;
-      }
-    };
     const unsigned row = g / P.chunks_per_row, chunk = g - row * P.chunks_per_row;
-    png_tokens(P, frame, row, chunk, [&](unsigned v) { put(s_codes[v]); }, [&](unsigned len) { put(s_codes[256u + len]); });
-    if (g == P.chunks_per_frame - 1u) put(s_codes[256u]);
-    if (fill) atomicOr(&s_out[w], (unsigned)acc);
+    const unsigned char *s_chunk = P.staged ? s_f + threadIdx.x * kPngLdsStride : nullptr;
+    if (in_lds) {
+      PngEmitSink sink{s_codes, s_out, pos >> 5, pos & 31u, 0ull};
+      png_tokens(P, s_chunk, frame, row, chunk, sink);
+      if (g == P.chunks_per_frame - 1u) sink.put(s_codes[256u]);
+      if (sink.fill) atomicOr(&s_out[sink.w], (unsigned)sink.acc);
+    } else { /* rare (frames that hardly compress): straight into the zeroed stream */
+      PngEmitSink sink{s_codes, dst, pos >> 5, pos & 31u, 0ull};
+      png_tokens(P, s_chunk, frame, row, chunk, sink);
+      if (g == P.chunks_per_frame - 1u) sink.put(s_codes[256u]);
+      if (sink.fill) atomicOr(&dst[sink.w], (unsigned)sink.acc);
+    }
+  }
+  if (!in_lds) {
+    if (threadIdx.x == 0u) atomicAdd(P.direct_blocks, 1u);
+    return;
   }
   __syncthreads();
-  unsigned *dst = P.out + (size_t)frame * P.out_words + (size_t)(base >> 5);
   for (unsigned k = threadIdx.x; k < words; k += kPngBlock) {
     const unsigned v = s_out[k];
     if (!v) continue;

@@ -6,7 +6,7 @@
 namespace {
 
 struct PngScratch { /* one allocation, carved */
-  size_t hist, adler, codes, block_bits, thread_bits, start_bit, frame_bits, out, total;
+  size_t hist, adler, direct_blocks, codes, block_bits, thread_bits, start_bit, frame_bits, out, total;
   size_t out_words;
 };
 
@@ -21,6 +21,8 @@ PngScratch png_scratch_layout(const PngParams &P) {
   off = up(off + (size_t)P.n_frames * kPngBins * sizeof(unsigned));
   L.adler = off;
   off = up(off + (size_t)P.n_frames * 2 * sizeof(unsigned long long));
+  L.direct_blocks = off;
+  off = up(off + sizeof(unsigned));
   L.codes = off;
   off = up(off + (size_t)P.n_frames * kPngCodes * sizeof(unsigned));
   L.block_bits = off;
@@ -59,12 +61,15 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   P.blocks_per_frame = (P.chunks_per_frame + kPngBlock - 1) / kPngBlock;
   P.n_frames = n_frames;
   P.aligned = (P.row_bytes % 16u) == 0u ? 1 : 0;
+  P.staged = (P.row_bytes % kPngChunk) == 0u ? 1 : 0;
+  P.grid_x = 8u * ((P.blocks_per_frame + 7u) / 8u);
   const PngScratch L = png_scratch_layout(P);
   int rc = ensure_device(ctx, ctx->d_png, ctx->png_cap, L.total);
   if (rc) return rc;
   unsigned char *base = ctx->d_png;
   P.hist = (unsigned *)(base + L.hist);
   P.adler = (unsigned long long *)(base + L.adler);
+  P.direct_blocks = (unsigned *)(base + L.direct_blocks);
   P.codes = (const unsigned *)(base + L.codes);
   P.block_bits = (unsigned long long *)(base + L.block_bits);
   P.thread_bits = (unsigned short *)(base + L.thread_bits);
@@ -72,11 +77,11 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   P.frame_bits = (unsigned long long *)(base + L.frame_bits);
   P.out = (unsigned *)(base + L.out);
   P.out_words = L.out_words;
-  const dim3 grid(P.blocks_per_frame, n_frames), block(kPngBlock);
+  const dim3 grid(P.grid_x, n_frames), block(kPngBlock); /* the 8 XCDs take contiguous eighths of a frame: png_logical_block */
   float ms_a = 0.f, ms_b = 0.f;
 
   /* pass 1: histograms + Adler sums */
-  HIP_TRY(ctx, hipMemsetAsync(base + L.hist, 0, L.codes - L.hist, ctx->stream)); /* hist and adler are adjacent */
+  HIP_TRY(ctx, hipMemsetAsync(base + L.hist, 0, L.codes - L.hist, ctx->stream)); /* hist, adler and the diagnostics counter are adjacent */
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(png_hist_kernel, grid, block, 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
@@ -132,7 +137,10 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   std::vector<unsigned long long> frame_bits(n_frames);
   HIP_TRY(ctx, hipMemcpyAsync(frame_bits.data(), base + L.frame_bits, frame_bits.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ctx->stream));
+  unsigned direct_blocks = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&direct_blocks, base + L.direct_blocks, sizeof direct_blocks, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->last_png_direct_blocks = direct_blocks;
   HIP_TRY(ctx, hipEventElapsedTime(&ms_b, ctx->ev0, ctx->ev1));
 
   /* streams to the host: deflate bytes, then the Adler-32 of the filtered scanlines */

@@ -33,6 +33,7 @@ struct curvis_ctx {
   size_t verify_cap = 0;
   unsigned char *d_png = nullptr;    /* scratch of the device PNG front end (kernels_png.h): histograms, codes, offsets, streams */
   size_t png_cap = 0;
+  uint32_t last_png_direct_blocks = 0; /* workgroups of the last deflate whose codes went straight to global memory */
   double last_png_ms = 0.0;          /* HIP-event time of the last curvis_ctx_deflate_frames */
   int relay_segment = 0;            /* steps between two hand-over points; 0 = automatic */
   int relay_max_hops = 0;           /* hand-overs per tile at most; 0 = no limit */

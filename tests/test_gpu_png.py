@@ -78,6 +78,27 @@ def test_batch_of_frames_and_black_frame(gpu_ctx, tmp_path):
     assert len(z) < 128 * 72 * 3 // 30                                 # 72 rows x (1 literal + 6 x (literal + match)) + header
 
 
+def test_frames_that_do_not_compress(gpu_ctx, tmp_path):
+    """white-noise skies: every pixel differs from its neighbours, literals cost ~8 bits each, a workgroup's codes no longer fit
+    its LDS image of the stream (> 256 bits per thread) and go straight to global memory -- same decoded pixels; the stream
+    is about as long as the raw frame"""
+    rng = np.random.default_rng(11)
+    skies_ = []
+    for _ in range(2):
+        t = rng.integers(0, 256, (2048, 4096, 4), dtype=np.uint8)      # ~3 texels per pixel: no two neighbours share one
+        t[..., 3] = 255
+        skies_.append(t)
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(skies_[0]))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(skies_[1]))
+    for res in ((256, 144), (200, 77)):            # staged (768-byte rows) and direct (600-byte rows: 16-byte loads, ragged last chunk)
+        _, _, pm, pc = common.scene("ellis", res=res)
+        rgb, _ = gpu_ctx.render_brute(pm, [pc, pc], 4096, 100.0, 0.05)
+        streams, _ = check_streams(gpu_ctx, tmp_path, list(rgb), res[0], res[1], "noise%d" % res[0])
+        ratios = [len(z) / (res[0] * res[1] * 3) for z in streams]
+        assert all(r > 0.4 for r in ratios), ratios                      # measured 0.48: noise outside the throat, flat inside
+        assert gpu_ctx.get_option("last_png_direct_blocks") > 0          # workgroups in the noisy rows took the global path
+
+
 def test_efficient_frames_and_full_hd(gpu_ctx, tmp_path):
     """what `curvis video` (default mode) saves: render_image_efficient frames, 1920x1080, left in HBM (download=False) and
     compressed there; the stream is a small fraction of the 6.2 MB frame and decodes to the frame a download gives"""
@@ -91,6 +112,7 @@ def test_efficient_frames_and_full_hd(gpu_ctx, tmp_path):
     want, _ = gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
     gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
     streams, ms = check_streams(gpu_ctx, tmp_path, list(want), 1920, 1080, "eff")
+    assert gpu_ctx.get_option("last_png_direct_blocks") == 0             # ordinary frames: every workgroup assembles its piece in LDS
     assert all(len(z) < 1920 * 1080 * 3 // 4 for z in streams)
     print("device PNG front end: 3 x 1080p in %.3f ms, streams %s bytes" % (ms, [len(z) for z in streams]))
 

@@ -31,5 +31,12 @@ run_workload ellis_1080p_static --variant 1 --no-cpu-baseline
 run_workload interstellar_1080p --metric interstellar --steps 8 --warmup 2 --no-cpu-baseline
 run_workload interstellar_4k --metric interstellar --width 3840 --height 2160 --max-iter 8192 --steps 4 --warmup 1 --no-cpu-baseline
 run_workload interstellar_4k_static --metric interstellar --width 3840 --height 2160 --max-iter 8192 --steps 4 --warmup 1 --variant 1 --no-cpu-baseline
+# device PNG front end (kernels_png.h): 8 efficient-mode 1080p frames per call; kernel trace and the two HBM passes
+PD=$OUT/png_front_end; mkdir -p "$PD"; cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$PD/stats" -o png -- python "$ROOT/tools/gpu_png_front_end.py" profile > "$PD/run.txt" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$PD/pmc_fetch" -o pmc -- python "$ROOT/tools/gpu_png_front_end.py" profile > "$PD/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$PD/pmc_write" -o pmc -- python "$ROOT/tools/gpu_png_front_end.py" profile > "$PD/pmc_write.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$PD/pmc_sq" -o pmc -- python "$ROOT/tools/gpu_png_front_end.py" profile > "$PD/pmc_sq.log" 2>&1
+cd "$ROOT"
 python tools/bench_configs.py > "$OUT/configs.md" 2> "$OUT/configs.err"
 ls -R "$OUT" | head -60

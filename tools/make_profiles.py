@@ -115,6 +115,45 @@ for name in sorted(os.listdir(G)):
         lines.append("| CPU baseline (oracle, 1 thread) | %.2f %s; %s |" % (bench["cpu_baseline"]["value"], bench["cpu_baseline"]["unit"], bench["cpu_baseline"]["sample"]))
     lines.append("")
     lines.append("```\n%s```\n" % open(os.path.join(d, "stats", "bench_kernel_stats.csv")).read())
+# ---- device PNG front end: per-kernel duration (trace) and HBM bytes (PMC), per call of 8 efficient-mode 1080p frames
+pd = os.path.join(G, "png_front_end")
+if os.path.exists(os.path.join(pd, "stats", "png_kernel_stats.csv")):
+    PNGK = ("png_hist_kernel", "png_count_kernel", "png_scan_kernel", "png_zero_kernel", "png_emit_kernel")
+
+    def pmc_png(path):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            short = next((k for k in PNGK if k in r["Kernel_Name"]), None)
+            if short:
+                agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        return {k: sorted(v)[len(v) // 2] for k, v in agg.items()}
+    ks = {next(k for k in PNGK if k in r["Name"]): r for r in csv.DictReader(open(os.path.join(pd, "stats", "png_kernel_stats.csv"))) if any(k in r["Name"] for k in PNGK)}
+    fe, wr = pmc_png(os.path.join(pd, "pmc_fetch", "pmc_counter_collection.csv")), pmc_png(os.path.join(pd, "pmc_write", "pmc_counter_collection.csv"))
+    sq = pmc_png(os.path.join(pd, "pmc_sq", "pmc_counter_collection.csv")) if os.path.exists(os.path.join(pd, "pmc_sq", "pmc_counter_collection.csv")) else {}
+    shutil.copy(os.path.join(pd, "stats", "png_kernel_stats.csv"), os.path.join(P, "%s_png_kernel_stats.csv" % rnd))
+    for kind in ("fetch", "write", "sq"):
+        f = os.path.join(pd, "pmc_%s" % kind, "pmc_counter_collection.csv")
+        if os.path.exists(f):
+            shutil.copy(f, os.path.join(P, "%s_png_pmc_%s.csv" % (rnd, kind)))
+    run = open(os.path.join(pd, "run.txt")).read().strip().splitlines()
+    nf, frame_b = 8, 1920 * 1080 * 3
+    lines.append("## PNG front end on the device (kernels_png.h): 8 efficient-mode 1920x1080 frames per call (`tools/gpu_png_front_end.py profile`)\n")
+    lines.append("```\n%s\n```\n" % "\n".join(ln for ln in run if "frames/call" in ln))
+    lines.append("| kernel | avg duration (trace) | HBM read + write per call (PMC, FETCH doubled) | bytes / duration | VALU busy | LDS bank-conflict share |\n|---|---|---|---|---|---|")
+    tot_ms, tot_b = 0.0, 0.0
+    for k in PNGK:
+        if k not in ks:
+            continue
+        ms = float(ks[k]["AverageNs"]) / 1e6
+        fb, wb = fe.get((k, "FETCH_SIZE"), 0.0) * KIB * 2, wr.get((k, "WRITE_SIZE"), 0.0) * KIB
+        gui = sq.get((k, "GRBM_GUI_ACTIVE"), 0.0) / 8.0
+        busy = "%.2f" % (4 * sq[(k, "SQ_ACTIVE_INST_VALU")] / (1024 * gui)) if gui else "-"
+        conf = "%.2f" % (sq.get((k, "SQ_LDS_BANK_CONFLICT"), 0.0) / sq[(k, "SQ_ACTIVE_INST_LDS")]) if sq.get((k, "SQ_ACTIVE_INST_LDS")) else "-"
+        lines.append("| `%s` | %.4f ms | %.2f + %.2f MB | %.0f GB/s | %s | %s |" % (k, ms, fb / 1e6, wb / 1e6, (fb + wb) / (ms * 1e-3) / 1e9 if ms else 0.0, busy, conf))
+        tot_ms += ms
+        tot_b += fb + wb
+    lines.append("| all five | %.4f ms per call = %.4f ms per frame | %.2f MB moved vs %.2f MB of pixels + streams (algorithmic) | %.0f GB/s moved, %.0f GB/s algorithmic of 8000 | | |\n" % (
+        tot_ms, tot_ms / nf, tot_b / 1e6, nf * frame_b / 1e6, tot_b / (tot_ms * 1e-3) / 1e9, nf * frame_b / (tot_ms * 1e-3) / 1e9))
 json.dump(traffic, open(traffic_path, "w"), indent=1)
 cfg = os.path.join(G, "configs.md")
 if os.path.exists(cfg):
