@@ -802,8 +802,8 @@ def pmc_traffic(args, kernel_name):
             st = t.get(key.replace("geodesic_relay", "geodesic_static"))
             e["excess_over_algorithmic"] = (
                 "deliberate: in the end-game of a launch unfinished 8x8 tiles are handed from wave to wave through HBM "
-                "(64 rays x 48 B parked and reloaded per hand-over, write-through / cache-bypassing) -- the price of "
-                "the 4-6 % the hand-over takes off a single-frame launch; it is not re-reading of inputs" +
+                "(64 rays x 40 B parked and reloaded per hand-over, ~5 300 hand-overs per 1080p frame, write-through / cache-bypassing) "
+                "-- the price of the 3-5 % the hand-over takes off a single-frame launch; it is not re-reading of inputs" +
                 ("; the static kernel on the same workload moves %d bytes" % st["integrate_kernel_bytes"] if st else ""))
         e["measured_in_this_run"] = False  # PMC counters cannot be read from inside an un-profiled run
         e["origin"] = "committed profile: rocprofv3 --pmc passes of this same command (see `source`)"

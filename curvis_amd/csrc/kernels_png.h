@@ -78,8 +78,9 @@ __device__ __forceinline__ unsigned png_logical_block(unsigned b, unsigned n_blo
 /* Staging (frames whose rows are a multiple of 64 bytes, i.e. every chunk is full and the 256 chunks of a workgroup are 16 KiB
  * of consecutive image bytes): the workgroup loads its span and the span one row above with fully coalesced 16-byte loads
  * (lane i reads bytes [16 i, 16 i + 16) of a 4 KiB piece), subtracts, and leaves the FILTERED bytes in LDS, chunk c at
- * c * 80: with that stride the four ds_read_b128 of a thread's chunk are bank-conflict free (16 lanes x 20 banks apart). */
-constexpr unsigned kPngLdsStride = 80;
+ * c * 68: the tokeniser reads its chunk one dword at a time, and with 17 banks between neighbouring threads' chunks the 64
+ * lanes of a wave hit 64 different banks (80 bytes, chosen first for 16-byte reads, gave 4-way conflicts on these). */
+constexpr unsigned kPngLdsStride = 68;
 __device__ __forceinline__ void png_stage(const PngParams &P, unsigned frame, unsigned block, unsigned char *s_f) {
   const unsigned char *f = P.fb + (size_t)frame * P.frame_bytes;
   const size_t base = (size_t)block * (kPngBlock * kPngChunk);
@@ -94,7 +95,11 @@ __device__ __forceinline__ void png_stage(const PngParams &P, unsigned frame, un
       if (off >= P.row_bytes) u = *reinterpret_cast<const uint4 *>(f + off - P.row_bytes);
       d = make_uint4(png_sub4(c.x, u.x), png_sub4(c.y, u.y), png_sub4(c.z, u.z), png_sub4(c.w, u.w));
     }
-    *reinterpret_cast<uint4 *>(s_f + (j >> 2) * kPngLdsStride + (j & 3u) * 16u) = d;
+    unsigned *dst = reinterpret_cast<unsigned *>(s_f + (j >> 2) * kPngLdsStride + (j & 3u) * 16u); /* 4-byte aligned only */
+    dst[0] = d.x;
+    dst[1] = d.y;
+    dst[2] = d.z;
+    dst[3] = d.w;
   }
 }
 
@@ -205,7 +210,7 @@ struct PngEmitSink { /* pass 3: codes ORed into the workgroup's LDS image of the
 __global__ __launch_bounds__(kPngBlock) void png_hist_kernel(const PngParams P) {
   __shared__ unsigned s_hist[kPngBins];
   __shared__ unsigned long long s_sum[2];
-  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
+  __shared__ __attribute__((aligned(4))) unsigned char s_f[kPngBlock * kPngLdsStride];
   const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
   if (block >= P.blocks_per_frame) return; /* the whole workgroup */
   const unsigned g = block * kPngBlock + threadIdx.x;
@@ -248,7 +253,7 @@ __device__ __forceinline__ unsigned png_thread_bits(const PngParams &P, const un
 __global__ __launch_bounds__(kPngBlock) void png_count_kernel(const PngParams P) {
   __shared__ unsigned s_codes[kPngCodes];
   __shared__ unsigned s_total;
-  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
+  __shared__ __attribute__((aligned(4))) unsigned char s_f[kPngBlock * kPngLdsStride];
   const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
   if (block >= P.blocks_per_frame) return;
   const unsigned g = block * kPngBlock + threadIdx.x;
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) 
   __shared__ unsigned s_codes[kPngCodes];
   __shared__ unsigned s_wave[kPngBlock / 64];
   __shared__ unsigned s_out[kPngLdsWords];
-  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
+  __shared__ __attribute__((aligned(4))) unsigned char s_f[kPngBlock * kPngLdsStride];
   const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
   if (block >= P.blocks_per_frame) return;
   const unsigned g = block * kPngBlock + threadIdx.x;
