@@ -494,11 +494,12 @@ def short(exc):
     return "%s: %s" % (type(exc).__name__, t[0][:200] if t else "")
 
 
-def product_comm(ctx, dist, world, rank, timeout_s=150.0):
+def product_comm(ctx, dist, world, rank, timeout_s=600.0):
     """An RCCL communicator over the ranks' contexts, made by the product's entry points: rank 0 draws the ncclUniqueId
     (curvis_rccl_unique_id), it travels over the control plane, every rank joins with curvis_ctx_rccl_comm_init.  The
     join runs on a helper thread with a time limit (ncclCommInitRank waits for all ranks: a rank that failed early would
-    leave the others inside it for ever), and the ranks agree on the outcome.  (comm, None) on every rank or
+    leave the others inside it for ever; the limit is generous because RCCL's start-up alone was seen to take 3 s on one
+    host and > 100 s on another), and the ranks agree on the outcome.  (comm, None) on every rank or
     (None, reason) on every rank."""
     import threading
     import curvis_amd
