@@ -36,6 +36,15 @@ def save_image(path, rgb, level=None):
         raise CurvisError(rc, (lib().curvis_last_error(None) or b"").decode())
 
 
+def save_zlib_stream(path, zlib_stream, width, height):
+    """A PNG file around a finished zlib stream of Up-filtered RGB8 scanlines -- what Context.deflate_frames returns per frame:
+    signature, IHDR, IDAT + CRC-32, IEND (curvis_image_save_zlib_rgb8)."""
+    buf = np.frombuffer(zlib_stream, dtype=np.uint8)
+    rc = lib().curvis_image_save_zlib_rgb8(str(path).encode(), buf.ctypes.data, buf.size, int(width), int(height))
+    if rc != 0:
+        raise CurvisError(rc, (lib().curvis_last_error(None) or b"").decode())
+
+
 def load_image_as_spherical_image(path, forward=None, up=None):
     """src/images.rs:186-193: forward / up default to x / z"""
     return SphericalImage(load_image(path), forward, up)

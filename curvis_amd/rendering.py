@@ -251,13 +251,19 @@ class VideoRenderingSystem:
             except OSError as err:
                 raise RuntimeError("Could not create tmp output folder %r due to error: %s" % (tmp, err))
 
-        def write(index, rgb, _stats):
+        from .images import save_zlib_stream
+
+        def write(index, frame, _stats):
             path = os.path.join(tmp, "frame_%d.png" % index)
             try:
-                save_image(path, rgb)
+                if isinstance(frame, (bytes, bytearray)):  # a zlib stream made on the device (curvis_ctx_deflate_frames)
+                    save_zlib_stream(path, frame, self.resolution[0], self.resolution[1])
+                else:
+                    save_image(path, frame)
             except Exception as err:
                 raise RuntimeError("Could not save image frame %r due to error: %s" % (path, err))
-        return self.render(on_frame=write, download=True)
+        # the frames are compressed where they are (filter, Huffman coding, Adler-32 as HIP kernels): only the streams cross PCIe
+        return self.render(on_frame=write, download=False, streams=True)
 
     def times_of_frames(self):
         return times_of_frames(self.interpolator.min_time(), self.interpolator.max_time(), self.frame_rate)
@@ -278,9 +284,11 @@ class VideoRenderingSystem:
                                              getattr(self, "max_iterations_sampling", self.sampling_initial_nums), thr1, thr1,
                                              download=download)
 
-    def render(self, on_frame=None, download=True):
+    def render(self, on_frame=None, download=True, streams=False):
         """Render this rank's shard, `batch` frames per launch.  on_frame(index, rgb_or_None, stats_dict) is
-        called per frame in index order of the shard.  Returns the list of per-frame statistics dicts: the
+        called per frame in index order of the shard; with streams=True the frames stay in HBM and on_frame receives each
+        frame's finished zlib stream (bytes; Context.deflate_frames) instead of pixels -- or the pixels after all, should a
+        batch not compress into the worst-case buffer.  Returns the list of per-frame statistics dicts: the
         early-termination statistics (rays, executed Euler steps, escaped +l / -l, capped, clamped texels) are
         exact PER FRAME -- the kernels keep one set of counters per frame of a launch
         (curvis_ctx_frame_stats); kernel_ms is the frame's share of its launch."""
@@ -290,9 +298,15 @@ class VideoRenderingSystem:
         for b0 in range(0, len(mine), self.batch):
             idx = mine[b0:b0 + self.batch]
             cams = [self.camera_at(times[k]) for k in idx]
-            rgb, st = self._render_batch(cams, download)
-            frames = list(rgb) if download else [None] * len(cams)
+            rgb, st = self._render_batch(cams, download and not streams)
+            frames = list(rgb) if (download and not streams) else [None] * len(cams)
             per = self.context.frame_stats()
+            if streams:
+                from ._abi import CurvisError
+                try:
+                    frames, _ = self.context.deflate_frames(self.resolution[0], self.resolution[1], len(cams))
+                except CurvisError:
+                    frames = list(self.context.download_frames(self.resolution[0], self.resolution[1], len(cams)))
             assert len(per) == len(idx)
             for k, frame, s in zip(idx, frames, per):
                 d = dict(frame=k, time=times[k], rank=self.rank, mode=self.mode, batch_frames=len(idx),

@@ -380,6 +380,12 @@ class Context:
         check(lib().curvis_ctx_framebuffer(self._h, C.byref(p), C.byref(n)), self._h)
         return p.value, n.value
 
+    def download_frames(self, width, height, n_frames=1):
+        """curvis_ctx_download: the frames the last render call left in HBM as an n x H x W x 3 uint8 array"""
+        rgb = np.empty((int(n_frames), int(height), int(width), 3), dtype=np.uint8)
+        check(lib().curvis_ctx_download(self._h, rgb.ctypes.data, rgb.size), self._h)
+        return rgb
+
     def render_brute(self, metric, cameras, max_iterations, max_radius, delta, download=True, debug=False, out=None):
         """cameras: one Camera or a list (one launch for the whole batch).  Returns (rgb, stats[, dbg]).
         out: a uint8 array of n*H*W*3 bytes to receive the frames (e.g. a HostBuffer: page-locked, one DMA transfer)."""
