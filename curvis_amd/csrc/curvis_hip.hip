@@ -757,6 +757,8 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->relay_segment = (int)value;
   else if (k == "relay_max_hops")
     ctx->relay_max_hops = (int)value;
+  else if (k == "relay_max_parks")
+    ctx->relay_max_parks = (int)value;
   else if (k == "relay_recheck_every")
     ctx->relay_recheck_every = (int)value;
   else if (k == "relay_max_frames")
@@ -805,6 +807,8 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->relay_segment;
   else if (k == "relay_max_hops")
     *value = ctx->relay_max_hops;
+  else if (k == "relay_max_parks")
+    *value = ctx->relay_max_parks;
   else if (k == "relay_max_frames")
     *value = ctx->relay_max_frames;
   else if (k == "relay_min_blocks")

@@ -426,6 +426,7 @@ struct RelayArgs {
   unsigned fresh_blocks; /* workgroups [0, fresh_blocks) start tiles, the rest relay parked ones */
   unsigned seg;          /* steps per segment */
   unsigned max_hops;     /* a tile is handed over at most this many times (0 = no limit) */
+  unsigned max_parks;    /* hand-overs per launch at most (0 = no limit) */
   unsigned corrupt_ticket; /* test hook (option "relay_test_corrupt"): non-zero = every relay wave of this launch perturbs the
                               state it reloads, so that the first-launch check below has something to find; 0 = off */
 };
@@ -562,9 +563,11 @@ void geodesic_relay(const IntegrateParams P, const RelayArgs A) {
      * with nobody waiting would sit idle until the dispatcher has placed another relay workgroup */
     if (fresh && __hip_atomic_load(&Q->started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)A.fresh_blocks)
       continue;
-    if (__hip_atomic_load(&Q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <=
-        __hip_atomic_load(&Q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      continue;
+    {
+      const unsigned long long tail_now = __hip_atomic_load(&Q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_load(&Q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= tail_now) continue;
+      if (A.max_parks != 0u && tail_now >= A.max_parks) continue; /* hand-over budget of the launch spent */
+    }
     /* a tile that has been handed over `max_hops` times stays where it is: every hop costs 2 x 64 x 40 B of HBM traffic */
     if (!fresh && A.max_hops != 0u && hops >= A.max_hops) continue;
     parked = true;

@@ -37,6 +37,7 @@ struct curvis_ctx {
   double last_png_ms = 0.0;          /* HIP-event time of the last curvis_ctx_deflate_frames */
   int relay_segment = 0;            /* steps between two hand-over points; 0 = automatic */
   int relay_max_hops = 0;           /* hand-overs per tile at most; 0 = no limit */
+  int relay_max_parks = 0;          /* hand-overs per launch at most; 0 = no limit */
   int relay_max_frames = 8;         /* largest launch (frames) the relay kernel is used for: the end-game it repairs is
                                        ~5 % of a one-frame launch and 1-2 % of a launch of three to six frames;
                                        beyond that its staging area (56 B per ray) buys nothing */
@@ -236,6 +237,7 @@ int launch_relay(curvis_ctx *ctx, const IntegrateParams &P, bool relay_only) {
     A.seg = ctx->relay_segment > 0 ? (unsigned)ctx->relay_segment : seg;
   }
   A.max_hops = (unsigned)std::max(0, ctx->relay_max_hops);
+  A.max_parks = (unsigned)std::max(0, ctx->relay_max_parks);
   A.corrupt_ticket = ctx->relay_test_corrupt ? 1u : 0u;
   ctx->relay_test_corrupt = 0;
   if (ctx->relay_resident_threads != (int)bt) {
