@@ -1046,8 +1046,9 @@ int video_main(const Args &a) {
       if (rc == CURVIS_OK && gpu_png) {
         zoff.resize(nb + 1);
         double pms = 0.0;
-        const int zrc = curvis_ctx_deflate_frames(ctx, c.cam.resolution_x, c.cam.resolution_y, (uint32_t)nb, rgb_ptr,
-                                                  batch_buf ? (size_t)a.batch * fbytes : nb * fbytes, zoff.data(), &pms);
+        /* test hook: pretend the streams do not fit (frames that do not compress), so that the fall-back below runs */
+        const size_t zcap = std::getenv("CURVIS_TEST_SMALL_PNG_BUFFER") ? (size_t)64 : batch_buf ? (size_t)a.batch * fbytes : nb * fbytes;
+        const int zrc = curvis_ctx_deflate_frames(ctx, c.cam.resolution_x, c.cam.resolution_y, (uint32_t)nb, rgb_ptr, zcap, zoff.data(), &pms);
         if (zrc == CURVIS_OK) {
           streams = true;
           ds.png_ms += pms;

@@ -143,17 +143,20 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   ctx->last_png_direct_blocks = direct_blocks;
   HIP_TRY(ctx, hipEventElapsedTime(&ms_b, ctx->ev0, ctx->ev1));
 
-  /* streams to the host: deflate bytes, then the Adler-32 of the filtered scanlines */
+  /* streams to the host: deflate bytes, then the Adler-32 of the filtered scanlines.  Sizes first, copies after: a call that
+   * fails for want of room must not leave transfers into the caller's buffer in flight */
   size_t off = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
     const size_t bytes = (size_t)((frame_bits[f] + 7) / 8);
     if (bytes > L.out_words * 4 || off + bytes + 4 > out_cap)
       return fail(ctx, CURVIS_E_INVALID, "output buffer too small for the compressed frames");
     offsets[f] = off;
-    HIP_TRY(ctx, hipMemcpyAsync(out + off, (const uint8_t *)(P.out + (size_t)f * L.out_words), bytes, hipMemcpyDeviceToHost, ctx->stream));
     off += bytes + 4;
   }
   offsets[n_frames] = off;
+  for (uint32_t f = 0; f < n_frames; ++f)
+    HIP_TRY(ctx, hipMemcpyAsync(out + offsets[f], (const uint8_t *)(P.out + (size_t)f * L.out_words), offsets[f + 1] - offsets[f] - 4,
+                                hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   const unsigned long long n = (unsigned long long)H * ((unsigned long long)W * 3 + 1);
   for (uint32_t f = 0; f < n_frames; ++f) {

@@ -148,6 +148,15 @@ def test_video_orbit_frames_and_quirks(scene_files):
     assert s3["gpu_png"] is False and s3["encode"]["deflate_ms"] > 0          # --encode-bench measures the host encoder
     for k in range(15):   # host fast writer == device front end == zlib, pixel for pixel
         assert np.array_equal(pngio.read_png(out2 / "tmp" / ("frame_%d.png" % k)), pngio.read_png(out / "tmp" / ("frame_%d.png" % k))), k
+    # frames whose streams do not fit the batch buffer (here: a test hook shrinks it) are fetched as pixels and go to the host encoder
+    r5 = run("video", d / "pos.png", d / "neg.png", out2, "-v", d / "vid.toml", "-s", d / "sim.toml", "-c", d / "cam.toml", "--stats", out2 / "st5.jsonl",
+             env=dict(os.environ, CURVIS_TEST_SMALL_PNG_BUFFER="1"))
+    assert r5.returncode == 0, r5.stderr
+    s5 = json.loads((out2 / "st5.jsonl.summary.json").read_text())
+    assert sum(dv["gpu_png_fallback_frames"] for dv in s5["devices"]) == 15 and sum(dv["gpu_png_frames"] for dv in s5["devices"]) == 0
+    assert s5["encode"]["deflate_ms"] > 0
+    for k in (0, 7, 14):
+        assert np.array_equal(pngio.read_png(out2 / "tmp" / ("frame_%d.png" % k)), pngio.read_png(out / "tmp" / ("frame_%d.png" % k))), k
     r4 = run("video", d / "pos.png", d / "neg.png", out2, "-v", d / "vid.toml", "-s", d / "sim.toml", "-c", d / "cam.toml", "--gpu-png", "off")
     assert r4.returncode == 0, r4.stderr
     assert np.array_equal(pngio.read_png(out2 / "tmp" / "frame_14.png"), pngio.read_png(out / "tmp" / "frame_14.png"))
