@@ -78,9 +78,9 @@ __device__ __forceinline__ unsigned png_logical_block(unsigned b, unsigned n_blo
 /* Staging (frames whose rows are a multiple of 64 bytes, i.e. every chunk is full and the 256 chunks of a workgroup are 16 KiB
  * of consecutive image bytes): the workgroup loads its span and the span one row above with fully coalesced 16-byte loads
  * (lane i reads bytes [16 i, 16 i + 16) of a 4 KiB piece), subtracts, and leaves the FILTERED bytes in LDS, chunk c at
- * c * 68: the tokeniser reads its chunk one dword at a time, and with 17 banks between neighbouring threads' chunks the 64
- * lanes of a wave hit 64 different banks (80 bytes, chosen first for 16-byte reads, gave 4-way conflicts on these). */
-constexpr unsigned kPngLdsStride = 68;
+ * c * 80: the tokeniser reads its chunk 16 bytes at a time (ds_read_b128), and with 20 banks between neighbouring threads'
+ * chunks the 16 lanes such a read serves per cycle hit 64 different banks. */
+constexpr unsigned kPngLdsStride = 80;
 __device__ __forceinline__ void png_stage(const PngParams &P, unsigned frame, unsigned block, unsigned char *s_f) {
   const unsigned char *f = P.fb + (size_t)frame * P.frame_bytes;
   const size_t base = (size_t)block * (kPngBlock * kPngChunk);
@@ -95,11 +95,7 @@ __device__ __forceinline__ void png_stage(const PngParams &P, unsigned frame, un
       if (off >= P.row_bytes) u = *reinterpret_cast<const uint4 *>(f + off - P.row_bytes);
       d = make_uint4(png_sub4(c.x, u.x), png_sub4(c.y, u.y), png_sub4(c.z, u.z), png_sub4(c.w, u.w));
     }
-    unsigned *dst = reinterpret_cast<unsigned *>(s_f + (j >> 2) * kPngLdsStride + (j & 3u) * 16u); /* 4-byte aligned only */
-    dst[0] = d.x;
-    dst[1] = d.y;
-    dst[2] = d.z;
-    dst[3] = d.w;
+    *reinterpret_cast<uint4 *>(s_f + (j >> 2) * kPngLdsStride + (j & 3u) * 16u) = d;
   }
 }
 
@@ -125,13 +121,45 @@ __device__ __forceinline__ void png_tokens(const PngParams &P, const unsigned ch
       run = 0u;                                        \
     }                                                  \
   } while (0)
+#define PNG_WORD(word)                                 \
+  do {                                                 \
+    unsigned d_ = (word);                              \
+    if (d_ == 0u) {                                    \
+      run += 4u;                                       \
+    } else {                                           \
+      _Pragma("unroll 1") for (unsigned b_ = 0; b_ < 4u; ++b_) { \
+        const unsigned v_ = d_ & 0xffu;                \
+        d_ >>= 8;                                      \
+        if (v_ == 0u) {                                \
+          ++run;                                       \
+        } else {                                       \
+          PNG_FLUSH_RUN();                             \
+          sink.lit(v_);                                \
+        }                                              \
+      }                                                \
+    }                                                  \
+  } while (0)
+  if (s_chunk) { /* staged: 64 filtered bytes in LDS, 16 at a time; zero runs of 16 cost one read and one compare */
+#pragma unroll 1
+    for (unsigned q = 0; q < kPngChunk; q += 16u) {
+      const uint4 d4 = *reinterpret_cast<const uint4 *>(s_chunk + q);
+      if ((d4.x | d4.y | d4.z | d4.w) == 0u) {
+        run += 16u;
+        continue;
+      }
+      PNG_WORD(d4.x);
+      PNG_WORD(d4.y);
+      PNG_WORD(d4.z);
+      PNG_WORD(d4.w);
+    }
+    PNG_FLUSH_RUN();
+    return;
+  }
   const unsigned n_words = (nb + 3u) >> 2;
 #pragma unroll 1
   for (unsigned w = 0; w < n_words; ++w) {
     unsigned d;
-    if (s_chunk) {
-      d = *reinterpret_cast<const unsigned *>(s_chunk + 4u * w);
-    } else if (P.aligned) {
+    if (P.aligned) {
       const unsigned c = *reinterpret_cast<const unsigned *>(cur + 4u * w);
       d = png_sub4(c, row != 0u ? *reinterpret_cast<const unsigned *>(up + 4u * w) : 0u);
     } else {
@@ -157,6 +185,7 @@ __device__ __forceinline__ void png_tokens(const PngParams &P, const unsigned ch
     }
   }
   PNG_FLUSH_RUN();
+#undef PNG_WORD
 #undef PNG_FLUSH_RUN
 }
 
@@ -164,7 +193,8 @@ struct PngHistSink { /* pass 1 */
   unsigned *hist; /* LDS */
   unsigned k;     /* index of the next filtered byte, counted from the thread's first (<= 65) */
   unsigned a, kv; /* Adler-32 partial sums in 32 bits: sum of bytes (<= 65 * 255), sum of k * byte_k (<= 65 * 65 * 255) */
-  unsigned zeros; /* literal zeros are the hottest bin by far: counted in a register, added once */
+  unsigned zeros; /* literal zeros are the hottest bin by far: counted in a register, added once (doing the same for +1 and -1,
+                     the next hottest after the Up filter, was measured SLOWER: 112 vs 86 us -- two more branches per literal) */
   __device__ __forceinline__ void lit(unsigned v) {
     if (v == 0u) {
       ++zeros;
@@ -210,7 +240,7 @@ struct PngEmitSink { /* pass 3: codes ORed into the workgroup's LDS image of the
 __global__ __launch_bounds__(kPngBlock) void png_hist_kernel(const PngParams P) {
   __shared__ unsigned s_hist[kPngBins];
   __shared__ unsigned long long s_sum[2];
-  __shared__ __attribute__((aligned(4))) unsigned char s_f[kPngBlock * kPngLdsStride];
+  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
   const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
   if (block >= P.blocks_per_frame) return; /* the whole workgroup */
   const unsigned g = block * kPngBlock + threadIdx.x;
@@ -253,7 +283,7 @@ __device__ __forceinline__ unsigned png_thread_bits(const PngParams &P, const un
 __global__ __launch_bounds__(kPngBlock) void png_count_kernel(const PngParams P) {
   __shared__ unsigned s_codes[kPngCodes];
   __shared__ unsigned s_total;
-  __shared__ __attribute__((aligned(4))) unsigned char s_f[kPngBlock * kPngLdsStride];
+  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
   const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
   if (block >= P.blocks_per_frame) return;
   const unsigned g = block * kPngBlock + threadIdx.x;
@@ -311,7 +341,7 @@ __global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) 
   __shared__ unsigned s_codes[kPngCodes];
   __shared__ unsigned s_wave[kPngBlock / 64];
   __shared__ unsigned s_out[kPngLdsWords];
-  __shared__ __attribute__((aligned(4))) unsigned char s_f[kPngBlock * kPngLdsStride];
+  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
   const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
   if (block >= P.blocks_per_frame) return;
   const unsigned g = block * kPngBlock + threadIdx.x;
