@@ -95,9 +95,11 @@ def flush_c_stdio():
 
 def self_launch(args):
     """--gpus N > 1 from a plain shell: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`"""
-    import torch
+    # the product's own device count (no `import torch` in a process that is about to exec the launcher: on a box with a cold
+    # page cache that import alone costs tens of seconds)
+    from curvis_amd import _abi
     share = os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1"
-    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    have = max(0, int(_abi.lib().curvis_device_count()))
     if have < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if have < args.gpus and not share:
