@@ -142,13 +142,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if os.environ.get("CURVIS_BENCH_SHARE_DEVICE") != "1" and torch.cuda.device_count() < world:
-        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible" % (world, torch.cuda.device_count()))
+    # a launcher may give every rank ONE visible device of its own (HIP_VISIBLE_DEVICES per rank): then each rank takes device 0,
+    # and the PCI identity check below still refuses ranks that really share a GPU
+    visible = torch.cuda.device_count()
+    one_device_per_rank = world > 1 and visible == 1 and os.environ.get("CURVIS_BENCH_SHARE_DEVICE") != "1"
+    if os.environ.get("CURVIS_BENCH_SHARE_DEVICE") != "1" and visible < world and not one_device_per_rank:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible" % (world, visible))
     # test hooks (1-GPU boxes): CURVIS_BENCH_SHARE_DEVICE=1 maps every rank to GPU 0; RCCL refuses two ranks on one GPU
     # ("Duplicate GPU detected"), so with it RCCL is only attempted when CURVIS_BENCH_TRY_RCCL=1 (which then exercises
     # the agreed fall-back with two real ranks); CURVIS_BENCH_BACKEND=gloo skips RCCL altogether.
     share_device = os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1"
-    device_index = 0 if share_device else local_rank
+    device_index = 0 if (share_device or one_device_per_rank) else local_rank
     try_rccl = os.environ.get("CURVIS_BENCH_BACKEND", "nccl") != "gloo" and (
         not share_device or os.environ.get("CURVIS_BENCH_TRY_RCCL") == "1")
     torch.cuda.set_device(device_index)
