@@ -247,7 +247,10 @@ def main():
 
     fence()
     phase("priming_and_warmup")
-    clock = ClockSampler(ctx, 0.02)  # shader clock / board power OF THE TIMED REGION (sysfs reads on a helper thread)
+    # shader clock / board power around the timed region: ONE sysfs read before and one after (no sampler thread inside the
+    # region: it would add host jitter to `value`; the sysfs level lags anyway -- the clock the region really ran at comes
+    # from the kernel's cycle count, `effective_sclk_mhz` below)
+    status_before = ctx.device_status()
     t0 = time.perf_counter()
     steps_executed = 0
     rays = 0
@@ -261,8 +264,43 @@ def main():
         shade_ms += st.shade_ms
     fence()
     elapsed = time.perf_counter() - t0
-    timed_clock = clock.stop()
+    status_after = ctx.device_status()
+    timed_clock = {"sclk_mhz_sysfs_before_after": [status_before["sclk_mhz"], status_after["sclk_mhz"]],
+                   "power_w_before_after": [status_before["power_w"], status_after["power_w"]]}
     phase("timed_region")
+
+    # The reference's output contract: render_image RETURNS an owned host image (src/systems.rs:314-329).  The same
+    # launches with the frame copied into page-locked host memory (curvis_host_alloc: one DMA transfer per frame, as
+    # `curvis video` does it) -- outside the contract's timed region, reported beside `value`, never as `value`.
+    with_download = None
+    if not args.download:
+        hb = curvis_amd.HostBuffer(args.width * args.height * 3)
+
+        def step_dl():
+            _, st_dl = ctx.render_brute(metric, cam, args.max_iter, R, DELTA, download=True, out=hb.array)
+            return st_dl
+        step_dl()
+        fence()
+        td = time.perf_counter()
+        dl_steps = 0
+        for _ in range(args.steps):
+            dl_steps += step_dl().steps
+        fence()
+        dl_elapsed = time.perf_counter() - td
+        if dist is not None:
+            tdl = torch.tensor([dl_elapsed], dtype=torch.float64)
+            dist.all_reduce(tdl, op=dist.ReduceOp.MAX)
+            dl_elapsed = float(tdl.item())
+            sdl = torch.tensor([float(dl_steps)], dtype=torch.float64)
+            dist.all_reduce(sdl, op=dist.ReduceOp.SUM)
+            dl_steps = float(sdl.item())
+        with_download = {"value": round(dl_steps / dl_elapsed / 1e6, 1), "ms_per_step": round(dl_elapsed / args.steps * 1e3, 3),
+                         "bytes_per_frame": args.width * args.height * 3, "steps": args.steps,
+                         "note": "the same %d single-frame launches, each frame DMA'd into a curvis_host_alloc (page-locked) buffer before the "
+                                 "next launch: what RelativisticSystem::render_image's caller gets (an owned host image, "
+                                 "src/systems.rs:314-329); measured right after the contract's timed region, max over ranks" % args.steps}
+        del hb
+        phase("with_download")
 
     # secondary figure, outside the contract's timed region: launches of several frames amortise the ramp and the
     # end-game of a launch (~5 % of a single 1080p frame), which is what a video shard runs as
@@ -310,8 +348,8 @@ def main():
                 "ms_per_step": round(own_elapsed / args.steps * 1e3, 4),
                 "kernel_ms_avg": round(kernel_ms / args.steps, 4),
                 "value": round(steps_executed / own_elapsed / 1e6, 1),
-                "sclk_mhz_timed_region": timed_clock["sclk_mhz_median"],
-                "power_w_timed_region": timed_clock["power_w_median"],
+                "sclk_mhz_sysfs_before_after_timed_region": timed_clock["sclk_mhz_sysfs_before_after"],
+                "power_w_before_after_timed_region": timed_clock["power_w_before_after"],
                 "sclk_mhz": sustained["sclk_mhz_median"] if sustained else None,
                 "power_w": sustained["power_w_median"] if sustained else None,
                 "value_sustained": sustained["value"] if sustained else None}
@@ -369,11 +407,14 @@ def main():
             "unit": "Mray-steps/s (executed Euler steps, all GPUs)",
             "value_nominal_cap": round(nominal, 1),
             "value_note": "single-frame launches (one frame per step): each carries the ramp and end-game tail of a launch",
-            # shader clock and board power while the timed region ran (rank 0's GPU; every rank's in per_rank): boxes differ by
-            # 2-6 % in the clock they hold under this load, and a short region runs at boost clock -- see value_sustained
-            "sclk_mhz": timed_clock["sclk_mhz_median"],
-            "power_w": timed_clock["power_w_median"],
-            "clock_samples": timed_clock["samples"],
+            # the clock the timed region ran at = the kernel's shader cycles per launch (live SQ pass: GRBM_GUI_ACTIVE / 8 XCDs,
+            # a property of the instruction stream) / the kernel time of THIS region (HIP events); boxes differ by 2-6 % in
+            # the clock they hold under this load.  The sysfs level (read once before and once after the region) lags a
+            # 0.2 s region and is kept only as a cross-reference; the 10 s run below samples it properly.
+            "effective_sclk_mhz": None,
+            "sclk_mhz_sysfs_before_after": timed_clock["sclk_mhz_sysfs_before_after"],
+            "power_w_before_after": timed_clock["power_w_before_after"],
+            "value_with_download": with_download,
             "value_multi_frame": multi,
             "n_gpus": world,
             "steps": args.steps,
@@ -426,6 +467,21 @@ def main():
                         "note": "7 B/ray algorithmic; the loop is register-resident, HBM fraction is ~0 by construction"},
             },
         }
+        if with_download is not None:
+            with_download["delta_ms_per_step"] = round(with_download["ms_per_step"] - out["ms_per_step"], 3)
+            with_download["fraction_of_value"] = round(with_download["value"] / out["value"], 4)
+        live_sq = traffic_note.get("live", {}).get("sq") if isinstance(traffic_note, dict) and isinstance(traffic_note.get("live"), dict) else None
+        if live_sq and kernel_s > 0:
+            eff = live_sq["shader_cycles_per_launch"] / kernel_s / 1e6
+            out["effective_sclk_mhz"] = round(eff, 1)
+            out["roofline"]["effective_sclk_mhz"] = round(eff, 1)
+            # the FP64 peak AT THAT CLOCK (78.6 TF is 256 CU x 4 SIMD x 16 lanes x 2 flop at 2400 MHz)
+            out["roofline"]["peak_at_effective_clock"] = round(FP64_VECTOR_PEAK_TFLOPS * eff / 2400.0, 2)
+            out["roofline"]["frac_at_effective_clock"] = round(achieved_tflops / (FP64_VECTOR_PEAK_TFLOPS * eff / 2400.0), 4)
+            out["roofline"]["effective_clock_note"] = (
+                "shader cycles per launch of the live SQ pass (%d, GRBM_GUI_ACTIVE / 8) / this region's average kernel time (%.4f ms); "
+                "the profiled child's own dispatches ran at %s MHz (same cycles / their own duration: a 4-launch process is "
+                "still ramping its clock)" % (live_sq["shader_cycles_per_launch"], kernel_s * 1e3, live_sq.get("sclk_mhz_profiled_dispatches")))
         if sustained is not None:
             out["value_sustained"] = sustained
         if comm_info is not None:
@@ -452,9 +508,12 @@ def main():
     # The JSON line must be the LAST thing on the job's stdout: libraries (RCCL's banner) write to the C stdout, which is
     # block-buffered when redirected and would otherwise be flushed at exit, after the line.  So: tear everything down,
     # flush the C streams on every rank, meet once more, and only then rank 0 prints.
-    ctx.close()
-    sky_dev.clear()
-    if dist is not None and not args.no_video_e2e and (world > 1 or os.environ.get("CURVIS_BENCH_FORCE_DIST") == "1"):
+    if not WEDGED["here"]:
+        ctx.close()
+        sky_dev.clear()
+    # one visible device per rank (HIP_VISIBLE_DEVICES set by the launcher): rank 0's child would see ONE GPU and
+    # `curvis video --devices N` could only fail -- the binary gets the launcher's restriction lifted instead
+    if dist is not None and not args.no_video_e2e and not WEDGED["any"] and (world > 1 or os.environ.get("CURVIS_BENCH_FORCE_DIST") == "1"):
         # the product's own multi-GPU design -- ONE process, N device threads, ncclCommInitAll + curvis_ctx_bcast_skies, shared
         # retry queue, page-locked batch buffers, PNG writer pool -- end to end on a 16N-frame rendition of configs[3]; every
         # rank has released its context, the others wait at the barrier while rank 0 runs the binary over all N GPUs
@@ -485,6 +544,9 @@ def main():
         out["phase_seconds"] = phases
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()
+    if WEDGED["any"]:
+        flush_c_stdio()
+        os._exit(0)  # a thread stuck inside ncclCommInitRank would keep the interpreter from exiting
 
 
 def agree(dist, world, ok, why=None):
@@ -498,6 +560,9 @@ def agree(dist, world, ok, why=None):
 def short(exc):
     t = str(exc).splitlines()
     return "%s: %s" % (type(exc).__name__, t[0][:200] if t else "")
+
+
+WEDGED = {"any": False, "here": False}  # set by product_comm: some rank's ncclCommInitRank never returned
 
 
 def product_comm(ctx, dist, world, rank, timeout_s=600.0):
@@ -534,7 +599,15 @@ def product_comm(ctx, dist, world, rank, timeout_s=600.0):
     th.start()
     th.join(float(os.environ.get("CURVIS_BENCH_RCCL_INIT_TIMEOUT", timeout_s)))
     mine_ok = "comm" in res
-    ok, why = agree(dist, world, mine_ok, res.get("why") or ("ncclCommInitRank did not return within the time limit" if th.is_alive() else None))
+    wedged = th.is_alive()   # the helper thread is still inside ncclCommInitRank, holding the context
+    ok, why = agree(dist, world, mine_ok, res.get("why") or ("ncclCommInitRank did not return within the time limit" if wedged else None))
+    # a rank whose join never came back must not open another RCCL communicator on the same GPU (torch's nccl group) nor
+    # destroy the context under the wedged thread: every rank learns of it and the run goes straight to the host-staged
+    # broadcast, leaks the context and leaves through os._exit once the line is out
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(wedged))
+    WEDGED["any"] = any(flags)
+    WEDGED["here"] = bool(wedged)
     if ok:
         return res["comm"], None
     if mine_ok and world == 1:  # with peers missing, destroying a half-connected communicator may block: leave it
@@ -580,12 +653,20 @@ def distribute_skies(ctx, dist, torch, world, rank, host_skies, sw, sh, try_rccl
                     for which in range(2):
                         ctx.set_sky(which, curvis_amd.SphericalImage(host_skies[which]))
                 torch.cuda.synchronize()
-                dist.barrier()
-                t0 = time.perf_counter()
-                ctx.bcast_skies(comm, 0)  # header + 2 x ncclBroadcast on the context's stream, synchronised inside
             except Exception as exc:  # noqa: BLE001
-                ok, why = False, short(exc)
-            ms = timed_ms(t0)
+                ok, why = False, "upload on rank 0: " + short(exc)
+            # every rank issues the SAME sequence of control-plane collectives whatever happened on rank 0 (a barrier
+            # inside the try was skipped by a rank that raised, and the others waited in it for ever): agree, barrier, broadcast
+            # only if the upload stood, timing reduction, agree
+            up_ok, _ = agree(dist, world, ok, why)
+            dist.barrier()
+            t0 = time.perf_counter()
+            if up_ok:
+                try:
+                    ctx.bcast_skies(comm, 0)  # header + 2 x ncclBroadcast on the context's stream, synchronised inside
+                except Exception as exc:  # noqa: BLE001
+                    ok, why = False, short(exc)
+            ms = timed_ms(t0)  # (the upload's failure stays rank 0's own outcome: the agreement below reports it once)
             ok, why = agree(dist, world, ok, why)
             try:
                 curvis_amd.Context.rccl_comm_destroy(comm)
@@ -600,7 +681,9 @@ def distribute_skies(ctx, dist, torch, world, rank, host_skies, sw, sh, try_rccl
             else:
                 fell.append("curvis_ctx_bcast_skies: " + str(why))
     group = None
-    if not done and try_rccl and not fail3:  # second choice: torch's RCCL
+    if not done and try_rccl and not fail3 and WEDGED["any"]:
+        fell.append("torch nccl group: not attempted (a rank is still inside ncclCommInitRank on its GPU)")
+    if not done and try_rccl and not fail3 and not WEDGED["any"]:  # second choice: torch's RCCL
         ok, why = True, None
         try:
             group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
@@ -753,6 +836,9 @@ def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gp
                "-v", os.path.join(d, "vid.toml"), "-s", os.path.join(d, "sim.toml"), "-c", os.path.join(d, "cam.toml"),
                "--mode", mode, "--devices", str(world), "--batch", "4" if mode == "brute" else "16", "--stats", os.path.join(d, "st.jsonl")]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        if world > 1 and not share_device:  # a per-rank device mask is the launcher's, not the binary's: it drives all N GPUs itself
+            for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+                env.pop(k, None)
         if share_device:
             env["CURVIS_TEST_SHARE_DEVICE"] = "1"
         elif world == 1 and mode == "brute":
@@ -885,12 +971,20 @@ def live_traffic(args, kernel_name, steps_per_launch):
             if rc != 0:
                 return "rocprofv3 --pmc %s exited with %d" % (" ".join(counters), rc)
             vals = {c: [] for c in counters}
+            durations = {}
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
                     for r in csv.DictReader(f):
                         if kernel_name in r.get("Kernel_Name", "") and r.get("Counter_Name") in vals:
                             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                            try:
+                                durations[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+                            except (KeyError, ValueError):
+                                pass
             res = {}
+            if durations:
+                dv = sorted(durations.values())
+                res["_dispatch_seconds"] = (dv[len(dv) // 2], len(dv))
             for c, v in vals.items():
                 if not v:
                     return "no %s rows for %s in the rocprofv3 output" % (c, kernel_name)
@@ -928,6 +1022,8 @@ def live_traffic(args, kernel_name, steps_per_launch):
                       "salu_instr_per_wave_step": round(sq["SQ_INSTS_SALU"][0] / wave_steps, 1),
                       "valu_busy": round(4 * sq["SQ_ACTIVE_INST_VALU"][0] / (1024 * gui), 4),
                       "shader_cycles_per_launch": int(gui),
+                      "sclk_mhz_profiled_dispatches": (round(gui / sq["_dispatch_seconds"][0] / 1e6, 1)
+                                                       if sq.get("_dispatch_seconds", (0,))[0] > 0 else None),
                       "cycles_per_wave_step_per_simd": round(gui * 1024 / wave_steps, 1),
                       "source": "this run: rocprofv3 --pmc " + " ".join(SQ) + " (third child run); busy = 4 x "
                                 "SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}

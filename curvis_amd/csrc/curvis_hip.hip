@@ -145,7 +145,23 @@ void curvis_ctx_destroy(curvis_ctx *ctx) {
 int curvis_ctx_device_info(const curvis_ctx *ctx, char *name, size_t name_cap, int *compute_units, int *clock_mhz) {
   if (!ctx) return CURVIS_E_INVALID;
   if (name && name_cap) {
-    std::snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    /* some hosts' driver stack reports no marketing name (hipDeviceProp_t::name empty: no amdgpu.ids entry): take the
+     * board's product name from sysfs then, and say so rather than print nothing */
+    std::string nm = ctx->prop.name;
+    if (nm.find_first_not_of(' ') == std::string::npos) {
+      char id[64] = {0};
+      if (hipDeviceGetPCIBusId(id, (int)sizeof id, ctx->device) == hipSuccess) {
+        for (char *p = id; *p; ++p) *p = (char)std::tolower((unsigned char)*p);
+        if (FILE *f = std::fopen((std::string("/sys/bus/pci/devices/") + id + "/product_name").c_str(), "r")) {
+          char line[128] = {0};
+          if (std::fgets(line, sizeof line, f)) nm = line;
+          std::fclose(f);
+          while (!nm.empty() && (nm.back() == '\n' || nm.back() == ' ')) nm.pop_back();
+        }
+      }
+      if (nm.find_first_not_of(' ') == std::string::npos) nm = "AMD GPU, name not reported by the driver";
+    }
+    std::snprintf(name, name_cap, "%s (%s)", nm.c_str(), ctx->prop.gcnArchName);
   }
   if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
   if (clock_mhz) *clock_mhz = ctx->prop.clockRate / 1000;
@@ -880,6 +896,66 @@ int curvis_selftest_math(curvis_ctx *ctx, int op, const double *a, const double 
   (void)hipFree(dout);
   if (db) (void)hipFree(db);
   return CURVIS_OK;
+}
+
+int curvis_selftest_math3(curvis_ctx *ctx, int op, const double *a, const double *b, const double *c, double *out, size_t n) {
+  if (!ctx || !a || !out) return CURVIS_E_INVALID;
+  if (n == 0) return CURVIS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const double *in[3] = {a, b, c};
+  double *dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int rc = CURVIS_OK;
+  for (int k = 0; k < 4 && rc == CURVIS_OK; ++k) {
+    if (k < 3 && !in[k]) continue;
+    if (hipMalloc((void **)&dev[k], n * sizeof(double)) != hipSuccess ||
+        (k < 3 && hipMemcpy(dev[k], in[k], n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess))
+      rc = fail(ctx, CURVIS_E_HIP, "curvis_selftest_math3: device buffer");
+  }
+  if (rc == CURVIS_OK) {
+    hipLaunchKernelGGL(selftest_math3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, dev[0], dev[1],
+                       dev[2], dev[3], n);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(out, dev[3], n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(ctx, CURVIS_E_HIP, "curvis_selftest_math3: launch");
+  }
+  for (double *d : dev)
+    if (d) (void)hipFree(d);
+  return rc;
+}
+
+int curvis_selftest_fast_step(curvis_ctx *ctx, const curvis_metric *metric, double delta, double max_radius, const double *states,
+                              size_t n, double *out) {
+  if (!ctx || !metric || !states || !out) return CURVIS_E_INVALID;
+  if (curvis_metric_validate(metric) != CURVIS_OK) return fail(ctx, CURVIS_E_INVALID, "curvis_selftest_fast_step: invalid metric");
+  if (n == 0) return CURVIS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const cvk::MetricParams MP = make_metric(*metric);
+  double *din = nullptr, *dout = nullptr;
+  int rc = CURVIS_OK;
+  if (hipMalloc((void **)&din, n * 5 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&dout, n * CURVIS_FAST_STEP_RECORD * sizeof(double)) != hipSuccess ||
+      hipMemcpy(din, states, n * 5 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+    rc = fail(ctx, CURVIS_E_HIP, "curvis_selftest_fast_step: device buffer");
+  if (rc == CURVIS_OK) {
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    switch (metric->kind) {
+      case CURVIS_METRIC_ELLIS:
+        hipLaunchKernelGGL((selftest_fast_step_kernel<cvk::METRIC_ELLIS>), grid, block, 0, ctx->stream, MP, delta, max_radius, din, n, dout);
+        break;
+      case CURVIS_METRIC_INTERSTELLAR:
+        hipLaunchKernelGGL((selftest_fast_step_kernel<cvk::METRIC_INTERSTELLAR>), grid, block, 0, ctx->stream, MP, delta, max_radius, din, n, dout);
+        break;
+      default:
+        hipLaunchKernelGGL((selftest_fast_step_kernel<cvk::METRIC_FLAT>), grid, block, 0, ctx->stream, MP, delta, max_radius, din, n, dout);
+        break;
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(out, dout, n * CURVIS_FAST_STEP_RECORD * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(ctx, CURVIS_E_HIP, "curvis_selftest_fast_step: launch");
+  }
+  if (din) (void)hipFree(din);
+  if (dout) (void)hipFree(dout);
+  return rc;
 }
 
 } /* extern "C" */

@@ -250,6 +250,28 @@ CV_HD bool metric_fast_ok(int kind, const MetricParams &M, double max_radius) {
   return ok;
 }
 
+/* Probe hook of the fast step's quotients.  The hot kernels pass none (NoProbe: every call is an empty inline and
+ * leaves no instruction); curvis_selftest_fast_step passes a recorder, so that the numerators, denominators and SHARED
+ * reciprocals the step really forms -- products of one refined 1/r and one refined 1/sin(theta) -- can be looked at
+ * from outside: how far each y is from 1/d decides how often div_with_recip can mis-round.
+ * k: 0 r' = l/r (Ellis), 1 1/r^2, 2 p_phi^2/sin^2, 3 dp_l = (b^2 r')/r^3, 4 cos/(r^2 sin^3), 5 1/(r^2 sin^2) (PHI). */
+struct NoProbe {
+#if defined(__HIPCC__) || defined(__HIP__)
+  __host__ __device__
+#endif
+  inline void rec(int, double, double, double) const {}
+};
+/* one Newton step on an approximate reciprocal.  For y within an ulp of 1/d the result is RN(1/d) unless d's
+ * significand is all ones (Markstein); with y = RN(1/d) div_with_recip is correctly rounded, not just almost always.
+ * Only the CV_CERTIFIED_DIV build (an A/B measurement, tools/gpu_ab.py) calls it inside the step. */
+CV_HD double recip_newton(double d, double y) {
+  const double e = CV_FMA(-d, y, 1.0);
+  return CV_FMA(y, e, y);
+}
+#ifndef CV_CERTIFIED_DIV
+#define CV_CERTIFIED_DIV 0
+#endif
+
 /* EQ (the sampling kernel of the efficient renderer only): every photon of compute_escape_angle starts at
  * theta = fl(pi/2) with p_theta = 0 (src/systems.rs:221-230) and keeps that theta for ever, so
  * while theta has exactly those bits the step is taken in its equatorial form: sin = 1 and cos = RN(pi/2 - fl(pi/2))
@@ -257,8 +279,8 @@ CV_HD bool metric_fast_ok(int kind, const MetricParams &M, double max_radius) {
  * 1/s = 1, s^2 = s^3 = 1, p_phi^2/s^2 = p_phi^2 (zero remainder), r^2 s^3 = r^2, 1/(r^2 s^2) = 1/r^2 -- so
  * the state is the generic step's bit for bit, with ~40 of ~95 instructions less in the dependency chain of the
  * lone waves these launches consist of.  A ray whose theta has moved takes the generic step (never observed). */
-template <int KIND, bool PHI, bool WIDE_T = false, bool EQ = false>
-CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_ok) {
+template <int KIND, bool PHI, bool WIDE_T = false, bool EQ = false, class PROBE = NoProbe>
+CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_ok, const PROBE &probe = PROBE()) {
   double s, c;
   int s_ok;
   const bool eq = EQ && cv_bits(q.th) == 0x3FF921FB54442D18ULL;
@@ -287,6 +309,8 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
   if (KIND == METRIC_ELLIS) {
     r2 = M.rho2 + q.l * q.l;
     sqrt_and_rsqrt(r2, r, y_r);
+    if (CV_CERTIFIED_DIV) y_r = recip_newton(r, y_r);
+    probe.rec(0, q.l, r, y_r);
     rd = div_with_recip(q.l, r, y_r);
     y_s = recip_refined(s);
   } else {
@@ -327,22 +351,31 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
     q.p2 = q.p2 + dp2e * delta;
     return;
   }
-  const double y_r2 = y_r * y_r;
-  const double y_ss = y_s * y_s;
+  double y_r2 = y_r * y_r;
+  double y_ss = y_s * y_s;
   const double ss = s * s;
+  if (CV_CERTIFIED_DIV) {
+    y_r2 = recip_newton(r2, y_r2);
+    y_ss = recip_newton(ss, y_ss);
+  }
+  probe.rec(1, 1.0, r2, y_r2);
   const double g22c = div_with_recip(1.0, r2, y_r2);
   const double dx1 = q.p1;
   const double dx2 = q.p2 * g22c;
+  probe.rec(2, q.p3sq, ss, y_ss);
   const double b2 = q.p2 * q.p2 + div_with_recip(q.p3sq, ss, y_ss);
   const double num = b2 * rd;
   const double r3 = r * (r * r);
+  double y_r3 = y_r2 * y_r;
+  if (CV_CERTIFIED_DIV) y_r3 = recip_newton(r3, y_r3);
+  probe.rec(3, num, r3, y_r3);
   /* dp_l = num / r^3: the shared-reciprocal quotient is checked AFTERWARDS with one class test.  Inside the guarded
    * domain a non-zero num has |num| >= 2^-300 |r'| >= 2^-745 (Ellis: |r'| = |l|/r >= 2^-191; Interstellar:
    * |r'| >= (2/pi) atan 2), hence the remainder fma cannot underflow and the true quotient
    * is a normal number (>= 2^-745 / 2^273) or overflows.  Whatever else can happen shows in the result: an
    * overflowing n*y or a non-finite num (|p_theta| exploding at a pole) gives inf or NaN; those are "not a normal
    * number" and take the IEEE division. */
-  double dp1 = div_with_recip(num, r3, y_r2 * y_r);
+  double dp1 = div_with_recip(num, r3, y_r3);
   if (!is_normal_number(dp1)) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("; IEEE division for dp_l"); /* not speculatable: keeps this a branch around ~25 instructions
@@ -350,9 +383,16 @@ CV_HD void ray_step_fast(const MetricParams &M, Ray &q, double delta, bool lane_
 #endif
     dp1 = num / r3;
   }
-  const double dp2 = q.p3sq * div_with_recip(c, r2 * (s * ss), y_r2 * (y_ss * y_s));
+  const double r2s3 = r2 * (s * ss);
+  double y_r2s3 = y_r2 * (y_ss * y_s);
+  if (CV_CERTIFIED_DIV) y_r2s3 = recip_newton(r2s3, y_r2s3);
+  probe.rec(4, c, r2s3, y_r2s3);
+  const double dp2 = q.p3sq * div_with_recip(c, r2s3, y_r2s3);
   if (PHI) {
-    const double g33c = div_with_recip(1.0, r2 * ss, y_r2 * y_ss);
+    double y_g33 = y_r2 * y_ss;
+    if (CV_CERTIFIED_DIV) y_g33 = recip_newton(r2 * ss, y_g33);
+    probe.rec(5, 1.0, r2 * ss, y_g33);
+    const double g33c = div_with_recip(1.0, r2 * ss, y_g33);
     q.ph = q.ph + (q.p3 * g33c) * delta;
   }
   q.l = q.l + dx1 * delta;

@@ -292,4 +292,85 @@ __global__ void selftest_math_kernel(int op, const double *a, const double *b, d
   out[i] = r;
 }
 
+/* Directed cases for the primitives of the fast step (tests/test_gpu_fast_step.py): three inputs per element.
+ * op 0 div_with_recip(a, b, c)   1 root of sqrt_and_rsqrt(a)   2 its y ~ 1/sqrt(a)
+ *    3 the square root's last residual step for given (x, g, y) = (a, b, c): fma(fma(-g, g, x), 0.5 y, g)
+ *    4 recip_refined(a)   5 cv_div_nr(a, b)   6 recip_newton(a, b) */
+__global__ void selftest_math3_kernel(int op, const double *a, const double *b, const double *c, double *out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b ? b[i] : 0.0, z = c ? c[i] : 0.0;
+  double r, t;
+  switch (op) {
+    case 0:
+      r = cvk::div_with_recip(x, y, z);
+      break;
+    case 1:
+      cvk::sqrt_and_rsqrt(x, r, t);
+      break;
+    case 2:
+      cvk::sqrt_and_rsqrt(x, t, r);
+      break;
+    case 3:
+      r = CV_FMA(CV_FMA(-y, y, x), 0.5 * z, y);
+      break;
+    case 4:
+      r = cvk::recip_refined(x);
+      break;
+    case 5:
+      r = cv_div_nr(x, y);
+      break;
+    default:
+      r = cvk::recip_newton(x, y);
+      break;
+  }
+  out[i] = r;
+}
+
+/* One fast Euler step per input state with every quotient of the step recorded (cvk::NoProbe's counterpart): for
+ * each state 6 x {numerator, denominator, the shared reciprocal the step used, the step's quotient, the IEEE
+ * quotient, the remainder n - d RN(n y), 1 - d y} (NaN rows: quotient not formed -- k = 0 outside Ellis, or the state took the strict step), then the new
+ * state (l, theta, phi, p_l, p_theta) of the fast step and of the strict step, and a flag (fast path taken). */
+struct StepRecorder {
+  double *o;
+  __device__ void rec(int k, double n, double d, double y) const {
+    o[7 * k + 0] = n;
+    o[7 * k + 1] = d;
+    o[7 * k + 2] = y;
+    o[7 * k + 3] = cvk::div_with_recip(n, d, y);
+    o[7 * k + 4] = n / d;
+    o[7 * k + 5] = CV_FMA(-d, n * y, n); /* the remainder div_with_recip sees (exact) */
+    o[7 * k + 6] = CV_FMA(-d, y, 1.0);   /* 1 - d y: how far the shared reciprocal is from 1/d (exact) */
+  }
+};
+
+
+template <int KIND>
+__global__ void selftest_fast_step_kernel(cvk::MetricParams M, double delta, double max_radius, const double *st, size_t n,
+                                          double *out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  M.T = cv_sc_table();
+  M.LT = cv_log_table();
+  M.AT = cv_atan_table();
+  cvk::Ray q;
+  q.l = st[5 * i + 0];
+  q.th = st[5 * i + 1];
+  q.ph = 0.0;
+  q.p1 = st[5 * i + 2];
+  q.p2 = st[5 * i + 3];
+  q.p3 = st[5 * i + 4];
+  q.p3sq = q.p3 * q.p3;
+  cvk::Ray q0 = q;
+  double *o = out + i * CURVIS_FAST_STEP_RECORD;
+  for (int k = 0; k < 42; ++k) o[k] = __builtin_nan("");
+  const bool lane_ok = cvk::metric_fast_ok(KIND, M, max_radius) && cvk::ray_fast_ok(q);
+  StepRecorder pr{o};
+  cvk::ray_step_fast<KIND, true, false, false, StepRecorder>(M, q, delta, lane_ok, pr);
+  cvk::ray_step<KIND, true>(M, q0, delta);
+  o[42] = q.l, o[43] = q.th, o[44] = q.ph, o[45] = q.p1, o[46] = q.p2;
+  o[47] = q0.l, o[48] = q0.th, o[49] = q0.ph, o[50] = q0.p1, o[51] = q0.p2;
+  o[52] = (o[8] == o[8]) ? 1.0 : 0.0; /* quotient 1 (1/r^2) is formed by every fast step */
+}
+
 }  // namespace

@@ -517,6 +517,33 @@ class Context:
                                          a.size), self._h)
         return out
 
+    def selftest_math3(self, op, a, b=None, c=None):
+        """primitives of the shared-reciprocal Euler step on three inputs (include/curvis_hip.h: op 0 div_with_recip(n, d, y),
+        1 / 2 sqrt_and_rsqrt's root / reciprocal root, 3 its last residual step (x, g, y), 4 recip_refined, 5 cv_div_nr,
+        6 recip_newton(d, y))"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+        cc = np.ascontiguousarray(c, dtype=np.float64) if c is not None else None
+        out = np.empty_like(a)
+        check(lib().curvis_selftest_math3(self._h, op, dptr(a), dptr(bb) if bb is not None else None,
+                                          dptr(cc) if cc is not None else None, dptr(out), a.size), self._h)
+        return out
+
+    FAST_STEP_QUOTIENTS = ("r' = l/r", "1/r^2", "p_phi^2/sin^2", "dp_l = b^2 r'/r^3", "cos/(r^2 sin^3)", "1/(r^2 sin^2)")
+
+    def selftest_fast_step(self, metric, states, delta=0.05, max_radius=100.0):
+        """ONE fast Euler step per state (n x {l, theta, p_l, p_theta, p_phi}) with every quotient recorded: returns
+        (quot [n, 6, 7] = numerator n, denominator d, shared reciprocal y, the step's quotient, the IEEE quotient, the
+        remainder n - d RN(n y), 1 - d y -- NaN rows where a quotient is not formed --, fast [n, 5], strict [n, 5] = the new (l, theta, phi - phi0, p_l, p_theta),
+        took_fast [n] bool)"""
+        st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 5)
+        n = st.shape[0]
+        out = np.zeros((n, 53))
+        m = metric._c()
+        check(lib().curvis_selftest_fast_step(self._h, C.byref(m), float(delta), float(max_radius), dptr(st), n, dptr(out)),
+              self._h)
+        return out[:, :42].reshape(n, 6, 7), out[:, 42:47], out[:, 47:52], out[:, 52] != 0.0
+
 
 _default_ctx = {}
 

@@ -332,6 +332,24 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
  * 9 raw v_rcp_f64(a), 10 raw v_rsq_f64(a) (hardware seeds, for accuracy measurements) */
 int curvis_selftest_math(curvis_ctx *ctx, int op, const double *a, const double *b, double *out, size_t n);
 
+/* the primitives of the shared-reciprocal Euler step, element-wise on three inputs (b, c may be NULL where unused):
+ * op 0 div_with_recip(n = a, d = b, y = c): the quotient the fast step forms from an approximate reciprocal y
+ *    1 sqrt_and_rsqrt(a): the square root    2 sqrt_and_rsqrt(a): its by-product y ~ 1/sqrt(a)
+ *    3 the square root's final residual step for given (x, g, y) = (a, b, c)
+ *    4 recip_refined(a)    5 cv_div_nr(a, b) (the -1/x of atan)    6 recip_newton(d = a, y = b)
+ * -- the directed hard cases of tests/test_gpu_fast_step.py go through here. */
+int curvis_selftest_math3(curvis_ctx *ctx, int op, const double *a, const double *b, const double *c, double *out, size_t n);
+
+/* ONE Euler step (src/metrics.rs:283-297) of the fast kernel per input state, every quotient recorded.
+ * states: n x {l, theta, p_l, p_theta, p_phi}; out: n x CURVIS_FAST_STEP_RECORD doubles =
+ *   6 x {numerator n, denominator d, shared reciprocal y used, the step's quotient, the IEEE quotient, the remainder
+ *        n - d RN(n y), 1 - d y}
+ *       (k = 0 r' = l/r [Ellis only], 1 1/r^2, 2 p_phi^2/sin^2, 3 dp_l, 4 cos/(r^2 sin^3), 5 1/(r^2 sin^2); NaN = not formed),
+ *   5 new state of the fast step (l, theta, phi - phi0, p_l, p_theta), 5 of the strict step, 1 flag (1 = fast path taken). */
+#define CURVIS_FAST_STEP_RECORD 53
+int curvis_selftest_fast_step(curvis_ctx *ctx, const curvis_metric *metric, double delta, double max_radius, const double *states,
+                              size_t n, double *out);
+
 #ifdef __cplusplus
 }
 #endif

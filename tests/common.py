@@ -42,6 +42,8 @@ def twin():
         L = C.CDLL(p)
         L.twin_math_array.restype = None
         L.twin_math_array.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.twin_math3_array.restype = None
+        L.twin_math3_array.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.twin_render.restype = None
         L.twin_render.argtypes = [C.POINTER(_abi.Metric), C.POINTER(_abi.CameraC), C.c_void_p, C.c_uint, C.c_uint,
                                   C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_double, C.c_double, C.c_void_p,
@@ -62,6 +64,16 @@ def twin_math(op, a, b=None):
     out = np.empty_like(a)
     bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
     twin().twin_math_array(op, a.ctypes.data, bb.ctypes.data if bb is not None else None, out.ctypes.data, a.size)
+    return out
+
+
+def twin_math3(op, a, b=None, c=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    bb = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+    cc = np.ascontiguousarray(c, dtype=np.float64) if c is not None else None
+    out = np.empty_like(a)
+    twin().twin_math3_array(op, a.ctypes.data, bb.ctypes.data if bb is not None else None,
+                            cc.ctypes.data if cc is not None else None, out.ctypes.data, a.size)
     return out
 
 

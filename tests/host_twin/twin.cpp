@@ -70,6 +70,25 @@ double twin_math(int op, double x, double y) {
     default: return CV_FMA(x, y, x);
   }
 }
+// the fast step's primitives on three inputs: the same ops as curvis_selftest_math3 (include/curvis_hip.h).  On x86
+// the hardware seeds are exact quotients (cv_device.h rcp_seed / rsq_seed), so ops 1, 2, 4 differ from the device in the
+// seed; ops 0, 3, 6 are pure fma sequences and must agree bit for bit.
+void twin_math3_array(int op, const double *a, const double *b, const double *c, double *out, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const double x = a[i], y = b ? b[i] : 0.0, z = c ? c[i] : 0.0;
+    double r, t;
+    switch (op) {
+      case 0: r = cvk::div_with_recip(x, y, z); break;
+      case 1: cvk::sqrt_and_rsqrt(x, r, t); break;
+      case 2: cvk::sqrt_and_rsqrt(x, t, r); break;
+      case 3: r = CV_FMA(CV_FMA(-y, y, x), 0.5 * z, y); break;
+      case 4: r = cvk::recip_refined(x); break;
+      case 5: r = cv_div_nr(x, y); break;
+      default: r = cvk::recip_newton(x, y); break;
+    }
+    out[i] = r;
+  }
+}
 void twin_math_array(int op, const double *a, const double *b, double *out, size_t n) {
   for (size_t i = 0; i < n; ++i) out[i] = twin_math(op, a[i], b ? b[i] : 0.0);
 }

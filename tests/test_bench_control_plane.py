@@ -35,8 +35,12 @@ WORKER = textwrap.dedent("""
         def rccl_comm_init(self, uid, n, r):
             assert uid == bytes(range(128)) and n == world and r == rank
             if SCEN == "init_fails_on_rank1" and rank == 1: raise RuntimeError("no RCCL on this rank")
+            if SCEN == "init_wedges_on_rank1" and rank == 1:
+                import time; time.sleep(3600)        # ncclCommInitRank that never returns (daemon thread: dies with the process)
             self.joined = (n, r); return "comm-token"
-        def set_sky(self, which, image): self.sky[which] = np.ascontiguousarray(image.rgba)
+        def set_sky(self, which, image):
+            if SCEN == "upload_fails_on_rank0": raise RuntimeError("hipMalloc failed")
+            self.sky[which] = np.ascontiguousarray(image.rgba)
         def bcast_skies(self, comm, root):
             assert comm == "comm-token"
             for w in range(2):                       # the stub moves the bytes over the control plane
@@ -73,8 +77,9 @@ WORKER = textwrap.dedent("""
         assert np.array_equal(np.asarray(ctx.sky[w]).reshape(sh, sw, 4), skies.smooth(sw, sh, blue))
     out = [None] * world
     dist.all_gather_object(out, {"backend": info["backend"], "fell": info.get("fallback_from"), "verified": info["readback_verified_on_every_rank"]})
-    if rank == 0: print(json.dumps(out))
+    if rank == 0: print(json.dumps(out + [dict(bench.WEDGED)]), flush=True)
     dist.barrier(); dist.destroy_process_group()
+    if bench.WEDGED["any"]: os._exit(0)             # what bench.py does after its line: a stuck join must not block the exit
 """)
 
 
@@ -90,9 +95,11 @@ def run_scenario(tmp_path, scenario):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1", SCENARIO=scenario,
-                                                                                   CURVIS_BENCH_RCCL_INIT_TIMEOUT="20"))
+                                                                                   CURVIS_BENCH_RCCL_INIT_TIMEOUT="8"))
     assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("[")][-1]), r.stderr
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("[")][-1])
+    run_scenario.wedged = out.pop()
+    return out, r.stderr
 
 
 def test_clean_path_takes_the_products_broadcast(tmp_path):
@@ -112,3 +119,20 @@ def test_both_ranks_fall_back_when_the_broadcast_fails_on_one(tmp_path):
     out, _ = run_scenario(tmp_path, "bcast_fails_on_rank1")
     assert [o["backend"] for o in out] == ["gloo"] * 2 and out[0]["fell"] == out[1]["fell"]
     assert out[0]["fell"][0].startswith("curvis_ctx_bcast_skies: rank 1: RuntimeError: ncclBroadcast failed")
+
+
+def test_upload_failure_on_rank0_does_not_strand_the_other_rank(tmp_path):
+    """rank 0's upload raises after the communicator is up -- every rank must still issue the same sequence of
+    control-plane collectives (no barrier skipped by the rank that raised) and both fall back together"""
+    out, _ = run_scenario(tmp_path, "upload_fails_on_rank0")
+    assert [o["backend"] for o in out] == ["gloo"] * 2 and out[0]["fell"] == out[1]["fell"] and all(o["verified"] for o in out)
+    assert out[0]["fell"][0] == "curvis_ctx_bcast_skies: rank 0: upload on rank 0: RuntimeError: hipMalloc failed"
+
+
+def test_wedged_join_skips_the_second_rccl_stage_on_every_rank(tmp_path):
+    """a rank whose ncclCommInitRank never returns still holds its GPU context: no rank may open torch's nccl group
+    then; all go straight to the host-staged broadcast and know that the process must leave through os._exit"""
+    out, _ = run_scenario(tmp_path, "init_wedges_on_rank1")
+    assert [o["backend"] for o in out] == ["gloo"] * 2 and out[0]["fell"] == out[1]["fell"] and all(o["verified"] for o in out)
+    assert "time limit" in out[0]["fell"][0] and out[0]["fell"][1].startswith("torch nccl group: not attempted")
+    assert run_scenario.wedged == {"any": True, "here": False}     # rank 0's view: somebody is wedged, not me

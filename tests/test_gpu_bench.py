@@ -50,8 +50,10 @@ def check_extras_of_a_multi_rank_line(out, world, one_device):
     pr = out["per_rank"]
     assert [p["rank"] for p in pr] == list(range(world))
     for p in pr:
-        assert p["ms_per_step"] > 0 and p["kernel_ms_avg"] > 0 and p["value"] > 0 and "sclk_mhz_timed_region" in p
-    assert "sclk_mhz" in out and out["clock_samples"] >= 1
+        assert p["ms_per_step"] > 0 and p["kernel_ms_avg"] > 0 and p["value"] > 0 and len(p["sclk_mhz_sysfs_before_after_timed_region"]) == 2
+    assert "effective_sclk_mhz" in out and len(out["sclk_mhz_sysfs_before_after"]) == 2
+    dl = out["value_with_download"]                          # the reference's output contract: the frame in host memory
+    assert 0 < dl["value"] <= out["value"] * 1.05 and dl["ms_per_step"] > 0 and dl["bytes_per_frame"] == 1920 * 1080 * 3
     col = out["collective"]
     assert col["ranks"] == world and col["allreduce_of_ones"] == world and col["readback_verified_on_every_rank"] is True
     assert col["sky_broadcast_ms"] > 0 and col["control_plane"].startswith("gloo")
@@ -112,8 +114,31 @@ def test_single_rank_line_carries_sustained_figure_and_device_identity(gpu_ctx):
     s = out["value_sustained"]
     assert s["seconds"] >= 1.0 and s["launches"] >= 1 and s["value"] > 0
     assert s["samples"] >= 5                              # the sampler ran; the clock itself may be unreadable in a container
-    assert "sclk_mhz" in out and out["clock_samples"] >= 1 and "sclk_mhz_median_second_half" in s
+    assert "sclk_mhz_median_second_half" in s and len(out["sclk_mhz_sysfs_before_after"]) == 2
+    assert out["effective_sclk_mhz"] is None               # no live SQ pass in this run (--no-live-traffic)
+    assert out["value_with_download"]["fraction_of_value"] <= 1.05
     assert "collective" not in out and "video_e2e" not in out
+
+
+def test_default_line_clock_agrees_with_itself_and_carries_the_download_figure():
+    """the clock of the timed region comes from the kernel's own cycle count (live SQ pass / this region's
+    kernel time) and must agree with what the 10 s run's sysfs samples say; `value_with_download` is on the default line."""
+    r = run_bench(["--no-cpu-baseline", "--multi-frame", "0", "--sustained-seconds", "4"], {}, timeout=1200)
+    out = the_line(r)
+    rf = out["roofline"]
+    assert rf["traffic_detail"]["measured_in_this_run"] is True, rf["traffic_detail"].get("live")
+    eff = out["effective_sclk_mhz"]
+    assert eff == rf["effective_sclk_mhz"] and 1200 < eff < 2600
+    # the identity the review checked by hand: value x cycles per wave-step per SIMD / (1024 SIMDs x 64 lanes) = clock
+    sq = rf["traffic_detail"]["live"]["sq"]
+    implied = out["config"]["executed_steps_per_frame"] / (rf["kernel_ms_avg"] * 1e-3) * sq["cycles_per_wave_step_per_simd"] / (1024 * 64) / 1e6
+    assert abs(implied - eff) / eff < 0.002
+    assert abs(rf["frac_at_effective_clock"] - rf["frac"] * 2400.0 / eff) < 2e-3
+    sus = out["value_sustained"]["sclk_mhz_median_second_half"]
+    if sus:                                                 # sysfs readable on this box
+        assert abs(eff - sus) / sus < 0.05, (eff, sus)
+    dl = out["value_with_download"]
+    assert dl["steps"] == out["steps"] and 0.5 < dl["fraction_of_value"] <= 1.02 and dl["delta_ms_per_step"] > -0.5
 
 
 def test_single_rank_over_rccl_takes_the_multi_gpu_code_path():

@@ -148,6 +148,120 @@ def test_video_config_full_size_frames(gpu_ctx, video):
         print("%s frame %d (l = %.4f): %d steps, +l %d, -l %d, capped %d" % ((video, i, poses[i][0][1]) + want[1:5]))
 
 
+def ray_classes(dbg, cap):
+    """the ray classes whose parity is ill-conditioned: rays that hit the step cap, rays whose theta
+    has left [0, pi] (they crossed a pole: 1/sin^2 exploded on the way), and rays that spent much longer than their
+    frame's median near the throat"""
+    steps = dbg["steps"].astype(np.int64)
+    th = dbg["x"][..., 2]
+    return {"capped": dbg["code"] == 0, "pole-crossing (final theta outside [0, pi])": (th < 0.0) | (th > np.pi),
+            "throat-whirling (steps > 1.25 x the frame's median)": steps > 1.25 * np.median(steps)}
+
+
+def compare_with_glibc(got_rgb, got_dbg, want_rgb, want_dbg, label):
+    """GPU frame + per-ray dump against ONE glibc flavour of the oracle: returns the measured fractions and, when
+    anything differs, which ray classes the differing rays belong to (printed -- the assertion is the caller's)"""
+    d = np.abs(got_rgb.astype(int) - want_rgb.astype(int)).max(axis=-1)
+    same = {f: got_dbg[f] == want_dbg[f] for f in ("steps", "code", "tx", "ty")}
+    texel = same["tx"] & same["ty"]
+    out = dict(pixels=float((d == 0).mean()), le1=float((d <= 1).mean()), texel=float(texel.mean()),
+               steps=float(same["steps"].mean()), code=float(same["code"].mean()))
+    bad = ~(texel & same["steps"] & same["code"]) | (d != 0)
+    if bad.any():
+        cls = ray_classes(got_dbg, 0)
+        print("%s: %d differing rays: %s" % (label, int(bad.sum()), ", ".join(
+            "%s %d" % (k, int((v & bad).sum())) for k, v in cls.items())))
+    return out
+
+
+@pytest.mark.parametrize("video", ["orbit", "through"])
+def test_video_config_every_frame_against_glibc(gpu_ctx, video):
+    """The arithmetic-independent parity check (it shares no elementary function with the product: the oracle's glibc
+    flavours call libm's sin/cos/sincos/atan/log/acos/atan2, src/metrics.rs:68,257,262,461-485) on the camera poses of
+    the two VIDEO configs -- every one of the 240 orbit poses at l = 3 and of the 480 fly-through poses from l = -4
+    through the Interstellar throat (|l| < 0.02) to l = +4 --, ALL THREE glibc flavours, reduced resolution, checkerboard
+    sky (a pixel is right only if the exact texel is): pixels, raw texel indices, step counts and escape codes of every
+    ray.  Measured: identical for every ray of every frame (CPU pre-run of round 5 and this test on the device); that is
+    what is asserted."""
+    metric, csv, fps, n_frames, res, _, cap = VIDEOS[video]
+    times, poses = video_poses(csv, fps)
+    om, pm = metrics_of(metric)
+    sp, sn = common.make_skies(512, 256, "check")
+    osp, osn = O.sky(sp), O.sky(sn)
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+
+    def work(p):
+        oc = O.camera(p[0], p[1], p[2], 15.0, 43.0, res)
+        return [O.render_image(fl, om, oc, osp, osn, cap, 100.0, 0.05, debug=True)[:2] for fl in O.GLIBC_FLAVOURS]
+    with ThreadPoolExecutor(THREADS) as ex:
+        want = list(ex.map(work, poses))
+    worst = {fl: dict(pixels=1.0, le1=1.0, texel=1.0, steps=1.0, code=1.0) for fl in O.GLIBC_FLAVOURS}
+    state_differs = 0
+    for k, p in enumerate(poses):
+        cam = curvis_amd.Camera(p[0], p[1], p[2], 15.0, 43.0, res[0], res[1])
+        rgb, _, dbg = gpu_ctx.render_brute(pm, cam, cap, 100.0, 0.05, debug=True)
+        for fl, (w_rgb, w_dbg) in zip(O.GLIBC_FLAVOURS, want[k]):
+            m = compare_with_glibc(rgb, dbg, w_rgb, w_dbg, "%s frame %d (l = %.4f) vs %s" % (video, k, p[0][1], O.FLAVOUR_NAMES[fl]))
+            for key, v in m.items():
+                worst[fl][key] = min(worst[fl][key], v)
+            state_differs += int((dbg["x"][..., 1:3].view(np.uint64) != w_dbg["x"][..., 1:3].view(np.uint64)).any())
+    for fl in O.GLIBC_FLAVOURS:
+        print("%s, %d frames at %dx%d vs %s: worst frame -- pixels identical %.6f, <= 1 LSB %.6f, texel indices %.6f, step "
+              "counts %.6f, escape codes %.6f" % ((video, n_frames) + res + (O.FLAVOUR_NAMES[fl],) + tuple(
+                  worst[fl][k] for k in ("pixels", "le1", "texel", "steps", "code"))))
+        assert all(v == 1.0 for v in worst[fl].values()), (O.FLAVOUR_NAMES[fl], worst[fl])
+    # ... while the trajectories themselves do differ from glibc's in their last bits (else this would prove nothing)
+    assert state_differs > n_frames
+
+
+@pytest.mark.parametrize("video", ["orbit", "through"])
+def test_video_config_full_size_frames_against_glibc(gpu_ctx, video):
+    """FULL-size frames of the two video configs at the hard poses -- orbit l = 3 (pole-crossing rays, the survey's
+    min-211-step rays) at 1920x1080; the fly-through's frame 0 (l = -4) and the two frames nearest l = 0 (camera inside
+    the Interstellar throat) at 3840x2160 cap 8192 -- against the glibc flavour LLVM's own lowering points at
+    (CVO_LIBM_SINCOS_INL, profiles/round3_llvm_sincos_probe.txt), every 8th row (sized for the 16-CPU quota of a GPU box;
+    all three flavours over all rows: tools/gpu_libm_parity.py -> profiles/round5_libm_parity_poses.txt), smooth AND
+    checkerboard sky semantics through the raw texel indices.  Measured and asserted: every pixel, texel index, step count
+    and escape code identical; the populations of the ill-conditioned ray classes are printed."""
+    metric, csv, fps, n_frames, _, res, cap = VIDEOS[video]
+    times, poses = video_poses(csv, fps)
+    sel = [0, 60] if video == "orbit" else full_size_frames(video, n_frames, poses)
+    om, pm = metrics_of(metric)
+    sp, sn = common.make_skies(8192, 4096, "smooth")
+    osp, osn = O.sky(sp), O.sky(sn)
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    W, H = res
+    T = common.host_threads(64)
+    for i in sel:
+        p = poses[i]
+        cam = curvis_amd.Camera(p[0], p[1], p[2], 15.0, 43.0, W, H)
+        rgb, _, dbg = gpu_ctx.render_brute(pm, cam, cap, 100.0, 0.05, debug=True)
+        oc = O.camera(p[0], p[1], p[2], 15.0, 43.0, res)
+        w_rgb = np.zeros((H, W, 3), np.uint8)
+        w_dbg = np.zeros((H, W), O.RAY_DEBUG)
+
+        def work(t):
+            r, d, st = O.render_image(O.LIBM_SINCOS_INL, om, oc, osp, osn, cap, 100.0, 0.05, row_begin=8 * t, row_step=8 * T,
+                                      debug=True)
+            w_rgb[8 * t::8 * T] = r[8 * t::8 * T]
+            w_dbg[8 * t::8 * T] = d[8 * t::8 * T]
+            return st.rays
+        with ThreadPoolExecutor(T) as ex:
+            assert sum(ex.map(work, range(T))) == W * len(range(0, H, 8))
+        g_rgb, g_dbg = rgb.reshape(H, W, 3)[::8], dbg.reshape(H, W)[::8]
+        label = "%s frame %d (l = %.4f), %dx%d every 8th row vs %s" % (video, i, p[0][1], W, H, O.FLAVOUR_NAMES[O.LIBM_SINCOS_INL])
+        m = compare_with_glibc(g_rgb, g_dbg, w_rgb[::8], w_dbg[::8], label)
+        cls = ray_classes(g_dbg, cap)
+        print("%s: pixels identical %.6f, <= 1 LSB %.6f, texel indices %.6f, step counts %.6f, escape codes %.6f; rays %d (%s); "
+              "final state bit-identical for %.4f of them" % ((label,) + tuple(m[k] for k in ("pixels", "le1", "texel", "steps", "code")) + (
+                  g_dbg.size, ", ".join("%s %d" % (k, int(v.sum())) for k, v in cls.items()),
+                  float((g_dbg["x"][..., 1:3].view(np.uint64) == w_dbg[::8]["x"][..., 1:3].view(np.uint64)).all(axis=-1).mean()))))
+        assert all(v == 1.0 for v in m.values()), (label, m)
+        assert (g_dbg["x"][..., 1:3].view(np.uint64) != w_dbg[::8]["x"][..., 1:3].view(np.uint64)).any()
+
+
 SIM = ("escape_radius = 100.0\nray_integration_max_itarations = %d\nray_integration_step = 0.05\n"
        "sampling_initial_nums = 100\nsampling_max_iterations = 50\n"
        "sampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 2e-5\n")

@@ -1,0 +1,126 @@
+"""The fast Euler step's guarantee, measured instead of estimated (cv_device.h: div_with_recip, sqrt_and_rsqrt, the
+shared reciprocals of ray_step_fast; reference operations: src/metrics.rs:223-297).
+
+div_with_recip(n, d, y) = RN(q0 + rem y), q0 = RN(n y), rem = n - d q0, returns RN(n/d) unless a rounding boundary lies
+within (n/d)(|kappa| + 1)^2 2^-106 of n/d, y = (1 + kappa 2^-53)/d (tools/gpu_fast_step_rounding.py has the derivation and the
+rates measured on real rays: profiles/round5_fast_step_rounding.txt).  These tests go to the boundary on purpose:
+operands whose exact quotient / root sits within a few quanta of 2^-106 of a rounding boundary (tests/hard_cases.py,
+exact integer constructions), fed with reciprocals that are off by the amounts the step's own reciprocals are off by."""
+import numpy as np
+import pytest
+
+import common
+import hard_cases as H
+import oracle_lib as O
+import curvis_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def test_div_with_recip_on_directed_hard_cases(gpu_ctx):
+    """(i) a mis-rounding IS reachable: with y one ulp or more from RN(1/d) and n/d within <= 15 quanta ABOVE a boundary the
+    quotient comes out one ulp low; (ii) it is confined: never more than ONE ulp, never on the other side of the boundary,
+    and only as far out as eps (eps + eta) reaches; (iii) with y = RN(1/d) (what interstellar_x uses for 1/(pi m)) it cannot
+    happen (Markstein); (iv) the device executes exactly the three roundings of the exact-arithmetic model."""
+    rng = np.random.default_rng(11)
+    n, d, j, expect, quanta = H.division_hard_cases(rng, 20000)
+    assert np.array_equal(n / d, expect)                                   # the construction itself (x86 IEEE division)
+    assert np.array_equal(gpu_ctx.selftest_math(6, n, d), expect)          # the device's IEEE division (strict step)
+    y0 = 1.0 / d
+    reached = {}
+    for u in range(-4, 5):
+        y = H.step_ulps(y0, u)
+        got = gpu_ctx.selftest_math3(0, n, d, y)
+        assert np.array_equal(got, common.twin_math3(0, n, d, y))          # device == x86 twin of the same source
+        assert np.array_equal(got[:1500], H.div_with_recip_model(n[:1500], d[:1500], y[:1500]))
+        bad = got != expect
+        reached[u] = int(bad.sum())
+        assert H.ulp_distance(got, expect).max() <= 1
+        if u == 0:
+            assert not bad.any(), "a correctly rounded reciprocal must give the correctly rounded quotient"
+            continue
+        kap = np.abs(H.recip_error_units_fast(d, y))                       # y = (1 +- kap 2^-53) / d
+        assert not (bad & (j < 0)).any(), "the value before the last rounding is never above n/d for |eps| >= |eta|"
+        assert (np.abs(got[bad]) < np.abs(expect[bad])).all()
+        # a boundary `quanta` units of 2^-106 away is crossed only if the gap reaches it: eps (eps + eta) plus the rounding of
+        # a remainder that no longer fits a double, together <= (kap + 1)^2 quanta
+        assert ((kap[bad] + 1.0) ** 2 >= quanta[bad]).all()
+    print("mis-rounded hard cases of 20000 by reciprocal offset u (ulp):", reached)
+    assert reached[0] == 0 and all(reached[u] > 0 for u in (-4, -3, -2, -1, 1, 2, 3, 4))
+    # ordinary operands: a reciprocal off by up to 8 ulp never shows
+    a = rng.uniform(1.0, 2.0, 2_000_000) * 2.0 ** rng.integers(-40, 40, 2_000_000)
+    b = rng.uniform(1.0, 2.0, 2_000_000) * 2.0 ** rng.integers(-40, 40, 2_000_000)
+    yb = H.step_ulps(1.0 / b, rng.integers(-8, 9, b.size))
+    assert np.array_equal(gpu_ctx.selftest_math3(0, a, b, yb), a / b)
+
+
+def test_sqrt_and_rsqrt_on_directed_hard_cases(gpu_ctx):
+    """square roots within |j| / (4 M) ulp of a boundary (exact constructions, every feasible |j| <= 2000): the device's IEEE
+    sqrt gets them all; sqrt_and_rsqrt's single residual step is one ulp off only on arguments with j = -1 -- significands
+    1 + 2^-51 (sqrt = 1 + 2^-52 - 2^-105...) and all-ones -- i.e. three significands out of 2^53 per pair of binades."""
+    x, j, expect = H.sqrt_hard_cases(2000)
+    assert len(x) > 600 and np.array_equal(np.sqrt(x), expect)
+    assert np.array_equal(gpu_ctx.selftest_math(7, x), expect)
+    root = gpu_ctx.selftest_math3(1, x)
+    bad = root != expect
+    print("sqrt_and_rsqrt: %d of %d hard cases one ulp off, j of those: %s" % (int(bad.sum()), len(x), sorted(set(j[bad].tolist()))))
+    assert H.ulp_distance(root, expect).max() <= 1
+    assert set(j[bad].tolist()) <= {-1}, "only the three j = -1 significands are within reach of a reciprocal root good to an ulp"
+    # the reciprocal root it hands to the step: within 1.5 units of 2^-53 of 1/sqrt(x)
+    y = gpu_ctx.selftest_math3(2, x)
+    kap = np.array([float((H.Fraction(a) * H.Fraction(b) ** 2 - 1) * (1 << 52)) for a, b in zip(x.tolist(), y.tolist())])
+    assert np.abs(kap).max() < 1.5, np.abs(kap).max()
+    xr = np.random.default_rng(5).uniform(1.0, 4.0, 4_000_000)
+    assert np.array_equal(gpu_ctx.selftest_math3(1, xr), np.sqrt(xr))
+
+
+def test_reciprocal_through_refined_seed(gpu_ctx):
+    """recip_refined and the -1/x of atan (cv_div_nr: seed, one third-order step, one Newton step = Markstein's
+    correctly rounded reciprocal): equal to IEEE on random arguments and on all-ones significands (the theorem's one
+    exception); recip_newton of a reciprocal that is an ulp off restores RN(1/d)."""
+    rng = np.random.default_rng(6)
+    ones = np.ldexp(float((1 << 53) - 1), np.arange(-104, -40))
+    xs = np.concatenate([ones[ones >= 2.0], rng.uniform(2.0, 2000.0, 2_000_000)])
+    got = gpu_ctx.selftest_math3(5, np.full_like(xs, -1.0), xs)
+    off = got != -1.0 / xs
+    print("cv_div_nr(-1, x): %d of %d differ from IEEE (all-ones significands among them: %d)" % (int(off.sum()), xs.size, int(off[:int((ones >= 2.0).sum())].sum())))
+    assert H.ulp_distance(got, -1.0 / xs).max() <= 1 and not off[int((ones >= 2.0).sum()):].any()
+    d = rng.uniform(1.0, 2.0, 1_000_000) * 2.0 ** rng.integers(-40, 40, 1_000_000)
+    r = gpu_ctx.selftest_math3(4, d)
+    assert H.ulp_distance(r, 1.0 / d).max() <= 1
+    for u in (-1, 1):
+        assert np.array_equal(gpu_ctx.selftest_math3(6, d, H.step_ulps(1.0 / d, u)), 1.0 / d)
+
+
+@pytest.mark.parametrize("metric,l_cam", [("ellis", 5.0), ("ellis", 3.0), ("interstellar", 5.0), ("interstellar", 0.008)])
+def test_shared_reciprocals_of_real_steps(gpu_ctx, metric, l_cam):
+    """the reciprocals the step REALLY forms (recorded through the probe hook of ray_step_fast) on every Euler step of
+    256 rays of the config's camera: how far each is from 1/d (kappa, in units of 2^-53) stays inside the envelope the
+    documented rate is computed from, every quotient equals the IEEE quotient, the fast step's new state equals the strict
+    step's bit for bit."""
+    om, oc, pm, pc = common.scene(metric, res=(1920, 1080), pos=(0.0, l_cam, common.HALF_PI, 0.0))
+    rng = np.random.default_rng(3)
+    nr = 256
+    px, py = rng.integers(0, 1920, nr), rng.integers(0, 1080, nr)
+    dirs = np.zeros((nr, 3))
+    for i in range(nr):
+        O.lib().cvo_camera_outward_world(O.C.byref(oc), int(px[i]), int(py[i]), O._dp(dirs[i]))
+    tr = gpu_ctx.compute_photon_trajectory(pm, np.tile([0.0, l_cam, common.HALF_PI, 0.0], (nr, 1)), dirs, 2300, 0.05)
+    keep = np.cumprod(np.abs(tr[:, :, 1]) <= 100.0, axis=1).astype(bool)
+    states = np.ascontiguousarray(tr[keep][:, [1, 2, 5, 6, 7]])
+    quot, fast, strict, took = gpu_ctx.selftest_fast_step(pm, states)
+    assert took.mean() > 0.98
+    assert np.array_equal(fast.view(np.uint64), strict.view(np.uint64))
+    envelope = {0: 2.0, 1: 4.0, 2: 3.0, 3: 7.0, 4: 9.0, 5: 6.0}       # |kappa| per quotient: the worst-case sums of cv_device.h's roundings
+    seen = {}
+    for k in range(6):
+        d, y, qf, qi, eps = quot[:, k, 1], quot[:, k, 2], quot[:, k, 3], quot[:, k, 4], quot[:, k, 6]
+        ok = took & (d == d)
+        if not ok.any():
+            continue
+        kap = np.abs(eps[ok]) * 2.0 ** 53
+        seen[curvis_amd.Context.FAST_STEP_QUOTIENTS[k]] = (round(float(kap.max()), 2), round(float(np.sqrt((kap ** 2).mean())), 2))
+        assert kap.max() <= envelope[k], (k, kap.max())
+        assert np.array_equal(qf[ok].view(np.uint64), qi[ok].view(np.uint64)), k
+    print("%s l = %g: %d steps; |kappa| (max, rms) per quotient: %s" % (metric, l_cam, len(states), seen))
+    assert (metric == "ellis") == ("r' = l/r" in seen)
