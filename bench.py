@@ -129,6 +129,8 @@ def main():
                          "asked for" % (args.gpus, world))
 
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap needs no network interface (torch's nccl group included)
+    if world > 1 or os.environ.get("CURVIS_BENCH_FORCE_DIST") == "1":
+        rccl_log_begin(rank)  # RCCL's own warnings per rank, quoted by `collective.failure_detail` should the data plane fail
     # The job's stdout carries the JSON line and nothing else: gloo ("[Gloo] Rank 0 is connected to ..."), RCCL (version
     # banner) and whatever else writes to the C stdout go to stderr -- file descriptor 1 points there until the line is due.
     flush_c_stdio()
@@ -235,7 +237,18 @@ def main():
 
     # setup, not a warm-up step: the first relay launch of a launch shape is checked once against the static kernel by the
     # library ("seat belt"); that one-off check must not land in the timed region when --warmup is 0
-    step()
+    render_why = None
+    try:
+        step()
+    except Exception as exc:  # noqa: BLE001 -- first render on this device: say which rank / device, on every rank
+        render_why = short(exc)
+    if dist is not None:
+        bad = gather_failures(dist, world, rank, None if render_why is None else {
+            "stage": "%s on device %s" % (STAGES[7], pci_bus_id), "error": render_why})
+        if bad:
+            raise SystemExit("bench.py: the first render failed: %s" % json.dumps(bad + FAILURES))
+    elif render_why is not None:
+        raise SystemExit("bench.py: the first render failed on device %s: %s" % (pci_bus_id, render_why))
     for _ in range(args.warmup):
         step()
 
@@ -353,6 +366,17 @@ def main():
                 "sclk_mhz": sustained["sclk_mhz_median"] if sustained else None,
                 "power_w": sustained["power_w_median"] if sustained else None,
                 "value_sustained": sustained["value"] if sustained else None}
+        # how this rank's GPU is connected to the other ranks' (xGMI or PCIe, hops): what the first measured
+        # sky_broadcast_gbps has to be read against (xGMI: 7 links x ~153 GB/s per GPU, point to point)
+        devs = [None] * world
+        dist.all_gather_object(devs, device_index)
+        if one_device_per_rank or share_device:
+            mine["links"] = None  # this process sees one device only (launcher's device mask / share hook): ask rocm-smi --showtopo
+        else:
+            try:
+                mine["links"] = {"to_rank_%d" % r: curvis_amd.Context.device_link(device_index, devs[r]) for r in range(world) if r != rank}
+            except Exception as exc:  # noqa: BLE001
+                mine["links"] = {"failed": short(exc)}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         tt = torch.tensor([elapsed], dtype=torch.float64)
@@ -562,7 +586,71 @@ def short(exc):
     return "%s: %s" % (type(exc).__name__, t[0][:200] if t else "")
 
 
-WEDGED = {"any": False, "here": False}  # set by product_comm: some rank's ncclCommInitRank never returned
+FAILURES = []  # failure records of the product's data plane, the same list on every rank (gather_failures)
+WEDGED = {"any": False, "here": False}  # set by product_comm / distribute_skies: some rank's RCCL call never returned
+
+# First contact between two devices must be self-diagnosing: every step of the data plane has a name,
+# and a failure is reported as {rank, stage, error, RCCL's own warnings} in `collective.failure_detail`.
+STAGES = ("bootstrap (ncclGetUniqueId, id over the control plane)", "ncclCommInitRank", "upload on the root",
+          "header_broadcast", "texture_broadcast(+l sky)", "texture_broadcast(-l sky)", "read-back", "render")
+
+
+def rccl_log_path(rank):
+    return os.environ.get("NCCL_DEBUG_FILE") or os.path.join("/tmp", "curvis_bench_rccl_rank%d_%d.log" % (rank, os.getpid()))
+
+
+def rccl_log_begin(rank):
+    """RCCL's warnings of THIS rank into a file of its own (NCCL_DEBUG=WARN unless the user asked for more), so that a
+    failure can quote them; must run before the first RCCL call of the process"""
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    if "NCCL_DEBUG_FILE" not in os.environ:
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log_path(rank)
+
+
+def rccl_log_tail(rank, limit=1500):
+    try:
+        with open(rccl_log_path(rank), "r", errors="replace") as f:
+            t = f.read()
+        return t[-limit:].strip() or None
+    except OSError:
+        return None
+
+
+def stage_of(message, default):
+    """the stage a library error names ("sky broadcast, stage header_broadcast: ...") or `default`"""
+    import re
+    m = re.search(r"stage ([a-z_]+(?:\([^)]*\))?)", message or "")
+    return m.group(1) if m else default
+
+
+def with_time_limit(fn, seconds):
+    """fn() on a helper thread: (result, None, False) | (None, reason, wedged) -- a collective whose peer never arrives
+    must not hold the rank for ever"""
+    import threading
+    res = {}
+
+    def run():
+        try:
+            res["value"] = fn()
+        except Exception as exc:  # noqa: BLE001
+            res["why"] = short(exc)
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return None, "did not return within %g s" % seconds, True
+    if "why" in res:
+        return None, res["why"], False
+    return res.get("value"), None, False
+
+
+def gather_failures(dist, world, rank, mine):
+    """every rank contributes its own failure record (or None); all get the list of the records that exist"""
+    if mine is not None:
+        mine = dict(mine, rank=rank, rccl_log=rccl_log_tail(rank))
+    table = [None] * world
+    dist.all_gather_object(table, mine)
+    return [t for t in table if t]
 
 
 def product_comm(ctx, dist, world, rank, timeout_s=600.0):
@@ -584,6 +672,7 @@ def product_comm(ctx, dist, world, rank, timeout_s=600.0):
             why = short(exc)
     dist.broadcast_object_list(uid, src=0)
     if uid[0] is None:
+        FAILURES.extend(gather_failures(dist, world, rank, {"stage": STAGES[0], "error": why} if rank == 0 else None))
         return None, agree(dist, world, rank != 0, why)[1]
     res = {}
 
@@ -608,6 +697,8 @@ def product_comm(ctx, dist, world, rank, timeout_s=600.0):
     dist.all_gather_object(flags, bool(wedged))
     WEDGED["any"] = any(flags)
     WEDGED["here"] = bool(wedged)
+    FAILURES.extend(gather_failures(dist, world, rank, None if mine_ok else {
+        "stage": STAGES[1], "error": res.get("why") or "ncclCommInitRank did not return within the time limit"}))
     if ok:
         return res["comm"], None
     if mine_ok and world == 1:  # with peers missing, destroying a half-connected communicator may block: leave it
@@ -659,19 +750,30 @@ def distribute_skies(ctx, dist, torch, world, rank, host_skies, sw, sh, try_rccl
             # inside the try was skipped by a rank that raised, and the others waited in it for ever): agree, barrier, broadcast
             # only if the upload stood, timing reduction, agree
             up_ok, _ = agree(dist, world, ok, why)
+            mine = None if ok else {"stage": STAGES[2], "error": why}
             dist.barrier()
             t0 = time.perf_counter()
             if up_ok:
-                try:
-                    ctx.bcast_skies(comm, 0)  # header + 2 x ncclBroadcast on the context's stream, synchronised inside
-                except Exception as exc:  # noqa: BLE001
-                    ok, why = False, short(exc)
+                # header + 2 x ncclBroadcast on the context's stream, synchronised per stage inside; on a helper thread with a
+                # time limit: a peer that never enters the collective must not hold this rank for ever
+                _, bwhy, wedged = with_time_limit(lambda: ctx.bcast_skies(comm, 0),
+                                                  float(os.environ.get("CURVIS_BENCH_RCCL_BCAST_TIMEOUT", "300")))
+                if bwhy is not None:
+                    ok, why = False, bwhy
+                    mine = {"stage": stage_of(bwhy, "sky broadcast"), "error": bwhy}
+                if wedged:
+                    WEDGED["here"] = True
             ms = timed_ms(t0)  # (the upload's failure stays rank 0's own outcome: the agreement below reports it once)
             ok, why = agree(dist, world, ok, why)
-            try:
-                curvis_amd.Context.rccl_comm_destroy(comm)
-            except Exception:  # noqa: BLE001
-                pass
+            FAILURES.extend(gather_failures(dist, world, rank, mine))
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(WEDGED["here"]))
+            WEDGED["any"] = WEDGED["any"] or any(flags)
+            if not WEDGED["any"]:  # destroying a communicator a thread is still inside of may block
+                try:
+                    curvis_amd.Context.rccl_comm_destroy(comm)
+                except Exception:  # noqa: BLE001
+                    pass
             if ok:
                 done = True
                 info.update({"backend": "rccl (product ABI)",
@@ -736,9 +838,12 @@ def distribute_skies(ctx, dist, torch, world, rank, host_skies, sw, sh, try_rccl
             got = ctx.read_sky(which, off, piece)
             if not np.array_equal(got, want[off:off + piece]):
                 ok, why = False, "sky %d differs at byte offset %d" % (which, off)
+    FAILURES.extend(gather_failures(dist, world, rank, None if ok else {"stage": STAGES[6], "error": why}))
     ok, why = agree(dist, world, ok, why)
+    if FAILURES:
+        info["failure_detail"] = list(FAILURES)
     if not ok:
-        raise SystemExit("bench.py: a sky texture arrived corrupted (%s)" % why)
+        raise SystemExit("bench.py: a sky texture arrived corrupted (%s); failure detail: %s" % (why, json.dumps(FAILURES)))
     info["readback_verified_on_every_rank"] = True
     return info
 

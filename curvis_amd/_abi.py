@@ -113,6 +113,7 @@ SYMBOLS = {
     "curvis_ctx_synchronize": (C.c_int, [_vp]),
     "curvis_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "curvis_ctx_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
+    "curvis_device_link": (C.c_int, [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 5),
     "curvis_selftest_math": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, C.c_size_t]),
     "curvis_selftest_math3": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, C.c_size_t]),
     "curvis_selftest_fast_step": (C.c_int, [_vp, C.POINTER(Metric), C.c_double, C.c_double, _dp, C.c_size_t, _dp]),

@@ -267,12 +267,36 @@ int curvis_ctx_set_sky_orientation(curvis_ctx *ctx, int which, const double forw
   return CURVIS_OK;
 }
 
+/* what RCCL itself has to say about a failure: the result's text, the communicator's last error, an asynchronous error */
+static std::string rccl_detail(ncclComm_t comm, ncclResult_t rc) {
+  std::string m = ncclGetErrorString(rc);
+  const char *last = ncclGetLastError(comm);
+  if (last && *last) m += std::string("; last RCCL error: ") + last;
+  ncclResult_t async = ncclSuccess;
+  if (comm && ncclCommGetAsyncError(comm, &async) == ncclSuccess && async != ncclSuccess)
+    m += std::string("; asynchronous: ") + ncclGetErrorString(async);
+  return m;
+}
+/* stream synchronisation of one stage of the broadcast, with the stage's name in the error (first contact between two
+ * devices must say WHERE it broke: a collective's enqueue succeeds, its failure shows at the synchronisation) */
+static int bcast_stage_sync(curvis_ctx *ctx, ncclComm_t comm, const char *stage) {
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  ncclResult_t async = ncclSuccess;
+  (void)ncclCommGetAsyncError(comm, &async);
+  if (e != hipSuccess || async != ncclSuccess)
+    return fail(ctx, e != hipSuccess ? CURVIS_E_HIP : CURVIS_E_RCCL,
+                std::string("sky broadcast, stage ") + stage + ": " + (e != hipSuccess ? hipGetErrorString(e) : "stream synchronised") +
+                    "; RCCL: " + rccl_detail(comm, async));
+  return CURVIS_OK;
+}
+
 int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root) {
   if (!ctx || !nccl_comm) return fail(ctx, CURVIS_E_INVALID, "null context or communicator");
   ncclComm_t comm = (ncclComm_t)nccl_comm;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rank = -1;
-  if (ncclCommUserRank(comm, &rank) != ncclSuccess) return fail(ctx, CURVIS_E_RCCL, "ncclCommUserRank failed");
+  ncclResult_t nrc = ncclCommUserRank(comm, &rank);
+  if (nrc != ncclSuccess) return fail(ctx, CURVIS_E_RCCL, "sky broadcast, stage communicator: ncclCommUserRank: " + rccl_detail(comm, nrc));
   /* header first: {root_ok, w0, h0, w1, h1}, then the two textures.  root_ok travels with the shapes so that a
    * root without skies makes EVERY rank return CURVIS_E_NO_SKY together -- a root that returned before the
    * collective would leave its peers waiting inside ncclBroadcast for ever. */
@@ -283,28 +307,64 @@ int curvis_ctx_bcast_skies(curvis_ctx *ctx, void *nccl_comm, int root) {
     hdr[0] = (ctx->d_sky[0] && ctx->d_sky[1]) ? 1u : 0u;
     HIP_TRY(ctx, hipMemcpyAsync(d_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, ctx->stream));
   }
-  if (ncclBroadcast(d_hdr, d_hdr, 5, ncclUint32, root, comm, ctx->stream) != ncclSuccess) {
+  nrc = ncclBroadcast(d_hdr, d_hdr, 5, ncclUint32, root, comm, ctx->stream);
+  if (nrc != ncclSuccess) {
     (void)hipFree(d_hdr);
-    return fail(ctx, CURVIS_E_RCCL, "ncclBroadcast(header) failed");
+    return fail(ctx, CURVIS_E_RCCL, "sky broadcast, stage header_broadcast: ncclBroadcast: " + rccl_detail(comm, nrc));
   }
-  HIP_TRY(ctx, hipMemcpyAsync(hdr, d_hdr, sizeof hdr, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  int rc = bcast_stage_sync(ctx, comm, "header_broadcast");
+  if (rc == CURVIS_OK) {
+    const hipError_t e = hipMemcpy(hdr, d_hdr, sizeof hdr, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(ctx, CURVIS_E_HIP, std::string("sky broadcast, stage header_broadcast: reading the header back: ") + hipGetErrorString(e));
+  }
   (void)hipFree(d_hdr);
+  if (rc != CURVIS_OK) return rc;
   if (hdr[0] != 1u)
     return fail(ctx, CURVIS_E_NO_SKY, rank == root ? "root rank must hold both skies before the broadcast"
                                                    : "the root rank of the sky broadcast holds no skies");
   const uint32_t *shape = hdr + 1;
   for (int s = 0; s < 2; ++s) {
     const uint32_t w = shape[2 * s], h = shape[2 * s + 1];
+    const char *stage = s == 0 ? "texture_broadcast(+l sky)" : "texture_broadcast(-l sky)";
     if (rank != root) {
-      int rc = curvis_ctx_set_sky(ctx, s, nullptr, w, h);
-      if (rc) return rc;
+      rc = curvis_ctx_set_sky(ctx, s, nullptr, w, h);
+      if (rc) return fail(ctx, rc, std::string("sky broadcast, stage ") + stage + ": allocating the receiving texture: " + ctx->err);
     }
-    if (ncclBroadcast(ctx->d_sky[s], ctx->d_sky[s], (size_t)w * h * 4, ncclUint8, root, comm, ctx->stream) !=
-        ncclSuccess)
-      return fail(ctx, CURVIS_E_RCCL, "ncclBroadcast(sky) failed");
+    nrc = ncclBroadcast(ctx->d_sky[s], ctx->d_sky[s], (size_t)w * h * 4, ncclUint8, root, comm, ctx->stream);
+    if (nrc != ncclSuccess)
+      return fail(ctx, CURVIS_E_RCCL, std::string("sky broadcast, stage ") + stage + ": ncclBroadcast: " + rccl_detail(comm, nrc));
+    rc = bcast_stage_sync(ctx, comm, stage); /* one synchronisation per texture: the error names the texture */
+    if (rc != CURVIS_OK) return rc;
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CURVIS_OK;
+}
+
+/* How two devices of this node are connected (hipExtGetLinkTypeAndHopCount / hipDeviceGetP2PAttribute): read next to the
+ * first measured sky_broadcast_gbps -- xGMI is point-to-point, 7 links x ~153 GB/s per MI355X; a pair that only has PCIe
+ * between it explains a broadcast an order of magnitude slower.  link_type: HSA_AMD_LINK_INFO_TYPE_* (2 PCIe, 4 xGMI),
+ * 0 with hops 0 for a == b, -1 unknown.  Every output pointer may be NULL. */
+int curvis_device_link(int device_a, int device_b, int *link_type, int *hops, int *peer_access, int *performance_rank,
+                       int *native_atomics) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_a < 0 || device_b < 0 || device_a >= n || device_b >= n)
+    return fail(nullptr, CURVIS_E_INVALID, "curvis_device_link: no such device");
+  int lt = -1, hp = -1, pa = -1, pr = -1, na = -1;
+  if (device_a == device_b) {
+    lt = 0, hp = 0, pa = 1;
+  } else {
+    uint32_t t = 0, h = 0;
+    if (hipExtGetLinkTypeAndHopCount(device_a, device_b, &t, &h) == hipSuccess) lt = (int)t, hp = (int)h;
+    int v = 0;
+    if (hipDeviceCanAccessPeer(&v, device_a, device_b) == hipSuccess) pa = v;
+    if (hipDeviceGetP2PAttribute(&v, hipDevP2PAttrPerformanceRank, device_a, device_b) == hipSuccess) pr = v;
+    if (hipDeviceGetP2PAttribute(&v, hipDevP2PAttrNativeAtomicSupported, device_a, device_b) == hipSuccess) na = v;
+    (void)hipGetLastError();
+  }
+  if (link_type) *link_type = lt;
+  if (hops) *hops = hp;
+  if (peer_access) *peer_access = pa;
+  if (performance_rank) *performance_rank = pr;
+  if (native_atomics) *native_atomics = na;
   return CURVIS_OK;
 }
 
@@ -336,7 +396,9 @@ int curvis_ctx_rccl_comm_init(curvis_ctx *ctx, const uint8_t id[CURVIS_RCCL_ID_B
   std::memcpy(&u, id, sizeof u);
   ncclComm_t comm = nullptr;
   const ncclResult_t rc = ncclCommInitRank(&comm, n_ranks, u, rank);
-  if (rc != ncclSuccess) return fail(ctx, CURVIS_E_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(rc));
+  if (rc != ncclSuccess)
+    return fail(ctx, CURVIS_E_RCCL, "ncclCommInitRank (rank " + std::to_string(rank) + " of " + std::to_string(n_ranks) + ", device " +
+                                        std::to_string(ctx->device) + "): " + rccl_detail(nullptr, rc));
   *comm_out = (void *)comm;
   return CURVIS_OK;
 }

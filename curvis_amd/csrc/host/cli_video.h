@@ -1,0 +1,485 @@
+/* cli_video.h -- part of the `curvis` binary (host/curvis_cli.cpp includes the parts in order; one translation unit):
+ * `curvis video` (src/main.rs:135-168, src/rendering.rs:258-327): device worker threads, shared retry queue, sky distribution, per-frame statistics. */
+#ifndef CURVIS_CLI_VIDEO_H
+#define CURVIS_CLI_VIDEO_H
+
+namespace {
+
+int video_main(const Args &a) {
+  std::printf("Video rendering\n");
+  Common c;
+  VideoSettings vs;
+  std::string err;
+  if (!a.video_toml.empty()) {
+    if (!path_exists(a.video_toml)) die("Error with video settings: File \"" + a.video_toml + "\" not found.");
+    if (!from_toml(a.video_toml, vs, err)) die("Error with video settings: " + err);
+  }
+  load_common(a, c, "video");
+  vs.filepath_to_camera_path = resolve_path(vs.filepath_to_camera_path); /* normalize() */
+  if (vs.video_name.empty()) die("Error in rendering video: Video name cannot be an empty string.");
+  if (!has_extension(vs.filepath_to_camera_path, "csv"))
+    die("Error in rendering video: The camera path \"" + vs.filepath_to_camera_path + "\" is not a csv file.");
+  if (!path_exists(vs.filepath_to_camera_path))
+    die("Error in rendering video: The camera path \"" + vs.filepath_to_camera_path + "\" does not exist.");
+  CameraPath path;
+  if (!load_path(vs.filepath_to_camera_path, path, err)) die("Error in rendering video: " + err, 101);
+  /* times_of_frames (src/rendering.rs:224-238) */
+  std::vector<double> times;
+  {
+    const double min_time = path.pos[0], max_time = path.pos[4 * (path.n - 1)], dt = 1.0 / vs.frame_rate;
+    for (double t = min_time; t < max_time; t += dt) times.push_back(t);
+  }
+  if (!path_exists(c.out) && ::mkdir(c.out.c_str(), 0777) != 0)
+    die("Error in rendering video: Could not create video output folder \"" + c.out + "\"");
+  const std::string tmp = c.out + "/tmp";
+  if (a.resume) { /* opt-in: keep the frames a previous (interrupted) run has written */
+    if (!path_exists(tmp) && ::mkdir(tmp.c_str(), 0777) != 0)
+      die("Error in rendering video: Could not create tmp output folder \"" + tmp + "\"");
+  } else {
+    if (path_exists(tmp) && rm_rf(tmp) != 0)
+      die("Error in rendering video: Could not remove pre-existing tmp folder \"" + tmp + "\"");
+    if (::mkdir(tmp.c_str(), 0777) != 0) die("Error in rendering video: Could not create tmp output folder \"" + tmp + "\"");
+  }
+  std::printf("Rendering %zu frames...\n", times.size());
+
+  /* cameras of all frames; the reference panics when it reaches the broken last segment, after having
+   * written the frames before it: frames up to the first failing one are rendered, then exit 101. */
+  std::vector<curvis_camera> cams;
+  std::string panic_msg;
+  for (size_t k = 0; k < times.size(); ++k) {
+    double pos[4], fwd[3], up[3];
+    const int prc = path_camera(path, times[k], pos, fwd, up);
+    if (prc != 0) {
+      panic_msg = prc == 2 ? "index out of bounds in the camera-path interpolation (src/interpolation.rs:76-90)"
+                           : "Interpolation time outside the camera path";
+      break;
+    }
+    curvis_camera cam;
+    const int rc = curvis_camera_init(&cam, pos, fwd, up, c.cam.focal_length, c.cam.diagonal, c.cam.resolution_x, c.cam.resolution_y);
+    if (rc != CURVIS_OK) {
+      panic_msg = "Forward and up vectors must not be parallel";
+      break;
+    }
+    cams.push_back(cam);
+  }
+  const size_t n_frames = cams.size();
+  const size_t fbytes = (size_t)c.cam.resolution_x * c.cam.resolution_y * 3;
+  std::mutex io_mu;
+  std::atomic<int> failed{0};
+  FILE *stats_f = a.stats.empty() ? nullptr : std::fopen(a.stats.c_str(), "w");
+  WriterPool writers(a.writers);
+  /* per-stage host profile (--stats): what the writer threads spent encoding and writing, what each device worker
+   * spent inside the render call (GPU kernels + D2H of the batch), waiting for work and handing frames over */
+  pngio::EncodeTimes enc_total;
+  pngio::EncodeTimes bench_total; /* --encode-bench: the extra encodes, kept apart */
+  struct DeviceSummary {
+    std::string pci_bus_id;
+    int sclk_mhz = -1, power_w = -1;
+    size_t frames = 0, batches = 0;
+    double render_s = 0, kernel_ms = 0, submit_s = 0, wait_s = 0, busy_s = 0, pool_wait_s = 0;
+    double png_ms = 0; /* device PNG front end: HIP-event time of its kernels */
+    size_t png_frames = 0, png_fallback_frames = 0;
+    double sky_s = 0, sky_bcast_s = 0; /* skies into this device's HBM: all of it / the curvis_ctx_bcast_skies call alone */
+    unsigned long long steps = 0;
+  };
+  /* workers = devices x contexts-per-device; worker r drives device r / contexts with a context of its own (`--mode efficient`
+   * spends half of a frame's render call on the host -- the adaptive sampler between its launches --, so a second context
+   * on the same GPU fills the gaps) */
+  const int n_workers = a.devices * a.contexts;
+  auto device_of = [&](int rank) { return a.device + rank / a.contexts; };
+  std::vector<DeviceSummary> dev_sum((size_t)n_workers);
+  std::vector<std::unique_ptr<PinnedPool>> pools((size_t)n_workers); /* destroyed after writers.finish() below */
+  const double t_video0 = pngio::now_s();
+  /* sky distribution: rank 0 uploads the two textures once; with --sky-broadcast rccl (default for
+   * --devices > 1) the other GPUs receive them with ncclBroadcast over xGMI (curvis_ctx_bcast_skies),
+   * otherwise every GPU uploads from host memory. */
+  std::vector<ncclComm_t> comms;
+  const bool share_device = std::getenv("CURVIS_TEST_SHARE_DEVICE") != nullptr; /* test hook: every worker on GPU a.device */
+  bool use_rccl = a.sky_broadcast == "rccl" && !share_device && (a.devices > 1 || std::getenv("CURVIS_FORCE_RCCL"));
+  if (use_rccl) {
+    std::vector<int> devs;
+    for (int r = 0; r < a.devices; ++r) devs.push_back(a.device + r);
+    comms.resize(a.devices);
+    /* one node, one process: RCCL's bootstrap needs no network.  Left to itself it picks the first "real" interface, and on
+     * hosts where that one is slow or unroutable communicator set-up was seen to take 6 s (lo: 2.7 s) up to ~80 s */
+    ::setenv("NCCL_SOCKET_IFNAME", "lo", 0 /* a value the user has set stays */);
+    ::setenv("NCCL_DEBUG", "WARN", 0); /* RCCL's own warnings on stderr: a first contact between two devices that fails says why */
+    const ncclResult_t nrc = ncclCommInitAll(comms.data(), a.devices, devs.data());
+    if (nrc != ncclSuccess) {
+      const char *last = ncclGetLastError(nullptr);
+      const std::string why = std::string("stage ncclCommInitAll over devices ") + std::to_string(a.device) + ".." +
+                              std::to_string(a.device + a.devices - 1) + ": " + ncclGetErrorString(nrc) +
+                              (last && *last ? std::string("; last RCCL error: ") + last : std::string());
+      /* asked for explicitly: a broken xGMI broadcast must not hide behind a silent fallback */
+      if (a.sky_broadcast_explicit) die("Error in rendering video: --sky-broadcast rccl: " + why);
+      std::fprintf(stderr, "warning: sky broadcast: %s; uploading the skies to every device instead\n", why.c_str());
+      comms.clear();
+      use_rccl = false;
+    }
+  }
+  /* Work list: frame k belongs to device k mod N (src/rendering.rs:291-316 has no cross-frame state), in batches of
+   * --batch frames per launch.  With --resume the frames already on disk are dropped first.  A batch whose render
+   * call fails goes to a shared retry queue and is taken by a DIFFERENT device (by the same one when there is only
+   * one); after max(2, N) failed attempts the run fails. */
+  struct Batch {
+    std::vector<size_t> frames;
+    int attempts = 0, last_device = -1, last_worker = -1; /* where the last failed attempt ran: GPU and worker thread */
+  };
+  std::vector<std::deque<Batch>> own((size_t)n_workers);
+  size_t n_skipped = 0, n_batches = 0;
+  for (int r = 0; r < n_workers; ++r) {
+    Batch cur;
+    for (size_t k = (size_t)r; k < n_frames; k += (size_t)n_workers) {
+      if (a.resume) {
+        struct stat sb;
+        const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
+        if (::stat(file.c_str(), &sb) == 0 && sb.st_size > 0) {
+          ++n_skipped;
+          continue;
+        }
+      }
+      cur.frames.push_back(k);
+      if (cur.frames.size() == (size_t)a.batch) {
+        own[(size_t)r].push_back(cur);
+        cur.frames.clear();
+      }
+    }
+    if (!cur.frames.empty()) own[(size_t)r].push_back(cur);
+    n_batches += own[(size_t)r].size();
+  }
+  if (a.resume) std::printf("Resuming: %zu of %zu frames already present in \"%s\"\n", n_skipped, n_frames, tmp.c_str());
+  /* PNG front end on the device: with the fast writer (the default) in the modes whose frames of a batch sit together in the
+   * context's framebuffer; --encode-bench measures the HOST encoder and therefore keeps it */
+  const bool gpu_png = a.gpu_png == "on" ? (a.mode != "direct")
+                       : a.gpu_png == "auto" ? (a.png_level < 0 && a.mode != "direct" && a.encode_bench == 0) : false;
+  std::mutex q_mu;
+  std::condition_variable q_cv;
+  std::deque<Batch> retry;
+  size_t batches_done = 0;
+  const int max_attempts = std::max(2, n_workers);
+  /* fault injection for the tests: "rank:n" makes the n-th render call of that worker fail once */
+  int fail_rank = -1, fail_call = -1;
+  if (const char *fi = std::getenv("CURVIS_TEST_FAIL_BATCH")) std::sscanf(fi, "%d:%d", &fail_rank, &fail_call);
+  auto worker = [&](int rank) {
+    curvis_ctx *ctx = make_ctx_bare(share_device ? a.device : device_of(rank), "video");
+    DeviceSummary &ds = dev_sum[(size_t)rank];
+    {
+      char id[64] = {0};
+      (void)curvis_ctx_device_status(ctx, id, sizeof id, nullptr, nullptr);
+      ds.pci_bus_id = id;
+    }
+    const double t_worker0 = pngio::now_s();
+    if (use_rccl && rank % a.contexts == 0) { /* one context per device takes part in the broadcast; its siblings upload */
+      if (rank == 0) upload_skies(ctx, c, "video");
+      const double t_b0 = pngio::now_s();
+      check(curvis_ctx_bcast_skies(ctx, comms[rank / a.contexts], 0), ctx, "video");
+      ds.sky_bcast_s = pngio::now_s() - t_b0;
+      /* every GPU checks what arrived over xGMI against the decoded files (head, middle and tail of both textures):
+       * a broken broadcast must stop the run, not colour its frames */
+      const pngio::Image *sk[2] = {&c.sky1, &c.sky2};
+      for (int w = 0; w < 2; ++w) {
+        const size_t total = sk[w]->rgba.size(), piece = std::min<size_t>(total, (size_t)1 << 16);
+        std::vector<uint8_t> got(piece);
+        for (size_t off : {(size_t)0, (total - piece) / 2, total - piece}) {
+          check(curvis_ctx_read_sky(ctx, w, off, piece, got.data()), ctx, "video");
+          if (std::getenv("CURVIS_TEST_CORRUPT_BCAST")) got[piece / 2] ^= 0x10;  /* test hook: pretend a flipped bit */
+          if (std::memcmp(got.data(), sk[w]->rgba.data() + off, piece) != 0)
+            die("Error in rendering video: background " + std::to_string(w + 1) + " arrived corrupted on device " +
+                std::to_string(device_of(rank)) + " after the RCCL broadcast");
+        }
+      }
+    } else {
+      upload_skies(ctx, c, "video");
+    }
+    ds.sky_s = pngio::now_s() - t_worker0;
+    std::vector<curvis_camera> bc;
+    std::vector<uint8_t> rgb_pageable; /* only if page-locked memory could not be had */
+    /* one being filled, up to two with the writers.  The pool belongs to video_main's scope: writer jobs hold its
+     * buffers (and its mutex, through the deleter) after this worker has returned */
+    pools[(size_t)rank].reset(new PinnedPool((size_t)a.batch * fbytes, 3));
+    PinnedPool &pool = *pools[(size_t)rank];
+    if (pool.buffers() < 2) {
+      std::lock_guard<std::mutex> gi(io_mu);
+      std::fprintf(stderr, "warning: device %d: no page-locked host memory for the frame buffers, using pageable memory\n", device_of(rank));
+    }
+    int calls = 0;
+    for (;;) {
+      Batch b;
+      {
+        std::unique_lock<std::mutex> g(q_mu);
+        for (;;) {
+          if (failed || batches_done == n_batches) {
+            g.unlock();
+            q_cv.notify_all(); /* nobody may sleep on while the others leave */
+            ds.busy_s = pngio::now_s() - t_worker0;
+            curvis_ctx_destroy(ctx);
+            return;
+          }
+          auto it = retry.begin();
+          /* a failed batch goes to another GPU; with several contexts per GPU the sibling context of the SAME GPU is not
+           * "another device" (a faulty GPU used up two attempts that way).  One GPU only: another context of it. */
+          while (it != retry.end() && n_workers > 1 &&
+                 (a.devices > 1 ? it->last_device == device_of(rank) : it->last_worker == rank))
+            ++it;
+          if (it != retry.end()) {
+            b = *it;
+            retry.erase(it);
+            break;
+          }
+          if (!own[(size_t)rank].empty()) {
+            b = own[(size_t)rank].front();
+            own[(size_t)rank].pop_front();
+            break;
+          }
+          const double tw = pngio::now_s();
+          q_cv.wait_for(g, std::chrono::milliseconds(200)); /* re-checks `failed`: a writer thread sets it without this lock */
+          ds.wait_s += pngio::now_s() - tw;
+        }
+      }
+      const size_t nb = b.frames.size();
+      bc.clear();
+      for (size_t j = 0; j < nb; ++j) bc.push_back(cams[b.frames[j]]);
+      std::shared_ptr<uint8_t> batch_buf;
+      uint8_t *rgb_ptr = nullptr;
+      if (pool.buffers() >= 2) {
+        batch_buf = pool.take(&ds.pool_wait_s);
+        rgb_ptr = batch_buf.get();
+      } else {
+        rgb_pageable.resize(nb * fbytes);
+        rgb_ptr = rgb_pageable.data();
+      }
+      curvis_stats st;
+      /* src/rendering.rs:305-306: threshold_1 is passed for both thresholds */
+      const double t_r0 = pngio::now_s();
+      /* with the device PNG front end the pixels stay in HBM (rgb_out = NULL) and the batch buffer receives the frames' zlib
+       * streams instead; should they not fit (frames that do not compress: > 1 byte per byte) the raw frames are fetched after
+       * all and the host encoder takes them */
+      std::vector<size_t> zoff;
+      bool streams = false;
+      int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, gpu_png ? nullptr : rgb_ptr, &st);
+      if (rc == CURVIS_OK && gpu_png) {
+        zoff.resize(nb + 1);
+        double pms = 0.0;
+        /* test hook: pretend the streams do not fit (frames that do not compress), so that the fall-back below runs */
+        const size_t zcap = std::getenv("CURVIS_TEST_SMALL_PNG_BUFFER") ? (size_t)64 : batch_buf ? (size_t)a.batch * fbytes : nb * fbytes;
+        const int zrc = curvis_ctx_deflate_frames(ctx, c.cam.resolution_x, c.cam.resolution_y, (uint32_t)nb, rgb_ptr, zcap, zoff.data(), &pms);
+        if (zrc == CURVIS_OK) {
+          streams = true;
+          ds.png_ms += pms;
+          ds.png_frames += nb;
+        } else {
+          rc = curvis_ctx_download(ctx, rgb_ptr, nb * fbytes);
+          ds.png_fallback_frames += nb;
+        }
+      }
+      const double batch_call_ms = (pngio::now_s() - t_r0) * 1e3;
+      ds.render_s += batch_call_ms * 1e-3;
+      const bool injected = rank == fail_rank && calls == fail_call;
+      if (injected) rc = CURVIS_E_HIP;
+      ++calls;
+      if (rc != CURVIS_OK) {
+        std::lock_guard<std::mutex> g(q_mu);
+        {
+          std::lock_guard<std::mutex> gi(io_mu);
+          std::fprintf(stderr, "warning: device %d: rendering frames %zu.. failed: %s (code %d), attempt %d of %d%s\n",
+                       device_of(rank), b.frames[0], injected ? "injected test fault" : curvis_last_error(ctx), rc,
+                       b.attempts + 1, max_attempts, b.attempts + 1 < max_attempts ? "; re-queued" : "");
+        }
+        b.attempts++;
+        b.last_device = device_of(rank);
+        b.last_worker = rank;
+        if (b.attempts >= max_attempts) {
+          std::lock_guard<std::mutex> gi(io_mu);
+          std::fprintf(stderr, "Error in rendering video: frames %zu.. could not be rendered on any device\n", b.frames[0]);
+          failed = 1;
+        } else {
+          retry.push_back(b);
+        }
+        q_cv.notify_all();
+        continue;
+      }
+      /* hand the frames of this batch to the writer pool (each job owns a copy of its frame and ITS statistics:
+       * the kernels keep one set of counters per frame of a launch) */
+      ds.frames += nb;
+      ds.batches += 1;
+      ds.kernel_ms += st.kernel_ms;
+      ds.steps += st.steps;
+      if (ds.batches % 8 == 1) { /* clock and power while the device is under load */
+        int sclk = -1, pw = -1;
+        (void)curvis_ctx_device_status(ctx, nullptr, 0, &sclk, &pw);
+        if (sclk > 0) ds.sclk_mhz = sclk;
+        if (pw > 0) ds.power_w = pw;
+      }
+      const double t_s0 = pngio::now_s();
+      for (size_t j = 0; j < nb; ++j) {
+        const size_t k = b.frames[j];
+        /* the writer job keeps the batch buffer alive and reads its frame in place; with pageable memory it owns a copy */
+        std::shared_ptr<std::vector<uint8_t>> copy;
+        const size_t f_off = streams ? zoff[j] : j * fbytes, f_len = streams ? zoff[j + 1] - zoff[j] : fbytes;
+        if (!batch_buf) copy = std::make_shared<std::vector<uint8_t>>(rgb_ptr + f_off, rgb_ptr + f_off + f_len);
+        const uint8_t *frame = batch_buf ? batch_buf.get() + f_off : copy->data();
+        curvis_stats fs;
+        std::memset(&fs, 0, sizeof fs);
+        if (a.mode == "direct" && j < g_direct_frame_stats.size())
+          fs = g_direct_frame_stats[j];
+        else
+          (void)curvis_ctx_frame_stats(ctx, (uint32_t)j, &fs);
+        const double batch_ms = st.kernel_ms;
+        writers.submit([&, k, frame, f_len, streams, batch_buf, copy, fs, nb, rank, batch_ms, batch_call_ms] {
+          const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
+          const std::string part = file + ".part"; /* written under another name, then renamed: --resume never sees half a file */
+          std::string e;
+          pngio::EncodeTimes tm, tb;
+          bool ok = streams ? pngio::save_zlib_stream_rgb8(part, frame, f_len, c.cam.resolution_x, c.cam.resolution_y, e, &tm)
+                            : pngio::save_rgb8(part, frame, c.cam.resolution_x, c.cam.resolution_y, e, a.png_level, &tm);
+          if (ok && std::rename(part.c_str(), file.c_str()) != 0) {
+            ok = false;
+            e = std::strerror(errno);
+          }
+          for (int rep = 0; ok && rep < a.encode_bench; ++rep) { /* diagnostics: the host's encode capacity with one GPU feeding it */
+            std::string e2;
+            if (streams)
+              (void)pngio::save_zlib_stream_rgb8(part + ".bench", frame, f_len, c.cam.resolution_x, c.cam.resolution_y, e2, &tb);
+            else
+              (void)pngio::save_rgb8(part + ".bench", frame, c.cam.resolution_x, c.cam.resolution_y, e2, a.png_level, &tb);
+          }
+          if (a.encode_bench) std::remove((part + ".bench").c_str());
+          std::lock_guard<std::mutex> g(io_mu);
+          if (!ok) {
+            std::fprintf(stderr, "Error in rendering video: Could not save image frame \"%s\" due to error: %s\n", file.c_str(), e.c_str());
+            failed = 1;
+            q_cv.notify_all(); /* device workers waiting for work must see it */
+            return;
+          }
+          for (auto pr : {std::make_pair(&enc_total, &tm), std::make_pair(&bench_total, &tb)}) {
+            pr.first->filter += pr.second->filter;
+            pr.first->deflate += pr.second->deflate;
+            pr.first->checksum += pr.second->checksum;
+            pr.first->write += pr.second->write;
+            pr.first->raw_bytes += pr.second->raw_bytes;
+            pr.first->file_bytes += pr.second->file_bytes;
+            pr.first->frames += pr.second->frames;
+          }
+          std::printf("Rendering frame %zu/%zu...\n", k + 1, times.size());
+          if (stats_f)
+            std::fprintf(stats_f, "{\"frame\": %zu, \"time\": %.17g, \"device\": %d, \"mode\": \"%s\", \"rays\": %llu, \"steps\": %llu, \"n_pos\": %llu, \"n_neg\": %llu, \"n_none\": %llu, \"n_oob\": %llu, \"kernel_ms\": %.4f, \"mray_steps_per_s\": %.1f, \"batch_frames\": %zu, \"batch_kernel_ms\": %.4f, \"batch_call_ms\": %.4f}\n",
+                         k, times[k], device_of(rank), a.mode.c_str(), (unsigned long long)fs.rays, (unsigned long long)fs.steps,
+                         (unsigned long long)fs.n_pos, (unsigned long long)fs.n_neg, (unsigned long long)fs.n_none,
+                         (unsigned long long)fs.n_oob, fs.kernel_ms, fs.kernel_ms > 0.0 ? (double)fs.steps / fs.kernel_ms / 1e3 : 0.0, nb,
+                         batch_ms, batch_call_ms);
+        });
+      }
+      ds.submit_s += pngio::now_s() - t_s0; /* frame copies + time blocked on a full writer queue */
+      {
+        std::lock_guard<std::mutex> g(q_mu);
+        ++batches_done;
+      }
+      q_cv.notify_all();
+    }
+  };
+  std::vector<std::thread> th;
+  for (int r = 0; r < n_workers; ++r) th.emplace_back(worker, r);
+  for (auto &t : th) t.join();
+  for (ncclComm_t cm : comms) ncclCommDestroy(cm);
+  const double t_workers_done = pngio::now_s();
+  writers.finish();
+  pools.clear(); /* every writer job is done: the page-locked buffers can go */
+  const double t_video1 = pngio::now_s();
+  if (stats_f) std::fclose(stats_f);
+  if (!a.stats.empty()) { /* <stats>.summary.json + a table: who rendered what at which clock, where the host's time went */
+    const double wall = t_video1 - t_video0;
+    size_t total_frames = 0;
+    for (const DeviceSummary &d : dev_sum) total_frames += d.frames;
+    std::string js = "{\"frames\": " + std::to_string(total_frames) + ", \"wall_s\": " + std::to_string(wall) +
+                     ", \"frames_per_s\": " + std::to_string(wall > 0 ? total_frames / wall : 0.0) +
+                     ", \"writers\": " + std::to_string(a.writers) + ", \"png_level\": " + std::to_string(a.png_level) +
+                     ", \"gpu_png\": " + (gpu_png ? "true" : "false") +
+                     ", \"writer_drain_s\": " + std::to_string(t_video1 - t_workers_done);
+    { /* how the two textures reached the devices: the slowest device's time; for RCCL the broadcast call alone as well
+       * (root: upload first, then header + 2 x ncclBroadcast; the first collective of a communicator carries its set-up) */
+      double sky_max = 0, bcast_max = 0;
+      for (const DeviceSummary &d : dev_sum) {
+        sky_max = std::max(sky_max, d.sky_s);
+        bcast_max = std::max(bcast_max, d.sky_bcast_s);
+      }
+      const double sky_bytes = (double)c.sky1.rgba.size() + (double)c.sky2.rgba.size();
+      char buf[384];
+      std::snprintf(buf, sizeof buf,
+                    ", \"sky_distribution\": {\"via\": \"%s\", \"bytes\": %.0f, \"seconds\": %.4f, \"broadcast_call_s\": %.4f, "
+                    "\"sky_broadcast_gbps\": %.2f}",
+                    use_rccl ? "rccl: ncclCommInitAll + curvis_ctx_bcast_skies" : "upload to every device", sky_bytes, sky_max, bcast_max,
+                    bcast_max > 0 ? sky_bytes / bcast_max / 1e9 : 0.0);
+      js += buf;
+    }
+    if (a.devices > 1 && !share_device) { /* how the GPUs are connected: what sky_broadcast_gbps has to be read against */
+      js += ", \"links\": [";
+      bool first = true;
+      for (int i = 0; i < a.devices; ++i)
+        for (int k = i + 1; k < a.devices; ++k) {
+          int lt = -1, hops = -1, peer = -1, perf = -1, atom = -1;
+          (void)curvis_device_link(a.device + i, a.device + k, &lt, &hops, &peer, &perf, &atom);
+          const char *name = lt == 4 ? "xGMI" : lt == 2 ? "PCIe" : lt == 0 ? "same device" : "unknown";
+          char buf[256];
+          std::snprintf(buf, sizeof buf, "%s{\"a\": %d, \"b\": %d, \"link\": \"%s\", \"link_type\": %d, \"hops\": %d, \"peer_access\": %d, "
+                        "\"performance_rank\": %d}", first ? "" : ", ", a.device + i, a.device + k, name, lt, hops, peer, perf);
+          js += buf;
+          if (i == 0) std::printf("link device %d <-> %d: %s, %d hop(s), peer access %d\n", a.device + i, a.device + k, name, hops, peer);
+          first = false;
+        }
+      js += "]";
+    }
+    js += ", \"devices\": [";
+    std::printf("device  pci_bus_id     frames  kernel ms/frame  render-call ms/frame  fps    sclk MHz  power W  wait s  hand-over s\n");
+    for (size_t r = 0; r < dev_sum.size(); ++r) {
+      const DeviceSummary &d = dev_sum[r];
+      const double kf = d.frames ? d.kernel_ms / d.frames : 0.0, rf = d.frames ? d.render_s * 1e3 / d.frames : 0.0;
+      std::printf("%-7zu %-14s %-7zu %-16.3f %-21.3f %-6.1f %-9d %-8d %-7.2f %.2f\n", (size_t)device_of((int)r), d.pci_bus_id.c_str(), d.frames, kf, rf,
+                  d.busy_s > 0 ? d.frames / d.busy_s : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s);
+      char buf[768];
+      std::snprintf(buf, sizeof buf,
+                    "%s{\"device\": %zu, \"pci_bus_id\": \"%s\", \"frames\": %zu, \"batches\": %zu, \"kernel_ms_per_frame\": %.4f, "
+                    "\"render_call_ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"mray_steps_per_s\": %.1f, \"sclk_mhz\": %d, \"power_w\": %d, "
+                    "\"wait_s\": %.3f, \"hand_over_s\": %.3f, \"buffer_wait_s\": %.3f, \"busy_s\": %.3f, \"gpu_png_frames\": %zu, "
+                    "\"gpu_png_kernel_ms_per_frame\": %.4f, \"gpu_png_fallback_frames\": %zu}",
+                    r ? ", " : "", (size_t)device_of((int)r), d.pci_bus_id.c_str(), d.frames, d.batches, kf, rf, d.busy_s > 0 ? d.frames / d.busy_s : 0.0,
+                    d.kernel_ms > 0 ? (double)d.steps / d.kernel_ms / 1e3 : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s, d.pool_wait_s, d.busy_s,
+                    d.png_frames, d.png_frames ? d.png_ms / d.png_frames : 0.0, d.png_fallback_frames);
+      js += buf;
+    }
+    js += "]";
+    for (auto pr : {std::make_pair("encode", &enc_total), std::make_pair("encode_bench", &bench_total)}) {
+      const pngio::EncodeTimes &t = *pr.second;
+      if (!t.frames) continue;
+      const double per = 1e3 / (double)t.frames, cpu = t.filter + t.deflate + t.checksum + t.write;
+      char buf[640];
+      std::snprintf(buf, sizeof buf,
+                    ", \"%s\": {\"frames\": %zu, \"filter_ms\": %.3f, \"deflate_ms\": %.3f, \"checksum_ms\": %.3f, \"write_ms\": %.3f, "
+                    "\"thread_ms_per_frame\": %.3f, \"raw_mb_per_frame\": %.3f, \"file_mb_per_frame\": %.3f, \"mb_per_s_per_thread\": %.1f, "
+                    "\"frames_per_s_per_thread\": %.1f}",
+                    pr.first, t.frames, t.filter * per, t.deflate * per, t.checksum * per, t.write * per, cpu * per, t.raw_bytes / 1e6 / t.frames,
+                    t.file_bytes / 1e6 / t.frames, cpu > 0 ? t.raw_bytes / 1e6 / cpu : 0.0, cpu > 0 ? t.frames / cpu : 0.0);
+      js += buf;
+      std::printf("%s: %zu frames, per frame and writer thread: filter %.2f + deflate %.2f + checksums %.2f + file write %.2f = %.2f ms "
+                  "(%.0f MB/s, %.1f frames/s per thread), %.2f -> %.2f MB\n",
+                  pr.first, t.frames, t.filter * per, t.deflate * per, t.checksum * per, t.write * per, cpu * per, cpu > 0 ? t.raw_bytes / 1e6 / cpu : 0.0,
+                  cpu > 0 ? t.frames / cpu : 0.0, t.raw_bytes / 1e6 / t.frames, t.file_bytes / 1e6 / t.frames);
+    }
+    js += "}\n";
+    std::printf("video: %zu frames in %.2f s wall = %.1f frames/s (%d writer threads, png level %d; writers still busy %.2f s after the last render)\n",
+                total_frames, wall, wall > 0 ? total_frames / wall : 0.0, a.writers, a.png_level, t_video1 - t_workers_done);
+    if (FILE *sf = std::fopen((a.stats + ".summary.json").c_str(), "w")) {
+      std::fputs(js.c_str(), sf);
+      std::fclose(sf);
+    }
+  }
+  if (failed) return 1;
+  if (!panic_msg.empty()) {
+    std::fprintf(stderr, "thread 'main' panicked: %s (frame %zu of %zu)\n", panic_msg.c_str(), n_frames, times.size());
+    return 101;
+  }
+  return 0;
+}
+
+}  // namespace
+
+#endif /* CURVIS_CLI_VIDEO_H */

@@ -323,6 +323,18 @@ class Context:
               self._h)
         self._sky_objs[which] = None
 
+    LINK_TYPES = {0: "same device", 2: "PCIe", 4: "xGMI", -1: "unknown"}
+
+    @staticmethod
+    def device_link(device_a, device_b):
+        """how two devices of this node are connected (curvis_device_link): {"link", "link_type", "hops", "peer_access",
+        "performance_rank", "native_atomics"}; xGMI is point-to-point, 7 links x ~153 GB/s per MI355X"""
+        v = [C.c_int(-1) for _ in range(5)]
+        check(lib().curvis_device_link(int(device_a), int(device_b), *[C.byref(x) for x in v]))
+        lt = v[0].value
+        return {"link": Context.LINK_TYPES.get(lt, "HSA link type %d" % lt), "link_type": lt, "hops": v[1].value,
+                "peer_access": v[2].value, "performance_rank": v[3].value, "native_atomics": v[4].value}
+
     @staticmethod
     def rccl_unique_id():
         """ncclGetUniqueId as bytes: rank 0 draws it and ships it to the other processes out of band"""

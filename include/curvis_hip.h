@@ -141,6 +141,14 @@ int curvis_rccl_comm_destroy(void *nccl_comm);
  * a broadcast texture equals the root's file). */
 int curvis_ctx_read_sky(curvis_ctx *ctx, int which, size_t offset, size_t bytes, uint8_t *out);
 
+/* how two devices of this node are connected (hipExtGetLinkTypeAndHopCount, hipDeviceCanAccessPeer, hipDeviceGetP2PAttribute):
+ * link_type = HSA_AMD_LINK_INFO_TYPE_* (2 PCIe, 4 xGMI; 0 with hops 0 for a == b; -1 unknown).  Read beside the measured
+ * sky-broadcast rate: xGMI is point-to-point, 7 links x ~153 GB/s per MI355X.  Output pointers may be NULL.  The errors of
+ * curvis_ctx_bcast_skies / curvis_ctx_rccl_comm_init name the stage that failed ("sky broadcast, stage header_broadcast: ...")
+ * and carry RCCL's own last error. */
+int curvis_device_link(int device_a, int device_b, int *link_type, int *hops, int *peer_access, int *performance_rank,
+                       int *native_atomics);
+
 /* Camera::new (src/cameras.rs:79-122) incl. Orientation::new (src/algebra.rs:16-38). */
 int curvis_camera_init(curvis_camera *out, const double pos[4], const double forward[3], const double up[3],
                        double focal_length, double sensor_diagonal, uint32_t res_x, uint32_t res_y);

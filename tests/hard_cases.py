@@ -108,3 +108,35 @@ def recip_error_units_fast(d, y):
 
 def ulp_distance(a, b):
     return np.abs(np.ascontiguousarray(a).view(np.int64) - np.ascontiguousarray(b).view(np.int64))
+
+
+def ulp_of(q):
+    q = np.abs(q)
+    return np.ldexp(1.0, np.frexp(q)[1] - 53)
+
+
+def two_prod(a, b):
+    """a b = p + e exactly (Veltkamp / Dekker; no overflow or underflow in the ranges used here)"""
+    def split(x):
+        c = 134217729.0 * x
+        hi = c - (c - x)
+        return hi, x - hi
+    p = a * b
+    ah, al = split(a)
+    bh, bl = split(b)
+    return p, ((ah * bh - p) + ah * bl + al * bh) + al * bl
+
+
+def gap_over_ulp(n, d, y, q_ieee, rem_recorded, eps_recorded):
+    """|q0 + rem y - n/d| / ulp(n/d) for q0 = RN(n y), rem = RN(n - d q0): the share of the boundary spacing inside which
+    div_with_recip's last rounding can go the wrong way.  d (q0 + rem y - n/d) = -rem (1 - d y) - (exact remainder - rem)."""
+    q0 = n * y
+    p, e = two_prod(d, q0)
+    t = n - p                                   # exact (n and p agree to a few ulp)
+    s = t - e
+    bb = s - t
+    err = (t - (s - bb)) + (-e - bb)            # exact remainder = s + err, s = RN(...) = the recorded remainder
+    with np.errstate(invalid="ignore", divide="ignore"):
+        g = (-s * eps_recorded - err) / d       # signed: (value before the last rounding) - n/d
+        out = np.abs(g) / ulp_of(q_ieee)
+    return np.where(np.isfinite(out) & (q_ieee != 0.0), out, 0.0), float((s != rem_recorded).sum()), g

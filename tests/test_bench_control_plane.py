@@ -25,6 +25,7 @@ WORKER = textwrap.dedent("""
 
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    bench.rccl_log_begin(rank)
     SCEN = os.environ["SCENARIO"]
     curvis_amd.Context.rccl_unique_id = staticmethod(lambda: bytes(range(128)))
     curvis_amd.Context.rccl_comm_destroy = staticmethod(lambda comm: None)
@@ -49,7 +50,9 @@ WORKER = textwrap.dedent("""
             # a rank that sees its part of the collective fail AFTER taking part (a failed stream synchronisation, say): its
             # peers returned fine -- only the agreement afterwards tells them.  (A rank that never enters a collective leaves its
             # peers inside it; no protocol on top can repair that, with RCCL or with this stub.)
-            if SCEN == "bcast_fails_on_rank1" and rank == 1: raise RuntimeError("ncclBroadcast failed")
+            if SCEN == "bcast_fails_on_rank1" and rank == 1:
+                with open(bench.rccl_log_path(rank), "w") as f: f.write("stub NCCL WARN Cuda failure 'invalid device ordinal'\\n")
+                raise RuntimeError("sky broadcast, stage texture_broadcast(-l sky): ncclBroadcast failed")
         def set_sky_device(self, which, ptr, w, h, copy=False): self.sky[which] = StubContext.tensors[ptr]
         def read_sky(self, which, off, n): return self.sky[which].reshape(-1)[off:off + n]
 
@@ -76,7 +79,8 @@ WORKER = textwrap.dedent("""
     for w, blue in ((0, 128), (1, 32)):
         assert np.array_equal(np.asarray(ctx.sky[w]).reshape(sh, sw, 4), skies.smooth(sw, sh, blue))
     out = [None] * world
-    dist.all_gather_object(out, {"backend": info["backend"], "fell": info.get("fallback_from"), "verified": info["readback_verified_on_every_rank"]})
+    dist.all_gather_object(out, {"backend": info["backend"], "fell": info.get("fallback_from"), "verified": info["readback_verified_on_every_rank"],
+                                 "detail": info.get("failure_detail")})
     if rank == 0: print(json.dumps(out + [dict(bench.WEDGED)]), flush=True)
     dist.barrier(); dist.destroy_process_group()
     if bench.WEDGED["any"]: os._exit(0)             # what bench.py does after its line: a stuck join must not block the exit
@@ -112,13 +116,21 @@ def test_both_ranks_fall_back_when_one_cannot_join(tmp_path):
     out, err = run_scenario(tmp_path, "init_fails_on_rank1")
     assert [o["backend"] for o in out] == ["gloo"] * 2 and out[0]["fell"] == out[1]["fell"] and all(o["verified"] for o in out)
     assert out[0]["fell"][0] == "curvis_ctx_rccl_comm_init: rank 1: RuntimeError: no RCCL on this rank" and "torch nccl group" in out[0]["fell"][1]
+    d = out[0]["detail"]
+    assert d == out[1]["detail"] and [(x["rank"], x["stage"]) for x in d] == [(1, "ncclCommInitRank")] and "no RCCL on this rank" in d[0]["error"]
     assert err.count("sky broadcast fell back") == 2
 
 
 def test_both_ranks_fall_back_when_the_broadcast_fails_on_one(tmp_path):
     out, _ = run_scenario(tmp_path, "bcast_fails_on_rank1")
     assert [o["backend"] for o in out] == ["gloo"] * 2 and out[0]["fell"] == out[1]["fell"]
-    assert out[0]["fell"][0].startswith("curvis_ctx_bcast_skies: rank 1: RuntimeError: ncclBroadcast failed")
+    assert out[0]["fell"][0].startswith("curvis_ctx_bcast_skies: rank 1: RuntimeError: sky broadcast, stage texture_broadcast(-l sky): ncclBroadcast failed")
+    # failure attribution: WHICH rank, WHICH stage, the error, and that rank's own RCCL warnings -- the same
+    # table on every rank
+    assert out[0]["detail"] == out[1]["detail"] and len(out[0]["detail"]) == 1
+    d = out[0]["detail"][0]
+    assert d["rank"] == 1 and d["stage"] == "texture_broadcast(-l sky)" and "ncclBroadcast failed" in d["error"]
+    assert "invalid device ordinal" in d["rccl_log"]
 
 
 def test_upload_failure_on_rank0_does_not_strand_the_other_rank(tmp_path):
@@ -127,6 +139,7 @@ def test_upload_failure_on_rank0_does_not_strand_the_other_rank(tmp_path):
     out, _ = run_scenario(tmp_path, "upload_fails_on_rank0")
     assert [o["backend"] for o in out] == ["gloo"] * 2 and out[0]["fell"] == out[1]["fell"] and all(o["verified"] for o in out)
     assert out[0]["fell"][0] == "curvis_ctx_bcast_skies: rank 0: upload on rank 0: RuntimeError: hipMalloc failed"
+    assert [(x["rank"], x["stage"]) for x in out[1]["detail"]] == [(0, "upload on the root")]
 
 
 def test_wedged_join_skips_the_second_rccl_stage_on_every_rank(tmp_path):
@@ -136,3 +149,23 @@ def test_wedged_join_skips_the_second_rccl_stage_on_every_rank(tmp_path):
     assert [o["backend"] for o in out] == ["gloo"] * 2 and out[0]["fell"] == out[1]["fell"] and all(o["verified"] for o in out)
     assert "time limit" in out[0]["fell"][0] and out[0]["fell"][1].startswith("torch nccl group: not attempted")
     assert run_scenario.wedged == {"any": True, "here": False}     # rank 0's view: somebody is wedged, not me
+    assert [(x["rank"], x["stage"]) for x in out[0]["detail"]] == [(1, "ncclCommInitRank")] and "time limit" in out[0]["detail"][0]["error"]
+
+
+def test_clean_path_reports_no_failure_detail(tmp_path):
+    out, _ = run_scenario(tmp_path, "clean")
+    assert all(o["detail"] is None for o in out)
+
+
+def test_stage_names_are_parsed_from_the_librarys_messages():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module_stage", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.stage_of("CurvisError: sky broadcast, stage header_broadcast: ncclBroadcast: unhandled system error", "x") == "header_broadcast"
+    assert bench.stage_of("sky broadcast, stage texture_broadcast(+l sky): stream synchronised; RCCL: ...", "x") == "texture_broadcast(+l sky)"
+    assert bench.stage_of("something else", "sky broadcast") == "sky broadcast"
+    v, why, wedged = bench.with_time_limit(lambda: 7, 5.0)
+    assert (v, why, wedged) == (7, None, False)
+    v, why, wedged = bench.with_time_limit(lambda: __import__("time").sleep(30), 0.2)
+    assert v is None and wedged and "did not return" in why

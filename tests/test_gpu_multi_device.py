@@ -32,19 +32,47 @@ def clean_env():
     return env
 
 
-def run_ranks(tmp_path, world):
+def rank_report(tmp_path, world):
+    """what every rank's status file says: the stage it reached, its error, RCCL's warnings, its links"""
+    lines = []
+    for r in range(world):
+        try:
+            st = json.loads((tmp_path / ("status_%d.json" % r)).read_text())
+        except (OSError, ValueError):
+            lines.append("rank %d: no status file (the process died before its first stage)" % r)
+            continue
+        if st.get("ok"):
+            lines.append("rank %d (device %s, %s): done; broadcast %.3f s = %.2f GB/s; links %s" % (
+                r, st.get("device"), st.get("pci"), st.get("bcast_s", 0.0), st.get("sky_broadcast_gbps", 0.0), json.dumps(st.get("links"))))
+        else:
+            lines.append("rank %d (device %s, %s): FAILED at stage `%s`: %s\n    links: %s\n    RCCL log: %s" % (
+                r, st.get("device"), st.get("pci"), st.get("stage"), st.get("error", "still inside the stage (killed by the time limit?)"),
+                json.dumps(st.get("links")), (st.get("rccl_log") or "(empty)").strip()[-1200:]))
+    return "\n".join(lines)
+
+
+def run_ranks(tmp_path, world, env_extra=None, expect_failure=False):
+    env = clean_env()
+    env.update(env_extra or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multi_device_worker.py"), str(r), str(world), str(r), str(tmp_path)],
-                              env=clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = []
     try:
         for p in procs:
-            outs.append(p.communicate(timeout=600))
+            try:
+                outs.append(p.communicate(timeout=600))
+            except subprocess.TimeoutExpired:
+                outs.append(("", "time limit"))
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()  # the exact processes this test started
+    report = rank_report(tmp_path, world)
+    print(report)                                           # the link table and the broadcast rate of every rank (pytest -s / on failure)
+    if expect_failure:
+        return report
     for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d: %s" % (r, outs[r][1][-2000:])
+        assert p.returncode == 0, "first contact failed -- per rank:\n%s\nrank %d stderr: %s" % (report, r, outs[r][1][-1500:])
     return [np.load(os.path.join(tmp_path, "rank_%d.npz" % r)) for r in range(world)]
 
 
@@ -71,6 +99,15 @@ def test_one_process_per_gpu_host_single_rank(tmp_path):
     rank on GPU 0 (what a 1-GPU box can host), frames against the oracle"""
     res = run_ranks(tmp_path, 1)
     check_against_oracle(res, 1)
+
+
+@pytest.mark.parametrize("stage", ["ncclCommInitRank", "read-back", "render on device 0"])
+def test_a_failing_rank_says_which_stage_broke(tmp_path, stage):
+    """the first contact between two devices must be self-diagnosing.  A rank made to fail at a given
+    stage leaves a status file naming the stage, the error and its own RCCL log; the test's failure message is built from it."""
+    report = run_ranks(tmp_path, 1, {"CURVIS_WORKER_FAIL_STAGE": stage}, expect_failure=True)
+    assert "FAILED at stage `%s`: RuntimeError: injected failure at stage %s" % (stage, stage) in report
+    assert "RCCL log:" in report and "links:" in report
 
 
 @two_gpus

@@ -37,36 +37,7 @@ import curvis_amd  # noqa: E402
 NAMES = curvis_amd.Context.FAST_STEP_QUOTIENTS
 
 
-def ulp_of(q):
-    q = np.abs(q)
-    return np.ldexp(1.0, np.frexp(q)[1] - 53)
-
-
-def two_prod(a, b):
-    """a b = p + e exactly (Veltkamp / Dekker; no overflow or underflow in the ranges used here)"""
-    def split(x):
-        c = 134217729.0 * x
-        hi = c - (c - x)
-        return hi, x - hi
-    p = a * b
-    ah, al = split(a)
-    bh, bl = split(b)
-    return p, ((ah * bh - p) + ah * bl + al * bh) + al * bl
-
-
-def gap_over_ulp(n, d, y, q_ieee, rem_recorded, eps_recorded):
-    """|q0 + rem y - n/d| / ulp(n/d) for q0 = RN(n y), rem = RN(n - d q0): the share of the boundary spacing inside which
-    div_with_recip's last rounding can go the wrong way.  d (q0 + rem y - n/d) = -rem (1 - d y) - (exact remainder - rem)."""
-    q0 = n * y
-    p, e = two_prod(d, q0)
-    t = n - p                                   # exact (n and p agree to a few ulp)
-    s = t - e
-    bb = s - t
-    err = (t - (s - bb)) + (-e - bb)            # exact remainder = s + err, s = RN(...) = the recorded remainder
-    with np.errstate(invalid="ignore", divide="ignore"):
-        g = (-s * eps_recorded - err) / d       # signed: (value before the last rounding) - n/d
-        out = np.abs(g) / ulp_of(q_ieee)
-    return np.where(np.isfinite(out) & (q_ieee != 0.0), out, 0.0), float((s != rem_recorded).sum()), g
+ulp_of, two_prod, gap_over_ulp = H.ulp_of, H.two_prod, H.gap_over_ulp
 
 
 def states_of(ctx, metric, pm, pose, nrays, iterations, rng, res=(1920, 1080)):
@@ -92,7 +63,7 @@ def measure(ctx, name, pm, states, steps_per_frame, frames_per_video=None):
     print("new state of the fast step bit-identical to the strict step's: %d of %d" % (int(same_state.sum()), n))
     print("| quotient | formed | max abs(kappa) | rms kappa | mean P(mis-rounded) per quotient | quotient != IEEE quotient |")
     print("|---|---|---|---|---|---|")
-    total = 0.0
+    total, total_phi = 0.0, 0.0
     for k in range(6):
         nn, d, y, qf, qi, rem, eps = (quot[:, k, i] for i in range(7))
         ok = took & np.isfinite(qi) & (d == d)
@@ -101,14 +72,24 @@ def measure(ctx, name, pm, states, steps_per_frame, frames_per_video=None):
         kappa = -eps[ok] / 2.0 ** -53                     # y = (1 + kappa 2^-53)/d
         p, rem_mismatch, _ = gap_over_ulp(nn[ok], d[ok], y[ok], qi[ok], rem[ok], eps[ok])
         assert rem_mismatch == 0, "host remainder != the device's fma"
-        total += p.sum() / n
+        if k == 5:
+            total_phi = p.sum() / n           # only the kernels that integrate phi form it (debug dump, escape angles)
+        else:
+            total += p.sum() / n
         print("| %s | %d | %.2f | %.2f | %.3g (= 2^%.1f) | %d |" % (
             NAMES[k], int(ok.sum()), np.abs(kappa).max(), np.sqrt((kappa ** 2).mean()), p.mean(), np.log2(max(p.mean(), 1e-300)),
             int((qf[ok].view(np.uint64) != qi[ok].view(np.uint64)).sum())))
-    print("expected mis-rounded quotients per Euler step (sum over the quotients): %.3g = 2^%.1f" % (total, np.log2(total)))
+    # the Ellis step's square root: its last residual step adds |sqrt x - g| kappa_y 2^-53 <= 1/2 ulp x 1.5 x 2^-53 to a value
+    # that is otherwise exact to 2^-107, against boundaries one ulp apart: <= 0.75 x 2^-53 (directed cases below: reachable
+    # at the three j = -1 significands only)
+    root = 0.75 * 2.0 ** -53 if "r' = l/r" in [NAMES[k] for k in range(6) if (took & (quot[:, k, 1] == quot[:, k, 1])).any()] else 0.0
+    total += root
+    print("expected mis-rounded operations per Euler step of the production kernels (the quotients above without 1/(r^2 sin^2)%s): "
+          "%.3g = 2^%.1f   [with phi integrated: %.3g]" % (", + <= %.2g for the square root" % root if root else "", total, np.log2(total), total + total_phi))
     print("  -> per frame of %.4g steps: %.3g" % (steps_per_frame, total * steps_per_frame))
     if frames_per_video:
-        print("  -> per render of %d such frames: %.3g" % (frames_per_video, total * steps_per_frame * frames_per_video))
+        print("  -> per render of %d such frames: %.3g  (probability that ONE quotient of the whole render is one ulp off)" % (
+            frames_per_video, total * steps_per_frame * frames_per_video))
     print()
     return total
 

@@ -21,7 +21,7 @@ import oracle_lib as O  # noqa: E402
 import curvis_amd  # noqa: E402
 from curvis_amd import skies  # noqa: E402
 
-THREADS = min(128, os.cpu_count() or 1)
+THREADS = common.host_threads(128)   # the cgroup's CPU quota, not the machine's core count
 
 
 def ulp_diff(a, b):
@@ -31,14 +31,25 @@ def ulp_diff(a, b):
     return np.abs(ia - ib)
 
 
-def compare_frame(ctx, name, metric, res, cap, sky_res):
-    om, oc, pm, pc = common.scene(metric, res=res)
+def compare_frame(ctx, name, metric, res, cap, sky_res, pose=None):
+    if pose is None:
+        om, oc, pm, pc = common.scene(metric, res=res)
+    else:
+        om, oc, pm, pc = common.scene(metric, res=res, pos=pose[0], fwd=pose[1], up=pose[2])
     sp, sn = skies.smooth(sky_res[0], sky_res[1], 128), skies.smooth(sky_res[0], sky_res[1], 32)
     cp, cn = skies.checker(sky_res[0], sky_res[1], seed=0xC0FFEE), skies.checker(sky_res[0], sky_res[1], seed=0xBADC0DE)
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc, context=ctx)
     got_rgb, got = sys_.render_image_debug(cap, 100.0, 0.05)
     n = got.size
     print("## %s: %s %dx%d cap %d, skies %dx%d, %d rays" % (name, metric, res[0], res[1], cap, sky_res[0], sky_res[1], n))
+    if pose is not None:
+        # the ray classes whose parity is ill-conditioned
+        steps = got["steps"].astype(np.int64)
+        th = got["x"][..., 2]
+        print("camera (t, l, theta, phi) = %s; ray classes: capped %d, pole-crossing (final theta outside [0, pi]) %d, throat-whirling "
+              "(steps > 1.25 x median %d) %d; step counts %d .. %d" % (
+                  tuple(round(float(v), 6) for v in pose[0]), int((got["code"] == 0).sum()), int(((th < 0) | (th > np.pi)).sum()),
+                  int(np.median(steps)), int((steps > 1.25 * np.median(steps)).sum()), int(steps.min()), int(steps.max())))
     res_all = {}
     for fl in O.GLIBC_FLAVOURS:
         res_all[fl] = compare_with_flavour(fl, got_rgb, got, om, oc, sp, sn, cp, cn, cap)
@@ -166,7 +177,34 @@ def function_sweep(ctx):
     print()
 
 
+def poses_main():
+    """the same comparison at the camera poses of the two VIDEO configs -- orbit l = 3 (pole-crossing
+    rays), the fly-through's frame 0 (l = -4) and its two frames nearest l = 0 (camera inside the Interstellar throat) -- at the
+    configs' FULL sizes, all three glibc flavours, every ray.  python tools/gpu_libm_parity.py poses > profiles/round5_libm_parity_poses.txt"""
+    from curvis_amd import paths, rendering
+    ctx = curvis_amd.Context(0)
+    print("# GPU (fast step, cv_math.h) vs the oracle's three glibc arithmetics (%s) at the camera poses of configs[3] and configs[4], full size" % (
+        os.confstr("CS_GNU_LIBC_VERSION")))
+    print("device: %s; host threads used by the oracle: %d" % (ctx.device_info()["name"], THREADS))
+    print()
+
+    def video_poses(csv, fps):
+        it = rendering.Interpolator.from_file(paths.path_file(csv))
+        times = rendering.times_of_frames(it.min_time(), it.max_time(), fps)
+        return [(tuple(it.camera_position(t)), tuple(it.camera_forward(t)), tuple(it.camera_up(t))) for t in times]
+    orbit = video_poses("path_orbit.csv", 4.0)
+    for k in (0, 60):
+        compare_frame(ctx, "configs[3] frame %d of 240" % k, "ellis", (1920, 1080), 4096, (8192, 4096), pose=orbit[k])
+    through = video_poses("path_through.csv", 24.0)
+    ls = np.array([abs(p[0][1]) for p in through])
+    for k in [0] + sorted(np.argsort(ls)[:2].tolist()):
+        compare_frame(ctx, "configs[4] frame %d of 480" % k, "interstellar", (3840, 2160), 8192, (8192, 4096), pose=through[k])
+    ctx.close()
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "poses":
+        return poses_main()
     ctx = curvis_amd.Context(0)
     print("# GPU (fast step, cv_math.h) vs the oracle's three glibc arithmetics (%s): sin/cos separate, one sincos() per "
           "reference function, sincos() with update inlined -- full-size BASELINE configurations" % (
