@@ -814,6 +814,19 @@ int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes) {
   return CURVIS_OK;
 }
 
+/* the other direction: RGB8 frames from host memory into the context's framebuffer (it grows as needed), so that frames
+ * made elsewhere -- a host that composites, a test with chosen contents -- can go through curvis_ctx_deflate_frames */
+int curvis_ctx_upload(curvis_ctx *ctx, const uint8_t *rgb, size_t bytes) {
+  if (!ctx || !rgb || bytes == 0) return fail(ctx, CURVIS_E_INVALID, "bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, bytes);
+  if (rc) return rc;
+  ctx->fb_bytes = bytes;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_fb, rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CURVIS_OK;
+}
+
 int curvis_ctx_synchronize(curvis_ctx *ctx) {
   if (!ctx) return CURVIS_E_INVALID;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -859,6 +872,8 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->fast_math = (int)value;
   else if (k == "fuse_shade")
     ctx->fuse_shade = (int)value;
+  else if (k == "png_path")
+    ctx->png_path = value != 0 ? 1 : 0;
   else if (k == "sampling_speculation")
     ctx->sampling_speculation = (int)value;
   else if (k == "sampling_speculation_first")
@@ -905,6 +920,10 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = (int64_t)ctx->relay_checks;
   else if (k == "last_png_direct_blocks")
     *value = (int64_t)ctx->last_png_direct_blocks;
+  else if (k == "png_path")
+    *value = ctx->png_path;
+  else if (k == "last_png_passes")
+    *value = ctx->last_png_passes;
   else if (k == "relay_recheck_every")
     *value = ctx->relay_recheck_every;
   else if (k == "relay_fallbacks")

@@ -156,10 +156,14 @@ CV_HD void ray_step(const MetricParams &M, Ray &q, double delta) {
  * final fma of either sequence returns the correctly rounded result for ANY y within a few ulp of
  * 1/d (Markstein), so the five divisions of a step do not each need their own rcp + Newton chain:
  * 1/r^2, 1/r^3 and 1/(r^2 sin^3) are products of ONE refined 1/r (a by-product of the sqrt) and
- * ONE refined 1/sin(theta).  The result of each division is still the individually, correctly
- * rounded quotient the reference computes (a mis-rounding needs the exact quotient within
- * ~2^-102 relative of a rounding boundary: probability ~2^-49 per division; tests compare the
- * fast kernels with the oracle over >10^10 divisions per frame).
+ * ONE refined 1/sin(theta).  The result of each division is still the individually rounded quotient
+ * the reference computes -- correctly rounded unless a rounding boundary lies within
+ * (|kappa| + 1)^2 2^-106 (relative) below the exact quotient, y = (1 + kappa 2^-53)/d.  MEASURED on
+ * the reciprocals the step really forms (probe hook below; tools/gpu_fast_step_rounding.py ->
+ * profiles/round5_fast_step_rounding.txt): |kappa| <= 2 .. 9 (Ellis), <= 6 .. 14
+ * (Interstellar), and summed over the quotients of a step 1.0e-15 (Ellis) / 1.9e-15 (Interstellar)
+ * expected mis-rounded operations per step = 4e-6 per 1080p frame, 1.5e-2 per configs[4] render; an
+ * event is ONE quotient one ulp low (tests/test_gpu_fast_step.py drives it there on purpose).
  *
  * Guards: the shortcut skips div_scale/div_fixup, so it is only taken when every operand is finite,
  * non-zero and far from the exponent limits; any lane failing the guard executes ray_step_core

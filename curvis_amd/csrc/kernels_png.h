@@ -48,6 +48,8 @@ struct PngParams {
   const unsigned *start_bit;      /* [n_frames]: where the token stream starts (after the zlib and the block header) */
   unsigned long long *frame_bits; /* [n_frames]: end of the stream in bits (start offset, tokens, end-of-block code) */
   unsigned *direct_blocks;        /* [1]: workgroups of pass 3 whose codes did not fit their LDS image (diagnostics, tests) */
+  unsigned short *block_hist;     /* two-pass path: [n_frames][blocks_per_frame][kPngBins] token counts per workgroup (<= 16 641 each) */
+  const unsigned *sym_bits;       /* two-pass path: [n_frames][kPngBins] bits a token of each symbol takes (code + extra + distance) */
   unsigned *out;                  /* [n_frames][out_words] */
   size_t out_words;
 };
@@ -393,6 +395,314 @@ __global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) 
   __syncthreads();
   for (unsigned k = threadIdx.x; k < words; k += kPngBlock) {
     const unsigned v = s_out[k];
+    if (!v) continue;
+    if (k == 0u || k + 1u == words)
+      atomicOr(&dst[k], v); /* shared with the neighbouring workgroups' spans */
+    else
+      dst[k] = v;
+  }
+}
+
+/* =====================================================================================================================
+ * Two-pass path (round 5; frames whose rows are a multiple of 64 bytes -- every common video size).
+ *
+ * The three-pass path above reads the frames three times because the bit offset of a workgroup's codes is known only after a
+ * pass that counted them.  But the bits a workgroup's tokens take are  sum over the symbols of  count x bits(symbol)  -- and
+ * the first pass already counts the tokens.  So pass 1 also leaves its 288 counts PER WORKGROUP (576 B per 16 KiB of
+ * pixels), the scan turns them into bit offsets with the frame's code lengths (png_scan2_kernel), and ONE more pass over
+ * the pixels counts each thread's bits, scans them inside the workgroup and writes the codes: two reads of the frames.
+ *
+ * Both passes use a word-parallel tokeniser instead of the byte-serial one: a thread holds its 64 filtered bytes in 16
+ * registers, classifies them four at a time (zero / +1 / -1 / other with carry-free byte tricks), builds the 64-bit map of
+ * its zero bytes and walks the RUNS of that map (one iteration per run, not per byte).  The hottest symbols (literal 0, 1,
+ * 255 and the match of a whole zero chunk) are counted in registers and reduced across the wave before they touch LDS --
+ * they were what serialised the LDS atomics of the first version.  Same tokens, same codes, same stream, bit for bit
+ * (tests/test_gpu_png.py compares the two paths).
+ * ===================================================================================================================== */
+
+constexpr unsigned kPngHistReplicas = 4;   /* LDS histogram copies (lane & 3): same-value literals of neighbouring lanes do not collide */
+constexpr unsigned kPngImageWords = 6272;  /* LDS image of a workgroup's piece of the stream in the two-pass emit: the worst case --
+                                              65 literals of 12 bits per thread = 780 bits x 256 threads = 6240 words -- fits */
+static_assert(kPngImageWords * 4u >= kPngBlock * kPngLdsStride, "the stream image re-uses the staging buffer");
+
+/* bit 7 of every byte of x that is zero (exact: no carries between bytes) */
+__device__ __forceinline__ unsigned png_zero_flags(unsigned x) { return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu); }
+/* the four flags (bits 7, 15, 23, 31) as a nibble: bits 0, 8, 16 gathered by one 24-bit multiply, bit 24 by a shift */
+__device__ __forceinline__ unsigned png_flags_nibble(unsigned f) {
+  return ((__umul24((f >> 7) & 0x00010101u, 0x00204081u) >> 21) & 7u) | ((f >> 28) & 8u);
+}
+__device__ __forceinline__ unsigned png_wave_sum(unsigned v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+/* a thread's chunk: 64 filtered bytes in registers + the map of its zero bytes */
+struct PngChunk {
+  unsigned d[16];
+  unsigned long long Z; /* bit i: byte i is zero */
+};
+__device__ __forceinline__ void png_chunk_load(const unsigned char *s_chunk, PngChunk &c) {
+#pragma unroll
+  for (unsigned q = 0; q < 4u; ++q) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(s_chunk + 16u * q);
+    c.d[4 * q + 0] = v.x, c.d[4 * q + 1] = v.y, c.d[4 * q + 2] = v.z, c.d[4 * q + 3] = v.w;
+  }
+  unsigned lo = 0u, hi = 0u;
+#pragma unroll
+  for (unsigned w = 0; w < 8u; ++w) lo |= png_flags_nibble(png_zero_flags(c.d[w])) << (4u * w);
+#pragma unroll
+  for (unsigned w = 0; w < 8u; ++w) hi |= png_flags_nibble(png_zero_flags(c.d[8u + w])) << (4u * w);
+  c.Z = ((unsigned long long)hi << 32) | lo;
+}
+/* length of the run of ones of Z that starts at bit s (Z has bit s set) */
+__device__ __forceinline__ unsigned png_run_length(unsigned long long Z, unsigned s) {
+  const unsigned long long t = ~(Z >> s); /* the run ends at the first zero bit of Z >> s; the shift brought zeros in from the top */
+  return (unsigned)__ffsll((long long)t) - 1u;   /* s > 0: bit 64 - s of t is set.  s == 0 and Z all ones: t == 0 -> ffs = 0 -> handled by the caller */
+}
+/* zero runs of a chunk in stream order: f(start, length); a run of L <= 3 zeros is L literals, a longer one a literal zero and a
+ * distance-1 match of L - 1 (3..63) -- exactly PNG_FLUSH_RUN of the byte-serial tokeniser */
+template <typename F>
+__device__ __forceinline__ void png_for_runs(unsigned long long Z, F f) {
+  if (Z == ~0ull) {
+    f(0u, 64u);
+    return;
+  }
+  while (Z) {
+    const unsigned s = (unsigned)__ffsll((long long)Z) - 1u;
+    const unsigned L = png_run_length(Z, s);
+    f(s, L);
+    Z = (s + L >= 64u) ? 0ull : (Z & (~0ull << (s + L)));
+  }
+}
+
+/* pass 1 of the two-pass path: token histogram per frame AND per workgroup, Adler-32 partial sums */
+__global__ __launch_bounds__(kPngBlock) void png_hist2_kernel(const PngParams P) {
+  __shared__ unsigned s_hist[kPngHistReplicas][kPngBins];
+  __shared__ unsigned long long s_sum[2];
+  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
+  const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
+  if (block >= P.blocks_per_frame) return; /* the whole workgroup */
+  const unsigned g = block * kPngBlock + threadIdx.x;
+  for (unsigned k = threadIdx.x; k < kPngHistReplicas * kPngBins; k += kPngBlock) (&s_hist[0][0])[k] = 0u;
+  if (threadIdx.x < 2u) s_sum[threadIdx.x] = 0ull;
+  png_stage(P, frame, block, s_f);
+  __syncthreads();
+  unsigned *my_hist = s_hist[threadIdx.x & (kPngHistReplicas - 1u)];
+  /* hot symbols in registers: literal 0, literal 1, literal 255, the match of a whole zero chunk (63) */
+  unsigned n_zero = 0u, n_one = 0u, n_ff = 0u, n_m63 = 0u, a = 0u, b_mod = 0u;
+  if (g < P.chunks_per_frame) {
+    const unsigned row = g / P.chunks_per_row, chunk = g - row * P.chunks_per_row;
+    PngChunk c;
+    png_chunk_load(s_f + threadIdx.x * kPngLdsStride, c);
+    const unsigned off = chunk == 0u ? 1u : 0u; /* chunk 0 of a row starts with the filter-type byte (2 = Up): stream index 0 */
+    unsigned kv = 0u;
+    if (off) {
+      atomicAdd(&my_hist[2], 1u);
+      a = 2u;
+    }
+    if (c.Z == ~0ull) { /* the common case after the Up filter: nothing but zeros */
+      n_zero = 1u;
+      n_m63 = 1u;
+    } else {
+#pragma unroll
+      for (unsigned w = 0; w < 16u; ++w) {
+        const unsigned x = c.d[w];
+        if (x == 0u) continue;
+        const unsigned f0 = png_zero_flags(x), f1 = png_zero_flags(x ^ 0x01010101u), ff = png_zero_flags(~x);
+        n_one += __popc(f1);
+        n_ff += __popc(ff);
+        const unsigned sum = __builtin_amdgcn_sad_u8(x, 0u, 0u); /* the four bytes added up */
+        a += sum;
+        /* sum of (stream index of the byte) x byte: index = off + 4 w + position in the word */
+        kv += (off + 4u * w) * sum + ((x >> 8) & 0xffu) + 2u * ((x >> 16) & 0xffu) + 3u * (x >> 24);
+        unsigned other = 0x80808080u & ~(f0 | f1 | ff); /* bytes that are neither 0, 1 nor 255: through LDS, one by one */
+        while (other) {
+          const unsigned sh = (unsigned)__ffs((int)other) - 8u; /* flag at bit 8 j + 7 -> shift 8 j */
+          atomicAdd(&my_hist[(x >> sh) & 0xffu], 1u);
+          other &= other - 1u;
+        }
+      }
+      png_for_runs(c.Z, [&](unsigned, unsigned L) {
+        if (L <= 3u) {
+          n_zero += L;
+        } else {
+          n_zero += 1u;
+          atomicAdd(&my_hist[png_len_symbol(L - 1u)], 1u);
+        }
+      });
+    }
+    /* Adler-32: s2 = n + sum over the stream of (n - i) * byte_i; this thread's bytes sit at i = i0 + k */
+    const unsigned long long n = (unsigned long long)P.H * (P.row_bytes + 1u);
+    const unsigned long long i0 = (unsigned long long)row * (P.row_bytes + 1u) + (chunk == 0u ? 0u : 1u + chunk * kPngChunk);
+    b_mod = (unsigned)(((n - i0) * a - kv) % 65521ull);
+  }
+  /* one LDS atomic per wave and hot symbol instead of one per thread on the same address */
+  const unsigned zero_one = png_wave_sum(n_zero | (n_one << 16)); /* <= 64 x 65 each: 16 bits are plenty */
+  const unsigned ff_m63 = png_wave_sum(n_ff | (n_m63 << 16));
+  const unsigned a_w = png_wave_sum(a), b_w = png_wave_sum(b_mod);
+  if ((threadIdx.x & 63u) == 0u) {
+    unsigned *h = s_hist[(threadIdx.x >> 6) & (kPngHistReplicas - 1u)];
+    atomicAdd(&h[0], zero_one & 0xffffu);
+    atomicAdd(&h[1], zero_one >> 16);
+    atomicAdd(&h[255], ff_m63 & 0xffffu);
+    atomicAdd(&h[png_len_symbol(63u)], ff_m63 >> 16);
+    atomicAdd(&s_sum[0], (unsigned long long)a_w);
+    atomicAdd(&s_sum[1], (unsigned long long)b_w);
+  }
+  __syncthreads();
+  unsigned short *bh = P.block_hist + ((size_t)frame * P.blocks_per_frame + block) * kPngBins;
+  for (unsigned k = threadIdx.x; k < kPngBins; k += kPngBlock) {
+    unsigned v = 0u;
+#pragma unroll
+    for (unsigned r = 0; r < kPngHistReplicas; ++r) v += s_hist[r][k];
+    bh[k] = (unsigned short)v; /* <= 16 384 + 257 tokens per workgroup */
+    if (v) atomicAdd(&P.hist[(size_t)frame * kPngBins + k], v);
+  }
+  if (threadIdx.x < 2u) atomicAdd(&P.adler[(size_t)frame * 2 + threadIdx.x], s_sum[threadIdx.x] % 65521ull);
+}
+
+/* one workgroup per frame: bits per workgroup = its token counts . bits per symbol (+ the end-of-block code after the last
+ * one), exclusive prefix over the workgroups, frame_bits = start + total */
+__global__ __launch_bounds__(kPngBlock) void png_scan2_kernel(const PngParams P) {
+  __shared__ unsigned s_bits[kPngBins];
+  __shared__ unsigned long long s_part[kPngBlock];
+  const unsigned frame = blockIdx.x, nb = P.blocks_per_frame;
+  for (unsigned k = threadIdx.x; k < kPngBins; k += kPngBlock) s_bits[k] = P.sym_bits[(size_t)frame * kPngBins + k];
+  __syncthreads();
+  unsigned long long *v = P.block_bits + (size_t)frame * nb;
+  const unsigned short *bh = P.block_hist + (size_t)frame * nb * kPngBins;
+  const unsigned per = (nb + kPngBlock - 1u) / kPngBlock;
+  const unsigned lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
+  unsigned long long sum = 0ull;
+  for (unsigned k = lo; k < hi; ++k) {
+    const uint4 *h4 = reinterpret_cast<const uint4 *>(bh + (size_t)k * kPngBins); /* 288 counts = 36 x 16 bytes */
+    unsigned bits = 0u;
+    for (unsigned q = 0; q < kPngBins / 8u; ++q) {
+      const uint4 h = h4[q];
+      const unsigned *sb = s_bits + 8u * q;
+      bits += (h.x & 0xffffu) * sb[0] + (h.x >> 16) * sb[1] + (h.y & 0xffffu) * sb[2] + (h.y >> 16) * sb[3] +
+              (h.z & 0xffffu) * sb[4] + (h.z >> 16) * sb[5] + (h.w & 0xffffu) * sb[6] + (h.w >> 16) * sb[7];
+    }
+    if (k + 1u == nb) bits += s_bits[256]; /* end of block */
+    v[k] = bits;
+    sum += bits;
+  }
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    unsigned long long run = 0ull;
+    for (unsigned k = 0; k < kPngBlock; ++k) {
+      const unsigned long long t = s_part[k];
+      s_part[k] = run;
+      run += t;
+    }
+    P.frame_bits[frame] = (unsigned long long)P.start_bit[frame] + run;
+  }
+  __syncthreads();
+  unsigned long long run = s_part[threadIdx.x];
+  for (unsigned k = lo; k < hi; ++k) {
+    const unsigned long long t = v[k];
+    v[k] = run;
+    run += t;
+  }
+}
+
+/* pass 2 of the two-pass path: count this thread's bits, scan inside the workgroup, write the codes */
+__global__ __launch_bounds__(kPngBlock) void png_emit2_kernel(const PngParams P) {
+  __shared__ unsigned s_codes[kPngCodes];
+  __shared__ unsigned s_wave[kPngBlock / 64];
+  __shared__ __attribute__((aligned(16))) unsigned s_image[kPngImageWords]; /* first the staged filtered bytes, then the stream image */
+  const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
+  if (block >= P.blocks_per_frame) return;
+  const unsigned g = block * kPngBlock + threadIdx.x;
+  for (unsigned k = threadIdx.x; k < kPngCodes; k += kPngBlock) s_codes[k] = P.codes[(size_t)frame * kPngCodes + k];
+  png_stage(P, frame, block, reinterpret_cast<unsigned char *>(s_image));
+  __syncthreads();
+  const bool live = g < P.chunks_per_frame;
+  const bool first = live && (g % P.chunks_per_row) == 0u, last = g + 1u == P.chunks_per_frame;
+  PngChunk c;
+  c.Z = 0ull;
+  unsigned long long ZL = 0ull, MS = 0ull; /* zero bytes that are emitted as literals; of those, the ones a match follows */
+  unsigned mine = 0u;
+  if (live) {
+    png_chunk_load(reinterpret_cast<const unsigned char *>(s_image) + threadIdx.x * kPngLdsStride, c);
+    if (first) mine += s_codes[2] >> 24;
+    if (c.Z != ~0ull) {
+#pragma unroll
+      for (unsigned w = 0; w < 16u; ++w) {
+        const unsigned x = c.d[w];
+        if (x == 0u) continue;
+#pragma unroll
+        for (unsigned b = 0; b < 4u; ++b) {
+          const unsigned v = (x >> (8u * b)) & 0xffu;
+          if (v) mine += s_codes[v] >> 24;
+        }
+      }
+    }
+    const unsigned len0 = s_codes[0] >> 24;
+    png_for_runs(c.Z, [&](unsigned s, unsigned L) {
+      if (L <= 3u) {
+        ZL |= ((1ull << L) - 1ull) << s;
+        mine += L * len0;
+      } else {
+        ZL |= 1ull << s;
+        MS |= 1ull << s;
+        mine += len0 + (s_codes[256u + L - 1u] >> 24);
+      }
+    });
+    if (last) mine += s_codes[256u] >> 24; /* end of block: stored in the unused slot "match of length 0" */
+  }
+  /* exclusive scan over the workgroup: inside the wave by shuffles, across the four waves through LDS */
+  unsigned incl = mine;
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned t = __shfl_up(incl, off, 64);
+    if ((int)lane >= off) incl += t;
+  }
+  if (lane == 63u) s_wave[wave] = incl;
+  __syncthreads(); /* every thread has its chunk in registers: the staging buffer becomes the stream image */
+  unsigned before = 0, total = 0;
+  for (unsigned w = 0; w < kPngBlock / 64; ++w) {
+    if (w < wave) before += s_wave[w];
+    total += s_wave[w];
+  }
+  const unsigned long long base = (unsigned long long)P.start_bit[frame] + P.block_bits[(size_t)frame * P.blocks_per_frame + block];
+  const unsigned shift = (unsigned)(base & 31ull);
+  const unsigned words = (shift + total + 31u) >> 5; /* <= 6241: always inside the image */
+  unsigned *dst = P.out + (size_t)frame * P.out_words + (size_t)(base >> 5);
+  for (unsigned k = threadIdx.x; k < words; k += kPngBlock) s_image[k] = 0u;
+  __syncthreads();
+  if (live) {
+    const unsigned pos = shift + before + (incl - mine);
+    PngEmitSink sink{s_codes, s_image, pos >> 5, pos & 31u, 0ull};
+    if (first) sink.put(s_codes[2]);
+    const unsigned lo_l = (unsigned)ZL, hi_l = (unsigned)(ZL >> 32);
+#pragma unroll
+    for (unsigned w = 0; w < 16u; ++w) {
+      const unsigned x = c.d[w];
+      const unsigned zl = ((w < 8u ? lo_l : hi_l) >> (4u * (w & 7u))) & 0xfu; /* literal zeros among the four bytes */
+      if (x == 0u && zl == 0u) continue; /* inside a match */
+#pragma unroll
+      for (unsigned b = 0; b < 4u; ++b) {
+        const unsigned v = (x >> (8u * b)) & 0xffu;
+        if (v) {
+          sink.put(s_codes[v]);
+        } else if ((zl >> b) & 1u) {
+          sink.put(s_codes[0]);
+          const unsigned i = 4u * w + b;
+          if ((MS >> i) & 1ull) {
+            const unsigned L = (i == 0u && c.Z == ~0ull) ? 64u : png_run_length(c.Z, i);
+            sink.put(s_codes[256u + L - 1u]);
+          }
+        }
+      }
+    }
+    if (last) sink.put(s_codes[256u]);
+    if (sink.fill) atomicOr(&s_image[sink.w], (unsigned)sink.acc);
+  }
+  __syncthreads();
+  for (unsigned k = threadIdx.x; k < words; k += kPngBlock) {
+    const unsigned v = s_image[k];
     if (!v) continue;
     if (k == 0u || k + 1u == words)
       atomicOr(&dst[k], v); /* shared with the neighbouring workgroups' spans */

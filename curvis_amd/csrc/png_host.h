@@ -6,7 +6,7 @@
 namespace {
 
 struct PngScratch { /* one allocation, carved */
-  size_t hist, adler, direct_blocks, codes, block_bits, thread_bits, start_bit, frame_bits, out, total;
+  size_t hist, adler, direct_blocks, codes, block_bits, thread_bits, start_bit, frame_bits, block_hist, sym_bits, out, total;
   size_t out_words;
 };
 
@@ -33,6 +33,10 @@ PngScratch png_scratch_layout(const PngParams &P) {
   off = up(off + (size_t)P.n_frames * sizeof(unsigned));
   L.frame_bits = off;
   off = up(off + (size_t)P.n_frames * sizeof(unsigned long long));
+  L.block_hist = off; /* two-pass path: token counts per workgroup */
+  off = up(off + (size_t)P.n_frames * P.blocks_per_frame * kPngBins * sizeof(unsigned short));
+  L.sym_bits = off;
+  off = up(off + (size_t)P.n_frames * kPngBins * sizeof(unsigned));
   L.out = off;
   off = up(off + (size_t)P.n_frames * L.out_words * sizeof(unsigned));
   L.total = off;
@@ -75,15 +79,24 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   P.thread_bits = (unsigned short *)(base + L.thread_bits);
   P.start_bit = (const unsigned *)(base + L.start_bit);
   P.frame_bits = (unsigned long long *)(base + L.frame_bits);
+  P.block_hist = (unsigned short *)(base + L.block_hist);
+  P.sym_bits = (const unsigned *)(base + L.sym_bits);
   P.out = (unsigned *)(base + L.out);
   P.out_words = L.out_words;
+  /* two reads of the frames instead of three (kernels_png.h, "two-pass path"): frames whose rows are a multiple of 64 bytes,
+   * unless the option "png_path" = 0 asks for the three-pass kernels (kept for ragged widths, and as the checker of the new ones) */
+  const bool two_pass = P.staged && ctx->png_path != 0;
+  ctx->last_png_passes = two_pass ? 2 : 3;
   const dim3 grid(P.grid_x, n_frames), block(kPngBlock); /* the 8 XCDs take contiguous eighths of a frame: png_logical_block */
   float ms_a = 0.f, ms_b = 0.f;
 
   /* pass 1: histograms + Adler sums */
   HIP_TRY(ctx, hipMemsetAsync(base + L.hist, 0, L.codes - L.hist, ctx->stream)); /* hist, adler and the diagnostics counter are adjacent */
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(png_hist_kernel, grid, block, 0, ctx->stream, P);
+  if (two_pass)
+    hipLaunchKernelGGL(png_hist2_kernel, grid, block, 0, ctx->stream, P);
+  else
+    hipLaunchKernelGGL(png_hist_kernel, grid, block, 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   std::vector<unsigned> hist((size_t)n_frames * kPngBins);
@@ -95,7 +108,7 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
 
   /* the frames' codes: lengths <= 12 bits over the 286 literal/length symbols (every symbol keeps a code: +1 on each count,
    * which also makes the block header the host writer's), one distance code */
-  std::vector<unsigned> codes((size_t)n_frames * kPngCodes, 0u), start_bit(n_frames);
+  std::vector<unsigned> codes((size_t)n_frames * kPngCodes, 0u), start_bit(n_frames), sym_bits((size_t)n_frames * kPngBins, 0u);
   std::vector<std::array<uint8_t, 176>> header(n_frames); /* zlib header + block header: 16 + 1222 bits, + BitWriter slack */
   for (uint32_t f = 0; f < n_frames; ++f) {
     uint32_t freq[286];
@@ -114,7 +127,9 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
       const unsigned cl = ll[sym] >> 16;
       const unsigned bits = (ll[sym] & 0xffffu) | ((unsigned)ev << cl); /* + the distance code: one zero bit */
       c[256 + len] = bits | ((cl + (unsigned)eb + 1u) << 24);
+      sym_bits[(size_t)f * kPngBins + (size_t)sym] = cl + (unsigned)eb + 1u; /* a match of this symbol: code + extra bits + distance code */
     }
+    for (int v = 0; v <= 256; ++v) sym_bits[(size_t)f * kPngBins + (size_t)v] = ll[v] >> 16; /* literals and end of block: the code */
     header[f].fill(0);
     header[f][0] = 0x78;
     header[f][1] = 0x01;
@@ -125,13 +140,21 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   }
   HIP_TRY(ctx, hipMemcpyAsync(base + L.codes, codes.data(), codes.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(base + L.start_bit, start_bit.data(), start_bit.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+  if (two_pass)
+    HIP_TRY(ctx, hipMemcpyAsync(base + L.sym_bits, sym_bits.data(), sym_bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
 
   /* passes 2 and 3 */
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(png_count_kernel, grid, block, 0, ctx->stream, P);
-  hipLaunchKernelGGL(png_scan_kernel, dim3(n_frames), block, 0, ctx->stream, P);
-  hipLaunchKernelGGL(png_zero_kernel, dim3(64, n_frames), block, 0, ctx->stream, P);
-  hipLaunchKernelGGL(png_emit_kernel, grid, block, 0, ctx->stream, P);
+  if (two_pass) { /* offsets from the workgroups' token counts, then ONE more pass over the pixels */
+    hipLaunchKernelGGL(png_scan2_kernel, dim3(n_frames), block, 0, ctx->stream, P);
+    hipLaunchKernelGGL(png_zero_kernel, dim3(64, n_frames), block, 0, ctx->stream, P);
+    hipLaunchKernelGGL(png_emit2_kernel, grid, block, 0, ctx->stream, P);
+  } else {
+    hipLaunchKernelGGL(png_count_kernel, grid, block, 0, ctx->stream, P);
+    hipLaunchKernelGGL(png_scan_kernel, dim3(n_frames), block, 0, ctx->stream, P);
+    hipLaunchKernelGGL(png_zero_kernel, dim3(64, n_frames), block, 0, ctx->stream, P);
+    hipLaunchKernelGGL(png_emit_kernel, grid, block, 0, ctx->stream, P);
+  }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   std::vector<unsigned long long> frame_bits(n_frames);

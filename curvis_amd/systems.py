@@ -392,6 +392,11 @@ class Context:
         check(lib().curvis_ctx_framebuffer(self._h, C.byref(p), C.byref(n)), self._h)
         return p.value, n.value
 
+    def upload_frames(self, rgb):
+        """curvis_ctx_upload: RGB8 frames (n x H x W x 3 uint8) from host memory into the context's framebuffer"""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        check(lib().curvis_ctx_upload(self._h, rgb.ctypes.data, rgb.size), self._h)
+
     def download_frames(self, width, height, n_frames=1):
         """curvis_ctx_download: the frames the last render call left in HBM as an n x H x W x 3 uint8 array"""
         rgb = np.empty((int(n_frames), int(height), int(width), 3), dtype=np.uint8)

@@ -310,6 +310,9 @@ void curvis_host_free(void *p);
 /* device framebuffer of the last render (RGB8, frames back to back) */
 int curvis_ctx_framebuffer(curvis_ctx *ctx, void **dev_ptr, size_t *bytes);
 int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);
+/* RGB8 frames from host memory into the context's framebuffer (frames back to back; it grows as needed): what
+ * curvis_ctx_deflate_frames then compresses */
+int curvis_ctx_upload(curvis_ctx *ctx, const uint8_t *rgb, size_t bytes);
 int curvis_ctx_synchronize(curvis_ctx *ctx);
 
 /* tuning knobs (not part of the reference surface): "variant" (-1 = automatic, the default: the static

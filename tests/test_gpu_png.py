@@ -45,6 +45,19 @@ def check_streams(ctx, tmp_path, frames, w, h, tag):
         assert np.array_equal(pngio.read_png(path), want), (tag, k)              # decoder 1: tests' own (zlib + unfilter)
         got = product_decode(path)                                               # decoder 2: the product's (host/png_io.h)
         assert np.array_equal(got[..., :3], want) and (got[..., 3] == 255).all(), (tag, k)
+    # the two-pass path (word-parallel tokeniser, offsets from per-workgroup token counts) and the three-pass kernels it
+    # replaced must produce the SAME stream, bit for bit: same tokens, same codes, same offsets
+    passes = ctx.get_option("last_png_passes")
+    assert passes == (2 if (w * 3) % 64 == 0 else 3), (tag, passes)
+    if passes == 2:
+        ctx.set_option("png_path", 0)
+        try:
+            old, _ = ctx.deflate_frames(w, h, len(frames))
+            assert ctx.get_option("last_png_passes") == 3
+        finally:
+            ctx.set_option("png_path", 1)
+        assert old == streams, (tag, [i for i, (a, b) in enumerate(zip(old, streams)) if a != b])
+        ctx.deflate_frames(w, h, len(frames))                          # leave the context's "last_*" options describing the default path
     return streams, ms
 
 
@@ -96,7 +109,9 @@ def test_frames_that_do_not_compress(gpu_ctx, tmp_path):
         streams, _ = check_streams(gpu_ctx, tmp_path, list(rgb), res[0], res[1], "noise%d" % res[0])
         ratios = [len(z) / (res[0] * res[1] * 3) for z in streams]
         assert all(r > 0.4 for r in ratios), ratios                      # measured 0.48: noise outside the throat, flat inside
-        assert gpu_ctx.get_option("last_png_direct_blocks") > 0          # workgroups in the noisy rows took the global path
+        # three-pass kernels (the ragged width): workgroups in the noisy rows took the global path; the two-pass path's LDS image
+        # holds the worst case (65 literals of 12 bits per thread), nothing leaves it
+        assert (gpu_ctx.get_option("last_png_direct_blocks") > 0) == (res[0] * 3 % 64 != 0)
 
 
 def test_efficient_frames_and_full_hd(gpu_ctx, tmp_path):
@@ -112,7 +127,7 @@ def test_efficient_frames_and_full_hd(gpu_ctx, tmp_path):
     want, _ = gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
     gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
     streams, ms = check_streams(gpu_ctx, tmp_path, list(want), 1920, 1080, "eff")
-    assert gpu_ctx.get_option("last_png_direct_blocks") == 0             # ordinary frames: every workgroup assembles its piece in LDS
+    assert gpu_ctx.get_option("last_png_direct_blocks") == 0 and gpu_ctx.get_option("last_png_passes") == 2
     assert all(len(z) < 1920 * 1080 * 3 // 4 for z in streams)
     print("device PNG front end: 3 x 1080p in %.3f ms, streams %s bytes" % (ms, [len(z) for z in streams]))
 
@@ -129,3 +144,33 @@ def test_errors(gpu_ctx):
     with pytest.raises(curvis_amd.CurvisError) as e:
         gpu_ctx.deflate_frames(32, 18, 1, out=np.empty(64, np.uint8))
     assert e.value.code == _abi.E_INVALID and "too small" in str(e.value)
+
+
+@pytest.mark.parametrize("w,h", [(64, 5), (192, 33), (320, 47), (1280, 9)])
+def test_two_pass_path_on_synthetic_contents(gpu_ctx, tmp_path, w, h):
+    """the word-parallel tokeniser against the byte-serial one on contents chosen to hit its cases: runs of every length at
+    every alignment (1..70 zeros between non-zero bytes), bytes 1 / 255 / others in every position of a word, whole zero
+    chunks, rows that differ from the row above in one byte only, white noise; frames put into the context's framebuffer
+    with curvis_ctx_upload -- streams identical to the three-pass kernels', decoded pixels identical"""
+    rng = np.random.default_rng(w * 1000 + h)
+    frames = []
+    n = w * h * 3
+    f = np.zeros(n, np.uint8)                       # runs of growing length separated by single non-zero bytes (filter Up of row 0 = the row)
+    i, run = 0, 1
+    while i < n:
+        f[i] = rng.choice([1, 255, 2, 128, 254, 77])
+        i += 1 + run
+        run = run % 70 + 1
+    frames.append(f.reshape(h, w, 3))
+    frames.append(np.cumsum(frames[0].astype(np.uint32), axis=0).astype(np.uint8))           # the same after the Up filter of every row
+    frames.append(rng.choice(np.array([0, 0, 0, 0, 1, 255], np.uint8), n).reshape(h, w, 3))  # hot symbols, short runs
+    frames.append(rng.integers(0, 256, n, dtype=np.uint8).reshape(h, w, 3))                  # noise: 12-bit literals, no runs
+    g = np.zeros((h, w, 3), np.uint8)
+    g[:, :, :] = (np.arange(w)[None, :, None] // 3).astype(np.uint8)                         # rows identical: all zero after row 0
+    g[h // 2, w // 2, 1] += 1
+    frames.append(g)
+    frames.append(np.zeros((h, w, 3), np.uint8))
+    batch = np.ascontiguousarray(np.stack(frames))
+    gpu_ctx.upload_frames(batch)
+    assert np.array_equal(gpu_ctx.download_frames(w, h, len(frames)), batch)
+    check_streams(gpu_ctx, tmp_path, list(batch), w, h, "synthetic%d" % w)

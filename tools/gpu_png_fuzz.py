@@ -3,7 +3,8 @@
 bytes, 16-byte-aligned rows, ragged rows; 1-pixel frames up to 1000 pixels wide), 1-6 frames per call, skies of white noise /
 hash checker / smooth gradient (streams from ~1.0 x down to ~0.01 x of the pixels), cap 0 (black frame) now and then.
 Every stream must inflate (Adler-32 checked by zlib) to the Up-filtered scanlines of the frame a download returns.
-python tools/gpu_png_fuzz.py [cases] [seed]   -> profiles/round4_png_fuzz.txt"""
+Staged frames go through the two-pass path (round 5) AND the three-pass kernels: the two streams must be identical.
+python tools/gpu_png_fuzz.py [cases] [seed]   -> profiles/round5_png_fuzz.txt"""
 import os, sys, time, zlib
 import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,7 @@ noise = []
 for _ in range(2):
     t = rng.integers(0, 256, (1024, 2048, 4), dtype=np.uint8); t[..., 3] = 255; noise.append(t)
 SKIES = {"noise": noise, "check": [skies.checker(1024, 512, 3), skies.checker(1024, 512, 4)], "smooth": [skies.smooth(2048, 1024, 128), skies.smooth(2048, 1024, 32)]}
-bad = 0; t0 = time.time(); kinds = {"staged": 0, "aligned": 0, "ragged": 0}; direct = 0; ratio_min, ratio_max = 9.0, 0.0
+bad = 0; two_pass = 0; t0 = time.time(); kinds = {"staged": 0, "aligned": 0, "ragged": 0}; direct = 0; ratio_min, ratio_max = 9.0, 0.0
 for it in range(N):
     mode = it % 3
     if mode == 0: w = int(rng.choice([64, 128, 192, 256, 320, 448, 640, 960]))                                                          # 3w % 64 == 0
@@ -35,6 +36,13 @@ for it in range(N):
     rgb, _ = ctx.render_brute(m, cams, cap, 100.0, 0.05)
     streams, _ = ctx.deflate_frames(w, h, nf)
     direct += ctx.get_option("last_png_direct_blocks") > 0
+    if ctx.get_option("last_png_passes") == 2:   # the same frames through the three-pass kernels: identical streams
+        two_pass += 1
+        ctx.set_option("png_path", 0)
+        old, _ = ctx.deflate_frames(w, h, nf)
+        ctx.set_option("png_path", 1)
+        if old != streams:
+            bad += 1; print("PATHS DIFFER case %d: %dx%d x%d %s cap %d" % (it, w, h, nf, sk, cap), flush=True)
     for k in range(nf):
         try:
             raw = np.frombuffer(zlib.decompress(streams[k]), np.uint8).reshape(h, 3 * w + 1)
@@ -45,6 +53,6 @@ for it in range(N):
         if w * h > 20000: ratio_min, ratio_max = min(ratio_min, r), max(ratio_max, r)
         if not ok:
             bad += 1; print("MISMATCH case %d frame %d: %dx%d x%d %s cap %d" % (it, k, w, h, nf, sk, cap), flush=True)
-print("cases %d (%s), calls with workgroups on the global-memory path %d, stream / pixels between %.4f and %.3f (frames > 20 000 pixels), mismatches %d, %.0f s" % (
-    N, ", ".join("%s %d" % kv for kv in kinds.items()), direct, ratio_min, ratio_max, bad, time.time() - t0))
+print("cases %d (%s; %d through the two-pass path and, for comparison, the three-pass kernels), calls with workgroups on the global-memory path %d, stream / pixels between %.4f and %.3f (frames > 20 000 pixels), mismatches %d, %.0f s" % (
+    N, ", ".join("%s %d" % kv for kv in kinds.items()), two_pass, direct, ratio_min, ratio_max, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
