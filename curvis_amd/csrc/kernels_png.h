@@ -420,7 +420,7 @@ __global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) 
  * (tests/test_gpu_png.py compares the two paths).
  * ===================================================================================================================== */
 
-constexpr unsigned kPngHistReplicas = 4;   /* LDS histogram copies (lane & 3): same-value literals of neighbouring lanes do not collide */
+constexpr unsigned kPngHistReplicas = 8;   /* LDS histogram copies (lane & 7): same-value literals of neighbouring lanes do not collide */
 constexpr unsigned kPngImageWords = 6272;  /* LDS image of a workgroup's piece of the stream in the two-pass emit: the worst case --
                                               65 literals of 12 bits per thread = 780 bits x 256 threads = 6240 words -- fits */
 static_assert(kPngImageWords * 4u >= kPngBlock * kPngLdsStride, "the stream image re-uses the staging buffer");
@@ -561,48 +561,62 @@ __global__ __launch_bounds__(kPngBlock) void png_hist2_kernel(const PngParams P)
   if (threadIdx.x < 2u) atomicAdd(&P.adler[(size_t)frame * 2 + threadIdx.x], s_sum[threadIdx.x] % 65521ull);
 }
 
-/* one workgroup per frame: bits per workgroup = its token counts . bits per symbol (+ the end-of-block code after the last
- * one), exclusive prefix over the workgroups, frame_bits = start + total */
-__global__ __launch_bounds__(kPngBlock) void png_scan2_kernel(const PngParams P) {
+/* bits per workgroup = its token counts . bits per symbol (+ the end-of-block code after the last one): one WAVE per
+ * workgroup's 288 counts (36 lanes x 16 bytes), four per launch workgroup */
+__global__ __launch_bounds__(kPngBlock) void png_blockbits_kernel(const PngParams P) {
   __shared__ unsigned s_bits[kPngBins];
-  __shared__ unsigned long long s_part[kPngBlock];
-  const unsigned frame = blockIdx.x, nb = P.blocks_per_frame;
+  const unsigned frame = blockIdx.y, nb = P.blocks_per_frame;
   for (unsigned k = threadIdx.x; k < kPngBins; k += kPngBlock) s_bits[k] = P.sym_bits[(size_t)frame * kPngBins + k];
   __syncthreads();
+  const unsigned lane = threadIdx.x & 63u, b = blockIdx.x * (kPngBlock / 64u) + (threadIdx.x >> 6);
+  if (b >= nb) return; /* the whole wave */
+  unsigned bits = 0u;
+  if (lane < kPngBins / 8u) {
+    const uint4 h = reinterpret_cast<const uint4 *>(P.block_hist + ((size_t)frame * nb + b) * kPngBins)[lane];
+    const unsigned *sb = s_bits + 8u * lane;
+    bits = (h.x & 0xffffu) * sb[0] + (h.x >> 16) * sb[1] + (h.y & 0xffffu) * sb[2] + (h.y >> 16) * sb[3] +
+           (h.z & 0xffffu) * sb[4] + (h.z >> 16) * sb[5] + (h.w & 0xffffu) * sb[6] + (h.w >> 16) * sb[7];
+  }
+  bits = png_wave_sum(bits);
+  if (lane == 0u) P.block_bits[(size_t)frame * nb + b] = bits + (b + 1u == nb ? s_bits[256] : 0u);
+}
+
+/* one workgroup per frame: block_bits -> exclusive prefix (in place), frame_bits = start + total; and the ONLY zeroing the
+ * two-pass emit needs: a workgroup of png_emit2_kernel stores every word strictly inside its span and ORs into the first and
+ * the last one, which it shares with its neighbours -- so the first word of every span, the words of the header before the
+ * first span (the host ORs the zlib and block headers into them) and the last word of the stream are cleared here
+ * (a few KB per frame instead of a pass over the whole stream) */
+__global__ __launch_bounds__(kPngBlock) void png_offsets_kernel(const PngParams P) {
+  __shared__ unsigned long long s_part[kPngBlock];
+  const unsigned frame = blockIdx.x, nb = P.blocks_per_frame;
   unsigned long long *v = P.block_bits + (size_t)frame * nb;
-  const unsigned short *bh = P.block_hist + (size_t)frame * nb * kPngBins;
+  unsigned *out = P.out + (size_t)frame * P.out_words;
+  const unsigned start = P.start_bit[frame];
   const unsigned per = (nb + kPngBlock - 1u) / kPngBlock;
   const unsigned lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
   unsigned long long sum = 0ull;
-  for (unsigned k = lo; k < hi; ++k) {
-    const uint4 *h4 = reinterpret_cast<const uint4 *>(bh + (size_t)k * kPngBins); /* 288 counts = 36 x 16 bytes */
-    unsigned bits = 0u;
-    for (unsigned q = 0; q < kPngBins / 8u; ++q) {
-      const uint4 h = h4[q];
-      const unsigned *sb = s_bits + 8u * q;
-      bits += (h.x & 0xffffu) * sb[0] + (h.x >> 16) * sb[1] + (h.y & 0xffffu) * sb[2] + (h.y >> 16) * sb[3] +
-              (h.z & 0xffffu) * sb[4] + (h.z >> 16) * sb[5] + (h.w & 0xffffu) * sb[6] + (h.w >> 16) * sb[7];
-    }
-    if (k + 1u == nb) bits += s_bits[256]; /* end of block */
-    v[k] = bits;
-    sum += bits;
-  }
+  for (unsigned k = lo; k < hi; ++k) sum += v[k];
   s_part[threadIdx.x] = sum;
+  for (unsigned k = threadIdx.x; k <= (start >> 5); k += kPngBlock) out[k] = 0u;
   __syncthreads();
-  if (threadIdx.x == 0u) {
+  if (threadIdx.x == 0u) { /* 256 partial sums: a serial pass is as fast as anything here */
     unsigned long long run = 0ull;
     for (unsigned k = 0; k < kPngBlock; ++k) {
       const unsigned long long t = s_part[k];
       s_part[k] = run;
       run += t;
     }
-    P.frame_bits[frame] = (unsigned long long)P.start_bit[frame] + run;
+    const unsigned long long end = (unsigned long long)start + run;
+    P.frame_bits[frame] = end;
+    out[end >> 5] = 0u;
+    out[(end >> 5) + 1u] = 0u;
   }
   __syncthreads();
   unsigned long long run = s_part[threadIdx.x];
   for (unsigned k = lo; k < hi; ++k) {
     const unsigned long long t = v[k];
     v[k] = run;
+    out[(start + run) >> 5] = 0u; /* first word of this workgroup's span (several tiny spans may share one: all clear it) */
     run += t;
   }
 }
@@ -631,11 +645,11 @@ __global__ __launch_bounds__(kPngBlock) void png_emit2_kernel(const PngParams P)
 #pragma unroll
       for (unsigned w = 0; w < 16u; ++w) {
         const unsigned x = c.d[w];
-        if (x == 0u) continue;
-#pragma unroll
-        for (unsigned b = 0; b < 4u; ++b) {
-          const unsigned v = (x >> (8u * b)) & 0xffu;
-          if (v) mine += s_codes[v] >> 24;
+        unsigned nz = 0x80808080u & ~png_zero_flags(x); /* one iteration per NON-ZERO byte: sparse after the Up filter */
+        while (nz) {
+          const unsigned sh = (unsigned)__ffs((int)nz) - 8u;
+          mine += s_codes[(x >> sh) & 0xffu] >> 24;
+          nz &= nz - 1u;
         }
       }
     }
@@ -681,19 +695,17 @@ __global__ __launch_bounds__(kPngBlock) void png_emit2_kernel(const PngParams P)
     for (unsigned w = 0; w < 16u; ++w) {
       const unsigned x = c.d[w];
       const unsigned zl = ((w < 8u ? lo_l : hi_l) >> (4u * (w & 7u))) & 0xfu; /* literal zeros among the four bytes */
-      if (x == 0u && zl == 0u) continue; /* inside a match */
-#pragma unroll
-      for (unsigned b = 0; b < 4u; ++b) {
+      /* the word's tokens, one iteration each: its non-zero bytes and its literal zeros (zeros inside a match: none) */
+      unsigned tok = png_flags_nibble(0x80808080u & ~png_zero_flags(x)) | zl;
+      while (tok) {
+        const unsigned b = (unsigned)__ffs((int)tok) - 1u;
+        tok &= tok - 1u;
         const unsigned v = (x >> (8u * b)) & 0xffu;
-        if (v) {
-          sink.put(s_codes[v]);
-        } else if ((zl >> b) & 1u) {
-          sink.put(s_codes[0]);
-          const unsigned i = 4u * w + b;
-          if ((MS >> i) & 1ull) {
-            const unsigned L = (i == 0u && c.Z == ~0ull) ? 64u : png_run_length(c.Z, i);
-            sink.put(s_codes[256u + L - 1u]);
-          }
+        sink.put(s_codes[v]);
+        const unsigned i = 4u * w + b;
+        if (v == 0u && ((MS >> i) & 1ull)) {
+          const unsigned L = (i == 0u && c.Z == ~0ull) ? 64u : png_run_length(c.Z, i);
+          sink.put(s_codes[256u + L - 1u]);
         }
       }
     }
@@ -703,11 +715,11 @@ __global__ __launch_bounds__(kPngBlock) void png_emit2_kernel(const PngParams P)
   __syncthreads();
   for (unsigned k = threadIdx.x; k < words; k += kPngBlock) {
     const unsigned v = s_image[k];
-    if (!v) continue;
-    if (k == 0u || k + 1u == words)
-      atomicOr(&dst[k], v); /* shared with the neighbouring workgroups' spans */
-    else
-      dst[k] = v;
+    if (k == 0u || k + 1u == words) {
+      if (v) atomicOr(&dst[k], v); /* shared with the neighbouring workgroups' spans: cleared by png_offsets_kernel */
+    } else {
+      dst[k] = v; /* every word strictly inside the span is this workgroup's alone: stored whatever it holds */
+    }
   }
 }
 

@@ -146,8 +146,8 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   /* passes 2 and 3 */
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   if (two_pass) { /* offsets from the workgroups' token counts, then ONE more pass over the pixels */
-    hipLaunchKernelGGL(png_scan2_kernel, dim3(n_frames), block, 0, ctx->stream, P);
-    hipLaunchKernelGGL(png_zero_kernel, dim3(64, n_frames), block, 0, ctx->stream, P);
+    hipLaunchKernelGGL(png_blockbits_kernel, dim3((P.blocks_per_frame + 3u) / 4u, n_frames), block, 0, ctx->stream, P);
+    hipLaunchKernelGGL(png_offsets_kernel, dim3(n_frames), block, 0, ctx->stream, P);
     hipLaunchKernelGGL(png_emit2_kernel, grid, block, 0, ctx->stream, P);
   } else {
     hipLaunchKernelGGL(png_count_kernel, grid, block, 0, ctx->stream, P);

@@ -20,7 +20,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from curvis_amd import paths, pngio, skies  # noqa: E402
 import gpu_cli_video as V  # noqa: E402
 
-CELLS = [(c, b) for c in (1, 2, 3) for b in (8, 16, 32)]
+CS = [int(v) for v in os.environ.get("SWEEP_C", "1,2,3").split(",")]
+BS = [int(v) for v in os.environ.get("SWEEP_B", "8,16,32").split(",")]
+CELLS = [(c, b) for c in CS for b in BS]
 
 
 def main():
@@ -58,11 +60,11 @@ def main():
                       rnd, c, b, s["frames_per_s"], s["wall_s"], s["frames"], np.mean([x["kernel_ms_per_frame"] for x in dv]),
                       np.mean([x.get("gpu_png_kernel_ms_per_frame", 0.0) for x in dv]), np.mean([x["render_call_ms_per_frame"] for x in dv]),
                       sum(x["buffer_wait_s"] for x in dv), s["writer_drain_s"]), flush=True)
-    print("\n| contexts per GPU | " + " | ".join("batch %d" % b for b in (8, 16, 32)) + " |")
-    print("|---|---|---|---|")
-    for c in (1, 2, 3):
-        print("| %d | " % c + " | ".join(("%.0f (%s)" % (np.median(res[(c, b)]), ", ".join("%.0f" % v for v in res[(c, b)]))) if res[(c, b)] else "-" for b in (8, 16, 32)) + " |")
-    best = {c: max((np.median(res[(c, b)]), b) for b in (8, 16, 32) if res[(c, b)]) for c in (1, 2, 3) if any(res[(c, b)] for b in (8, 16, 32))}
+    print("\n| contexts per GPU | " + " | ".join("batch %d" % b for b in BS) + " |")
+    print("|---|" + "---|" * len(BS))
+    for c in CS:
+        print("| %d | " % c + " | ".join(("%.0f (%s)" % (np.median(res[(c, b)]), ", ".join("%.0f" % v for v in res[(c, b)]))) if res[(c, b)] else "-" for b in BS) + " |")
+    best = {c: max((np.median(res[(c, b)]), b) for b in BS if res[(c, b)]) for c in CS if any(res[(c, b)] for b in BS)}
     for c, (v, b) in best.items():
         print("best of C = %d: %.0f frames/s at --batch %d" % (c, v, b))
     if 1 in best and 2 in best:
