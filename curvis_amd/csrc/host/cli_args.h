@@ -10,8 +10,8 @@ struct Args {
   std::string sub, bg1, bg2, out, image_toml, video_toml, metric_toml, camera_toml, sim_toml, mode = "efficient", stats,
       sky_broadcast = "rccl";
   bool sky_broadcast_explicit = false, resume = false;
-  int contexts = 0; /* 0 = automatic (2 in --mode efficient, else 1); video: contexts (= host worker threads) per device: while one waits on the host-side sampler or the D2H copy another's kernels run */
-  int devices = 1, device = 0, batch = 8, writers = 0; /* writers 0 = automatic: a quarter of the host's threads, 4..64 */
+  int contexts = 0; /* 0 = automatic (4 in --mode efficient, else 1); video: contexts (= host worker threads) per device: while one waits on the host-side sampler or the D2H copy another's kernels run */
+  int devices = 1, device = 0, batch = 0, writers = 0; /* batch 0 = automatic (video: 8 frames per launch, in --mode efficient up to 32: cli_video.h); writers 0 = automatic: a quarter of the host's threads, 4..64 */
   int png_level = -1; /* -1 = the fast PNG writer (png_io.h; the reference's image crate also saves with its fast setting), 0..9 = zlib */
   int encode_bench = 0; /* video, diagnostics: every rendered frame is encoded this many extra times into a scratch file */
   std::string gpu_png = "auto"; /* video: PNG front end on the device (curvis_ctx_deflate_frames): auto = with the fast writer, on, off */
@@ -90,11 +90,13 @@ Args parse_args(int argc, char **argv) {
   if (a.sky_broadcast != "rccl" && a.sky_broadcast != "upload") die("error: --sky-broadcast must be rccl or upload", 2);
   if (a.gpu_png != "auto" && a.gpu_png != "on" && a.gpu_png != "off") die("error: --gpu-png must be auto, on or off", 2);
   if (a.devices < 1) a.devices = 1;
-  /* --mode efficient spends about half of a frame's render call on the host (the adaptive sampler between its launches of
-   * lone waves): two contexts per GPU overlap that with each other's kernels (measured: 1830 -> 2500 1080p frames/s on one
-   * MI355X, three or four contexts are slower again).  The per-pixel modes keep the GPU busy by themselves. */
-  if (a.contexts == 0) a.contexts = a.mode == "efficient" ? 2 : 1;
-  if (a.batch < 1) a.batch = 1;
+  /* --mode efficient spends more than half of a frame's render call on the host (the adaptive sampler between its launches of
+   * lone waves) and its kernels do not fill the GPU: several contexts per GPU overlap one's host work and another's kernels, and
+   * the kernels of different contexts run side by side.  Measured at 30 000 frames per cell on one MI355X, 32 frames per launch
+   * (profiles/round5_eff_contexts_sweep.txt): 2 757 / 4 058 / 5 488 / 6 116 / 5 936 1080p frames/s with 1 / 2 / 3 / 4 / 6 contexts.
+   * The per-pixel modes keep the GPU busy by themselves. */
+  if (a.contexts == 0) a.contexts = a.mode == "efficient" ? 4 : 1;
+  if (a.batch < 0) a.batch = 0;
   if (a.writers < 1) { /* encoding a 1080p frame costs 5-25 ms of a host thread (zlib: 20-230): the GPU renders one in 0.4-10 ms */
     unsigned hw = std::thread::hardware_concurrency();
     /* a container may see every CPU of the host behind a much smaller cgroup quota ("1600000 100000" = 16 CPUs) */

@@ -5,7 +5,8 @@
 
 namespace {
 
-int video_main(const Args &a) {
+int video_main(const Args &a_in) {
+  Args a = a_in; /* --batch 0 (automatic) is resolved below, once the frame size is known */
   std::printf("Video rendering\n");
   Common c;
   VideoSettings vs;
@@ -15,6 +16,14 @@ int video_main(const Args &a) {
     if (!from_toml(a.video_toml, vs, err)) die("Error with video settings: " + err);
   }
   load_common(a, c, "video");
+  if (a.batch < 1) {
+    /* frames per launch.  The per-pixel modes keep the GPU busy with 8 frames per launch.  --mode efficient is launch- and
+     * host-paced (lone waves between host-side sampler rounds): longer batches amortise both -- 1 568 / 2 202 / 2 757 frames/s at
+     * 8 / 16 / 32 frames per launch with one context, the same trend with two to four (profiles/round5_eff_contexts_sweep.txt) --
+     * as far as the page-locked batch buffers stay modest (three per worker of batch x frame bytes: 256 MB each at most) */
+    const size_t fbytes0 = (size_t)c.cam.resolution_x * c.cam.resolution_y * 3;
+    a.batch = a.mode == "efficient" ? (int)std::max<size_t>(4, std::min<size_t>(32, ((size_t)256 << 20) / std::max<size_t>(1, fbytes0))) : 8;
+  }
   vs.filepath_to_camera_path = resolve_path(vs.filepath_to_camera_path); /* normalize() */
   if (vs.video_name.empty()) die("Error in rendering video: Video name cannot be an empty string.");
   if (!has_extension(vs.filepath_to_camera_path, "csv"))

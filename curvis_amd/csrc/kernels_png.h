@@ -420,7 +420,8 @@ __global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) 
  * (tests/test_gpu_png.py compares the two paths).
  * ===================================================================================================================== */
 
-constexpr unsigned kPngHistReplicas = 8;   /* LDS histogram copies (lane & 7): same-value literals of neighbouring lanes do not collide */
+constexpr unsigned kPngHistReplicas = 4;   /* LDS histogram copies (lane & 3): same-value literals of neighbouring lanes do not collide */
+constexpr unsigned kPngMatchReplicas = 16; /* copies of the 32 bins from 256 on (lane & 15): neighbouring chunks tend to hold runs of the SAME length */
 constexpr unsigned kPngImageWords = 6272;  /* LDS image of a workgroup's piece of the stream in the two-pass emit: the worst case --
                                               65 literals of 12 bits per thread = 780 bits x 256 threads = 6240 words -- fits */
 static_assert(kPngImageWords * 4u >= kPngBlock * kPngLdsStride, "the stream image re-uses the staging buffer");
@@ -478,16 +479,19 @@ __device__ __forceinline__ void png_for_runs(unsigned long long Z, F f) {
 /* pass 1 of the two-pass path: token histogram per frame AND per workgroup, Adler-32 partial sums */
 __global__ __launch_bounds__(kPngBlock) void png_hist2_kernel(const PngParams P) {
   __shared__ unsigned s_hist[kPngHistReplicas][kPngBins];
+  __shared__ unsigned s_match[kPngMatchReplicas][32];
   __shared__ unsigned long long s_sum[2];
   __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
   const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
   if (block >= P.blocks_per_frame) return; /* the whole workgroup */
   const unsigned g = block * kPngBlock + threadIdx.x;
   for (unsigned k = threadIdx.x; k < kPngHistReplicas * kPngBins; k += kPngBlock) (&s_hist[0][0])[k] = 0u;
+  for (unsigned k = threadIdx.x; k < kPngMatchReplicas * 32u; k += kPngBlock) (&s_match[0][0])[k] = 0u;
   if (threadIdx.x < 2u) s_sum[threadIdx.x] = 0ull;
   png_stage(P, frame, block, s_f);
   __syncthreads();
   unsigned *my_hist = s_hist[threadIdx.x & (kPngHistReplicas - 1u)];
+  unsigned *my_match = s_match[threadIdx.x & (kPngMatchReplicas - 1u)];
   /* hot symbols in registers: literal 0, literal 1, literal 255, the match of a whole zero chunk (63) */
   unsigned n_zero = 0u, n_one = 0u, n_ff = 0u, n_m63 = 0u, a = 0u, b_mod = 0u;
   if (g < P.chunks_per_frame) {
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(kPngBlock) void png_hist2_kernel(const PngParams P)
           n_zero += L;
         } else {
           n_zero += 1u;
-          atomicAdd(&my_hist[png_len_symbol(L - 1u)], 1u);
+          atomicAdd(&my_match[png_len_symbol(L - 1u) - 256u], 1u);
         }
       });
     }
@@ -555,6 +559,8 @@ __global__ __launch_bounds__(kPngBlock) void png_hist2_kernel(const PngParams P)
     unsigned v = 0u;
 #pragma unroll
     for (unsigned r = 0; r < kPngHistReplicas; ++r) v += s_hist[r][k];
+    if (k >= 256u)
+      for (unsigned r = 0; r < kPngMatchReplicas; ++r) v += s_match[r][k - 256u];
     bh[k] = (unsigned short)v; /* <= 16 384 + 257 tokens per workgroup */
     if (v) atomicAdd(&P.hist[(size_t)frame * kPngBins + k], v);
   }
@@ -715,10 +721,13 @@ __global__ __launch_bounds__(kPngBlock) void png_emit2_kernel(const PngParams P)
   __syncthreads();
   for (unsigned k = threadIdx.x; k < words; k += kPngBlock) {
     const unsigned v = s_image[k];
-    if (k == 0u || k + 1u == words) {
-      if (v) atomicOr(&dst[k], v); /* shared with the neighbouring workgroups' spans: cleared by png_offsets_kernel */
+    /* the first word of the span was cleared by png_offsets_kernel and may hold the previous span's tail; the last word is the
+     * NEXT span's (cleared) first word -- unless this span ends exactly on a word boundary, in which case it is this
+     * workgroup's alone like every word strictly inside, and nobody has cleared it: stored, whatever it holds */
+    if (k == 0u || (k + 1u == words && ((shift + total) & 31u) != 0u)) {
+      if (v) atomicOr(&dst[k], v);
     } else {
-      dst[k] = v; /* every word strictly inside the span is this workgroup's alone: stored whatever it holds */
+      dst[k] = v;
     }
   }
 }

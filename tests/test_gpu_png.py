@@ -146,7 +146,7 @@ def test_errors(gpu_ctx):
     assert e.value.code == _abi.E_INVALID and "too small" in str(e.value)
 
 
-@pytest.mark.parametrize("w,h", [(64, 5), (192, 33), (320, 47), (1280, 9)])
+@pytest.mark.parametrize("w,h", [(64, 5), (192, 33), (320, 47), (1280, 9), (960, 235), (512, 143)])
 def test_two_pass_path_on_synthetic_contents(gpu_ctx, tmp_path, w, h):
     """the word-parallel tokeniser against the byte-serial one on contents chosen to hit its cases: runs of every length at
     every alignment (1..70 zeros between non-zero bytes), bytes 1 / 255 / others in every position of a word, whole zero
@@ -171,6 +171,16 @@ def test_two_pass_path_on_synthetic_contents(gpu_ctx, tmp_path, w, h):
     frames.append(g)
     frames.append(np.zeros((h, w, 3), np.uint8))
     batch = np.ascontiguousarray(np.stack(frames))
+    # the scratch (stream buffers, counters) is re-used from call to call: leave the longest possible streams of OTHER
+    # contents in it first -- a path that relies on memory being zero where it did not clear it shows up here
+    gpu_ctx.upload_frames(rng.integers(0, 256, batch.shape, dtype=np.uint8))
+    gpu_ctx.deflate_frames(w, h, len(frames))
     gpu_ctx.upload_frames(batch)
     assert np.array_equal(gpu_ctx.download_frames(w, h, len(frames)), batch)
-    check_streams(gpu_ctx, tmp_path, list(batch), w, h, "synthetic%d" % w)
+    first, _ = check_streams(gpu_ctx, tmp_path, list(batch), w, h, "synthetic%d" % w)
+    for dirt in (255, 0x55):                                            # ... and again over all-ones / alternating bits
+        gpu_ctx.upload_frames(np.full(batch.shape, dirt, np.uint8) ^ rng.integers(0, 2, batch.shape, dtype=np.uint8))
+        gpu_ctx.deflate_frames(w, h, len(frames))
+        gpu_ctx.upload_frames(batch)
+        again, _ = gpu_ctx.deflate_frames(w, h, len(frames))
+        assert again == first
