@@ -550,7 +550,7 @@ def main():
                 out["video_e2e"] = {"failed": short(exc)}
             try:  # the reference's DEFAULT renderer on the same node: ~0.3 ms of GPU per frame, where the host used to be the limit
                 out["video_e2e_efficient"] = video_e2e(args, world, host_skies, os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1",
-                                                       mode="efficient", frames_per_gpu=8 * max(1, args.video_e2e_frames_per_gpu))
+                                                       mode="efficient", frames_per_gpu=64 * max(1, args.video_e2e_frames_per_gpu))
             except Exception as exc:  # noqa: BLE001
                 out["video_e2e_efficient"] = {"failed": short(exc)}
             phase("video_e2e_both_modes")
@@ -939,7 +939,7 @@ def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gp
         t_files = time.perf_counter() - t_files
         cmd = [exe, "video", os.path.join(d, "pos.png"), os.path.join(d, "neg.png"), os.path.join(d, "out"),
                "-v", os.path.join(d, "vid.toml"), "-s", os.path.join(d, "sim.toml"), "-c", os.path.join(d, "cam.toml"),
-               "--mode", mode, "--devices", str(world), "--batch", "4" if mode == "brute" else "16", "--stats", os.path.join(d, "st.jsonl")]
+               "--mode", mode, "--devices", str(world), "--stats", os.path.join(d, "st.jsonl")] + (["--batch", "4"] if mode == "brute" else [])  # efficient: the binary's defaults (4 contexts per GPU, up to 32 frames per launch)
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
         if world > 1 and not share_device:  # a per-rank device mask is the launcher's, not the binary's: it drives all N GPUs itself
             for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
@@ -960,8 +960,8 @@ def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gp
             recs = [json.loads(ln) for ln in f if ln.strip()]
         frames_on_disk = len([n for n in os.listdir(os.path.join(d, "out", "tmp")) if n.endswith(".png")])
         steps = sum(rc["steps"] for rc in recs)
-        return {"command": "curvis video --mode %s --devices %d --batch %s --stats (configs[3]: Ellis, path_orbit.csv at %.4g fps, %dx%d, cap %d)" % (
-                    mode, world, "4" if mode == "brute" else "16", fps, args.width, args.height, args.max_iter),
+        return {"command": "curvis video --mode %s --devices %d%s --stats (configs[3]: Ellis, path_orbit.csv at %.4g fps, %dx%d, cap %d)" % (
+                    mode, world, " --batch 4" if mode == "brute" else "", fps, args.width, args.height, args.max_iter),
                 "frames": summ["frames"], "frames_on_disk": frames_on_disk,
                 "frames_per_s": round(summ["frames_per_s"], 2), "wall_s": round(summ["wall_s"], 3),
                 "process_wall_s": round(wall, 3),
@@ -972,7 +972,7 @@ def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gp
                 "per_device": summ["devices"], "encode": summ.get("encode"),
                 "distinct_gpus": len(set(dv["pci_bus_id"] for dv in summ["devices"])),
                 "input_files_s": round(t_files, 2),
-                "note": "one process, one host thread + context per GPU (two per GPU in --mode efficient), frames k mod workers, skies decoded once and broadcast from "
+                "note": "one process, one host thread + context per GPU (four per GPU in --mode efficient), frames k mod workers, skies decoded once and broadcast from "
                         "device 0 (ncclCommInitAll + curvis_ctx_bcast_skies), PNG frames written by the writer pool; wall_s "
                         "includes context creation, sky decode/upload/broadcast and the first-launch check of the relay kernel"}
     finally:

@@ -88,7 +88,12 @@ __device__ __forceinline__ void png_stage(const PngParams &P, unsigned frame, un
   const size_t base = (size_t)block * (kPngBlock * kPngChunk);
 #pragma unroll
   for (unsigned k = 0; k < 4u; ++k) {
-    const unsigned j = threadIdx.x + kPngBlock * k; /* 16-byte piece of the span */
+    /* 16-byte piece of the span.  A wave covers 64 consecutive pieces (1 KiB: the loads coalesce whatever the order inside);
+     * lane L takes piece 4 (L mod 16) + L div 16 of them, so that the 16 lanes an LDS write serves together store the SAME
+     * quarter of 16 DIFFERENT chunks -- bank offsets 20 c mod 64, a perfect cover -- instead of all quarters of 4 chunks, whose
+     * fourth chunk lands on the banks of the first (round 5: the staging writes were the LDS bank conflicts that remained) */
+    const unsigned j0 = threadIdx.x + kPngBlock * k, l = j0 & 63u;
+    const unsigned j = (j0 & ~63u) + 4u * (l & 15u) + (l >> 4);
     const size_t off = base + (size_t)j * 16u;
     uint4 d = make_uint4(0u, 0u, 0u, 0u);
     if (off < P.frame_bytes) {

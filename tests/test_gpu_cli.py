@@ -119,10 +119,11 @@ def test_video_orbit_frames_and_quirks(scene_files):
     # --stats also writes the host profile: per-device table (PCI identity, frames, kernel / render-call time) and the
     # writer threads' stage times
     summ = json.loads((out / "st.jsonl.summary.json").read_text())
-    # --mode efficient runs two contexts (two host threads) on the one GPU by default: half of its render call is host work
-    assert summ["frames"] == 15 and summ["png_level"] == -1 and len(summ["devices"]) == 2
+    # --mode efficient runs four contexts (four host threads) on the one GPU by default: more than half of its render call is
+    # host work and its kernels do not fill the GPU (profiles/round5_eff_contexts_sweep.txt)
+    assert summ["frames"] == 15 and summ["png_level"] == -1 and len(summ["devices"]) == 4
     devs = summ["devices"]
-    assert devs[0]["device"] == devs[1]["device"] == 0 and devs[0]["pci_bus_id"] == devs[1]["pci_bus_id"] and len(devs[0]["pci_bus_id"].split(":")) == 3
+    assert {dv["device"] for dv in devs} == {0} and len({dv["pci_bus_id"] for dv in devs}) == 1 and len(devs[0]["pci_bus_id"].split(":")) == 3
     assert sum(dv["frames"] for dv in devs) == 15 and all(dv["kernel_ms_per_frame"] > 0 for dv in devs)
     # the default writer: PNG front end on the device (filter, Huffman coding, Adler-32 in HIP kernels; the frames checked above
     # against the oracle were decoded from ITS streams), a writer thread only wraps the stream and adds the CRC
