@@ -112,7 +112,8 @@ int video_main(const Args &a_in) {
     /* one node, one process: RCCL's bootstrap needs no network.  Left to itself it picks the first "real" interface, and on
      * hosts where that one is slow or unroutable communicator set-up was seen to take 6 s (lo: 2.7 s) up to ~80 s */
     ::setenv("NCCL_SOCKET_IFNAME", "lo", 0 /* a value the user has set stays */);
-    ::setenv("NCCL_DEBUG", "WARN", 0); /* RCCL's own warnings on stderr: a first contact between two devices that fails says why */
+    ::setenv("NCCL_DEBUG", "WARN", 0); /* RCCL's own warnings: a first contact between two devices that fails says why ... */
+    ::setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0); /* ... on stderr, its version banner included: stdout stays the reference's */
     const ncclResult_t nrc = ncclCommInitAll(comms.data(), a.devices, devs.data());
     if (nrc != ncclSuccess) {
       const char *last = ncclGetLastError(nullptr);
