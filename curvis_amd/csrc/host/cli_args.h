@@ -173,6 +173,17 @@ curvis_ctx *make_ctx_bare(int device, const char *what) {
   curvis_ctx *ctx = nullptr;
   int rc = curvis_ctx_create(device, &ctx);
   if (rc != CURVIS_OK) die(std::string("Error in rendering ") + what + ": " + curvis_last_error(nullptr));
+  /* tuning knobs of the library for experiments (tools/gpu_eff_speculation_sweep.py): CURVIS_CTX_OPTIONS="key=value,key=value"
+   * is applied to every context of the run; an unknown key is an error, not a silent no-op */
+  if (const char *opts = std::getenv("CURVIS_CTX_OPTIONS")) {
+    std::stringstream ss(opts);
+    std::string kv;
+    while (std::getline(ss, kv, ',')) {
+      const size_t eq = kv.find('=');
+      if (eq == std::string::npos || curvis_ctx_set_option(ctx, kv.substr(0, eq).c_str(), std::atoll(kv.c_str() + eq + 1)) != CURVIS_OK)
+        die("error: CURVIS_CTX_OPTIONS: cannot set `" + kv + "`", 2);
+    }
+  }
   return ctx;
 }
 void upload_skies(curvis_ctx *ctx, const Common &c, const char *what) {
