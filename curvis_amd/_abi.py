@@ -106,6 +106,9 @@ SYMBOLS = {
     "curvis_ctx_deflate_frames": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.POINTER(C.c_size_t),
                                             C.POINTER(C.c_double)]),
     "curvis_image_save_zlib_rgb8": (C.c_int, [C.c_char_p, _vp, C.c_size_t, C.c_uint32, C.c_uint32]),
+    "curvis_ctx_deflate_frames_crc": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.POINTER(C.c_size_t),
+                                                C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "curvis_image_save_zlib_rgb8_crc": (C.c_int, [C.c_char_p, _vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32]),
     "curvis_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "curvis_host_free": (None, [_vp]),
     "curvis_ctx_framebuffer": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),

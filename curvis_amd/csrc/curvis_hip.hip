@@ -777,6 +777,19 @@ int curvis_ctx_deflate_frames(curvis_ctx *ctx, uint32_t res_x, uint32_t res_y, u
   return deflate_frames_impl(ctx, res_x, res_y, n_frames, zlib_out, out_cap, offsets, kernel_ms);
 }
 
+int curvis_ctx_deflate_frames_crc(curvis_ctx *ctx, uint32_t res_x, uint32_t res_y, uint32_t n_frames, uint8_t *zlib_out, size_t out_cap,
+                                  size_t *offsets, double *kernel_ms, uint32_t *idat_crc, int *crc_valid) {
+  if (!idat_crc || !crc_valid) return fail(ctx, CURVIS_E_INVALID, "null idat_crc / crc_valid");
+  return deflate_frames_impl(ctx, res_x, res_y, n_frames, zlib_out, out_cap, offsets, kernel_ms, idat_crc, crc_valid);
+}
+
+int curvis_image_save_zlib_rgb8_crc(const char *path, const uint8_t *zlib_stream, size_t len, uint32_t w, uint32_t h, uint32_t idat_crc) {
+  if (!path || !zlib_stream || len < 6 || w == 0 || h == 0) return fail(nullptr, CURVIS_E_INVALID, "null argument or empty stream");
+  std::string err;
+  if (!pngio::save_zlib_stream_rgb8(path, zlib_stream, len, w, h, err, nullptr, &idat_crc)) return fail(nullptr, CURVIS_E_IO, err);
+  return CURVIS_OK;
+}
+
 int curvis_image_save_zlib_rgb8(const char *path, const uint8_t *zlib_stream, size_t len, uint32_t w, uint32_t h) {
   if (!path || !zlib_stream || len < 6 || w == 0 || h == 0) return fail(nullptr, CURVIS_E_INVALID, "null argument or empty stream");
   std::string err;

@@ -265,14 +265,19 @@ int video_main(const Args &a_in) {
        * streams instead; should they not fit (frames that do not compress: > 1 byte per byte) the raw frames are fetched after
        * all and the host encoder takes them */
       std::vector<size_t> zoff;
-      bool streams = false;
+      std::vector<uint32_t> zcrc;
+      bool streams = false, have_crc = false; /* have_crc: the device also computed the PNG chunks' CRC-32 (two-pass front end) */
       int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, gpu_png ? nullptr : rgb_ptr, &st);
       if (rc == CURVIS_OK && gpu_png) {
         zoff.resize(nb + 1);
         double pms = 0.0;
         /* test hook: pretend the streams do not fit (frames that do not compress), so that the fall-back below runs */
         const size_t zcap = std::getenv("CURVIS_TEST_SMALL_PNG_BUFFER") ? (size_t)64 : batch_buf ? (size_t)a.batch * fbytes : nb * fbytes;
-        const int zrc = curvis_ctx_deflate_frames(ctx, c.cam.resolution_x, c.cam.resolution_y, (uint32_t)nb, rgb_ptr, zcap, zoff.data(), &pms);
+        zcrc.assign(nb, 0u);
+        int crc_ok = 0;
+        const int zrc = curvis_ctx_deflate_frames_crc(ctx, c.cam.resolution_x, c.cam.resolution_y, (uint32_t)nb, rgb_ptr, zcap, zoff.data(), &pms,
+                                                      zcrc.data(), &crc_ok);
+        have_crc = crc_ok != 0;
         if (zrc == CURVIS_OK) {
           streams = true;
           ds.png_ms += pms;
@@ -335,12 +340,14 @@ int video_main(const Args &a_in) {
         else
           (void)curvis_ctx_frame_stats(ctx, (uint32_t)j, &fs);
         const double batch_ms = st.kernel_ms;
-        writers.submit([&, k, frame, f_len, streams, batch_buf, copy, fs, nb, rank, batch_ms, batch_call_ms] {
+        const uint32_t frame_crc = streams && have_crc ? zcrc[j] : 0u;
+        const bool frame_has_crc = streams && have_crc;
+        writers.submit([&, k, frame, f_len, streams, batch_buf, copy, fs, nb, rank, batch_ms, batch_call_ms, frame_crc, frame_has_crc] {
           const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
           const std::string part = file + ".part"; /* written under another name, then renamed: --resume never sees half a file */
           std::string e;
           pngio::EncodeTimes tm, tb;
-          bool ok = streams ? pngio::save_zlib_stream_rgb8(part, frame, f_len, c.cam.resolution_x, c.cam.resolution_y, e, &tm)
+          bool ok = streams ? pngio::save_zlib_stream_rgb8(part, frame, f_len, c.cam.resolution_x, c.cam.resolution_y, e, &tm, frame_has_crc ? &frame_crc : nullptr)
                             : pngio::save_rgb8(part, frame, c.cam.resolution_x, c.cam.resolution_y, e, a.png_level, &tm);
           if (ok && std::rename(part.c_str(), file.c_str()) != 0) {
             ok = false;
@@ -349,7 +356,7 @@ int video_main(const Args &a_in) {
           for (int rep = 0; ok && rep < a.encode_bench; ++rep) { /* diagnostics: the host's encode capacity with one GPU feeding it */
             std::string e2;
             if (streams)
-              (void)pngio::save_zlib_stream_rgb8(part + ".bench", frame, f_len, c.cam.resolution_x, c.cam.resolution_y, e2, &tb);
+              (void)pngio::save_zlib_stream_rgb8(part + ".bench", frame, f_len, c.cam.resolution_x, c.cam.resolution_y, e2, &tb, frame_has_crc ? &frame_crc : nullptr);
             else
               (void)pngio::save_rgb8(part + ".bench", frame, c.cam.resolution_x, c.cam.resolution_y, e2, a.png_level, &tb);
           }

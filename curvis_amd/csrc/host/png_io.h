@@ -616,7 +616,7 @@ inline bool write_file(const std::string &path, const uint8_t *data, size_t n, s
 /* A PNG file around a finished zlib stream of the filtered scanlines (what curvis_ctx_deflate_frames hands back: filtering,
  * Huffman coding and Adler-32 were done on the GPU): signature, IHDR, IDAT chunk(s) with their CRC-32, IEND. */
 inline bool save_zlib_stream_rgb8(const std::string &path, const uint8_t *z, size_t len, uint32_t w, uint32_t h, std::string &err,
-                                  EncodeTimes *tm = nullptr) {
+                                  EncodeTimes *tm = nullptr, const uint32_t *idat_crc = nullptr) {
   const double t0 = now_s();
   FILE *f = std::fopen(path.c_str(), "wb");
   if (!f) {
@@ -648,8 +648,13 @@ inline bool save_zlib_stream_rgb8(const std::string &path, const uint8_t *z, siz
     be(ch, (uint32_t)piece);
     std::memcpy(ch + 4, "IDAT", 4);
     const double tc = now_s();
-    uLong crc = crc32(0L, ch + 4, 4);
-    crc = crc32(crc, z + off, (uInt)piece);
+    uLong crc;
+    if (idat_crc && len <= kIdatMax) { /* computed on the device (curvis_ctx_deflate_frames_crc): one chunk, nothing to do here */
+      crc = *idat_crc;
+    } else {
+      crc = crc32(0L, ch + 4, 4);
+      crc = crc32(crc, z + off, (uInt)piece);
+    }
     t_crc += now_s() - tc;
     be(tail, (uint32_t)crc);
     ok = std::fwrite(ch, 1, 8, f) == 8 && std::fwrite(z + off, 1, piece, f) == piece && std::fwrite(tail, 1, 4, f) == 4;

@@ -32,6 +32,7 @@ constexpr unsigned kPngCodeBits = 12;    /* longest literal/length code */
 /* LDS image of a workgroup's piece of the stream: 8 KiB = 256 bits per thread on average, i.e. frames that compress at least
  * 2 x; a workgroup whose codes need more (at most 65 literals of 12 bits per thread = 780 bits) ORs them into global memory */
 constexpr unsigned kPngLdsWords = 2048;
+constexpr unsigned kPngHeaderWords = 44; /* zlib header (16 bits) + dynamic block header (<= 1222 bits) + slack: 176 bytes */
 
 struct PngParams {
   const unsigned char *fb;        /* n_frames frames of H rows of row_bytes bytes, back to back */
@@ -50,6 +51,9 @@ struct PngParams {
   unsigned *direct_blocks;        /* [1]: workgroups of pass 3 whose codes did not fit their LDS image (diagnostics, tests) */
   unsigned short *block_hist;     /* two-pass path: [n_frames][blocks_per_frame][kPngBins] token counts per workgroup (<= 16 641 each) */
   const unsigned *sym_bits;       /* two-pass path: [n_frames][kPngBins] bits a token of each symbol takes (code + extra + distance) */
+  const unsigned *header;         /* two-pass path: [n_frames][kPngHeaderWords] zlib + block header bits (zero from start_bit on) */
+  const unsigned *crc_tables;     /* [4][256] slice-by-4 tables of CRC-32 (reflected 0xEDB88320), then x^(2^k) mod p for k = 0..31 */
+  unsigned *crc;                  /* [n_frames]: XOR of the threads' contributions = CRC state after "IDAT" + the frame's stream */
   unsigned *out;                  /* [n_frames][out_words] */
   size_t out_words;
 };
@@ -594,8 +598,8 @@ __global__ __launch_bounds__(kPngBlock) void png_blockbits_kernel(const PngParam
 
 /* one workgroup per frame: block_bits -> exclusive prefix (in place), frame_bits = start + total; and the ONLY zeroing the
  * two-pass emit needs: a workgroup of png_emit2_kernel stores every word strictly inside its span and ORs into the first and
- * the last one, which it shares with its neighbours -- so the first word of every span, the words of the header before the
- * first span (the host ORs the zlib and block headers into them) and the last word of the stream are cleared here
+ * the last one, which it shares with its neighbours -- so the first word of every span and the last word of the stream are
+ * cleared here, and the words before the first span receive the zlib and block headers
  * (a few KB per frame instead of a pass over the whole stream) */
 __global__ __launch_bounds__(kPngBlock) void png_offsets_kernel(const PngParams P) {
   __shared__ unsigned long long s_part[kPngBlock];
@@ -608,7 +612,9 @@ __global__ __launch_bounds__(kPngBlock) void png_offsets_kernel(const PngParams 
   unsigned long long sum = 0ull;
   for (unsigned k = lo; k < hi; ++k) sum += v[k];
   s_part[threadIdx.x] = sum;
-  for (unsigned k = threadIdx.x; k <= (start >> 5); k += kPngBlock) out[k] = 0u;
+  /* the zlib and block headers the host built from this frame's code lengths: bits [0, start); the word holding bit `start`
+   * carries the header's last bits and is ORed into by the first span */
+  for (unsigned k = threadIdx.x; k <= (start >> 5); k += kPngBlock) out[k] = k < kPngHeaderWords ? P.header[(size_t)frame * kPngHeaderWords + k] : 0u;
   __syncthreads();
   if (threadIdx.x == 0u) { /* 256 partial sums: a serial pass is as fast as anything here */
     unsigned long long run = 0ull;
@@ -735,6 +741,79 @@ __global__ __launch_bounds__(kPngBlock) void png_emit2_kernel(const PngParams P)
       dst[k] = v;
     }
   }
+}
+
+/* CRC-32 of the PNG chunk (type "IDAT" + the frame's finished stream) on the device: the last per-frame host cost of the
+ * front end that grew with the stream (0.31 ms of a writer thread per 1080p frame, as much as writing the file).
+ * A CRC is linear over GF(2): with raw(B) the register after the bytes B from a zero start,
+ *     state(A || B) = state(A) * x^(8 |B|)  XOR  raw(B)      (mod p, reflected arithmetic as in zlib's crc32_combine)
+ * so every thread takes 64 bytes of the stream, computes their raw CRC with slice-by-4 tables in LDS, multiplies it by
+ * x^(8 x bytes that follow it) (square-and-multiply over a table of x^(2^k)) and XORs the result into the frame's word; the
+ * thread holding byte 0 adds the state after "IDAT" moved over the whole stream.  The host appends the four Adler-32 bytes
+ * and continues the CRC over them. */
+constexpr unsigned kPngCrcPoly = 0xEDB88320u;
+constexpr unsigned kPngCrcAfterIdat = 0xCA50F9E1u; /* register after "IDAT" from the all-ones start (tests compare with zlib) */
+__device__ __forceinline__ unsigned png_multmodp(unsigned a, unsigned b) { /* a(x) b(x) mod p, bit 31 = x^0 */
+  unsigned p = 0u;
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i) {
+    p ^= (a & 0x80000000u) ? b : 0u;
+    a <<= 1;
+    b = (b >> 1) ^ ((b & 1u) ? kPngCrcPoly : 0u);
+  }
+  return p;
+}
+__device__ __forceinline__ unsigned png_x8n(const unsigned *x2n, unsigned long long n) { /* x^(8 n) mod p */
+  unsigned p = 0x80000000u, k = 3u;
+  while (n) {
+    if (n & 1ull) p = png_multmodp(x2n[k & 31u], p);
+    n >>= 1;
+    ++k;
+  }
+  return p;
+}
+__global__ __launch_bounds__(kPngBlock) void png_crc_kernel(const PngParams P) {
+  __shared__ unsigned s_t[4][256];
+  __shared__ unsigned s_x2n[32];
+  __shared__ unsigned s_acc;
+  const unsigned frame = blockIdx.y;
+  const unsigned long long L = (P.frame_bits[frame] + 7ull) >> 3; /* bytes of the stream (without the Adler-32 trailer) */
+  const unsigned long long base = (unsigned long long)blockIdx.x * (kPngBlock * 64u);
+  if (base >= L) return; /* the whole workgroup */
+  for (unsigned k = threadIdx.x; k < 1024u; k += kPngBlock) (&s_t[0][0])[k] = P.crc_tables[k];
+  if (threadIdx.x < 32u) s_x2n[threadIdx.x] = P.crc_tables[1024u + threadIdx.x];
+  if (threadIdx.x == 0u) s_acc = 0u;
+  __syncthreads();
+  const unsigned long long pos = base + (unsigned long long)threadIdx.x * 64u;
+  unsigned v = 0u;
+  if (pos < L) {
+    const unsigned n = (unsigned)min(64ull, L - pos);
+    const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(P.out + (size_t)frame * P.out_words) + pos);
+    unsigned d[16];
+#pragma unroll
+    for (unsigned q = 0; q < 4u; ++q) {
+      uint4 t = make_uint4(0u, 0u, 0u, 0u);
+      if (16u * q < n) t = src[q]; /* inside the frame's buffer: out_words is rounded up generously */
+      d[4 * q + 0] = t.x, d[4 * q + 1] = t.y, d[4 * q + 2] = t.z, d[4 * q + 3] = t.w;
+    }
+    unsigned c = 0u;
+#pragma unroll
+    for (unsigned w = 0; w < 16u; ++w) {
+      if (4u * w + 4u <= n) {
+        c ^= d[w];
+        c = s_t[3][c & 0xffu] ^ s_t[2][(c >> 8) & 0xffu] ^ s_t[1][(c >> 16) & 0xffu] ^ s_t[0][c >> 24];
+      } else if (4u * w < n) {
+        for (unsigned b = 0; b < n - 4u * w; ++b) c = s_t[0][(c ^ (d[w] >> (8u * b))) & 0xffu] ^ (c >> 8);
+      }
+    }
+    const unsigned long long after = L - pos - n;
+    v = after ? png_multmodp(png_x8n(s_x2n, after), c) : c;
+    if (pos == 0ull) v ^= png_multmodp(png_x8n(s_x2n, L), kPngCrcAfterIdat);
+  }
+  for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63u) == 0u) atomicXor(&s_acc, v);
+  __syncthreads();
+  if (threadIdx.x == 0u) atomicXor(&P.crc[frame], s_acc);
 }
 
 }  // namespace

@@ -6,7 +6,7 @@
 namespace {
 
 struct PngScratch { /* one allocation, carved */
-  size_t hist, adler, direct_blocks, codes, block_bits, thread_bits, start_bit, frame_bits, block_hist, sym_bits, out, total;
+  size_t hist, adler, direct_blocks, crc, codes, block_bits, thread_bits, start_bit, frame_bits, block_hist, sym_bits, header, crc_tables, out, total;
   size_t out_words;
 };
 
@@ -23,6 +23,8 @@ PngScratch png_scratch_layout(const PngParams &P) {
   off = up(off + (size_t)P.n_frames * 2 * sizeof(unsigned long long));
   L.direct_blocks = off;
   off = up(off + sizeof(unsigned));
+  L.crc = off; /* cleared with the histograms */
+  off = up(off + (size_t)P.n_frames * sizeof(unsigned));
   L.codes = off;
   off = up(off + (size_t)P.n_frames * kPngCodes * sizeof(unsigned));
   L.block_bits = off;
@@ -37,16 +39,49 @@ PngScratch png_scratch_layout(const PngParams &P) {
   off = up(off + (size_t)P.n_frames * P.blocks_per_frame * kPngBins * sizeof(unsigned short));
   L.sym_bits = off;
   off = up(off + (size_t)P.n_frames * kPngBins * sizeof(unsigned));
+  L.header = off;
+  off = up(off + (size_t)P.n_frames * kPngHeaderWords * sizeof(unsigned));
+  L.crc_tables = off;
+  off = up(off + (1024 + 32) * sizeof(unsigned));
   L.out = off;
   off = up(off + (size_t)P.n_frames * L.out_words * sizeof(unsigned));
   L.total = off;
   return L;
 }
 
+/* CRC-32 tables for png_crc_kernel: slice-by-4 (reflected 0xEDB88320) and x^(2^k) mod p, k = 0..31 (zlib's x2n_table) */
+const std::array<unsigned, 1024 + 32> &png_crc_tables() {
+  static const std::array<unsigned, 1024 + 32> T = [] {
+    std::array<unsigned, 1024 + 32> t{};
+    for (unsigned i = 0; i < 256; ++i) {
+      unsigned c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
+      t[i] = c;
+    }
+    for (unsigned s = 1; s < 4; ++s)
+      for (unsigned i = 0; i < 256; ++i) t[256 * s + i] = (t[256 * (s - 1) + i] >> 8) ^ t[t[256 * (s - 1) + i] & 0xffu];
+    auto mul = [](unsigned a, unsigned b) {
+      unsigned p = 0;
+      for (int i = 0; i < 32; ++i) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+      }
+      return p;
+    };
+    unsigned p = 1u << 30; /* x^1 */
+    t[1024] = p;
+    for (unsigned n = 1; n < 32; ++n) t[1024 + n] = p = mul(p, p);
+    return t;
+  }();
+  return T;
+}
+
 /* frames [0, n_frames) of W x H RGB8 in ctx->d_fb -> zlib streams, back to back in `out`; offsets[f] .. offsets[f + 1] is
  * frame f's stream.  kernel_ms: HIP-event time of the five launches (the host's code construction between them excluded). */
 int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_frames, uint8_t *out, size_t out_cap, size_t *offsets,
-                        double *kernel_ms) {
+                        double *kernel_ms, uint32_t *idat_crc = nullptr, int *crc_valid = nullptr) {
+  if (crc_valid) *crc_valid = 0;
   if (!ctx || !out || !offsets || W == 0 || H == 0 || n_frames == 0) return fail(ctx, CURVIS_E_INVALID, "bad argument");
   const size_t frame_bytes = (size_t)W * 3 * H;
   if (!ctx->d_fb || frame_bytes * n_frames > ctx->fb_bytes)
@@ -81,6 +116,9 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   P.frame_bits = (unsigned long long *)(base + L.frame_bits);
   P.block_hist = (unsigned short *)(base + L.block_hist);
   P.sym_bits = (const unsigned *)(base + L.sym_bits);
+  P.header = (const unsigned *)(base + L.header);
+  P.crc_tables = (const unsigned *)(base + L.crc_tables);
+  P.crc = (unsigned *)(base + L.crc);
   P.out = (unsigned *)(base + L.out);
   P.out_words = L.out_words;
   /* two reads of the frames instead of three (kernels_png.h, "two-pass path"): frames whose rows are a multiple of 64 bytes,
@@ -140,8 +178,17 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   }
   HIP_TRY(ctx, hipMemcpyAsync(base + L.codes, codes.data(), codes.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(base + L.start_bit, start_bit.data(), start_bit.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-  if (two_pass)
+  std::vector<unsigned> header_words;
+  if (two_pass) {
     HIP_TRY(ctx, hipMemcpyAsync(base + L.sym_bits, sym_bits.data(), sym_bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+    /* the headers go to the device too: the stream it leaves is then complete (but for the Adler-32 trailer), which is what
+     * lets it compute the PNG chunk's CRC-32 as well */
+    header_words.assign((size_t)n_frames * kPngHeaderWords, 0u);
+    for (uint32_t f = 0; f < n_frames; ++f) std::memcpy(header_words.data() + (size_t)f * kPngHeaderWords, header[f].data(), sizeof header[f]);
+    static_assert(sizeof(std::array<uint8_t, 176>) == kPngHeaderWords * sizeof(unsigned), "header staging");
+    HIP_TRY(ctx, hipMemcpyAsync(base + L.header, header_words.data(), header_words.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(base + L.crc_tables, png_crc_tables().data(), sizeof(unsigned) * (1024 + 32), hipMemcpyHostToDevice, ctx->stream));
+  }
 
   /* passes 2 and 3 */
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -149,6 +196,7 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
     hipLaunchKernelGGL(png_blockbits_kernel, dim3((P.blocks_per_frame + 3u) / 4u, n_frames), block, 0, ctx->stream, P);
     hipLaunchKernelGGL(png_offsets_kernel, dim3(n_frames), block, 0, ctx->stream, P);
     hipLaunchKernelGGL(png_emit2_kernel, grid, block, 0, ctx->stream, P);
+    hipLaunchKernelGGL(png_crc_kernel, dim3((unsigned)((P.out_words * 4 + kPngBlock * 64 - 1) / (kPngBlock * 64)), n_frames), block, 0, ctx->stream, P);
   } else {
     hipLaunchKernelGGL(png_count_kernel, grid, block, 0, ctx->stream, P);
     hipLaunchKernelGGL(png_scan_kernel, dim3(n_frames), block, 0, ctx->stream, P);
@@ -162,6 +210,9 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
                               ctx->stream));
   unsigned direct_blocks = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&direct_blocks, base + L.direct_blocks, sizeof direct_blocks, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<unsigned> crc_state(n_frames, 0u);
+  if (two_pass)
+    HIP_TRY(ctx, hipMemcpyAsync(crc_state.data(), base + L.crc, crc_state.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->last_png_direct_blocks = direct_blocks;
   HIP_TRY(ctx, hipEventElapsedTime(&ms_b, ctx->ev0, ctx->ev1));
@@ -192,7 +243,10 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
     a[1] = (uint8_t)s2;
     a[2] = (uint8_t)(s1 >> 8);
     a[3] = (uint8_t)s1;
+    /* CRC-32 of the PNG chunk: the device's register after "IDAT" + stream, finalised, continued over the four trailer bytes */
+    if (two_pass && idat_crc) idat_crc[f] = (uint32_t)crc32((uLong)(crc_state[f] ^ 0xFFFFFFFFu), a, 4);
   }
+  if (two_pass && crc_valid) *crc_valid = 1;
   if (kernel_ms) *kernel_ms = (double)ms_a + (double)ms_b;
   ctx->last_png_ms = (double)ms_a + (double)ms_b;
   return CURVIS_OK;

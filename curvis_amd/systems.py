@@ -379,6 +379,18 @@ class Context:
                                               C.byref(ms)), self._h)
         return [out[offs[k]:offs[k + 1]].tobytes() for k in range(int(n_frames))], ms.value
 
+    def deflate_frames_crc(self, width, height, n_frames=1, out=None):
+        """curvis_ctx_deflate_frames_crc: as deflate_frames, plus the PNG chunk CRC-32 ("IDAT" + stream) of every frame computed
+        on the device: (streams, kernel ms, [crc, ...] or None when the path taken does not compute it)"""
+        if out is None:
+            out = np.empty(int(n_frames) * ((height * (width * 3 + 1)) * 3 // 2 + 512), dtype=np.uint8)
+        offs = (C.c_size_t * (int(n_frames) + 1))()
+        ms, valid = C.c_double(0.0), C.c_int(0)
+        crc = (C.c_uint32 * int(n_frames))()
+        check(lib().curvis_ctx_deflate_frames_crc(self._h, int(width), int(height), int(n_frames), out.ctypes.data, out.size, offs,
+                                                  C.byref(ms), crc, C.byref(valid)), self._h)
+        return [out[offs[k]:offs[k + 1]].tobytes() for k in range(int(n_frames))], ms.value, (list(crc) if valid.value else None)
+
     def set_option(self, key, value):
         check(lib().curvis_ctx_set_option(self._h, key.encode(), int(value)), self._h)
 

@@ -58,6 +58,18 @@ def check_streams(ctx, tmp_path, frames, w, h, tag):
             ctx.set_option("png_path", 1)
         assert old == streams, (tag, [i for i, (a, b) in enumerate(zip(old, streams)) if a != b])
         ctx.deflate_frames(w, h, len(frames))                          # leave the context's "last_*" options describing the default path
+    # the PNG chunk's CRC-32 ("IDAT" + stream) from the device: equal to zlib's over the same bytes, for every frame; the file
+    # written with it is byte-identical to the one whose CRC the host computed
+    s2, _, crcs = ctx.deflate_frames_crc(w, h, len(frames))
+    assert s2 == streams
+    if passes == 2:
+        assert crcs is not None and [zlib.crc32(b"IDAT" + z) for z in streams] == crcs, tag
+        buf = np.frombuffer(streams[0], np.uint8)
+        pa, pb = tmp_path / ("%s_crc_dev.png" % tag), tmp_path / ("%s_0.png" % tag)
+        _abi.check(_abi.lib().curvis_image_save_zlib_rgb8_crc(str(pa).encode(), buf.ctypes.data, buf.size, w, h, crcs[0]))
+        assert pa.read_bytes() == pb.read_bytes()
+    else:
+        assert crcs is None                                            # three-pass kernels: the host computes it
     return streams, ms
 
 

@@ -34,7 +34,9 @@ for it in range(N):
                               (float(rng.normal()) - 1.0, float(rng.normal()), float(rng.normal())), (0.0, 0.0, 1.0), float(rng.uniform(8, 40)), 43.0, w, h) for _ in range(nf)]
     cap = 0 if rng.random() < 0.05 else 3000
     rgb, _ = ctx.render_brute(m, cams, cap, 100.0, 0.05)
-    streams, _ = ctx.deflate_frames(w, h, nf)
+    streams, _, crcs = ctx.deflate_frames_crc(w, h, nf)
+    if crcs is not None and crcs != [zlib.crc32(b"IDAT" + z) for z in streams]:   # the chunk CRC-32 the device computed (two-pass path)
+        bad += 1; print("CRC DIFFERS case %d: %dx%d x%d" % (it, w, h, nf), flush=True)
     direct += ctx.get_option("last_png_direct_blocks") > 0
     if ctx.get_option("last_png_passes") == 2:   # the same frames through the three-pass kernels: identical streams
         two_pass += 1
