@@ -625,7 +625,7 @@ __global__ __launch_bounds__(kPngBlock) void png_offsets_kernel(const PngParams 
     }
     const unsigned long long end = (unsigned long long)start + run;
     P.frame_bits[frame] = end;
-    out[end >> 5] = 0u;
+    if ((end >> 5) > (start >> 5)) out[end >> 5] = 0u; /* (never the word that holds the header's last bits) */
     out[(end >> 5) + 1u] = 0u;
   }
   __syncthreads();
@@ -633,7 +633,9 @@ __global__ __launch_bounds__(kPngBlock) void png_offsets_kernel(const PngParams 
   for (unsigned k = lo; k < hi; ++k) {
     const unsigned long long t = v[k];
     v[k] = run;
-    out[(start + run) >> 5] = 0u; /* first word of this workgroup's span (several tiny spans may share one: all clear it) */
+    /* first word of this workgroup's span (several tiny spans may share one: all clear it) -- except the word the header ends
+     * in, which the first span ORs into: it was written above with the header's bits */
+    if (((start + run) >> 5) > (start >> 5)) out[(start + run) >> 5] = 0u;
     run += t;
   }
 }

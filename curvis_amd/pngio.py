@@ -34,6 +34,9 @@ def read_png(path):
     while pos < len(data):
         n, tag = struct.unpack(">I4s", data[pos:pos + 8])
         body = data[pos + 8:pos + 8 + n]
+        # every chunk carries the CRC-32 of type + data; a reader that skipped it would not notice a writer that got it wrong
+        if zlib.crc32(tag + body) != struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]:
+            raise ValueError("%s: CRC mismatch in chunk %s" % (path, tag.decode("latin-1")))
         if tag == b"IHDR":
             w, h, depth, ctype, _, _, inter = struct.unpack(">IIBBBBB", body)
             assert depth == 8 and inter == 0 and ctype in (0, 2, 4, 6)

@@ -34,6 +34,13 @@ def test_wrap_zlib_stream_into_png(tmp_path, shape):
     got = np.ctypeslib.as_array(p, shape=(hh.value, ww.value, 4)).copy()
     _abi.lib().curvis_image_free(p)
     assert (ww.value, hh.value) == (w, h) and np.array_equal(got[..., :3], img) and (got[..., 3] == 255).all()
+    # with the chunk's CRC-32 supplied (what curvis_ctx_deflate_frames_crc computes on the device): the same file, byte for byte,
+    # and the decoders -- which verify the CRC of critical chunks -- refuse a wrong one
+    with_crc = tmp_path / "x_crc.png"
+    _abi.check(_abi.lib().curvis_image_save_zlib_rgb8_crc(str(with_crc).encode(), buf.ctypes.data, buf.size, w, h, zlib.crc32(b"IDAT" + z)))
+    assert with_crc.read_bytes() == path.read_bytes()
+    _abi.check(_abi.lib().curvis_image_save_zlib_rgb8_crc(str(with_crc).encode(), buf.ctypes.data, buf.size, w, h, zlib.crc32(b"IDAT" + z) ^ 1))
+    assert _abi.lib().curvis_image_load(str(with_crc).encode(), C.byref(p), C.byref(ww), C.byref(hh)) != 0
 
 
 def test_wrap_rejects_nonsense(tmp_path):
