@@ -52,7 +52,7 @@ struct PngParams {
   unsigned short *block_hist;     /* two-pass path: [n_frames][blocks_per_frame][kPngBins] token counts per workgroup (<= 16 641 each) */
   const unsigned *sym_bits;       /* two-pass path: [n_frames][kPngBins] bits a token of each symbol takes (code + extra + distance) */
   const unsigned *header;         /* two-pass path: [n_frames][kPngHeaderWords] zlib + block header bits (zero from start_bit on) */
-  const unsigned *crc_tables;     /* [4][256] slice-by-4 tables of CRC-32 (reflected 0xEDB88320), then x^(2^k) mod p for k = 0..31 */
+  const unsigned *crc_tables;     /* [4][256] slice-by-4 tables of CRC-32 (reflected 0xEDB88320), then x^(8 d 16^i) mod p, [i = 0..7][d = 0..15] */
   unsigned *crc;                  /* [n_frames]: XOR of the threads' contributions = CRC state after "IDAT" + the frame's stream */
   unsigned *out;                  /* [n_frames][out_words] */
   size_t out_words;
@@ -765,25 +765,27 @@ __device__ __forceinline__ unsigned png_multmodp(unsigned a, unsigned b) { /* a(
   }
   return p;
 }
-__device__ __forceinline__ unsigned png_x8n(const unsigned *x2n, unsigned long long n) { /* x^(8 n) mod p */
-  unsigned p = 0x80000000u, k = 3u;
-  while (n) {
-    if (n & 1ull) p = png_multmodp(x2n[k & 31u], p);
-    n >>= 1;
-    ++k;
+/* x^(8 n) mod p for n < 2^32 from a table of x^(8 d 16^i), d = 0..15, i = 0..7: one multiplication per non-zero hex digit of
+ * n (square-and-multiply over x^(2^k) took one per set BIT: 3 x the length of the dependent chain every thread waits for) */
+__device__ __forceinline__ unsigned png_x8n(const unsigned *xw, unsigned long long n) {
+  unsigned p = 0x80000000u; /* x^0 */
+#pragma unroll 1
+  for (unsigned i = 0; n; ++i, n >>= 4) {
+    const unsigned d = (unsigned)n & 15u;
+    if (d) p = png_multmodp(xw[16u * i + d], p);
   }
   return p;
 }
 __global__ __launch_bounds__(kPngBlock) void png_crc_kernel(const PngParams P) {
   __shared__ unsigned s_t[4][256];
-  __shared__ unsigned s_x2n[32];
+  __shared__ unsigned s_x2n[128];
   __shared__ unsigned s_acc;
   const unsigned frame = blockIdx.y;
   const unsigned long long L = (P.frame_bits[frame] + 7ull) >> 3; /* bytes of the stream (without the Adler-32 trailer) */
   const unsigned long long base = (unsigned long long)blockIdx.x * (kPngBlock * 64u);
   if (base >= L) return; /* the whole workgroup */
   for (unsigned k = threadIdx.x; k < 1024u; k += kPngBlock) (&s_t[0][0])[k] = P.crc_tables[k];
-  if (threadIdx.x < 32u) s_x2n[threadIdx.x] = P.crc_tables[1024u + threadIdx.x];
+  if (threadIdx.x < 128u) s_x2n[threadIdx.x] = P.crc_tables[1024u + threadIdx.x];
   if (threadIdx.x == 0u) s_acc = 0u;
   __syncthreads();
   const unsigned long long pos = base + (unsigned long long)threadIdx.x * 64u;

@@ -42,17 +42,17 @@ PngScratch png_scratch_layout(const PngParams &P) {
   L.header = off;
   off = up(off + (size_t)P.n_frames * kPngHeaderWords * sizeof(unsigned));
   L.crc_tables = off;
-  off = up(off + (1024 + 32) * sizeof(unsigned));
+  off = up(off + (1024 + 128) * sizeof(unsigned));
   L.out = off;
   off = up(off + (size_t)P.n_frames * L.out_words * sizeof(unsigned));
   L.total = off;
   return L;
 }
 
-/* CRC-32 tables for png_crc_kernel: slice-by-4 (reflected 0xEDB88320) and x^(2^k) mod p, k = 0..31 (zlib's x2n_table) */
-const std::array<unsigned, 1024 + 32> &png_crc_tables() {
-  static const std::array<unsigned, 1024 + 32> T = [] {
-    std::array<unsigned, 1024 + 32> t{};
+/* CRC-32 tables for png_crc_kernel: slice-by-4 (reflected 0xEDB88320) and x^(8 d 16^i) mod p for the hex digits d of a byte count */
+const std::array<unsigned, 1024 + 128> &png_crc_tables() {
+  static const std::array<unsigned, 1024 + 128> T = [] {
+    std::array<unsigned, 1024 + 128> t{};
     for (unsigned i = 0; i < 256; ++i) {
       unsigned c = i;
       for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
@@ -69,9 +69,16 @@ const std::array<unsigned, 1024 + 32> &png_crc_tables() {
       }
       return p;
     };
-    unsigned p = 1u << 30; /* x^1 */
-    t[1024] = p;
-    for (unsigned n = 1; n < 32; ++n) t[1024 + n] = p = mul(p, p);
+    unsigned base = 1u << 30; /* x^1 */
+    for (int k = 0; k < 3; ++k) base = mul(base, base); /* x^8: one byte */
+    for (unsigned i = 0; i < 8; ++i) { /* base = x^(8 16^i) */
+      unsigned p = 0x80000000u; /* x^0 */
+      for (unsigned d = 0; d < 16; ++d) {
+        t[1024 + 16 * i + d] = p;
+        p = mul(p, base);
+      }
+      base = p; /* x^(8 16^(i+1)) */
+    }
     return t;
   }();
   return T;
@@ -187,7 +194,7 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
     for (uint32_t f = 0; f < n_frames; ++f) std::memcpy(header_words.data() + (size_t)f * kPngHeaderWords, header[f].data(), sizeof header[f]);
     static_assert(sizeof(std::array<uint8_t, 176>) == kPngHeaderWords * sizeof(unsigned), "header staging");
     HIP_TRY(ctx, hipMemcpyAsync(base + L.header, header_words.data(), header_words.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(base + L.crc_tables, png_crc_tables().data(), sizeof(unsigned) * (1024 + 32), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(base + L.crc_tables, png_crc_tables().data(), sizeof(unsigned) * (1024 + 128), hipMemcpyHostToDevice, ctx->stream));
   }
 
   /* passes 2 and 3 */

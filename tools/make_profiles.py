@@ -119,7 +119,7 @@ for name in sorted(os.listdir(G)):
 pd = os.path.join(G, "png_front_end")
 if os.path.exists(os.path.join(pd, "stats", "png_kernel_stats.csv")):
     # two-pass path (round 5) first: "png_hist_kernel" is no prefix of "png_hist2_kernel", but list the longer names first anyway
-    PNGK = ("png_hist2_kernel", "png_blockbits_kernel", "png_offsets_kernel", "png_emit2_kernel",
+    PNGK = ("png_hist2_kernel", "png_blockbits_kernel", "png_offsets_kernel", "png_emit2_kernel", "png_crc_kernel",
             "png_hist_kernel", "png_count_kernel", "png_scan_kernel", "png_zero_kernel", "png_emit_kernel")
 
     def pmc_png(path):
