@@ -550,7 +550,7 @@ def main():
                 out["video_e2e"] = {"failed": short(exc)}
             try:  # the reference's DEFAULT renderer on the same node: ~0.3 ms of GPU per frame, where the host used to be the limit
                 out["video_e2e_efficient"] = video_e2e(args, world, host_skies, os.environ.get("CURVIS_BENCH_SHARE_DEVICE") == "1",
-                                                       mode="efficient", frames_per_gpu=64 * max(1, args.video_e2e_frames_per_gpu))
+                                                       mode="efficient", frames_per_gpu=32 * max(1, args.video_e2e_frames_per_gpu))
             except Exception as exc:  # noqa: BLE001
                 out["video_e2e_efficient"] = {"failed": short(exc)}
             phase("video_e2e_both_modes")
