@@ -101,6 +101,20 @@ def test_one_process_per_gpu_host_single_rank(tmp_path):
     check_against_oracle(res, 1)
 
 
+def test_device_link_query():
+    """curvis_device_link: a device to itself, an index that does not exist, and -- when the box has them -- two devices
+    (the link type and hop count printed: what the first measured broadcast rate is read against)"""
+    import curvis_amd
+    me = curvis_amd.Context.device_link(0, 0)
+    assert me["link"] == "same device" and me["hops"] == 0 and me["peer_access"] == 1
+    with pytest.raises(curvis_amd.CurvisError):
+        curvis_amd.Context.device_link(0, 64)
+    if common.device_count() >= 2:
+        ln = curvis_amd.Context.device_link(0, 1)
+        print("device 0 <-> 1:", ln)
+        assert ln["link"] in ("xGMI", "PCIe") and ln["hops"] >= 1
+
+
 @pytest.mark.parametrize("stage", ["ncclCommInitRank", "read-back", "render on device 0"])
 def test_a_failing_rank_says_which_stage_broke(tmp_path, stage):
     """the first contact between two devices must be self-diagnosing.  A rank made to fail at a given
