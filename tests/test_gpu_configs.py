@@ -309,6 +309,39 @@ def test_video_config_every_frame_efficient_against_glibc(gpu_ctx, video):
         assert differs_on_axis[fl] == ([29, 168] if video == "orbit" else [])      # as measured
 
 
+@pytest.mark.parametrize("video", ["orbit", "through"])
+def test_video_config_full_size_efficient_against_glibc(gpu_ctx, video):
+    """the same at the configs' FULL size (1920x1080 / 3840x2160, 8192x4096 checkerboard skies) at the hard poses: orbit frames 0
+    and 29 (the one with the 0/0 pixel), the fly-through's frame 0 and the two frames inside the throat -- all three glibc flavours,
+    sample tables and every pixel; measured identical but for (960, 540) of orbit frame 29"""
+    metric, csv, fps, n_frames, _, res, cap = VIDEOS[video]
+    times, poses = video_poses(csv, fps)
+    sel = [0, 29] if video == "orbit" else full_size_frames(video, n_frames, poses)
+    om, pm = metrics_of(metric)
+    sp, sn = common.make_skies(8192, 4096, "check")
+    osp, osn = O.sky(sp), O.sky(sn)
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    cams = [curvis_amd.Camera(poses[i][0], poses[i][1], poses[i][2], 15.0, 43.0, res[0], res[1]) for i in sel]
+    rgb, _ = gpu_ctx.render_efficient(pm, cams, cap, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+    tables = [gpu_ctx.samples(j) for j in range(len(sel))]
+
+    def work(job):
+        j, fl = job
+        p = poses[sel[j]]
+        oc = O.camera(p[0], p[1], p[2], 15.0, 43.0, res)
+        return j, fl, O.render_image_efficient(fl, om, oc, osp, osn, cap, 100.0, 0.05, 100, 100, 1e-5, 1e-5)[:2]
+    with ThreadPoolExecutor(min(THREADS, 12)) as ex:
+        for j, fl, (w_rgb, w_smp) in ex.map(work, [(j, fl) for j in range(len(sel)) for fl in O.GLIBC_FLAVOURS]):
+            a, e, s_ = tables[j]
+            assert np.array_equal(a, w_smp["a"]) and np.array_equal(s_, w_smp["s"]) and np.nanmax(np.abs(e - w_smp["e"])) < 1e-7
+            d = (rgb[j] != w_rgb).any(axis=2)
+            expect = [[res[1] // 2, res[0] // 2]] if (video, sel[j]) == ("orbit", 29) else []
+            assert np.argwhere(d).tolist() == expect, (video, sel[j], O.FLAVOUR_NAMES[fl], np.argwhere(d)[:5].tolist())
+    print("%s frames %s at %dx%d, efficient renderer vs three glibc flavours: identical%s" % (
+        video, sel, res[0], res[1], " except pixel (960, 540) of frame 29" if video == "orbit" else ""))
+
+
 SIM = ("escape_radius = 100.0\nray_integration_max_itarations = %d\nray_integration_step = 0.05\n"
        "sampling_initial_nums = 100\nsampling_max_iterations = 50\n"
        "sampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 2e-5\n")
