@@ -95,19 +95,23 @@ Args parse_args(int argc, char **argv) {
    * the kernels of different contexts run side by side.  Measured at 30 000 frames per cell on one MI355X, 32 frames per launch
    * (profiles/round5_eff_contexts_sweep.txt): 2 757 / 4 058 / 5 488 / 6 116 / 5 936 1080p frames/s with 1 / 2 / 3 / 4 / 6 contexts.
    * The per-pixel modes keep the GPU busy by themselves. */
-  if (a.contexts == 0) a.contexts = a.mode == "efficient" ? 4 : 1;
-  if (a.batch < 0) a.batch = 0;
-  if (a.writers < 1) { /* encoding a 1080p frame costs 5-25 ms of a host thread (zlib: 20-230): the GPU renders one in 0.4-10 ms */
-    unsigned hw = std::thread::hardware_concurrency();
-    /* a container may see every CPU of the host behind a much smaller cgroup quota ("1600000 100000" = 16 CPUs) */
-    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-      double quota = 0.0, period = 0.0;
-      if (std::fscanf(f, "%lf %lf", &quota, &period) == 2 && quota > 0.0 && period > 0.0)
-        hw = std::min(hw, (unsigned)(quota / period + 0.5) * 4u); /* the quota itself: this many writers at most */
-      std::fclose(f);
+  /* CPUs this process may really use: a container may see every CPU of the host behind a much smaller cgroup quota
+   * ("1600000 100000" = 16 CPUs) */
+  unsigned hw = std::max(1u, std::thread::hardware_concurrency()), cpus = hw;
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    double quota = 0.0, period = 0.0;
+    if (std::fscanf(f, "%lf %lf", &quota, &period) == 2 && quota > 0.0 && period > 0.0) {
+      cpus = std::max(1u, std::min(hw, (unsigned)(quota / period + 0.5)));
+      hw = std::min(hw, cpus * 4u); /* the quota itself: this many writers at most */
     }
-    a.writers = (int)std::min(64u, std::max(4u, hw / 4u));
+    std::fclose(f);
   }
+  /* four contexts per GPU in --mode efficient -- as far as the host has two CPUs per worker thread (each context's thread runs
+   * the sampler's host side; 8 GPUs behind a 16-CPU quota get one context each, not 32 threads fighting the writers) */
+  if (a.contexts == 0) a.contexts = a.mode == "efficient" ? (int)std::max(1u, std::min(4u, cpus / (2u * (unsigned)a.devices))) : 1;
+  if (a.batch < 0) a.batch = 0;
+  if (a.writers < 1) /* encoding a 1080p frame costs 5-25 ms of a host thread (zlib: 20-230): the GPU renders one in 0.4-10 ms */
+    a.writers = (int)std::min(64u, std::max(4u, hw / 4u));
   return a;
 }
 

@@ -46,7 +46,7 @@ def check_extras_of_a_multi_rank_line(out, world, one_device):
     assert e2e["distinct_gpus"] == (1 if one_device else world)
     eff = out["video_e2e_efficient"]                       # the reference's default renderer through the same binary
     assert "failed" not in eff, eff
-    assert eff["frames"] == eff["frames_on_disk"] >= 100 * world and eff["gpu_png"] is True and eff["workers"] == 4 * world   # four contexts per GPU in this mode (profiles/round5_eff_contexts_sweep.txt)
+    assert eff["frames"] == eff["frames_on_disk"] >= 100 * world and eff["gpu_png"] is True and eff["workers"] % world == 0 and world <= eff["workers"] <= 4 * world   # up to four contexts per GPU in this mode (two CPUs per worker thread)
     pr = out["per_rank"]
     assert [p["rank"] for p in pr] == list(range(world))
     for p in pr:
