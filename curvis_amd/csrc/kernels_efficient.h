@@ -90,40 +90,54 @@ struct EfficientPixelParams {
   FrameCounters counters;
 };
 
-/* K3: steps 2, 4, 5 of render_image_efficient + sky lookup, one thread per pixel. */
+/* K3: steps 2, 4, 5 of render_image_efficient + sky lookup, one thread per pixel.
+ * The interpolation's search over the frame's sample abscissae (interp_slice: ~10 dependent probes of a 500-700-entry table)
+ * runs in LDS: the 256 pixels of a workgroup belong to one frame (but for the workgroup at a frame boundary, whose second
+ * frame searches in global memory), so the workgroup copies that frame's abscissae once -- in global memory every probe was
+ * an L2 round trip in the dependency chain of every wave (round 5: the kernel is half of the GPU time of `curvis video` in
+ * the reference's default mode). */
+constexpr unsigned kEffLdsSamples = 2048; /* abscissae staged per workgroup (16 KiB); longer tables are searched in global memory */
 __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPixelParams P) {
+  __shared__ double s_x[kEffLdsSamples];
   const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long npix = (unsigned long long)P.W * P.H;
-  unsigned pos = 0, neg = 0, none = 0, oob = 0;
+  bool pos = false, neg = false, none = false, oob = false;
   const bool valid = o < npix * P.n_frames;
   const unsigned f = valid ? (unsigned)(o / npix) : 0u;
+  /* the frame of the workgroup's first pixel (always valid: the grid is ceil(total / 256) workgroups) */
+  const unsigned f_wg = (unsigned)(((unsigned long long)blockIdx.x * blockDim.x) / npix);
+  const unsigned n_wg = P.tab_n[f_wg], off_wg = P.tab_off[f_wg];
+  const bool staged = n_wg >= 2u && n_wg <= kEffLdsSamples;
+  if (staged)
+    for (unsigned k = threadIdx.x; k < n_wg; k += blockDim.x) s_x[k] = P.sx[off_wg + k];
+  __syncthreads();
   if (valid) {
     const unsigned pix = (unsigned)(o - (unsigned long long)f * npix);
     const unsigned py = pix / P.W, px = pix - py * P.W;
     const unsigned off = P.tab_off[f], n = P.tab_n[f];
     double fin[3], space;
-    cvk::efficient_pixel(P.cams[f], P.frames[f], px, py, P.sx + off, P.m_e + off, P.c_e + off, P.m_s + off,
-                         P.c_s + off, n, fin, space);
+    cvk::efficient_pixel(P.cams[f], P.frames[f], px, py, (staged && f == f_wg) ? (const double *)s_x : P.sx + off, P.m_e + off, P.c_e + off,
+                         P.m_s + off, P.c_s + off, n, fin, space);
     unsigned texel = 0xFF000000u;
     if (space == 1.0 || space == -1.0) { /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black } */
       const cvk::SkyParams &S = P.sky[space == 1.0 ? 0 : 1];
       unsigned tx, ty;
       cvk::sky_indices(S, fin[0], fin[1], fin[2], tx, ty);
-      if (tx >= S.w || ty >= S.h) oob = 1;
+      if (tx >= S.w || ty >= S.h) oob = true;
       if (tx >= S.w) tx = S.w - 1;
       if (ty >= S.h) ty = S.h - 1;
       texel = S.texels[(size_t)ty * S.w + tx];
       pos = (space == 1.0);
       neg = (space == -1.0);
     } else {
-      none = 1;
+      none = true;
     }
     unsigned char *dst = P.fb + o * 3;
     dst[0] = (unsigned char)(texel & 0xFF);
     dst[1] = (unsigned char)((texel >> 8) & 0xFF);
     dst[2] = (unsigned char)((texel >> 16) & 0xFF);
   }
-  flush_frame_counts(P.counters, f, valid, 0ull, 1u, pos, neg, none, oob);
+  flush_frame_flags(P.counters, f, valid, pos, neg, none, oob);
 }
 
 /* "direct" mode (NOT in the reference; SURVEY 8f N1 names it as a quality option): what render_image_efficient

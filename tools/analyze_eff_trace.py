@@ -4,6 +4,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 import numpy as np
@@ -12,7 +13,8 @@ d = sys.argv[1]
 rows = []
 for p in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(p)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("::")[-1], r.get("Queue_Id", "")))
+        m = re.search(r"(?:\)::|^)(\w+)\s*(?:<|\()", r["Kernel_Name"].replace("void ", ""))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1) if m else r["Kernel_Name"][:40], r.get("Queue_Id", "")))
 rows.sort()
 t0, t1 = rows[0][0], max(r[1] for r in rows)
 span = (t1 - t0) * 1e-9

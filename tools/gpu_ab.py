@@ -31,6 +31,12 @@ for _ in range(8):
     _, st = ctx.render_efficient(curvis_amd.EllisMetric(1.0), cam, 40000, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
     ts.append(st.integrate_ms)
 out.append(float(np.median(ts[2:])))   # efficient renderer, one image: sampling kernels (lone waves)
+cams = [curvis_amd.Camera((0.0, 3.0 + 0.05 * k, np.pi / 2, 0.1 * k), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 15.0, 43.0, 1920, 1080) for k in range(32)]
+ts = []
+for _ in range(8):
+    _, st = ctx.render_efficient(curvis_amd.EllisMetric(1.0), cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
+    ts.append(st.shade_ms / 32)
+out.append(float(np.median(ts[2:])))   # efficient renderer, 32 frames per call: the per-pixel kernel, per frame
 print(" ".join("%%.4f" %% v for v in out))
 ''' % root
 res = {"old": [], "new": []}
@@ -43,4 +49,4 @@ for rnd in range(int(os.environ.get("ROUNDS", "4"))):
         print(name, r.stdout.strip() if vals else r.stderr[-400:], flush=True)
         if vals: res[name].append(vals)
 for name in res:
-    print(name, "median over rounds [ellis x1, ellis x6 per frame, interstellar x1, efficient-image sampling kernels] ms:", np.median(np.array(res[name]), axis=0))
+    print(name, "median over rounds [ellis x1, ellis x6 per frame, interstellar x1, efficient-image sampling kernels, efficient pixel kernel per frame of a 32-frame call] ms:", np.median(np.array(res[name]), axis=0))
