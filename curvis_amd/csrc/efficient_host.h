@@ -367,6 +367,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
 
   /* device buffers for K3 */
   const size_t npix = (size_t)W * H;
+  if (npix > 0xFFFFFFFFull || n_frames > 65535u) return fail(ctx, CURVIS_E_INVALID, "frame or batch too large");
   const size_t fb_bytes = npix * 3 * n_frames;
   rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, fb_bytes);
   if (rc) return rc;
@@ -422,9 +423,9 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   Q.H = H;
   Q.fb = ctx->d_fb;
   Q.counters = FC;
-  const unsigned long long blocks = ((unsigned long long)npix * n_frames + 255ull) / 256ull;
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, Q);
+  hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)((npix + kEffPixelsPerGroup - 1) / kEffPixelsPerGroup), n_frames), dim3(256), 0,
+                     ctx->stream, Q);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words,

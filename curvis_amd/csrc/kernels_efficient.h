@@ -91,53 +91,98 @@ struct EfficientPixelParams {
 };
 
 /* K3: steps 2, 4, 5 of render_image_efficient + sky lookup, one thread per pixel.
- * The interpolation's search over the frame's sample abscissae (interp_slice: ~10 dependent probes of a 500-700-entry table)
- * runs in LDS: the 256 pixels of a workgroup belong to one frame (but for the workgroup at a frame boundary, whose second
- * frame searches in global memory), so the workgroup copies that frame's abscissae once -- in global memory every probe was
- * an L2 round trip in the dependency chain of every wave (round 5: the kernel is half of the GPU time of `curvis video` in
- * the reference's default mode). */
-constexpr unsigned kEffLdsSamples = 2048; /* abscissae staged per workgroup (16 KiB); longer tables are searched in global memory */
+ *
+ * Grid: (chunks of kEffPixelsPerGroup pixels, frames).  A workgroup walks its chunk 256 pixels at a time and keeps its
+ * statistics -- escaped to +l / -l, black, texel index clamped -- in registers, reduces them ONCE (wave sums, LDS) and adds
+ * them to its frame's counters with five global atomics.  Round 5 found the first version, in which every WAVE added its
+ * counts straight to the frame's counter lines, spending 42 % of its time in those atomics (a million waves per 32-frame
+ * launch on a few hundred cache lines; without the statistics the same kernel ran 0.057 instead of 0.099 ms per 1080p frame) --
+ * and the kernel is more than half of the GPU time of `curvis video` in the reference's default mode.
+ * The interpolation's search over the frame's sample abscissae runs in LDS (copied once per workgroup); the RGB8 bytes of a
+ * wave's 64 pixels are transposed through LDS and stored as 48 dwords. */
+constexpr unsigned kEffLdsSamples = 2048;       /* abscissae staged per workgroup (16 KiB); longer tables are searched in global memory */
+constexpr unsigned kEffGroupsPerBlock = 16;     /* groups of 256 pixels a workgroup walks */
+constexpr unsigned kEffPixelsPerGroup = 256u * kEffGroupsPerBlock;
 __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPixelParams P) {
   __shared__ double s_x[kEffLdsSamples];
-  const unsigned long long o = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long npix = (unsigned long long)P.W * P.H;
-  bool pos = false, neg = false, none = false, oob = false;
-  const bool valid = o < npix * P.n_frames;
-  const unsigned f = valid ? (unsigned)(o / npix) : 0u;
-  /* the frame of the workgroup's first pixel (always valid: the grid is ceil(total / 256) workgroups) */
-  const unsigned f_wg = (unsigned)(((unsigned long long)blockIdx.x * blockDim.x) / npix);
-  const unsigned n_wg = P.tab_n[f_wg], off_wg = P.tab_off[f_wg];
-  const bool staged = n_wg >= 2u && n_wg <= kEffLdsSamples;
+  __shared__ __attribute__((aligned(16))) unsigned char s_rgb[256 * 3];
+  __shared__ unsigned s_cnt[3];
+  const unsigned f = blockIdx.y;
+  const unsigned npix = P.W * P.H; /* < 2^32: checked on the host */
+  const unsigned off = P.tab_off[f], n = P.tab_n[f];
+  const bool staged = n >= 2u && n <= kEffLdsSamples;
   if (staged)
-    for (unsigned k = threadIdx.x; k < n_wg; k += blockDim.x) s_x[k] = P.sx[off_wg + k];
+    for (unsigned k = threadIdx.x; k < n; k += blockDim.x) s_x[k] = P.sx[off + k];
+  if (threadIdx.x < 3u) s_cnt[threadIdx.x] = 0u;
   __syncthreads();
-  if (valid) {
-    const unsigned pix = (unsigned)(o - (unsigned long long)f * npix);
-    const unsigned py = pix / P.W, px = pix - py * P.W;
-    const unsigned off = P.tab_off[f], n = P.tab_n[f];
-    double fin[3], space;
-    cvk::efficient_pixel(P.cams[f], P.frames[f], px, py, (staged && f == f_wg) ? (const double *)s_x : P.sx + off, P.m_e + off, P.c_e + off,
-                         P.m_s + off, P.c_s + off, n, fin, space);
+  const cvk::CameraParams &cam = P.cams[f];
+  const cvk::EfficientFrame &frame = P.frames[f];
+  const double *sx = staged ? (const double *)s_x : P.sx + off;
+  unsigned char *fb = P.fb + (size_t)f * npix * 3u;
+  /* dword stores need the frame to start on a 4-byte boundary (every frame of a batch does unless W*H*3 is not a multiple of 4) */
+  const bool dwords = ((((size_t)f * npix * 3u) & 3u) == 0u);
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned c_pn = 0u, c_no = 0u, c_rays = 0u; /* (+l | -l << 16), (black | clamped << 16): <= 16 each per thread */
+  const unsigned first = blockIdx.x * kEffPixelsPerGroup;
+#pragma unroll 1
+  for (unsigned g = 0; g < kEffGroupsPerBlock; ++g) {
+    const unsigned pix = first + g * 256u + threadIdx.x;
+    const bool valid = pix < npix;
+    if (first + g * 256u >= npix) break; /* the whole workgroup */
     unsigned texel = 0xFF000000u;
-    if (space == 1.0 || space == -1.0) { /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black } */
-      const cvk::SkyParams &S = P.sky[space == 1.0 ? 0 : 1];
-      unsigned tx, ty;
-      cvk::sky_indices(S, fin[0], fin[1], fin[2], tx, ty);
-      if (tx >= S.w || ty >= S.h) oob = true;
-      if (tx >= S.w) tx = S.w - 1;
-      if (ty >= S.h) ty = S.h - 1;
-      texel = S.texels[(size_t)ty * S.w + tx];
-      pos = (space == 1.0);
-      neg = (space == -1.0);
-    } else {
-      none = true;
+    if (valid) {
+      const unsigned py = pix / P.W, px = pix - py * P.W;
+      double fin[3], space;
+      cvk::efficient_pixel(cam, frame, px, py, sx, P.m_e + off, P.c_e + off, P.m_s + off, P.c_s + off, n, fin, space);
+      ++c_rays;
+      if (space == 1.0 || space == -1.0) { /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black } */
+        const cvk::SkyParams &S = P.sky[space == 1.0 ? 0 : 1];
+        unsigned tx, ty;
+        cvk::sky_indices(S, fin[0], fin[1], fin[2], tx, ty);
+        if (tx >= S.w || ty >= S.h) c_no += 1u << 16;
+        if (tx >= S.w) tx = S.w - 1;
+        if (ty >= S.h) ty = S.h - 1;
+        texel = S.texels[(size_t)ty * S.w + tx];
+        c_pn += space == 1.0 ? 1u : (1u << 16);
+      } else {
+        c_no += 1u;
+      }
     }
-    unsigned char *dst = P.fb + o * 3;
-    dst[0] = (unsigned char)(texel & 0xFF);
-    dst[1] = (unsigned char)((texel >> 8) & 0xFF);
-    dst[2] = (unsigned char)((texel >> 16) & 0xFF);
+    if (dwords && __builtin_amdgcn_ballot_w64(valid) == ~0ull) {
+      unsigned char *sw = s_rgb + wave * 192u;
+      sw[3u * lane + 0u] = (unsigned char)(texel & 0xFF);
+      sw[3u * lane + 1u] = (unsigned char)((texel >> 8) & 0xFF);
+      sw[3u * lane + 2u] = (unsigned char)((texel >> 16) & 0xFF);
+      __builtin_amdgcn_wave_barrier(); /* LDS operations of one wave complete in order; the buffer is this wave's alone */
+      if (lane < 48u) reinterpret_cast<unsigned *>(fb + (size_t)(pix - lane) * 3u)[lane] = reinterpret_cast<const unsigned *>(sw)[lane];
+      __builtin_amdgcn_wave_barrier();
+    } else if (valid) {
+      unsigned char *dst = fb + (size_t)pix * 3u;
+      dst[0] = (unsigned char)(texel & 0xFF);
+      dst[1] = (unsigned char)((texel >> 8) & 0xFF);
+      dst[2] = (unsigned char)((texel >> 16) & 0xFF);
+    }
   }
-  flush_frame_flags(P.counters, f, valid, pos, neg, none, oob);
+  /* statistics: per wave by shuffles (fields <= 16 x 64 = 1024 fit their 16 bits), per workgroup in LDS, then one set of atomics */
+  for (int o = 32; o > 0; o >>= 1) {
+    c_pn += __shfl_xor(c_pn, o, 64);
+    c_no += __shfl_xor(c_no, o, 64);
+    c_rays += __shfl_xor(c_rays, o, 64);
+  }
+  if (lane == 0u) {
+    atomicAdd(&s_cnt[0], c_pn);
+    atomicAdd(&s_cnt[1], c_no);
+    atomicAdd(&s_cnt[2], c_rays);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0u && s_cnt[2]) {
+    unsigned long long *c = frame_counter_line(P.counters, f);
+    atomicAdd(&c[FC_RAYS], (unsigned long long)s_cnt[2]);
+    if (s_cnt[0] & 0xffffu) atomicAdd(&c[FC_POS], (unsigned long long)(s_cnt[0] & 0xffffu));
+    if (s_cnt[0] >> 16) atomicAdd(&c[FC_NEG], (unsigned long long)(s_cnt[0] >> 16));
+    if (s_cnt[1] & 0xffffu) atomicAdd(&c[FC_NONE], (unsigned long long)(s_cnt[1] & 0xffffu));
+    if (s_cnt[1] >> 16) atomicAdd(&c[FC_OOB], (unsigned long long)(s_cnt[1] >> 16));
+  }
 }
 
 /* "direct" mode (NOT in the reference; SURVEY 8f N1 names it as a quality option): what render_image_efficient
