@@ -399,7 +399,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   std::memcpy(stage.data() + o_cs, c_s.data(), sizeof(double) * T);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eff, stage.data(), off, hipMemcpyHostToDevice, ctx->stream));
   FrameCounters FC;
-  rc = prepare_counters(ctx, n_frames, FC);
+  rc = prepare_counters(ctx, n_frames, FC, 64u); /* one workgroup in 256 pixels adds to them: spread over 64 lines per frame */
   if (rc) return rc;
   const size_t cnt_words = counter_words(n_frames, FC.slots);
   EfficientPixelParams Q;
@@ -424,8 +424,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   Q.fb = ctx->d_fb;
   Q.counters = FC;
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)((npix + kEffPixelsPerGroup - 1) / kEffPixelsPerGroup), n_frames), dim3(256), 0,
-                     ctx->stream, Q);
+  hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)((npix + 255) / 256), n_frames), dim3(256), 0, ctx->stream, Q);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words,

@@ -92,96 +92,80 @@ struct EfficientPixelParams {
 
 /* K3: steps 2, 4, 5 of render_image_efficient + sky lookup, one thread per pixel.
  *
- * Grid: (chunks of kEffPixelsPerGroup pixels, frames).  A workgroup walks its chunk 256 pixels at a time and keeps its
- * statistics -- escaped to +l / -l, black, texel index clamped -- in registers, reduces them ONCE (wave sums, LDS) and adds
- * them to its frame's counters with five global atomics.  Round 5 found the first version, in which every WAVE added its
- * counts straight to the frame's counter lines, spending 42 % of its time in those atomics (a million waves per 32-frame
- * launch on a few hundred cache lines; without the statistics the same kernel ran 0.057 instead of 0.099 ms per 1080p frame) --
- * and the kernel is more than half of the GPU time of `curvis video` in the reference's default mode.
- * The interpolation's search over the frame's sample abscissae runs in LDS (copied once per workgroup); the RGB8 bytes of a
- * wave's 64 pixels are transposed through LDS and stored as 48 dwords. */
-constexpr unsigned kEffLdsSamples = 2048;       /* abscissae staged per workgroup (16 KiB); longer tables are searched in global memory */
-constexpr unsigned kEffGroupsPerBlock = 16;     /* groups of 256 pixels a workgroup walks */
-constexpr unsigned kEffPixelsPerGroup = 256u * kEffGroupsPerBlock;
+ * Grid: (groups of 256 pixels, frames) -- the frame index is uniform, the camera and the frame's constants come in through
+ * scalar loads.  Statistics (escaped to +l / -l, black, texel index clamped) are reduced per WORKGROUP -- ballots and
+ * population counts per wave, LDS across the four waves -- and then added to the frame's counters by one lane; the counters are
+ * spread over 64 cache lines per frame.  Round 5 found the first version, in which every WAVE added its counts straight to one of
+ * 8 lines per frame, spending 42 % of its time in those atomics (a million waves per 32-frame launch: without the statistics the
+ * same kernel ran 0.057 instead of 0.099 ms per 1080p frame) -- and this kernel is more than half of the GPU time of
+ * `curvis video` in the reference's default mode.  (Walking several groups per workgroup to reduce even less often was worse: the
+ * compiler hoists the frame's constants out of the loop into 155 VGPRs -- 3 waves per SIMD instead of 8 --, and as a
+ * non-inlined call the body spills.)  The RGB8 bytes of a wave's 64 pixels are transposed through LDS and stored as 48 dwords. */
 __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPixelParams P) {
-  __shared__ double s_x[kEffLdsSamples];
   __shared__ __attribute__((aligned(16))) unsigned char s_rgb[256 * 3];
-  __shared__ unsigned s_cnt[3];
+  __shared__ unsigned s_cnt[5];
   const unsigned f = blockIdx.y;
   const unsigned npix = P.W * P.H; /* < 2^32: checked on the host */
-  const unsigned off = P.tab_off[f], n = P.tab_n[f];
-  const bool staged = n >= 2u && n <= kEffLdsSamples;
-  if (staged)
-    for (unsigned k = threadIdx.x; k < n; k += blockDim.x) s_x[k] = P.sx[off + k];
-  if (threadIdx.x < 3u) s_cnt[threadIdx.x] = 0u;
-  __syncthreads();
-  const cvk::CameraParams &cam = P.cams[f];
-  const cvk::EfficientFrame &frame = P.frames[f];
-  const double *sx = staged ? (const double *)s_x : P.sx + off;
+  const unsigned pix = blockIdx.x * 256u + threadIdx.x;
+  const bool valid = pix < npix;
+  if (threadIdx.x < 5u) s_cnt[threadIdx.x] = 0u;
+  bool pos = false, neg = false, none = false, oob = false;
+  unsigned texel = 0xFF000000u;
+  if (valid) {
+    const unsigned py = pix / P.W, px = pix - py * P.W;
+    const unsigned off = P.tab_off[f], n = P.tab_n[f];
+    double fin[3], space;
+    cvk::efficient_pixel(P.cams[f], P.frames[f], px, py, P.sx + off, P.m_e + off, P.c_e + off, P.m_s + off, P.c_s + off, n, fin, space);
+    if (space == 1.0 || space == -1.0) { /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black } */
+      const cvk::SkyParams &S = P.sky[space == 1.0 ? 0 : 1];
+      unsigned tx, ty;
+      cvk::sky_indices(S, fin[0], fin[1], fin[2], tx, ty);
+      if (tx >= S.w || ty >= S.h) oob = true;
+      if (tx >= S.w) tx = S.w - 1;
+      if (ty >= S.h) ty = S.h - 1;
+      texel = S.texels[(size_t)ty * S.w + tx];
+      pos = (space == 1.0);
+      neg = (space == -1.0);
+    } else {
+      none = true;
+    }
+  }
   unsigned char *fb = P.fb + (size_t)f * npix * 3u;
-  /* dword stores need the frame to start on a 4-byte boundary (every frame of a batch does unless W*H*3 is not a multiple of 4) */
-  const bool dwords = ((((size_t)f * npix * 3u) & 3u) == 0u);
   const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  unsigned c_pn = 0u, c_no = 0u, c_rays = 0u; /* (+l | -l << 16), (black | clamped << 16): <= 16 each per thread */
-  const unsigned first = blockIdx.x * kEffPixelsPerGroup;
-#pragma unroll 1
-  for (unsigned g = 0; g < kEffGroupsPerBlock; ++g) {
-    const unsigned pix = first + g * 256u + threadIdx.x;
-    const bool valid = pix < npix;
-    if (first + g * 256u >= npix) break; /* the whole workgroup */
-    unsigned texel = 0xFF000000u;
-    if (valid) {
-      const unsigned py = pix / P.W, px = pix - py * P.W;
-      double fin[3], space;
-      cvk::efficient_pixel(cam, frame, px, py, sx, P.m_e + off, P.c_e + off, P.m_s + off, P.c_s + off, n, fin, space);
-      ++c_rays;
-      if (space == 1.0 || space == -1.0) { /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black } */
-        const cvk::SkyParams &S = P.sky[space == 1.0 ? 0 : 1];
-        unsigned tx, ty;
-        cvk::sky_indices(S, fin[0], fin[1], fin[2], tx, ty);
-        if (tx >= S.w || ty >= S.h) c_no += 1u << 16;
-        if (tx >= S.w) tx = S.w - 1;
-        if (ty >= S.h) ty = S.h - 1;
-        texel = S.texels[(size_t)ty * S.w + tx];
-        c_pn += space == 1.0 ? 1u : (1u << 16);
-      } else {
-        c_no += 1u;
-      }
-    }
-    if (dwords && __builtin_amdgcn_ballot_w64(valid) == ~0ull) {
-      unsigned char *sw = s_rgb + wave * 192u;
-      sw[3u * lane + 0u] = (unsigned char)(texel & 0xFF);
-      sw[3u * lane + 1u] = (unsigned char)((texel >> 8) & 0xFF);
-      sw[3u * lane + 2u] = (unsigned char)((texel >> 16) & 0xFF);
-      __builtin_amdgcn_wave_barrier(); /* LDS operations of one wave complete in order; the buffer is this wave's alone */
-      if (lane < 48u) reinterpret_cast<unsigned *>(fb + (size_t)(pix - lane) * 3u)[lane] = reinterpret_cast<const unsigned *>(sw)[lane];
-      __builtin_amdgcn_wave_barrier();
-    } else if (valid) {
-      unsigned char *dst = fb + (size_t)pix * 3u;
-      dst[0] = (unsigned char)(texel & 0xFF);
-      dst[1] = (unsigned char)((texel >> 8) & 0xFF);
-      dst[2] = (unsigned char)((texel >> 16) & 0xFF);
-    }
+  const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+  /* dword stores need the frame to start on a 4-byte boundary (every frame of a batch does unless W*H*3 is not a multiple of 4) */
+  if (vm == ~0ull && ((((size_t)f * npix * 3u) & 3u) == 0u)) {
+    unsigned char *sw = s_rgb + wave * 192u;
+    sw[3u * lane + 0u] = (unsigned char)(texel & 0xFF);
+    sw[3u * lane + 1u] = (unsigned char)((texel >> 8) & 0xFF);
+    sw[3u * lane + 2u] = (unsigned char)((texel >> 16) & 0xFF);
+    __builtin_amdgcn_wave_barrier(); /* LDS operations of one wave complete in order; the buffer is this wave's alone */
+    if (lane < 48u) reinterpret_cast<unsigned *>(fb + (size_t)(pix - lane) * 3u)[lane] = reinterpret_cast<const unsigned *>(sw)[lane];
+  } else if (valid) {
+    unsigned char *dst = fb + (size_t)pix * 3u;
+    dst[0] = (unsigned char)(texel & 0xFF);
+    dst[1] = (unsigned char)((texel >> 8) & 0xFF);
+    dst[2] = (unsigned char)((texel >> 16) & 0xFF);
   }
-  /* statistics: per wave by shuffles (fields <= 16 x 64 = 1024 fit their 16 bits), per workgroup in LDS, then one set of atomics */
-  for (int o = 32; o > 0; o >>= 1) {
-    c_pn += __shfl_xor(c_pn, o, 64);
-    c_no += __shfl_xor(c_no, o, 64);
-    c_rays += __shfl_xor(c_rays, o, 64);
-  }
-  if (lane == 0u) {
-    atomicAdd(&s_cnt[0], c_pn);
-    atomicAdd(&s_cnt[1], c_no);
-    atomicAdd(&s_cnt[2], c_rays);
+  /* statistics: ballots per wave, LDS across the waves, one lane of the workgroup for the frame's counters */
+  const unsigned n_pos = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(pos)), n_neg = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(neg));
+  const unsigned n_none = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(none)), n_oob = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(oob));
+  __syncthreads(); /* s_cnt cleared */
+  if (lane == 0u && vm) {
+    atomicAdd(&s_cnt[0], (unsigned)__popcll(vm));
+    if (n_pos) atomicAdd(&s_cnt[1], n_pos);
+    if (n_neg) atomicAdd(&s_cnt[2], n_neg);
+    if (n_none) atomicAdd(&s_cnt[3], n_none);
+    if (n_oob) atomicAdd(&s_cnt[4], n_oob);
   }
   __syncthreads();
-  if (threadIdx.x == 0u && s_cnt[2]) {
+  if (threadIdx.x == 0u && s_cnt[0]) {
     unsigned long long *c = frame_counter_line(P.counters, f);
-    atomicAdd(&c[FC_RAYS], (unsigned long long)s_cnt[2]);
-    if (s_cnt[0] & 0xffffu) atomicAdd(&c[FC_POS], (unsigned long long)(s_cnt[0] & 0xffffu));
-    if (s_cnt[0] >> 16) atomicAdd(&c[FC_NEG], (unsigned long long)(s_cnt[0] >> 16));
-    if (s_cnt[1] & 0xffffu) atomicAdd(&c[FC_NONE], (unsigned long long)(s_cnt[1] & 0xffffu));
-    if (s_cnt[1] >> 16) atomicAdd(&c[FC_OOB], (unsigned long long)(s_cnt[1] >> 16));
+    atomicAdd(&c[FC_RAYS], (unsigned long long)s_cnt[0]);
+    if (s_cnt[1]) atomicAdd(&c[FC_POS], (unsigned long long)s_cnt[1]);
+    if (s_cnt[2]) atomicAdd(&c[FC_NEG], (unsigned long long)s_cnt[2]);
+    if (s_cnt[3]) atomicAdd(&c[FC_NONE], (unsigned long long)s_cnt[3]);
+    if (s_cnt[4]) atomicAdd(&c[FC_OOB], (unsigned long long)s_cnt[4]);
   }
 }
 

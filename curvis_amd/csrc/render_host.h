@@ -136,8 +136,8 @@ int ensure_device(curvis_ctx *ctx, T *&ptr, size_t &cap, size_t need) {
 }
 
 /* counter block for a launch of n_frames frames: device block + pinned mirror, zeroed on the stream */
-int prepare_counters(curvis_ctx *ctx, unsigned n_frames, FrameCounters &C) {
-  C.slots = counter_slots_for(n_frames);
+int prepare_counters(curvis_ctx *ctx, unsigned n_frames, FrameCounters &C, unsigned slots = 0u) {
+  C.slots = slots ? slots : counter_slots_for(n_frames); /* a power of two */
   const size_t words = counter_words(n_frames, C.slots);
   int rc = ensure_device(ctx, ctx->d_counters, ctx->counters_cap, words);
   if (rc) return rc;
