@@ -28,6 +28,7 @@ CELLS = [(c, b) for c in CS for b in BS]
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     fps = float(os.environ.get("SWEEP_FPS", "500"))
+    mode = os.environ.get("SWEEP_MODE", "efficient")   # "brute": the per-pixel integrator (configs[3]); use SWEEP_FPS=8 (480 frames)
     base = None  # a RAM file system when it has room for a cell's frames (~0.1 MB each), else the default temporary directory
     try:
         st = os.statvfs("/dev/shm")
@@ -44,13 +45,13 @@ def main():
                          "sampling_max_iterations = 50\nsampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 1e-5\n")
     open(cam, "w").write("resolution_x = 1920\nresolution_y = 1080\ndiagonal = 43.0\nfocal_length = 15.0\n")
     open(vid, "w").write('video_name = "v"\nframe_rate = %r\nfilepath_to_camera_path = "%s"\n' % (fps, paths.path_file("path_orbit.csv")))
-    print("# curvis video --mode efficient, 1920x1080, path_orbit.csv at %g fps, ONE MI355X, device PNG front end, 16 writer threads, output in %s" % (fps, d))
+    print("# curvis video --mode %s, 1920x1080, path_orbit.csv at %g fps, ONE MI355X, device PNG front end, 16 writer threads, output in %s" % (mode, fps, d))
     print("# host: %d logical CPUs visible, cgroup CPU quota %s; %d interleaved rounds over the %d cells" % (os.cpu_count(), V.cpu_quota(), rounds, len(CELLS)))
     res = {cell: [] for cell in CELLS}
     for rnd in range(rounds):
         for (c, b) in CELLS:
             s = V.run(d, "c%d_b%d_r%d" % (c, b, rnd), sky, vid, cam, sim,
-                      ["--gpu-png", "on", "--writers", "16", "--contexts-per-device", str(c), "--batch", str(b)], None, mode="efficient")
+                      ["--gpu-png", "on", "--writers", "16", "--contexts-per-device", str(c), "--batch", str(b)], None, mode=mode)
             if not s:
                 continue
             dv = s["devices"]
