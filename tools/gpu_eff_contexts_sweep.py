@@ -51,7 +51,7 @@ def main():
     for rnd in range(rounds):
         for (c, b) in CELLS:
             s = V.run(d, "c%d_b%d_r%d" % (c, b, rnd), sky, vid, cam, sim,
-                      ["--gpu-png", "on", "--writers", "16", "--contexts-per-device", str(c), "--batch", str(b)], None, mode=mode)
+                      ["--gpu-png", "on", "--writers", os.environ.get("SWEEP_WRITERS", "16"), "--contexts-per-device", str(c), "--batch", str(b)], None, mode=mode)
             if not s:
                 continue
             dv = s["devices"]
