@@ -115,6 +115,7 @@ SYMBOLS = {
     "curvis_ctx_download": (C.c_int, [_vp, _vp, C.c_size_t]),
     "curvis_ctx_upload": (C.c_int, [_vp, _vp, C.c_size_t]),
     "curvis_ctx_synchronize": (C.c_int, [_vp]),
+    "curvis_ctx_download_wait": (C.c_int, [_vp]),
     "curvis_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "curvis_ctx_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "curvis_device_link": (C.c_int, [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 5),

@@ -121,9 +121,14 @@ void curvis_ctx_destroy(curvis_ctx *ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream); /* a download still in flight reads d_fb / d_fb_alt */
   for (int s = 0; s < 2; ++s)
     if (ctx->d_sky[s] && ctx->sky_owned[s]) (void)hipFree(ctx->d_sky[s]);
   if (ctx->d_fb) (void)hipFree(ctx->d_fb);
+  if (ctx->d_fb_alt) (void)hipFree(ctx->d_fb_alt);
+  if (ctx->ev_fb) (void)hipEventDestroy(ctx->ev_fb);
+  if (ctx->ev_dl) (void)hipEventDestroy(ctx->ev_dl);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
   if (ctx->d_store) (void)hipFree(ctx->d_store);
   if (ctx->d_rq) (void)hipFree(ctx->d_rq);
@@ -832,7 +837,7 @@ int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes) {
 int curvis_ctx_upload(curvis_ctx *ctx, const uint8_t *rgb, size_t bytes) {
   if (!ctx || !rgb || bytes == 0) return fail(ctx, CURVIS_E_INVALID, "bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, bytes);
+  const int rc = fb_begin_write(ctx, bytes);
   if (rc) return rc;
   ctx->fb_bytes = bytes;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_fb, rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -844,6 +849,13 @@ int curvis_ctx_synchronize(curvis_ctx *ctx) {
   if (!ctx) return CURVIS_E_INVALID;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return CURVIS_OK;
+}
+
+/* option "async_download": the frames of the last render call that was given `rgb_out` are in host memory on return */
+int curvis_ctx_download_wait(curvis_ctx *ctx) {
+  if (!ctx) return CURVIS_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return download_wait(ctx);
 }
 
 int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
@@ -865,7 +877,14 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->relay_max_parks = (int)value;
   else if (k == "relay_recheck_every")
     ctx->relay_recheck_every = (int)value;
-  else if (k == "relay_max_frames")
+  else if (k == "async_download") { /* overlapped download of the frames, see fb_download (render_host.h) */
+    if (!value) {
+      HIP_TRY(ctx, hipSetDevice(ctx->device));
+      const int rc = download_wait(ctx);
+      if (rc) return rc;
+    }
+    ctx->async_download = value ? 1 : 0;
+  } else if (k == "relay_max_frames")
     ctx->relay_max_frames = (int)value;
   else if (k == "relay_min_blocks")
     ctx->relay_min_blocks = (long long)value;
@@ -939,6 +958,12 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->last_png_passes;
   else if (k == "relay_recheck_every")
     *value = ctx->relay_recheck_every;
+  else if (k == "async_download")
+    *value = ctx->async_download;
+  else if (k == "downloads_overlapped")
+    *value = (int64_t)ctx->downloads_overlapped;
+  else if (k == "download_pending")
+    *value = ctx->dl_pending ? 1 : 0;
   else if (k == "relay_fallbacks")
     *value = ctx->relay_fallbacks;
   else if (k == "last_frames")

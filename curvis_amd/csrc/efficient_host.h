@@ -369,7 +369,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   const size_t npix = (size_t)W * H;
   if (npix > 0xFFFFFFFFull || n_frames > 65535u) return fail(ctx, CURVIS_E_INVALID, "frame or batch too large");
   const size_t fb_bytes = npix * 3 * n_frames;
-  rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, fb_bytes);
+  rc = fb_begin_write(ctx, fb_bytes);
   if (rc) return rc;
   ctx->fb_bytes = fb_bytes;
   const size_t T = sx.size();
@@ -429,8 +429,12 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words,
                               hipMemcpyDeviceToHost, ctx->stream));
-  if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (rgb_out) {
+    rc = fb_download(ctx, rgb_out, fb_bytes); /* leaves the stream idle; option "async_download": the frames follow */
+    if (rc) return rc;
+  } else {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   float ms = 0.f;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   uint64_t tot[FC_N] = {0};
@@ -515,7 +519,7 @@ int render_direct_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvi
   P.delta = delta;
   P.fast_ok = cvk::metric_fast_ok(metric->kind, P.metric, max_radius) ? 1 : 0;
   const size_t npix = (size_t)W * H, fb_bytes = npix * 3;
-  rc = ensure_device(ctx, ctx->d_fb, ctx->fb_cap, fb_bytes);
+  rc = fb_begin_write(ctx, fb_bytes);
   if (rc) return rc;
   ctx->fb_bytes = fb_bytes;
   P.fb = ctx->d_fb;
@@ -540,8 +544,12 @@ int render_direct_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvi
   if (rc) return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words, hipMemcpyDeviceToHost, ctx->stream));
-  if (rgb_out) HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, fb_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (rgb_out) {
+    rc = fb_download(ctx, rgb_out, fb_bytes); /* leaves the stream idle; option "async_download": the frames follow */
+    if (rc) return rc;
+  } else {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   float ms = 0.f;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   uint64_t fc[FC_N];

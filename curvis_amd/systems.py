@@ -409,6 +409,11 @@ class Context:
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         check(lib().curvis_ctx_upload(self._h, rgb.ctypes.data, rgb.size), self._h)
 
+    def download_wait(self):
+        """curvis_ctx_download_wait: with option "async_download" = 1, the frames of the last render call that was given
+        an output buffer are in host memory when this returns (they also are once the NEXT such call has returned)"""
+        check(lib().curvis_ctx_download_wait(self._h), self._h)
+
     def download_frames(self, width, height, n_frames=1):
         """curvis_ctx_download: the frames the last render call left in HBM as an n x H x W x 3 uint8 array"""
         rgb = np.empty((int(n_frames), int(height), int(width), 3), dtype=np.uint8)
@@ -458,8 +463,9 @@ class Context:
         return rgb, st
 
     def render_efficient(self, metric, cameras, max_iterations_propagation, max_radius, delta, alpha_nums,
-                         max_iterations_sampling, thr1, thr2, download=True):
-        """render_image_efficient for one Camera or a list (samplers advance in lock step)."""
+                         max_iterations_sampling, thr1, thr2, download=True, out=None):
+        """render_image_efficient for one Camera or a list (samplers advance in lock step).
+        out: as in render_brute (a page-locked HostBuffer array to receive the frames)."""
         single = isinstance(cameras, Camera)
         cams = [cameras] if single else list(cameras)
         n = len(cams)
@@ -467,7 +473,12 @@ class Context:
         arr = (CameraC * n)(*[c._c for c in cams])
         m = metric._c()
         st = Stats()
-        rgb = np.empty((n, H, W, 3), dtype=np.uint8) if download else None
+        if out is not None:
+            if out.dtype != np.uint8 or out.size < n * H * W * 3 or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous uint8 array of at least n*H*W*3 bytes")
+            rgb, download = out.reshape(-1)[:n * H * W * 3].reshape(n, H, W, 3), True
+        else:
+            rgb = np.empty((n, H, W, 3), dtype=np.uint8) if download else None
         check(lib().curvis_render_efficient_batch(self._h, C.byref(m), arr, n, max_iterations_propagation, max_radius,
                                                   delta, alpha_nums, max_iterations_sampling, thr1, thr2,
                                                   rgb.ctypes.data if download else None, C.byref(st)), self._h)
@@ -475,13 +486,18 @@ class Context:
             rgb = rgb[0]
         return rgb, st
 
-    def render_direct(self, metric, camera, max_iterations, max_radius, delta, download=True):
+    def render_direct(self, metric, camera, max_iterations, max_radius, delta, download=True, out=None):
         """"direct" mode (not in the reference): compute_escape_angle for the alpha of every pixel instead of sampling and
         interpolating (curvis_render_direct).  Returns (rgb or None, stats)."""
         W, H = camera.resolution_width, camera.resolution_height
         m = metric._c()
         st = Stats()
-        rgb = np.empty((H, W, 3), dtype=np.uint8) if download else None
+        if out is not None:
+            if out.dtype != np.uint8 or out.size < H * W * 3 or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous uint8 array of at least H*W*3 bytes")
+            rgb, download = out.reshape(-1)[:H * W * 3].reshape(H, W, 3), True
+        else:
+            rgb = np.empty((H, W, 3), dtype=np.uint8) if download else None
         check(lib().curvis_render_direct(self._h, C.byref(m), C.byref(camera._c), max_iterations, max_radius, delta,
                                          rgb.ctypes.data if download else None, C.byref(st)), self._h)
         return rgb, st

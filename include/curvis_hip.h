@@ -321,6 +321,19 @@ int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);
  * curvis_ctx_deflate_frames then compresses */
 int curvis_ctx_upload(curvis_ctx *ctx, const uint8_t *rgb, size_t bytes);
 int curvis_ctx_synchronize(curvis_ctx *ctx);
+/* Overlapped download (option "async_download" = 1, default 0).  The reference's render_image returns an owned host
+ * image (src/systems.rs:314-329), so a host that renders frame after frame pays the PCIe copy behind every kernel
+ * (+0.25 ms on a 10.2 ms 1080p frame).  With the option set, a render call given `rgb_out` (brute, rows, batch, efficient,
+ * direct) returns as soon as its kernels have finished and its statistics are valid, with the copy into `rgb_out` QUEUED
+ * on a copy stream of the context; the next call renders into a second frame buffer while the copy engine drains the
+ * first.  A pipeline one frame deep: `rgb_out` of call k is complete when call k + 1 with an `rgb_out` on the same
+ * context returns, or when curvis_ctx_download_wait returns -- not before.  `rgb_out` should come from
+ * curvis_host_alloc (into pageable memory the runtime's copy is not asynchronous; still correct).  Everything that reads
+ * "the frames of the last render" (curvis_ctx_deflate_frames, curvis_ctx_download, curvis_ctx_framebuffer) keeps seeing them;
+ * the device pointer curvis_ctx_framebuffer returns alternates between two buffers from call to call.  Setting the
+ * option back to 0 waits for the download in flight, and so does curvis_ctx_destroy.  get_option: "downloads_overlapped"
+ * (so far), "download_pending" (0 / 1). */
+int curvis_ctx_download_wait(curvis_ctx *ctx);
 
 /* tuning knobs (not part of the reference surface): "variant" (-1 = automatic, the default: the static
  * one-ray-per-thread kernel, and for launches of up to "relay_max_frames" (default 8) frames with at least "relay_min_blocks" workgroups

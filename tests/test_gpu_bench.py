@@ -139,6 +139,9 @@ def test_default_line_clock_agrees_with_itself_and_carries_the_download_figure()
         assert abs(eff - sus) / sus < 0.05, (eff, sus)
     dl = out["value_with_download"]
     assert dl["steps"] == out["steps"] and 0.5 < dl["fraction_of_value"] <= 1.02 and dl["delta_ms_per_step"] > -0.5
+    ov = dl["overlapped"]                                   # option async_download: the DMA of frame k under the kernel of frame k + 1
+    assert "failed" not in ov, ov
+    assert ov["value"] >= dl["value"] * 0.99 and 0.5 < ov["fraction_of_value"] <= 1.03, (ov, dl)
 
 
 def test_single_rank_over_rccl_takes_the_multi_gpu_code_path():
