@@ -22,11 +22,13 @@ CAP, R, DELTA = 4096, 100.0, 0.05
 
 
 def poses(n):
-    """n cameras on the orbit of configs[3] (l = 3) -- every frame differs from its neighbours"""
+    """n cameras that give n different frames: radial positions from both sides of the throat, the view tilted a little more
+    each time (a camera's phi alone would not do: the per-pixel path looks the sky up by the photon's final MOMENTUM
+    direction, src/metrics.rs:339-349, so frames along the orbit of configs[3] are identical)"""
     out = []
     for k in range(n):
-        phi = 2.0 * np.pi * k / n
-        out.append(((0.0, 3.0, common.HALF_PI, phi), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0)))
+        l = (-1.0) ** k * (1.5 + 0.6 * k)
+        out.append(((0.0, l, common.HALF_PI, 0.3 * k), (-1.0, 0.05 * k, 0.02 * k), (0.0, 0.0, 1.0)))
     return out
 
 
@@ -58,7 +60,7 @@ def test_pipelined_frames_equal_synchronous_frames(ctx, metric):
         rgb, st = c.render_brute(pm, pc, CAP, R, DELTA)
         want.append(rgb.copy())
         want_st.append((st.rays, st.steps, st.n_pos, st.n_neg, st.n_none))
-    assert any(not np.array_equal(want[0], w) for w in want[1:])      # the frames really differ
+    assert all(not np.array_equal(want[i], want[j]) for i in range(n) for j in range(i))   # the frames really differ
     bufs = [curvis_amd.HostBuffer(W * H * 3) for _ in range(2)]
     c.set_option("async_download", 1)
     try:
@@ -87,6 +89,7 @@ def test_last_render_stays_visible_to_download_and_deflate(ctx):
     c, sp, sn = ctx
     scenes = cams_of("ellis", 5)
     sync = [c.render_brute(pm, pc, CAP, R, DELTA)[0].copy() for pm, pc in scenes]
+    assert all(not np.array_equal(sync[i], sync[j]) for i in range(len(sync)) for j in range(i))
     bufs = [curvis_amd.HostBuffer(W * H * 3) for _ in range(2)]
     c.set_option("async_download", 1)
     try:
