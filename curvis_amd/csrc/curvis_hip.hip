@@ -956,6 +956,8 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->png_path;
   else if (k == "last_png_passes")
     *value = ctx->last_png_passes;
+  else if (k == "last_png_stream_bytes")
+    *value = (int64_t)ctx->last_png_stream_bytes;
   else if (k == "relay_recheck_every")
     *value = ctx->relay_recheck_every;
   else if (k == "async_download")

@@ -10,6 +10,7 @@ struct Args {
   std::string sub, bg1, bg2, out, image_toml, video_toml, metric_toml, camera_toml, sim_toml, mode = "efficient", stats,
       sky_broadcast = "rccl";
   bool sky_broadcast_explicit = false, resume = false;
+  bool contexts_auto = false; /* --contexts-per-device 0 / not given: video_main may lower the count for short videos */
   int contexts = 0; /* 0 = automatic (4 in --mode efficient, else 1); video: contexts (= host worker threads) per device: while one waits on the host-side sampler or the D2H copy another's kernels run */
   int devices = 1, device = 0, batch = 0, writers = 0; /* batch 0 = automatic (video: 8 frames per launch, in --mode efficient up to 32: cli_video.h); writers 0 = automatic: a quarter of the host's threads, 4..64 */
   int png_level = -1; /* -1 = the fast PNG writer (png_io.h; the reference's image crate also saves with its fast setting), 0..9 = zlib */
@@ -108,12 +109,25 @@ Args parse_args(int argc, char **argv) {
   }
   /* four contexts per GPU in --mode efficient -- as far as the host has two CPUs per worker thread (each context's thread runs
    * the sampler's host side; 8 GPUs behind a 16-CPU quota get one context each, not 32 threads fighting the writers) */
+  a.contexts_auto = a.contexts == 0;
   if (a.contexts == 0) a.contexts = a.mode == "efficient" ? (int)std::max(1u, std::min(4u, cpus / (2u * (unsigned)a.devices))) : 1;
   if (a.batch < 0) a.batch = 0;
   if (a.writers < 1) /* encoding a 1080p frame costs 5-25 ms of a host thread (zlib: 20-230): the GPU renders one in 0.4-10 ms */
     a.writers = (int)std::min(64u, std::max(4u, hw / 4u));
   return a;
 }
+
+/* CURVIS_DEBUG_TIMING=1: the phases of a run on stderr (settings, background images, contexts, render, save) */
+struct PhaseClock {
+  const bool on = std::getenv("CURVIS_DEBUG_TIMING") != nullptr;
+  double t0 = pngio::now_s(), last = t0;
+  void mark(const char *what) {
+    if (!on) return;
+    const double t = pngio::now_s();
+    std::fprintf(stderr, "[curvis timing] %-34s %8.1f ms  (at %8.1f ms)\n", what, (t - last) * 1e3, (t - t0) * 1e3);
+    last = t;
+  }
+};
 
 struct Common {
   curvis_metric metric{CURVIS_METRIC_ELLIS, 0, 1.0, 0.0, 0.0}; /* default: Ellis rho = 1 (ellis_metric_settings.toml) */

@@ -14,7 +14,9 @@ int image_main(const Args &a) {
     if (!path_exists(a.image_toml)) die("Error with image settings: File \"" + a.image_toml + "\" not found.");
     if (!from_toml(a.image_toml, is, err)) die("Error with image settings: " + err);
   }
+  PhaseClock clk;
   load_common(a, c, "image");
+  clk.mark("settings + background images");
   if (is.image_name.empty()) die("Error in rendering image: Image name cannot be an empty string.");
   const double pos[4] = {is.t, is.l, is.theta, is.phi}, fwd[3] = {is.forward_x, is.forward_y, is.forward_z},
                up[3] = {is.up_x, is.up_y, is.up_z};
@@ -23,6 +25,7 @@ int image_main(const Args &a) {
   if (rc == CURVIS_E_PARALLEL) die("Error in rendering image: Forward and up vectors must not be parallel", 101);
   if (rc != CURVIS_OK) die("Error in rendering image: invalid camera settings");
   curvis_ctx *ctx = make_ctx(a.device, c, "image");
+  clk.mark("context + sky upload");
   if (!path_exists(c.out) && ::mkdir(c.out.c_str(), 0777) != 0)
     die("Error in rendering image: Could not create video output folder \"" + c.out + "\"");
   std::vector<uint8_t> rgb((size_t)cam.res_x * cam.res_y * 3);
@@ -65,10 +68,12 @@ int image_main(const Args &a) {
   } else {
     check(render_frames(ctx, a, c, &cam, 1, c.sim.sampling_convergence_threshold_2, rgb.data(), &st), ctx, "image");
   }
+  clk.mark("render");
   /* PathBuf::join(image_name).with_extension("png") (src/rendering.rs:108): an existing extension is REPLACED */
   const std::string file = (std::filesystem::path(c.out) / std::filesystem::path(is.image_name).replace_extension("png")).string();
   if (!pngio::save_rgb8(file, rgb.data(), cam.res_x, cam.res_y, err, a.png_level))
     die("Error in rendering image: Could not save image frame \"" + file + "\" due to error: " + err);
+  clk.mark("PNG encode + write");
   if (!a.stats.empty()) {
     FILE *f = std::fopen(a.stats.c_str(), "w");
     if (f) {

@@ -15,7 +15,9 @@ int video_main(const Args &a_in) {
     if (!path_exists(a.video_toml)) die("Error with video settings: File \"" + a.video_toml + "\" not found.");
     if (!from_toml(a.video_toml, vs, err)) die("Error with video settings: " + err);
   }
+  PhaseClock clk;
   load_common(a, c, "video");
+  clk.mark("settings + background images");
   if (a.batch < 1) {
     /* frames per launch.  The per-pixel modes keep the GPU busy with 8 frames per launch.  --mode efficient is launch- and
      * host-paced (lone waves between host-side sampler rounds): longer batches amortise both -- 1 568 / 2 202 / 2 757 frames/s at
@@ -87,16 +89,25 @@ int video_main(const Args &a_in) {
     size_t frames = 0, batches = 0;
     double render_s = 0, kernel_ms = 0, submit_s = 0, wait_s = 0, busy_s = 0, pool_wait_s = 0;
     double png_ms = 0; /* device PNG front end: HIP-event time of its kernels */
-    size_t png_frames = 0, png_fallback_frames = 0;
+    size_t png_frames = 0, png_fallback_frames = 0, png_regrown = 0; /* png_regrown: batches whose streams needed a larger buffer */
     double sky_s = 0, sky_bcast_s = 0; /* skies into this device's HBM: all of it / the curvis_ctx_bcast_skies call alone */
     unsigned long long steps = 0;
   };
   /* workers = devices x contexts-per-device; worker r drives device r / contexts with a context of its own (`--mode efficient`
    * spends half of a frame's render call on the host -- the adaptive sampler between its launches --, so a second context
    * on the same GPU fills the gaps) */
+  if (a.contexts_auto && a.contexts > 1) {
+    /* every extra context costs a start-up of its own (stream, buffers, first launches: ~30-50 ms) and pays only over enough
+     * frames: 240 / 960 / 2 400 / 6 000 1080p frames on one GPU took 0.63 / 0.91 / 1.36 / 2.46 s with one context, 0.64 / 0.77 /
+     * 1.11 / 1.76 s with two, 0.71 / 0.85 / 1.04 / 1.50 s with four (profiles/round5_cli_startup.txt) */
+    const size_t per_device = (n_frames + (size_t)a.devices - 1) / (size_t)a.devices;
+    const int cap = per_device < 600 ? 1 : per_device < 2000 ? 2 : a.contexts;
+    a.contexts = std::min(a.contexts, cap);
+  }
   const int n_workers = a.devices * a.contexts;
   auto device_of = [&](int rank) { return a.device + rank / a.contexts; };
   std::vector<DeviceSummary> dev_sum((size_t)n_workers);
+  clk.mark("camera path, folders");
   std::vector<std::unique_ptr<PinnedPool>> pools((size_t)n_workers); /* destroyed after writers.finish() below */
   const double t_video0 = pngio::now_s();
   /* sky distribution: rank 0 uploads the two textures once; with --sky-broadcast rccl (default for
@@ -171,7 +182,15 @@ int video_main(const Args &a_in) {
   int fail_rank = -1, fail_call = -1;
   if (const char *fi = std::getenv("CURVIS_TEST_FAIL_BATCH")) std::sscanf(fi, "%d:%d", &fail_rank, &fail_call);
   auto worker = [&](int rank) {
+    const double t_w_start = pngio::now_s();
+    auto wmark = [&](const char *what) { /* CURVIS_DEBUG_TIMING: where a worker's start-up goes */
+      if (clk.on) {
+        std::lock_guard<std::mutex> gi(io_mu);
+        std::fprintf(stderr, "[curvis timing]   worker %d: %-24s at %8.1f ms of the worker\n", rank, what, (pngio::now_s() - t_w_start) * 1e3);
+      }
+    };
     curvis_ctx *ctx = make_ctx_bare(share_device ? a.device : device_of(rank), "video");
+    wmark("context created");
     DeviceSummary &ds = dev_sum[(size_t)rank];
     {
       char id[64] = {0};
@@ -202,16 +221,25 @@ int video_main(const Args &a_in) {
       upload_skies(ctx, c, "video");
     }
     ds.sky_s = pngio::now_s() - t_worker0;
+    wmark("skies in HBM");
     std::vector<curvis_camera> bc;
     std::vector<uint8_t> rgb_pageable; /* only if page-locked memory could not be had */
     /* one being filled, up to two with the writers.  The pool belongs to video_main's scope: writer jobs hold its
      * buffers (and its mutex, through the deleter) after this worker has returned */
-    pools[(size_t)rank].reset(new PinnedPool((size_t)a.batch * fbytes, 3));
+    /* With the device PNG front end a batch buffer receives zlib streams, not pixels: an eighth of the raw size holds what
+     * rendered frames compress to several times over (0.05-0.7 MB per 6.2 MB frame); a batch that does not fit (frames that do
+     * not compress) takes the fall-back below through pageable memory. */
+    const size_t pool_bytes = gpu_png ? std::max<size_t>((size_t)8 << 20, (size_t)a.batch * fbytes / 8) : (size_t)a.batch * fbytes;
+    size_t pool_first = std::min(pool_bytes, (size_t)a.batch * fbytes);
+    if (const char *tb = std::getenv("CURVIS_TEST_STREAM_POOL_BYTES")) /* test hook: start with buffers this small, so that the growth path runs */
+      if (gpu_png) pool_first = std::max<size_t>(64, (size_t)std::atoll(tb));
+    pools[(size_t)rank].reset(new PinnedPool(pool_first, 3));
     PinnedPool &pool = *pools[(size_t)rank];
     if (pool.buffers() < 2) {
       std::lock_guard<std::mutex> gi(io_mu);
       std::fprintf(stderr, "warning: device %d: no page-locked host memory for the frame buffers, using pageable memory\n", device_of(rank));
     }
+    wmark("page-locked buffers");
     int calls = 0;
     for (;;) {
       Batch b;
@@ -222,7 +250,9 @@ int video_main(const Args &a_in) {
             g.unlock();
             q_cv.notify_all(); /* nobody may sleep on while the others leave */
             ds.busy_s = pngio::now_s() - t_worker0;
+            wmark("last batch done");
             curvis_ctx_destroy(ctx);
+            wmark("context destroyed");
             return;
           }
           auto it = retry.begin();
@@ -251,8 +281,8 @@ int video_main(const Args &a_in) {
       for (size_t j = 0; j < nb; ++j) bc.push_back(cams[b.frames[j]]);
       std::shared_ptr<uint8_t> batch_buf;
       uint8_t *rgb_ptr = nullptr;
-      if (pool.buffers() >= 2) {
-        batch_buf = pool.take(&ds.pool_wait_s);
+      if (pool.buffers() >= 2) batch_buf = pool.take(&ds.pool_wait_s);
+      if (batch_buf) {
         rgb_ptr = batch_buf.get();
       } else {
         rgb_pageable.resize(nb * fbytes);
@@ -272,17 +302,43 @@ int video_main(const Args &a_in) {
         zoff.resize(nb + 1);
         double pms = 0.0;
         /* test hook: pretend the streams do not fit (frames that do not compress), so that the fall-back below runs */
-        const size_t zcap = std::getenv("CURVIS_TEST_SMALL_PNG_BUFFER") ? (size_t)64 : batch_buf ? (size_t)a.batch * fbytes : nb * fbytes;
+        const size_t zcap = std::getenv("CURVIS_TEST_SMALL_PNG_BUFFER") ? (size_t)64 : batch_buf ? pool.bytes_each() : nb * fbytes;
         zcrc.assign(nb, 0u);
         int crc_ok = 0;
-        const int zrc = curvis_ctx_deflate_frames_crc(ctx, c.cam.resolution_x, c.cam.resolution_y, (uint32_t)nb, rgb_ptr, zcap, zoff.data(), &pms,
-                                                      zcrc.data(), &crc_ok);
+        int zrc = curvis_ctx_deflate_frames_crc(ctx, c.cam.resolution_x, c.cam.resolution_y, (uint32_t)nb, rgb_ptr, zcap, zoff.data(), &pms,
+                                                zcrc.data(), &crc_ok);
+        if (zrc != CURVIS_OK && batch_buf && !std::getenv("CURVIS_TEST_SMALL_PNG_BUFFER")) {
+          /* the streams need more than the stream-sized buffer holds (backgrounds that compress badly): the pool hands out
+           * larger buffers from now on -- half as much again as this batch needs, the raw size at most -- and the streams are
+           * made once more (their kernels take ~0.02 ms per 1080p frame) */
+          int64_t need = 0;
+          (void)curvis_ctx_get_option(ctx, "last_png_stream_bytes", &need);
+          if (need > 0 && (size_t)need > pool.bytes_each() && (size_t)need <= (size_t)a.batch * fbytes) {
+            pool.resize(std::min((size_t)a.batch * fbytes, (size_t)need + (size_t)need / 2));
+            batch_buf.reset(); /* back to the pool, which lets go of it */
+            batch_buf = pool.take(&ds.pool_wait_s);
+            if (batch_buf) {
+              rgb_ptr = batch_buf.get();
+              zrc = curvis_ctx_deflate_frames_crc(ctx, c.cam.resolution_x, c.cam.resolution_y, (uint32_t)nb, rgb_ptr, pool.bytes_each(), zoff.data(),
+                                                  &pms, zcrc.data(), &crc_ok);
+              ds.png_regrown += 1;
+            } else {
+              rgb_pageable.resize(nb * fbytes);
+              rgb_ptr = rgb_pageable.data();
+            }
+          }
+        }
         have_crc = crc_ok != 0;
         if (zrc == CURVIS_OK) {
           streams = true;
           ds.png_ms += pms;
           ds.png_frames += nb;
         } else {
+          if (batch_buf && pool.bytes_each() < nb * fbytes) { /* the stream-sized buffer cannot take the pixels: pageable memory, copied per frame below */
+            batch_buf.reset();
+            rgb_pageable.resize(nb * fbytes);
+            rgb_ptr = rgb_pageable.data();
+          }
           rc = curvis_ctx_download(ctx, rgb_ptr, nb * fbytes);
           ds.png_fallback_frames += nb;
         }
@@ -399,9 +455,12 @@ int video_main(const Args &a_in) {
   for (auto &t : th) t.join();
   for (ncclComm_t cm : comms) ncclCommDestroy(cm);
   const double t_workers_done = pngio::now_s();
+  clk.mark("device workers (contexts, skies, frames)");
   writers.finish();
+  clk.mark("writer drain");
   pools.clear(); /* every writer job is done: the page-locked buffers can go */
   const double t_video1 = pngio::now_s();
+  clk.mark("page-locked buffers released");
   if (stats_f) std::fclose(stats_f);
   if (!a.stats.empty()) { /* <stats>.summary.json + a table: who rendered what at which clock, where the host's time went */
     const double wall = t_video1 - t_video0;
@@ -457,10 +516,10 @@ int video_main(const Args &a_in) {
                     "%s{\"device\": %zu, \"pci_bus_id\": \"%s\", \"frames\": %zu, \"batches\": %zu, \"kernel_ms_per_frame\": %.4f, "
                     "\"render_call_ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"mray_steps_per_s\": %.1f, \"sclk_mhz\": %d, \"power_w\": %d, "
                     "\"wait_s\": %.3f, \"hand_over_s\": %.3f, \"buffer_wait_s\": %.3f, \"busy_s\": %.3f, \"gpu_png_frames\": %zu, "
-                    "\"gpu_png_kernel_ms_per_frame\": %.4f, \"gpu_png_fallback_frames\": %zu}",
+                    "\"gpu_png_kernel_ms_per_frame\": %.4f, \"gpu_png_fallback_frames\": %zu, \"gpu_png_buffer_regrown\": %zu}",
                     r ? ", " : "", (size_t)device_of((int)r), d.pci_bus_id.c_str(), d.frames, d.batches, kf, rf, d.busy_s > 0 ? d.frames / d.busy_s : 0.0,
                     d.kernel_ms > 0 ? (double)d.steps / d.kernel_ms / 1e3 : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s, d.pool_wait_s, d.busy_s,
-                    d.png_frames, d.png_frames ? d.png_ms / d.png_frames : 0.0, d.png_fallback_frames);
+                    d.png_frames, d.png_frames ? d.png_ms / d.png_frames : 0.0, d.png_fallback_frames, d.png_regrown);
       js += buf;
     }
     js += "]";

@@ -64,40 +64,77 @@ class WriterPool {
  * the back-pressure of a host that cannot keep up. */
 class PinnedPool {
  public:
-  PinnedPool(size_t bytes_each, int n) : bytes_(bytes_each) {
-    for (int i = 0; i < n; ++i) {
-      void *p = nullptr;
-      if (curvis_host_alloc(bytes_each, &p) != CURVIS_OK || !p) break;
-      free_.push_back((uint8_t *)p);
-      all_.push_back((uint8_t *)p);
-    }
-  }
+  /* up to `n` page-locked buffers of `bytes_each`.  ONE is made here (so that the caller learns at once whether page-locked
+   * memory can be had), the others when a taker finds none free: pinning costs ~0.2 ms per MB and releasing as much again, a
+   * worker of a short run never needs its third buffer, and four contexts per GPU each held three of 200 MB for a 240-frame
+   * video -- 0.4 s of a 1.3 s run went into pinning and un-pinning memory nobody wrote to.  resize() makes the buffers handed
+   * out from then on larger (a batch of zlib streams that turned out not to fit); smaller ones are released as they return. */
+  PinnedPool(size_t bytes_each, int n) : bytes_(bytes_each), max_(n) { (void)grow(); }
   ~PinnedPool() {
-    for (uint8_t *p : all_) curvis_host_free(p);
+    for (auto &b : all_) curvis_host_free(b.first);
   }
-  size_t buffers() const { return all_.size(); }
-  /* a buffer that returns to the pool when the last holder lets go of it */
+  /* buffers this pool has or can still try to make (0: page-locked memory cannot be had at all) */
+  size_t buffers() const { return all_.empty() ? 0 : (size_t)max_; }
+  size_t bytes_each() const { return bytes_; }
+  void resize(size_t bytes_each) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (bytes_each <= bytes_) return;
+    bytes_ = bytes_each;
+    for (uint8_t *p : free_) drop(p);
+    free_.clear();
+  }
+  /* a buffer of bytes_each() that returns to the pool when the last holder lets go of it; empty when none can be had */
   std::shared_ptr<uint8_t> take(double *waited_s) {
     std::unique_lock<std::mutex> g(mu_);
     const double t0 = pngio::now_s();
-    cv_.wait(g, [this] { return !free_.empty(); });
+    while (free_.empty()) {
+      if ((int)all_.size() < max_) {
+        if (grow()) break;
+        if (all_.empty()) return std::shared_ptr<uint8_t>(); /* no page-locked memory (any more): the caller uses pageable memory */
+        max_ = (int)all_.size();                             /* live with what there is */
+      }
+      cv_.wait(g);
+    }
     if (waited_s) *waited_s += pngio::now_s() - t0;
     uint8_t *p = free_.back();
     free_.pop_back();
     return std::shared_ptr<uint8_t>(p, [this](uint8_t *q) {
       {
         std::lock_guard<std::mutex> g2(mu_);
-        free_.push_back(q);
+        size_t sz = 0;
+        for (auto &b : all_)
+          if (b.first == q) sz = b.second;
+        if (sz < bytes_)
+          drop(q); /* made before a resize(): too small for what is handed out now */
+        else
+          free_.push_back(q);
       }
       cv_.notify_one();
     });
   }
 
  private:
+  bool grow() {
+    void *p = nullptr;
+    if (curvis_host_alloc(bytes_, &p) != CURVIS_OK || !p) return false;
+    free_.push_back((uint8_t *)p);
+    all_.emplace_back((uint8_t *)p, bytes_);
+    return true;
+  }
+  void drop(uint8_t *p) {
+    for (size_t i = 0; i < all_.size(); ++i)
+      if (all_[i].first == p) {
+        all_.erase(all_.begin() + (long)i);
+        break;
+      }
+    curvis_host_free(p);
+  }
   size_t bytes_;
+  int max_;
   std::mutex mu_;
   std::condition_variable cv_;
-  std::vector<uint8_t *> free_, all_;
+  std::vector<uint8_t *> free_;
+  std::vector<std::pair<uint8_t *, size_t>> all_;
 };
 
 }  // namespace

@@ -227,14 +227,18 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   /* streams to the host: deflate bytes, then the Adler-32 of the filtered scanlines.  Sizes first, copies after: a call that
    * fails for want of room must not leave transfers into the caller's buffer in flight */
   size_t off = 0;
+  bool fits_scratch = true;
   for (uint32_t f = 0; f < n_frames; ++f) {
     const size_t bytes = (size_t)((frame_bits[f] + 7) / 8);
-    if (bytes > L.out_words * 4 || off + bytes + 4 > out_cap)
-      return fail(ctx, CURVIS_E_INVALID, "output buffer too small for the compressed frames");
+    if (bytes > L.out_words * 4) fits_scratch = false; /* a frame that does not compress: its stream never left the kernels whole */
     offsets[f] = off;
     off += bytes + 4;
   }
   offsets[n_frames] = off;
+  /* what the streams of this call take (option "last_png_stream_bytes"; 0 = a frame did not compress): a caller whose buffer
+   * was too small can come back with a larger one instead of giving up on the device front end */
+  ctx->last_png_stream_bytes = fits_scratch ? off : 0;
+  if (!fits_scratch || off > out_cap) return fail(ctx, CURVIS_E_INVALID, "output buffer too small for the compressed frames");
   for (uint32_t f = 0; f < n_frames; ++f)
     HIP_TRY(ctx, hipMemcpyAsync(out + offsets[f], (const uint8_t *)(P.out + (size_t)f * L.out_words), offsets[f + 1] - offsets[f] - 4,
                                 hipMemcpyDeviceToHost, ctx->stream));

@@ -138,6 +138,73 @@ def test_png_decoder_matches_pillow(tmp_path):
     assert np.array_equal(got[..., :3], want) and (got[..., 3] == 255).all()
 
 
+def _paeth_pred(a, b, c):
+    a, b, c = a.astype(np.int32), b.astype(np.int32), c.astype(np.int32)
+    p = a + b - c
+    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+    return np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c)).astype(np.uint8)
+
+
+def _write_png_filtered(path, img, filters, level=1):
+    """an 8-bit PNG whose row y uses filter type filters[y % len(filters)] (PNG specification 9.2) -- Pillow-free, so that the
+    decoder's five reconstruction loops are covered wherever the tests run"""
+    import zlib
+    img = np.ascontiguousarray(img if img.ndim == 3 else img[:, :, None])
+    h, w, ch = img.shape
+    rows = img.reshape(h, w * ch)
+    zero = np.zeros(w * ch, np.uint8)
+    out = bytearray()
+    for y in range(h):
+        cur, up = rows[y], (rows[y - 1] if y else zero)
+        a = np.concatenate([np.zeros(ch, np.uint8), cur])[:w * ch]
+        c = np.concatenate([np.zeros(ch, np.uint8), up])[:w * ch]
+        ft = filters[y % len(filters)]
+        pred = (zero, a, up, ((a.astype(np.int32) + up.astype(np.int32)) >> 1).astype(np.uint8), _paeth_pred(a, up, c))[ft]
+        out.append(ft)
+        out += (cur - pred).astype(np.uint8).tobytes()
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch], 0, 0, 0)
+    open(path, "wb").write(_png([(b"IHDR", ihdr), (b"IDAT", zlib.compress(bytes(out), level)), (b"IEND", b"")]))
+
+
+def test_png_decoder_every_filter_type(tmp_path):
+    """Sub / Up / Average / Paeth / None and mixtures of them, RGB and RGBA (the decoder's in-place fast path: one loop per filter
+    type, a follower thread behind the inflater, hand-over every MiB of inflated data) and grey / grey+alpha (the generic
+    path); widths of one to a few pixels (the first pixel of a row has no left neighbour), a single row (no row above), and
+    an image of several MiB so that rows straddle the hand-over points"""
+    rng = np.random.default_rng(11)
+
+    def smoothish(h, w, ch):
+        x = np.cumsum(rng.integers(-5, 6, size=(h, w, ch)), axis=1) + np.cumsum(rng.integers(-3, 4, size=(h, 1, ch)), axis=0)
+        return (x % 256).astype(np.uint8)
+    mixes = [[0], [1], [2], [3], [4], [4, 1, 2, 3, 0], [3, 4], [2, 2, 4, 1]]
+    for ch in (3, 4, 1, 2):
+        for (h, w) in ((1, 1), (1, 7), (5, 1), (4, 2), (3, 3), (33, 17), (64, 300)):
+            img = smoothish(h, w, ch)
+            for fl in mixes:
+                p = tmp_path / "f.png"
+                _write_png_filtered(p, img, fl)
+                got = _decode_with_binary(p, tmp_path)
+                want = {3: lambda: np.dstack([img, np.full((h, w, 1), 255, np.uint8)]), 4: lambda: img,
+                        1: lambda: np.dstack([img[..., 0]] * 3 + [np.full((h, w), 255, np.uint8)]),
+                        2: lambda: np.dstack([img[..., 0]] * 3 + [img[..., 1]])}[ch]()
+                assert np.array_equal(got, want), (ch, h, w, fl)
+    for ch in (3, 4):                                     # > 1 MiB of scanlines: several hand-overs between the two threads
+        img = smoothish(700, 1500, ch)
+        p = tmp_path / "big.png"
+        _write_png_filtered(p, img, [4, 1, 2, 3, 4, 4, 0, 4])
+        got = _decode_with_binary(p, tmp_path)
+        assert np.array_equal(got[..., :ch], img) and (got[..., 3] == 255).all() if ch == 3 else np.array_equal(got, img)
+    # a filter type that does not exist, and a stream that ends early: an error message, not a crash or a hang of the follower
+    import zlib
+    row = lambda ft: bytes([ft]) + bytes(12)
+    ihdr = struct.pack(">IIBBBBB", 4, 3, 8, 2, 0, 0, 0)
+    for name, body in (("badfilter", row(0) + row(7) + row(0)), ("short", row(0) + row(1))):
+        p = tmp_path / (name + ".png")
+        p.write_bytes(_png([(b"IHDR", ihdr), (b"IDAT", zlib.compress(body)), (b"IEND", b"")]))
+        r = run("selftest-png", p, tmp_path / "o.rgba")
+        assert r.returncode == 1 and "corrupt PNG" in r.stderr, (name, r.returncode, r.stderr)
+
+
 def test_python_png_helpers_round_trip(tmp_path):
     rng = np.random.default_rng(1)
     for shape in ((5, 7, 3), (4, 4, 4), (3, 9)):

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Wall time of `curvis image` and of a short `curvis video` as a user runs them -- process start to files on disk -- with
+8192x4096 PNG backgrounds, and where it goes (CURVIS_DEBUG_TIMING=1: the binary's own phase clock on stderr).
+
+The render kernels of the reference's default mode take ~4 ms per 1080p image; a run is decode (two 128 MiB textures),
+runtime start-up, upload, render, PNG encode -- so for one image or a short video (BASELINE configs[3] is 240 frames) the
+host side decides what the user waits for.
+
+    python tools/gpu_cli_startup.py [runs] > gpurun_out/cli_startup.txt       -> profiles/round5_cli_startup.txt"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from curvis_amd import paths, pngio, skies  # noqa: E402
+
+BIN = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
+
+
+def once(args, env_extra):
+    env = dict(os.environ, CURVIS_DEBUG_TIMING="1", **env_extra)
+    t0 = time.perf_counter()
+    r = subprocess.run([BIN] + args, capture_output=True, text=True, env=env)
+    dt = time.perf_counter() - t0
+    if r.returncode not in (0, 101):
+        raise SystemExit("curvis failed: rc %d\n%s" % (r.returncode, r.stderr[-800:]))
+    phases = [ln for ln in r.stderr.splitlines() if ln.startswith("[curvis timing]") and ("worker" not in ln or "worker 0" in ln or "device workers" in ln)]
+    return dt, phases
+
+
+def main():
+    runs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=base) as d:
+        sky = [os.path.join(d, "sky_pos.png"), os.path.join(d, "sky_neg.png")]
+        t0 = time.perf_counter()
+        pngio.write_png(sky[0], skies.smooth(8192, 4096, 128))
+        pngio.write_png(sky[1], skies.smooth(8192, 4096, 32))
+        print("# two 8192x4096 RGBA PNG backgrounds (%.1f / %.1f MB on disk), written in %.1f s; files in %s" % (
+            os.path.getsize(sky[0]) / 1e6, os.path.getsize(sky[1]) / 1e6, time.perf_counter() - t0, d))
+        cam, sim, img, vid = (os.path.join(d, n) for n in ("cam.toml", "sim.toml", "img.toml", "vid.toml"))
+        open(cam, "w").write("resolution_x = 1920\nresolution_y = 1080\ndiagonal = 43.0\nfocal_length = 15.0\n")
+        open(sim, "w").write("ray_integration_step = 0.05\nescape_radius = 100.0\nray_integration_max_itarations = 4096\nsampling_initial_nums = 100\n"
+                             "sampling_max_iterations = 50\nsampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 1e-5\n")
+        open(img, "w").write('image_name = "img"\nt = 0.0\nl = 5.0\ntheta = 1.5707963267948966\nphi = 0.0\nforward_x = -1.0\nforward_y = 0.0\nforward_z = 0.0\n'
+                             'up_x = 0.0\nup_y = 0.0\nup_z = 1.0\n')
+        open(vid, "w").write('video_name = "v"\nframe_rate = 4.0\nfilepath_to_camera_path = "%s"\n' % paths.path_file("path_orbit.csv"))
+        cases = [("curvis image (default mode: efficient), 1920x1080", ["image", sky[0], sky[1], os.path.join(d, "o_img"), "-i", img, "-c", cam, "-s", sim]),
+                 ("curvis image --mode brute, 1920x1080 cap 4096 (configs[1])", ["image", sky[0], sky[1], os.path.join(d, "o_img"), "-i", img, "-c", cam, "-s", sim, "--mode", "brute"]),
+                 ("curvis video (default mode), path_orbit.csv at 4 fps = 240 frames of 1920x1080 (configs[3])", ["video", sky[0], sky[1], os.path.join(d, "o_vid"), "-v", vid, "-c", cam, "-s", sim])]
+        for title, args in cases:
+            print("\n## " + title)
+            walls, last = [], None
+            for r in range(runs):
+                for o in ("o_img", "o_vid"):
+                    subprocess.run(["rm", "-rf", os.path.join(d, o)])
+                    os.mkdir(os.path.join(d, o))
+                dt, last = once(args, {})
+                walls.append(dt)
+            v = np.array(walls) * 1e3
+            print("wall (process start to exit) %s ms, median %.0f" % (" ".join("%.0f" % x for x in v), np.median(v)))
+            for ln in last:
+                print("    " + ln)
+
+
+if __name__ == "__main__":
+    main()
