@@ -85,6 +85,7 @@ int image_main(const Args &a) {
     }
   }
   curvis_ctx_destroy(ctx);
+  clk.mark("context destroyed");
   return 0;
 }
 
