@@ -160,7 +160,11 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
   size_t pos = 8;
   uint32_t W = 0, H = 0;
   int depth = 0, ctype = 0, interlace = 0;
-  std::vector<uint8_t> idat, plte, trns;
+  std::vector<uint8_t> plte, trns;
+  /* the IDAT chunks stay where they are in the file: (data, length, CRC field) -- inflated span by span, their CRC-32s checked
+   * by a helper thread meanwhile (a 36 MB star map: 95 ms of copying and checksumming before the first byte was inflated) */
+  struct Span { const uint8_t *data; uint32_t len; const uint8_t *type; };
+  std::vector<Span> idat;
   bool have_ihdr = false;
   while (pos + 12 <= file.size()) {
     const uint32_t len = be32(&file[pos]);
@@ -173,6 +177,11 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
     /* every chunk carries a CRC-32 of type + data.  Like the reference's png crate, a mismatch is fatal for CRITICAL
      * chunks only (upper-case first letter: IHDR, PLTE, IDAT, IEND); an ancillary chunk with a damaged CRC (tEXt, iCCP,
      * ... and tRNS) is skipped, so a star map with a broken metadata chunk loads here as it does there */
+    if (!std::memcmp(type, "IDAT", 4)) {
+      idat.push_back(Span{data, len, &file[pos + 4]});
+      pos += 12 + (size_t)len;
+      continue;
+    }
     if ((uint32_t)crc32(0L, &file[pos + 4], (uInt)(4 + len)) != be32(&file[pos + 8 + len])) {
       if (!(type[0] & 0x20)) {
         err = "PNG chunk CRC mismatch";
@@ -189,14 +198,26 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
       plte.assign(data, data + len);
     } else if (!std::memcmp(type, "tRNS", 4)) {
       trns.assign(data, data + len);
-    } else if (!std::memcmp(type, "IDAT", 4)) {
-      idat.insert(idat.end(), data, data + len);
     } else if (!std::memcmp(type, "IEND", 4)) {
       break;
     }
     pos += 12 + (size_t)len;
   }
-  mark("chunks + CRC-32");
+  mark("chunks");
+  bool idat_crc_bad = false;
+  std::thread crc_thread([&] {
+    for (const Span &sp : idat)
+      if ((uint32_t)crc32(0L, sp.type, (uInt)(4 + sp.len)) != be32(sp.data + sp.len)) idat_crc_bad = true;
+  });
+  struct Joiner { /* whichever way decode() is left, the helper has finished with `file` first */
+    std::thread &t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } crc_joiner{crc_thread};
+  auto idat_crc_ok = [&] { /* a damaged critical chunk is THE error, whatever the inflater made of its bytes */
+    if (crc_thread.joinable()) crc_thread.join();
+    if (idat_crc_bad) err = "PNG chunk CRC mismatch";
+    return !idat_crc_bad;
+  };
   if (!have_ihdr || W == 0 || H == 0) { err = "missing IHDR"; return false; }
   int channels;
   switch (ctype) {
@@ -241,8 +262,15 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
     z_stream zs;
     std::memset(&zs, 0, sizeof zs);
     if (inflateInit(&zs) != Z_OK) { err = "zlib init failed"; return false; }
-    zs.next_in = idat.data();
-    zs.avail_in = (uInt)idat.size();
+    size_t span_i = 0;
+    auto feed = [&] { /* next non-empty IDAT chunk; false when there is none */
+      while (zs.avail_in == 0 && span_i < idat.size()) {
+        zs.next_in = const_cast<Bytef *>(idat[span_i].data);
+        zs.avail_in = idat[span_i].len;
+        ++span_i;
+      }
+      return zs.avail_in != 0;
+    };
     /* the inflated stream of a valid file is exactly the filtered scanlines; an interlaced image adds at most one
      * filter byte per pass row (< 2 H rows in total) plus rounding: the buffer never grows beyond that, so a
      * decompression bomb fails instead of exhausting memory */
@@ -293,10 +321,17 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
     size_t have = 0;
     int rc;
     do {
-      if (have == raw.size()) { inflateEnd(&zs); finish_follower(); err = "PNG data stream larger than its header allows"; return false; }
+      if (have == raw.size()) {
+        inflateEnd(&zs);
+        finish_follower();
+        if (idat_crc_ok()) err = "PNG data stream larger than its header allows";
+        return false;
+      }
       zs.next_out = raw.data() + have;
       zs.avail_out = (uInt)std::min<size_t>(raw.size() - have, fast ? ((size_t)1 << 20) : ((size_t)1 << 30));
+      if (!feed()) { rc = Z_BUF_ERROR; break; } /* the stream wants more than the file holds */
       rc = inflate(&zs, Z_NO_FLUSH);
+      if (rc == Z_BUF_ERROR && zs.avail_in == 0 && zs.avail_out != 0) rc = Z_OK; /* this chunk is used up: on to the next */
       have = zs.total_out;
       if (fast) {
         {
@@ -308,6 +343,7 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
     } while (rc == Z_OK);
     inflateEnd(&zs);
     finish_follower();
+    if (!idat_crc_ok()) return false;
     if (rc != Z_STREAM_END) { err = "corrupt PNG data stream"; return false; }
     raw.resize(have);
   }

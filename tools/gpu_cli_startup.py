@@ -53,6 +53,19 @@ def main():
         cases = [("curvis image (default mode: efficient), 1920x1080", ["image", sky[0], sky[1], os.path.join(d, "o_img"), "-i", img, "-c", cam, "-s", sim]),
                  ("curvis image --mode brute, 1920x1080 cap 4096 (configs[1])", ["image", sky[0], sky[1], os.path.join(d, "o_img"), "-i", img, "-c", cam, "-s", sim, "--mode", "brute"]),
                  ("curvis video (default mode), path_orbit.csv at 4 fps = 240 frames of 1920x1080 (configs[3])", ["video", sky[0], sky[1], os.path.join(d, "o_vid"), "-v", vid, "-c", cam, "-s", sim])]
+        try:  # the reference's README suggests JPEG star maps: the same run with 8192x4096 JPEG backgrounds (Pillow writes them)
+            from PIL import Image
+            rng = np.random.default_rng(3)
+            jp = [os.path.join(d, "sky_pos.jpg"), os.path.join(d, "sky_neg.jpg")]
+            for path, blue in zip(jp, (128, 32)):
+                a = skies.smooth(8192, 4096, blue)[..., :3].astype(np.int16)
+                stars = rng.random((4096, 8192)) < 0.004                                    # a few stars on a smooth sky: mostly flat blocks, as in a star map
+                a[stars] = np.minimum(255, a[stars] + rng.integers(60, 200, size=(int(stars.sum()), 1)))
+                Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(path, quality=92, subsampling=2)
+            print("# two 8192x4096 JPEG backgrounds (4:2:0, quality 92; %.1f / %.1f MB)" % (os.path.getsize(jp[0]) / 1e6, os.path.getsize(jp[1]) / 1e6))
+            cases.append(("curvis image (default mode), JPEG backgrounds", ["image", jp[0], jp[1], os.path.join(d, "o_img"), "-i", img, "-c", cam, "-s", sim]))
+        except ImportError:
+            pass
         for title, args in cases:
             print("\n## " + title)
             walls, last = [], None
