@@ -519,10 +519,24 @@ struct Decoder {
     }
     std::vector<std::thread> th;
     const int per = (n + threads - 1) / threads;
-    for (int t = 1; t < threads; ++t)
-      if (t * per < n) th.emplace_back(fn, t * per, std::min(n, (t + 1) * per));
-    fn(0, std::min(n, per));
+    bool oom = false; /* an exception must not leave a helper thread (std::terminate): it is passed on by the caller's */
+    auto guarded = [&fn, &oom](int b, int e) {
+      try {
+        fn(b, e);
+      } catch (const std::bad_alloc &) {
+        oom = true;
+      }
+    };
+    int next = per; /* the caller's own piece is [0, per); pieces no thread could be made for are done here as well */
+    try {
+      th.reserve((size_t)threads);
+      for (; next < n; next += per) th.emplace_back(guarded, next, std::min(n, next + per));
+    } catch (const std::exception &) { /* no more threads to be had (or no memory for one) */
+    }
+    guarded(0, std::min(n, per));
+    for (; next < n; next += per) guarded(next, std::min(n, next + per));
     for (auto &x : th) x.join();
+    if (oom) throw std::bad_alloc();
   }
   /* Reconstruction is independent per block and per pixel row (the entropy decoding before it is not): block rows of the
    * inverse DCT and pixel rows of upsampling + colour conversion are shared out over a few threads -- a large image only

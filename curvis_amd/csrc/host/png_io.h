@@ -21,6 +21,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <new>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -252,8 +253,23 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
   std::condition_variable fcv;
   size_t f_have = 0;      /* inflated bytes the follower may touch (guarded by fmu) */
   bool f_done = false;    /* the inflater has stopped (end of stream or error) */
-  bool f_bad_filter = false;
+  bool f_bad_filter = false, f_oom = false;
   std::thread follower;
+  struct FollowerGuard { /* however decode() is left -- an exception included -- the follower is told to stop and joined first */
+    std::thread &t;
+    std::mutex &mu;
+    std::condition_variable &cv;
+    bool &done;
+    ~FollowerGuard() {
+      if (!t.joinable()) return;
+      {
+        std::lock_guard<std::mutex> g(mu);
+        done = true;
+      }
+      cv.notify_all();
+      t.join();
+    }
+  } follower_guard{follower, fmu, fcv, f_done};
   img.w = W;
   img.h = H;
   /* inflate */
@@ -278,7 +294,12 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
     raw.resize(cap);
     if (fast)
       follower = std::thread([&] {
-        img.rgba.resize((size_t)W * H * 4);
+        try {
+          img.rgba.resize((size_t)W * H * 4);
+        } catch (const std::bad_alloc &) { /* must not leave a thread: the inflater's caller reports it */
+          f_oom = true;
+          return;
+        }
         const uint8_t *up = nullptr;
         size_t seen = 0;
         for (size_t y = 0; y < H; ++y) {
@@ -349,6 +370,7 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
   }
   mark(fast ? "inflate (+ unfilter, RGBA)" : "inflate");
   if (fast) {
+    if (f_oom) throw std::bad_alloc(); /* in THIS thread, where the callers expect it */
     if (f_bad_filter || raw.size() < (size_t)H * (fstride + 1)) { err = "corrupt PNG scanlines"; return false; }
     return true;
   }
