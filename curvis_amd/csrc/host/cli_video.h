@@ -227,8 +227,9 @@ int video_main(const Args &a_in) {
     /* one being filled, up to two with the writers.  The pool belongs to video_main's scope: writer jobs hold its
      * buffers (and its mutex, through the deleter) after this worker has returned */
     /* With the device PNG front end a batch buffer receives zlib streams, not pixels: an eighth of the raw size holds what
-     * rendered frames compress to several times over (0.05-0.7 MB per 6.2 MB frame); a batch that does not fit (frames that do
-     * not compress) takes the fall-back below through pageable memory. */
+     * frames rendered from smooth or star-field backgrounds compress to several times over (0.05-0.7 MB per 6.2 MB frame).  A
+     * batch that needs more makes the pool hand out larger buffers from then on (below); only frames that do not compress at
+     * all take the host encoder, through pageable memory. */
     const size_t pool_bytes = gpu_png ? std::max<size_t>((size_t)8 << 20, (size_t)a.batch * fbytes / 8) : (size_t)a.batch * fbytes;
     size_t pool_first = std::min(pool_bytes, (size_t)a.batch * fbytes);
     if (const char *tb = std::getenv("CURVIS_TEST_STREAM_POOL_BYTES")) /* test hook: start with buffers this small, so that the growth path runs */
@@ -511,7 +512,7 @@ int video_main(const Args &a_in) {
       const double kf = d.frames ? d.kernel_ms / d.frames : 0.0, rf = d.frames ? d.render_s * 1e3 / d.frames : 0.0;
       std::printf("%-7zu %-14s %-7zu %-16.3f %-21.3f %-6.1f %-9d %-8d %-7.2f %.2f\n", (size_t)device_of((int)r), d.pci_bus_id.c_str(), d.frames, kf, rf,
                   d.busy_s > 0 ? d.frames / d.busy_s : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s);
-      char buf[768];
+      char buf[1024];
       std::snprintf(buf, sizeof buf,
                     "%s{\"device\": %zu, \"pci_bus_id\": \"%s\", \"frames\": %zu, \"batches\": %zu, \"kernel_ms_per_frame\": %.4f, "
                     "\"render_call_ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"mray_steps_per_s\": %.1f, \"sclk_mhz\": %d, \"power_w\": %d, "

@@ -74,7 +74,10 @@ class PinnedPool {
     for (auto &b : all_) curvis_host_free(b.first);
   }
   /* buffers this pool has or can still try to make (0: page-locked memory cannot be had at all) */
-  size_t buffers() const { return all_.empty() ? 0 : (size_t)max_; }
+  size_t buffers() const {
+    std::lock_guard<std::mutex> g(mu_); /* writer threads let go of buffers (and drop outgrown ones) at any time */
+    return all_.empty() ? 0 : (size_t)max_;
+  }
   size_t bytes_each() const { return bytes_; }
   void resize(size_t bytes_each) {
     std::lock_guard<std::mutex> g(mu_);
@@ -131,7 +134,7 @@ class PinnedPool {
   }
   size_t bytes_;
   int max_;
-  std::mutex mu_;
+  mutable std::mutex mu_;
   std::condition_variable cv_;
   std::vector<uint8_t *> free_;
   std::vector<std::pair<uint8_t *, size_t>> all_;

@@ -154,7 +154,7 @@ int ensure_device(curvis_ctx *ctx, T *&ptr, size_t &cap, size_t need) {
  * before it queues its own download, waits for the previous one (long finished: it ran under this call's kernels).  So the
  * contract is a pipeline one frame deep: `rgb_out` of call k is complete when call k + 1 on the same context returns, or
  * after curvis_ctx_download_wait.  ctx->d_fb is always the buffer of the LAST render (what curvis_ctx_deflate_frames,
- * curvis_ctx_fetch_frames and the seat belt read); only a call that is about to WRITE frames steps aside. */
+ * curvis_ctx_download and the seat belt read); only a call that is about to WRITE frames steps aside. */
 int download_wait(curvis_ctx *ctx) {
   if (!ctx->dl_pending) return CURVIS_OK;
   ctx->dl_pending = false;
