@@ -23,6 +23,7 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <system_error>
 
 #include <new>
 
@@ -711,6 +712,8 @@ inline bool decode(const std::vector<uint8_t> &file, pngio::Image &img, std::str
     ok = d->run(img);
   } catch (const std::bad_alloc &) { /* extern "C" callers and decoder threads must see an error, not std::terminate */
     err = "out of memory while decoding the JPEG file";
+  } catch (const std::system_error &e) { /* a helper thread could not be started */
+    err = std::string("could not decode the JPEG file: ") + e.what();
   }
   delete d;
   if (!ok && err.empty()) err = "corrupt JPEG";
@@ -729,6 +732,9 @@ inline bool load_image(const std::string &path, pngio::Image &img, std::string &
     return pngio::decode(file, img, err);
   } catch (const std::bad_alloc &) {
     err = "out of memory while decoding the PNG file";
+    return false;
+  } catch (const std::system_error &e) { /* a helper thread (follower, CRC) could not be started */
+    err = std::string("could not decode the PNG file: ") + e.what();
     return false;
   }
 }
