@@ -21,6 +21,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <memory>
 #include <new>
 #include <condition_variable>
 #include <mutex>
@@ -273,7 +274,16 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
   img.w = W;
   img.h = H;
   /* inflate */
-  std::vector<uint8_t> raw;
+  struct RawBuffer { /* the inflated scanlines: NOT zero-filled (a vector's resize would write 134 MB that inflate overwrites) */
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    uint8_t *data() const { return p.get(); }
+    size_t size() const { return n; }
+    void resize(size_t bytes) { /* grows once, from empty; afterwards only shrinks */
+      if (!p) p.reset(new uint8_t[bytes]);
+      n = bytes;
+    }
+  } raw;
   {
     z_stream zs;
     std::memset(&zs, 0, sizeof zs);
