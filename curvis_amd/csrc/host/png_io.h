@@ -11,6 +11,7 @@
 #ifndef CURVIS_PNG_IO_H
 #define CURVIS_PNG_IO_H
 #include <zlib.h>
+#include "inflate_fast.h"
 
 #include <time.h>
 
@@ -273,8 +274,8 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
   } follower_guard{follower, fmu, fcv, f_done};
   img.w = W;
   img.h = H;
-  /* inflate */
-  struct RawBuffer { /* the inflated scanlines: NOT zero-filled (a vector's resize would write 134 MB that inflate overwrites) */
+  /* inflate (inflate_fast.h: the stream contiguous in memory, the output buffer its own window) */
+  struct RawBuffer { /* the inflated scanlines: NOT zero-filled (a vector's resize would write 134 MB that the inflater overwrites) */
     std::unique_ptr<uint8_t[]> p;
     size_t n = 0;
     uint8_t *data() const { return p.get(); }
@@ -284,19 +285,19 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
       n = bytes;
     }
   } raw;
+  uint32_t follower_adler = 1; /* Adler-32 of the scanlines the follower has taken (it sums a row before it rewrites it) */
   {
-    z_stream zs;
-    std::memset(&zs, 0, sizeof zs);
-    if (inflateInit(&zs) != Z_OK) { err = "zlib init failed"; return false; }
-    size_t span_i = 0;
-    auto feed = [&] { /* next non-empty IDAT chunk; false when there is none */
-      while (zs.avail_in == 0 && span_i < idat.size()) {
-        zs.next_in = const_cast<Bytef *>(idat[span_i].data);
-        zs.avail_in = idat[span_i].len;
-        ++span_i;
+    size_t zbytes = 0;
+    for (const Span &sp : idat) zbytes += sp.len;
+    std::unique_ptr<uint8_t[]> zin(new uint8_t[zbytes + cvinflate::kInputPadding]);
+    {
+      size_t o = 0;
+      for (const Span &sp : idat) {
+        std::memcpy(zin.get() + o, sp.data, sp.len);
+        o += sp.len;
       }
-      return zs.avail_in != 0;
-    };
+      std::memset(zin.get() + zbytes, 0, cvinflate::kInputPadding);
+    }
     /* the inflated stream of a valid file is exactly the filtered scanlines; an interlaced image adds at most one
      * filter byte per pass row (< 2 H rows in total) plus rounding: the buffer never grows beyond that, so a
      * decompression bomb fails instead of exhausting memory */
@@ -304,41 +305,84 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
     raw.resize(cap);
     if (fast)
       follower = std::thread([&] {
+        /* a third stage behind this one: reconstructed rows -> the RGBA image (its 128 MiB of first-touch page faults included),
+         * so that checksum + reconstruction, the serial part, has this thread to itself */
+        std::mutex cmu;
+        std::condition_variable ccv;
+        size_t rows_ready = 0;
+        bool rows_done = false, c_oom = false;
+        std::thread converter;
         try {
-          img.rgba.resize((size_t)W * H * 4);
-        } catch (const std::bad_alloc &) { /* must not leave a thread: the inflater's caller reports it */
+          converter = std::thread([&] {
+            try {
+              img.rgba.resize((size_t)W * H * 4);
+            } catch (const std::bad_alloc &) {
+              c_oom = true;
+              return;
+            }
+            size_t y = 0;
+            for (;;) {
+              size_t avail;
+              {
+                std::unique_lock<std::mutex> g(cmu);
+                ccv.wait(g, [&] { return rows_ready > y || rows_done; });
+                avail = rows_ready;
+                if (avail <= y) return;
+              }
+              for (; y < avail; ++y) {
+                const uint8_t *src = raw.data() + y * (fstride + 1) + 1;
+                uint8_t *o = &img.rgba[y * (size_t)W * 4];
+                if (channels == 4) {
+                  std::memcpy(o, src, fstride);
+                } else {
+                  for (size_t x = 0; x < W; ++x) {
+                    o[4 * x + 0] = src[3 * x + 0];
+                    o[4 * x + 1] = src[3 * x + 1];
+                    o[4 * x + 2] = src[3 * x + 2];
+                    o[4 * x + 3] = 255;
+                  }
+                }
+              }
+            }
+          });
+        } catch (const std::exception &) { /* no thread to be had: this stage cannot run */
           f_oom = true;
           return;
         }
+        auto hand_over = [&](size_t rows, bool last) {
+          {
+            std::lock_guard<std::mutex> g(cmu);
+            rows_ready = rows;
+            rows_done = rows_done || last;
+          }
+          ccv.notify_one();
+        };
         const uint8_t *up = nullptr;
-        size_t seen = 0;
-        for (size_t y = 0; y < H; ++y) {
+        size_t seen = 0, y = 0;
+        uLong adler = 1;
+        for (; y < H; ++y) {
           const size_t need = (y + 1) * (fstride + 1);
           if (seen < need) {
+            hand_over(y, false); /* about to wait: what is reconstructed can go on meanwhile */
             std::unique_lock<std::mutex> g(fmu);
             fcv.wait(g, [&] { return f_have >= need || f_done; });
             seen = f_have;
-            if (seen < need) return; /* the stream ended short: the inflater's caller reports it */
+            if (seen < need) break; /* the stream ended short: the inflater's caller reports it */
           }
           uint8_t *line = raw.data() + y * (fstride + 1);
+          adler = adler32(adler, line, (uInt)(fstride + 1)); /* before the row is rewritten */
           const bool ok = channels == 4 ? unfilter_row_inplace<4>(line[0], line + 1, up, fstride) : unfilter_row_inplace<3>(line[0], line + 1, up, fstride);
           if (!ok) {
             f_bad_filter = true;
-            return;
+            break;
           }
           up = line + 1;
-          uint8_t *o = &img.rgba[y * (size_t)W * 4];
-          if (channels == 4) {
-            std::memcpy(o, up, fstride);
-          } else {
-            for (size_t x = 0; x < W; ++x) {
-              o[4 * x + 0] = up[3 * x + 0];
-              o[4 * x + 1] = up[3 * x + 1];
-              o[4 * x + 2] = up[3 * x + 2];
-              o[4 * x + 3] = 255;
-            }
-          }
+          if ((y & 31) == 31) hand_over(y + 1, false);
         }
+        hand_over(y, true);
+        converter.join();
+        if (c_oom) f_oom = true;
+        follower_adler = (uint32_t)adler;
       });
     auto finish_follower = [&] {
       if (!follower.joinable()) return;
@@ -349,34 +393,49 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
       fcv.notify_all();
       follower.join();
     };
-    size_t have = 0;
-    int rc;
-    do {
-      if (have == raw.size()) {
-        inflateEnd(&zs);
-        finish_follower();
-        if (idat_crc_ok()) err = "PNG data stream larger than its header allows";
-        return false;
-      }
-      zs.next_out = raw.data() + have;
-      zs.avail_out = (uInt)std::min<size_t>(raw.size() - have, fast ? ((size_t)1 << 20) : ((size_t)1 << 30));
-      if (!feed()) { rc = Z_BUF_ERROR; break; } /* the stream wants more than the file holds */
-      rc = inflate(&zs, Z_NO_FLUSH);
-      if (rc == Z_BUF_ERROR && zs.avail_in == 0 && zs.avail_out != 0) rc = Z_OK; /* this chunk is used up: on to the next */
-      have = zs.total_out;
-      if (fast) {
+    struct Publish { /* inflate_fast's progress: bytes the decoder no longer reads back may be rewritten by the follower */
+      std::mutex &mu;
+      std::condition_variable &cv;
+      size_t &have;
+      static void call(void *u, size_t settled) {
+        Publish *p = (Publish *)u;
         {
-          std::lock_guard<std::mutex> g(fmu);
-          f_have = have;
+          std::lock_guard<std::mutex> g(p->mu);
+          p->have = settled;
         }
-        fcv.notify_one();
+        p->cv.notify_one();
       }
-    } while (rc == Z_OK);
-    inflateEnd(&zs);
+    } publish{fmu, fcv, f_have};
+    cvinflate::Progress prog;
+    if (fast) {
+      prog.fn = &Publish::call;
+      prog.user = &publish;
+    }
+    size_t have = 0;
+    uint32_t adler_stored = 0;
+    const int rc = cvinflate::inflate_zlib(zin.get(), zbytes, raw.data(), raw.size(), &have, &adler_stored, prog);
     finish_follower();
     if (!idat_crc_ok()) return false;
-    if (rc != Z_STREAM_END) { err = "corrupt PNG data stream"; return false; }
+    if (rc == cvinflate::E_OUTPUT_FULL) { err = "PNG data stream larger than its header allows"; return false; }
+    if (rc != cvinflate::OK) { err = "corrupt PNG data stream"; return false; }
     raw.resize(have);
+    /* Adler-32 of the inflated data (RFC 1950), as zlib checks it: the follower has summed the rows it took before it rewrote
+     * them; whatever it did not take is still as inflated */
+    if (!f_bad_filter && !f_oom) {
+      uLong adler = 1;
+      size_t from = 0;
+      if (fast) {
+        const size_t rows_taken = std::min((size_t)H, have / (fstride + 1));
+        adler = follower_adler;
+        from = rows_taken * (fstride + 1);
+      }
+      for (size_t o = from; o < have;) { /* zlib's adler32 takes a 32-bit length */
+        const size_t n = std::min<size_t>(have - o, (size_t)1 << 30);
+        adler = adler32(adler, raw.data() + o, (uInt)n);
+        o += n;
+      }
+      if ((uint32_t)adler != adler_stored) { err = "corrupt PNG data stream"; return false; }
+    }
   }
   mark(fast ? "inflate (+ unfilter, RGBA)" : "inflate");
   if (fast) {

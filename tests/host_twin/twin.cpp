@@ -217,3 +217,15 @@ extern "C" int twin_render_efficient(const curvis_metric *m, const curvis_camera
     }
   return 0;
 }
+
+/* inflate_fast.h (the PNG backgrounds' inflater) for tests/test_inflate_host.py: zlib stream in, bytes out.  The input is copied
+ * into a buffer with the padding the decoder asks for; returns its status, *out_len = bytes produced, *adler = stored Adler-32 */
+#include "../../curvis_amd/csrc/host/inflate_fast.h"
+#include <memory>
+extern "C" int twin_inflate_zlib(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *out_len, uint32_t *adler) {
+  std::unique_ptr<uint8_t[]> buf(new uint8_t[in_len + cvinflate::kInputPadding]);
+  std::memcpy(buf.get(), in, in_len);
+  std::memset(buf.get() + in_len, 0, cvinflate::kInputPadding);
+  return cvinflate::inflate_zlib(buf.get(), in_len, out, out_cap, out_len, adler);
+}
+
