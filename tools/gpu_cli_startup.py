@@ -66,6 +66,26 @@ def main():
             cases.append(("curvis image (default mode), JPEG backgrounds", ["image", jp[0], jp[1], os.path.join(d, "o_img"), "-i", img, "-c", cam, "-s", sim]))
         except ImportError:
             pass
+        # a star-map-like PNG pair (Pillow's adaptive filters, ~35 MB each): what a real background costs to load
+        try:
+            from PIL import Image
+            rng = np.random.default_rng(5)
+            sp = [os.path.join(d, "stars_pos.png"), os.path.join(d, "stars_neg.png")]
+            yy = np.linspace(-1, 1, 4096)[:, None]
+            xx = np.linspace(0, 1, 8192)[None, :]
+            band = np.exp(-(yy * 3 + 0.3 * np.sin(xx * 6.28)) ** 2) * 60
+            for path, tint in zip(sp, ((1.0, 0.9, 0.8), (0.8, 0.9, 1.0))):
+                a = np.zeros((4096, 8192, 3), np.float32) + band[..., None] * np.array(tint, np.float32)
+                n = 200000
+                ys, xs, br = rng.integers(0, 4096, n), rng.integers(0, 8192, n), rng.pareto(2.0, n) * 40
+                for c in range(3):
+                    np.add.at(a[..., c], (ys, xs), br * rng.uniform(0.7, 1.0, n))
+                a += rng.normal(0, 1.5, a.shape)
+                Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(path)
+            print("# two 8192x4096 star-map-like RGB PNG backgrounds (adaptive filters; %.1f / %.1f MB)" % (os.path.getsize(sp[0]) / 1e6, os.path.getsize(sp[1]) / 1e6))
+            cases.append(("curvis image (default mode), star-map PNG backgrounds", ["image", sp[0], sp[1], os.path.join(d, "o_img"), "-i", img, "-c", cam, "-s", sim]))
+        except ImportError:
+            pass
         for title, args in cases:
             print("\n## " + title)
             walls, last = [], None
