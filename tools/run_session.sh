@@ -16,5 +16,5 @@ from curvis_amd import pngio, skies
 pngio.write_png('/dev/shm/smooth.png', skies.smooth(8192, 4096, 128))
 print(os.path.getsize('/dev/shm/stars.png'), os.path.getsize('/dev/shm/smooth.png'))
 PY
-for rep in 1 2 3; do for v in orig old new; do echo -n "$v: "; build/pngab/b_$v /dev/shm/stars.png /dev/shm/smooth.png | tr '\n' ' '; echo; done; done > gpurun_out/png_decode_ab.txt 2>&1
-cat gpurun_out/png_decode_ab.txt
+for rep in 1 2 3; do for v in old new new2; do echo -n "$v: "; build/pngab/b_$v /dev/shm/stars.png /dev/shm/smooth.png | tr '\n' ' '; echo; done; done > gpurun_out/png_decode_ab2.txt 2>&1
+cat gpurun_out/png_decode_ab2.txt
