@@ -1,20 +1,5 @@
 mkdir -p gpurun_out
-python - <<'PY'
-import numpy as np, os
-from PIL import Image
-rng = np.random.default_rng(5)
-yy = np.linspace(-1, 1, 4096)[:, None]; xx = np.linspace(0, 1, 8192)[None, :]
-band = np.exp(-(yy * 3 + 0.3 * np.sin(xx * 6.28)) ** 2) * 60
-a = np.zeros((4096, 8192, 3), np.float32) + band[..., None] * np.array((1.0, 0.9, 0.8), np.float32)
-n = 200000
-ys, xs, br = rng.integers(0, 4096, n), rng.integers(0, 8192, n), rng.pareto(2.0, n) * 40
-for c in range(3): np.add.at(a[..., c], (ys, xs), br * rng.uniform(0.7, 1.0, n))
-a += rng.normal(0, 1.5, a.shape)
-Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save('/dev/shm/stars.png')
-import sys; sys.path.insert(0, '.')
-from curvis_amd import pngio, skies
-pngio.write_png('/dev/shm/smooth.png', skies.smooth(8192, 4096, 128))
-print(os.path.getsize('/dev/shm/stars.png'), os.path.getsize('/dev/shm/smooth.png'))
-PY
-for rep in 1 2 3; do for v in old new new2; do echo -n "$v: "; build/pngab/b_$v /dev/shm/stars.png /dev/shm/smooth.png | tr '\n' ' '; echo; done; done > gpurun_out/png_decode_ab2.txt 2>&1
-cat gpurun_out/png_decode_ab2.txt
+(time timeout 1200 python -m pytest tests -m gpu -x -q) > gpurun_out/s6_gpu_tests.txt 2>&1; tail -4 gpurun_out/s6_gpu_tests.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py > gpurun_out/s6_bench.json 2> gpurun_out/s6_bench.err; tail -c 400 gpurun_out/s6_bench.json
+python tools/gpu_cli_startup.py 3 > gpurun_out/cli_startup3.txt 2>&1; grep -E '^##|^wall' gpurun_out/cli_startup3.txt
