@@ -69,6 +69,32 @@ def test_image_default_pose_efficient_and_brute(scene_files):
     assert st["steps"] == st_d.steps and st["mode"] == "direct"
 
 
+def test_backgrounds_written_with_every_png_filter_give_the_same_image(scene_files, tmp_path):
+    """the backgrounds' decoder (own inflater, rows reconstructed in place by a stage that trails it, a third writing the RGBA
+    image) inside the whole run: skies whose rows cycle through Sub / Up / Average / Paeth / None, large enough for many
+    hand-overs between the stages (2048 x 1024: 6-8 MiB of scanlines), must give the file the filter-None skies give"""
+    from test_cli_host import _write_png_filtered
+    d, _, _ = scene_files
+    sp, sn = common.make_skies(2048, 1024, "check")
+    rng = np.random.default_rng(12)
+    sp = sp.copy()
+    sp[..., :3] = np.clip(sp[..., :3].astype(np.int16) + rng.integers(-9, 10, size=sp[..., :3].shape), 0, 255).astype(np.uint8)
+    outs = []
+    for tag, filters in (("none", [0]), ("mixed", [4, 1, 2, 3, 4, 4, 0, 3]), ("paeth", [4])):
+        a, b = tmp_path / ("pos_%s.png" % tag), tmp_path / ("neg_%s.png" % tag)
+        _write_png_filtered(a, sp[..., :3], filters)   # RGB
+        _write_png_filtered(b, sn, filters)            # RGBA
+        out = tmp_path / ("out_" + tag)
+        out.mkdir()
+        r = run("image", a, b, out, "-s", d / "sim.toml", "-c", d / "cam.toml")
+        assert r.returncode == 0, r.stderr
+        outs.append(pngio.read_png(out / "output_image.png"))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    om, oc, _, _ = common.scene("ellis", res=(96, 54))
+    want, _, _ = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05, 100, 100, 1e-5, 2e-5)
+    assert np.array_equal(outs[0], want)
+
+
 def test_image_rows_split_over_devices(scene_files):
     """image --mode brute --devices 3: three contexts render row bands of the one frame (one band per GPU when the box
     has three; all on GPU 0 through the CURVIS_TEST_SHARE_DEVICE hook only when it has fewer); file and statistics equal
