@@ -20,6 +20,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <thread>
@@ -82,7 +83,29 @@ struct Component {
   int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, dc_pred = 0;
   int blocks_w = 0, blocks_h = 0;          /* allocated size in blocks (whole MCUs) */
   int w = 0, h_px = 0;                     /* true size in pixels of this component */
-  std::vector<int16_t> coef;               /* blocks_w * blocks_h * 64 */
+  struct Zeroed { /* blocks_w * blocks_h * 64 coefficients, zero to begin with: calloc -- zero pages straight from the kernel, no pass
+                     over 100-200 MB that the entropy decoder then writes once */
+    int16_t *p = nullptr;
+    size_t n = 0;
+    Zeroed() = default;
+    Zeroed(const Zeroed &) = delete;
+    Zeroed &operator=(const Zeroed &) = delete;
+    void alloc(size_t count) {
+      release();
+      if (!count) return;
+      p = (int16_t *)std::calloc(count, sizeof(int16_t));
+      if (!p) throw std::bad_alloc();
+      n = count;
+    }
+    void release() {
+      std::free(p);
+      p = nullptr;
+      n = 0;
+    }
+    int16_t &operator[](size_t i) { return p[i]; }
+    const int16_t &operator[](size_t i) const { return p[i]; }
+    ~Zeroed() { release(); }
+  } coef;
   std::vector<uint8_t> plane;              /* blocks_w*8 x blocks_h*8 */
 };
 
@@ -330,8 +353,20 @@ struct Decoder {
       c.blocks_h = mcus_y * c.v;
       c.w = (W * c.h + hmax - 1) / hmax;
       c.h_px = (H * c.v + vmax - 1) / vmax;
-      c.coef.assign((size_t)c.blocks_w * c.blocks_h * 64, 0);
+      c.coef.alloc((size_t)c.blocks_w * c.blocks_h * 64);
     }
+    /* a large image: helper threads have the kernel populate the coefficient arrays while the entropy decoder starts at their
+     * front (png_io.h populate_pages: the first-touch faults of 100-200 MB leave its critical path) */
+    join_helpers();
+    if ((size_t)W * (size_t)H >= ((size_t)1 << 22) && !std::getenv("CURVIS_NO_POPULATE"))
+      for (int i = 0; i < ncomp; ++i) {
+        int16_t *ptr = comp[i].coef.p;
+        const size_t bytes = comp[i].coef.n * sizeof(int16_t);
+        try {
+          helpers.emplace_back([ptr, bytes] { pngio::populate_pages((uint8_t *)ptr, bytes); });
+        } catch (const std::exception &) { /* then the pages arrive one fault at a time */
+        }
+      }
     progressive = prog;
     have_sof = true;
     return true;
@@ -547,7 +582,15 @@ struct Decoder {
     if (const char *e = std::getenv("CURVIS_DECODE_THREADS")) return std::max(1, std::min(64, std::atoi(e)));
     return (int)std::max(1u, std::min(4u, std::thread::hardware_concurrency() / 2u));
   }
+  std::vector<std::thread> helpers; /* page-populating helpers of the coefficient arrays (read_sof) */
+  void join_helpers() {
+    for (auto &t : helpers)
+      if (t.joinable()) t.join();
+    helpers.clear();
+  }
+  ~Decoder() { join_helpers(); }
   bool reconstruct(pngio::Image &img) {
+    join_helpers();
     const int threads = reconstruct_threads();
     const bool timing = std::getenv("CURVIS_DEBUG_TIMING") != nullptr;
     double t_last = timing ? pngio::now_s() : 0.0;
@@ -568,13 +611,21 @@ struct Decoder {
           for (int bx = 0; bx < c.blocks_w; ++bx)
             idct_block(&c.plane[((size_t)by * 8) * stride + (size_t)bx * 8], stride, &c.coef[((size_t)by * c.blocks_w + bx) * 64], q);
       });
-      c.coef.clear();
-      c.coef.shrink_to_fit();
+      c.coef.release();
     }
     mark("inverse DCT");
     img.w = (uint32_t)W;
     img.h = (uint32_t)H;
-    img.rgba.assign((size_t)W * H * 4, 255);
+    { /* the RGBA image: its pages populated by the threads that will write them, then sized (convert_rows writes all four bytes) */
+      const size_t row_bytes = (size_t)W * 4;
+      img.rgba.clear();
+      img.rgba.reserve(row_bytes * (size_t)H);
+      if (threads > 1 && !std::getenv("CURVIS_NO_POPULATE")) {
+        uint8_t *base = img.rgba.data();
+        parallel_ranges(H, threads, [base, row_bytes](int y0, int y1) { pngio::populate_pages(base + (size_t)y0 * row_bytes, (size_t)(y1 - y0) * row_bytes); });
+      }
+      img.rgba.resize(row_bytes * (size_t)H);
+    }
     const bool rgb_direct = ncomp == 3 && (adobe_transform == 0 || (adobe_transform < 0 && !jfif && comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B'));
     parallel_ranges(H, threads, [this, &img, rgb_direct](int y0, int y1) { convert_rows(img, rgb_direct, y0, y1); });
     mark("upsampling + colour");
@@ -637,12 +688,16 @@ struct Decoder {
       }
       uint8_t *o = &img.rgba[(size_t)y * W * 4];
       if (ncomp == 1) {
-        for (int x = 0; x < W; ++x) o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = rows[0][x];
+        for (int x = 0; x < W; ++x) {
+          o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = rows[0][x];
+          o[4 * x + 3] = 255;
+        }
       } else if (rgb_direct) {
         for (int x = 0; x < W; ++x) {
           o[4 * x] = rows[0][x];
           o[4 * x + 1] = rows[1][x];
           o[4 * x + 2] = rows[2][x];
+          o[4 * x + 3] = 255;
         }
       } else {
         for (int x = 0; x < W; ++x) {
@@ -650,6 +705,7 @@ struct Decoder {
           o[4 * x] = clamp8(yy + ((45 * cr) >> 5));
           o[4 * x + 1] = clamp8(yy - ((11 * cb + 23 * cr) >> 5));
           o[4 * x + 2] = clamp8(yy + ((113 * cb) >> 6));
+          o[4 * x + 3] = 255;
         }
       }
     }
