@@ -173,6 +173,20 @@ void load_common(const Args &a, Common &c, const char *what) {
    * unfilter); errors are reported in the reference's order, image 1 first */
   std::string err2;
   bool ok2 = false;
+  /* the HIP runtime comes up (hipInit, behind curvis_device_count) while the backgrounds are decoded: the two slow each other
+   * down -- the decode 90 -> 150 ms, the runtime's start-up 70 -> ~110 -- and still finish 10-25 ms sooner than one after the
+   * other (251 -> 235 ms per `curvis image`; CURVIS_NO_EARLY_INIT=1 switches it off) */
+  std::thread early_init;
+  if (!std::getenv("CURVIS_NO_EARLY_INIT")) {
+    try {
+      early_init = std::thread([] { (void)curvis_device_count(); });
+    } catch (const std::exception &) {
+    }
+  }
+  struct JoinEarly {
+    std::thread &t;
+    ~JoinEarly() { if (t.joinable()) t.join(); }
+  } join_early{early_init};
   std::thread second([&] { ok2 = jpegio::load_image(a.bg2, c.sky2, err2); });
   const bool ok1 = jpegio::load_image(a.bg1, c.sky1, err);
   second.join();
