@@ -107,10 +107,10 @@ Args parse_args(int argc, char **argv) {
     }
     std::fclose(f);
   }
-  /* four contexts per GPU in --mode efficient -- as far as the host has two CPUs per worker thread (each context's thread runs
+  /* up to six contexts per GPU in --mode efficient (four below 12 000 frames per GPU, see video_main) -- as far as the host has two CPUs per worker thread (each context's thread runs
    * the sampler's host side; 8 GPUs behind a 16-CPU quota get one context each, not 32 threads fighting the writers) */
   a.contexts_auto = a.contexts == 0;
-  if (a.contexts == 0) a.contexts = a.mode == "efficient" ? (int)std::max(1u, std::min(4u, cpus / (2u * (unsigned)a.devices))) : 1;
+  if (a.contexts == 0) a.contexts = a.mode == "efficient" ? (int)std::max(1u, std::min(6u, cpus / (2u * (unsigned)a.devices))) : 1; /* video_main: fewer for shorter videos */
   if (a.batch < 0) a.batch = 0;
   if (a.writers < 1) /* encoding a 1080p frame costs 5-25 ms of a host thread (zlib: 20-230): the GPU renders one in 0.4-10 ms */
     a.writers = (int)std::min(64u, std::max(4u, hw / 4u));

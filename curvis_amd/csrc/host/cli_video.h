@@ -18,6 +18,7 @@ int video_main(const Args &a_in) {
   PhaseClock clk;
   load_common(a, c, "video");
   clk.mark("settings + background images");
+  const bool batch_auto = a.batch < 1;
   if (a.batch < 1) {
     /* frames per launch.  The per-pixel modes keep the GPU busy with 8 frames per launch.  --mode efficient is launch- and
      * host-paced (lone waves between host-side sampler rounds): longer batches amortise both -- 1 568 / 2 202 / 2 757 frames/s at
@@ -101,8 +102,14 @@ int video_main(const Args &a_in) {
      * frames: 240 / 960 / 2 400 / 6 000 1080p frames on one GPU took 0.63 / 0.91 / 1.36 / 2.46 s with one context, 0.64 / 0.77 /
      * 1.11 / 1.76 s with two, 0.71 / 0.85 / 1.04 / 1.50 s with four (profiles/round5_cli_startup.txt) */
     const size_t per_device = (n_frames + (size_t)a.devices - 1) / (size_t)a.devices;
-    const int cap = per_device < 600 ? 1 : per_device < 2000 ? 2 : a.contexts;
+    const int cap = per_device < 600 ? 1 : per_device < 2000 ? 2 : per_device < 12000 ? 4 : a.contexts;
     a.contexts = std::min(a.contexts, cap);
+  }
+  if (batch_auto && a.mode == "efficient" && (n_frames + (size_t)a.devices - 1) / (size_t)a.devices >= 2000) {
+    /* long videos: 64 frames per launch -- with the batch buffers sized for streams their length no longer costs pinned memory, and at
+     * 29 970 frames 3 / 4 / 6 contexts read 6 953 / 8 169 / 8 956 frames/s at 32 per launch, 7 491 / 8 451 / 9 330 at 64
+     * (profiles/round5_eff_contexts_sweep_final.txt); the frames of a launch sit together in HBM: 512 MB at most */
+    a.batch = (int)std::max<size_t>(4, std::min<size_t>(64, ((size_t)512 << 20) / std::max<size_t>(1, fbytes)));
   }
   const int n_workers = a.devices * a.contexts;
   auto device_of = [&](int rank) { return a.device + rank / a.contexts; };
