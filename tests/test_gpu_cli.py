@@ -145,7 +145,7 @@ def test_video_orbit_frames_and_quirks(scene_files):
     # --stats also writes the host profile: per-device table (PCI identity, frames, kernel / render-call time) and the
     # writer threads' stage times
     summ = json.loads((out / "st.jsonl.summary.json").read_text())
-    # --mode efficient runs up to four contexts (four host threads) per GPU: more than half of its render call is host work and
+    # --mode efficient runs several contexts (host threads) per GPU -- up to six for long videos: more than half of its render call is host work and
     # its kernels do not fill the GPU (profiles/round5_eff_contexts_sweep.txt).  Asked for explicitly here: the automatic choice
     # gives a video this short ONE context (each costs a start-up of its own; checked at the end of this test)
     assert summ["frames"] == 15 and summ["png_level"] == -1 and len(summ["devices"]) == 4
