@@ -1,3 +1,4 @@
 mkdir -p gpurun_out
-SWEEP_C=0 SWEEP_B=0 timeout 600 python tools/gpu_eff_contexts_sweep.py 3 > gpurun_out/eff_auto.txt 2>&1; grep -E '^round' gpurun_out/eff_auto.txt
-(time timeout 900 python -m pytest tests/test_gpu_cli.py tests/test_gpu_configs.py -m gpu -x -q) 2>&1 | tail -5
+(time timeout 1200 python -m pytest tests -m gpu -x -q) > gpurun_out/s8_gpu_tests.txt 2>&1; tail -4 gpurun_out/s8_gpu_tests.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py > gpurun_out/s8_bench.json 2> gpurun_out/s8_bench.err; tail -c 200 gpurun_out/s8_bench.json
