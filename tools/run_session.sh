@@ -1,4 +1,1 @@
-mkdir -p gpurun_out
-(time timeout 1200 python -m pytest tests -m gpu -x -q) > gpurun_out/s8_gpu_tests.txt 2>&1; tail -4 gpurun_out/s8_gpu_tests.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-python bench.py > gpurun_out/s8_bench.json 2> gpurun_out/s8_bench.err; tail -c 200 gpurun_out/s8_bench.json
+bash tools/gpu_eff_pixel_profile.sh 2>&1 | tail -40
