@@ -321,6 +321,56 @@ def test_jpeg_decoder_against_libjpeg(tmp_path):
         assert r.returncode in (0, 1), r.returncode
 
 
+def test_large_jpeg_reconstructed_behind_the_scan_equals_the_ordinary_way(tmp_path):
+    """a large baseline JPEG (one interleaved scan) is reconstructed by worker threads in bands of MCU rows WHILE the entropy
+    decoder runs (jpeg_io.h stream_worker); CURVIS_NO_JPEG_STREAM=1 takes the ordinary way (everything after the scan).  Same
+    pixels, for every subsampling, for sizes that are no multiple of a band / an MCU, with restart markers, with one worker and
+    with several; progressive and grey files do not stream and must not care; a damaged large file is an error or an image, never
+    a hang"""
+    PIL = pytest.importorskip("PIL.Image")
+
+    def decode(path, **env):
+        out = tmp_path / "dump.rgba"
+        r = subprocess.run([BIN, "selftest-png", str(path), str(out)], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        raw = out.read_bytes()
+        w, h = struct.unpack("<II", raw[:8])
+        return np.frombuffer(raw[8:], np.uint8).reshape(h, w, 4)
+    variants = [("420", dict(subsampling=2)), ("422", dict(subsampling=1)), ("444", dict(subsampling=0)), ("rst", dict(subsampling=2, restart_marker_rows=3)),
+                ("prog", dict(subsampling=2, progressive=True))]
+    for (h, w) in ((1024, 1040), (901, 1201), (1160, 913)):
+        img = _jpeg_test_image(h, w, seed=h)
+        for name, kw in variants:
+            p = tmp_path / ("big_%s.jpg" % name)
+            try:
+                PIL.fromarray(img).save(p, **dict({"quality": 88}, **kw))
+            except TypeError:
+                continue
+            plain = decode(p, CURVIS_NO_JPEG_STREAM="1", CURVIS_DECODE_THREADS="1")
+            for threads in ("2", "5"):
+                assert np.array_equal(decode(p, CURVIS_DECODE_THREADS=threads), plain), (h, w, name, threads)
+            want = np.asarray(PIL.open(p).convert("RGB"))
+            d = np.abs(plain[..., :3].astype(int) - want.astype(int))
+            assert d.max() <= 24 and d.mean() < 0.8 and (plain[..., 3] == 255).all(), (name, d.max(), d.mean())   # two conforming decoders (upsampling filters differ)
+    p = tmp_path / "big_grey.jpg"
+    PIL.fromarray(_jpeg_test_image(1100, 1000, seed=2)[..., 0]).save(p, quality=90)
+    assert np.array_equal(decode(p, CURVIS_DECODE_THREADS="4"), decode(p, CURVIS_NO_JPEG_STREAM="1", CURVIS_DECODE_THREADS="1"))
+    blob = (tmp_path / "big_420.jpg").read_bytes()
+    rng = np.random.default_rng(21)
+    for k in range(24):
+        b = bytearray(blob)
+        if k % 2:
+            del b[int(rng.integers(700, len(b))):]
+        else:
+            for pos in rng.integers(650, len(b), 5):
+                b[pos] = int(rng.integers(0, 256))
+        q = tmp_path / "hurt.jpg"
+        q.write_bytes(bytes(b))
+        r = subprocess.run([BIN, "selftest-png", str(q), str(tmp_path / "o.rgba")], capture_output=True, text=True, timeout=60,
+                           env=dict(os.environ, CURVIS_DECODE_THREADS="4"))
+        assert r.returncode in (0, 1), (k, r.returncode, r.stderr[-200:])
+
+
 def test_library_image_codecs_equal_the_binarys(tmp_path):
     """curvis_image_load / curvis_image_save_rgb8 (the library's counterpart of images::load_image / save_image,
     src/images.rs:7-20) are the binary's decoders: same texels for PNG and JPEG, errors as CurvisError"""

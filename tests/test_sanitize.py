@@ -58,6 +58,42 @@ def test_image_decoders_are_clean_under_asan_and_ubsan_on_hostile_files(tmp_path
     assert "decoded" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
 
 
+def test_large_images_on_several_threads_are_clean_under_asan_and_ubsan(tmp_path):
+    """large files take the decoders' multi-threaded paths -- a JPEG reconstructed behind its scan by worker threads, a PNG inflated
+    by one stage, reconstructed in place by a second, written as RGBA by a third -- intact and damaged, under ASan + UBSan"""
+    import numpy as np
+    PIL = __import__("pytest").importorskip("PIL.Image")
+    subprocess.run(["make", "-s", "-C", D, "san_images"], check=True)
+    rng = np.random.default_rng(13)
+    yy, xx = np.mgrid[0:1000, 0:1100]
+    img = np.clip(np.stack([127 + 100 * np.sin(xx / 50.0), xx * 0.2, yy * 0.25], axis=2) + rng.normal(0, 6, (1000, 1100, 3)), 0, 255).astype(np.uint8)
+    seeds = []
+    for name, kw in (("a.jpg", dict(quality=85, subsampling=2)), ("b.jpg", dict(quality=85, subsampling=0, restart_marker_rows=2)), ("c.png", {})):
+        p = tmp_path / name
+        try:
+            PIL.fromarray(img).save(p, **kw)
+        except TypeError:
+            PIL.fromarray(img).save(p)
+        seeds.append(p.read_bytes())
+    files = []
+    for k in range(27):
+        b = bytearray(seeds[k % 3])
+        if k >= 3:
+            if k % 2:
+                b = b[:int(rng.integers(600, len(b)))]
+            else:
+                for pos in rng.integers(600, len(b), 5):
+                    b[pos] = int(rng.integers(0, 256))
+        f = tmp_path / ("big%02d.bin" % k)
+        f.write_bytes(bytes(b))
+        files.append(str(f))
+    env = dict(os.environ, CURVIS_DECODE_THREADS="3", ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(D, "san_images")] + files, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "decoded" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+    assert int(r.stdout.split("decoded")[1].split(",")[0]) >= 3          # the intact ones at least
+
+
 def test_fast_png_writer_is_clean_under_asan_and_ubsan():
     """the fast PNG writer of `curvis video` (png_io.h) on 400 small images of awkward shapes and contents (all zero, noise,
     long runs, gradients, short runs), each decoded again and compared, under ASan + UBSan: its bit writer stores eight
