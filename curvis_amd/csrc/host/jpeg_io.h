@@ -24,8 +24,6 @@
 #include <string>
 #include <vector>
 #include <thread>
-#include <condition_variable>
-#include <mutex>
 #include <system_error>
 
 #include <new>
@@ -373,84 +371,7 @@ struct Decoder {
     have_sof = true;
     return true;
   }
-  /* ---- reconstruction BEHIND the entropy decoder (baseline, one interleaved scan of all three components: what a camera or
-   * an image editor writes).  The entropy decoder is serial and takes about half of a large JPEG's decode; the inverse DCT and
-   * the colour conversion are independent per block / per row.  Worker threads take bands of kBandMcuRows MCU rows as the scan
-   * completes them: inverse DCT of the band, then upsampling + colour for the pixel rows whose chroma neighbours are final --
-   * a band's last 8 pixel rows wait for the next band (its first chroma row), the first 8 of a band are done with it, which
-   * needs the band above to have finished ITS inverse DCT.  Same functions, same pixels as reconstruct(). */
-  enum : int { kBandMcuRows = 8 };
-  pngio::Image *stream_img = nullptr; /* run() sets it: where a streamed reconstruction writes */
-  bool streamed = false;              /* the image has been reconstructed behind the scan: reconstruct() has nothing left to do */
-  int scans_read = 0;
-  struct Stream {
-    std::mutex mu;
-    std::condition_variable cv;
-    int mcu_rows_done = 0, next_band = 0, n_bands = 0;
-    bool scan_finished = false, abort = false, rgba_ready = false, oom = false;
-    std::vector<char> idct_done;
-    std::vector<std::thread> workers;
-  };
-  void stream_worker(Stream &S, bool rgb_direct, bool first) {
-    try {
-      if (first) { /* the RGBA image: populated and sized here, while the entropy decoder fills the first band */
-        pngio::Image &img = *stream_img;
-        const size_t bytes = (size_t)W * (size_t)H * 4;
-        img.rgba.clear();
-        img.rgba.reserve(bytes);
-        if (!std::getenv("CURVIS_NO_POPULATE")) pngio::populate_pages(img.rgba.data(), bytes);
-        img.rgba.resize(bytes);
-        {
-          std::lock_guard<std::mutex> g(S.mu);
-          S.rgba_ready = true;
-        }
-        S.cv.notify_all();
-      }
-      for (;;) {
-        int b, row0, row1;
-        {
-          std::unique_lock<std::mutex> g(S.mu);
-          S.cv.wait(g, [&] {
-            if (S.abort || S.next_band >= S.n_bands) return true;
-            const int end = std::min(mcus_y, (S.next_band + 1) * (int)kBandMcuRows);
-            return S.mcu_rows_done >= end;
-          });
-          if (S.abort || S.next_band >= S.n_bands) return;
-          b = S.next_band++;
-          row0 = b * (int)kBandMcuRows;
-          row1 = std::min(mcus_y, row0 + (int)kBandMcuRows);
-        }
-        for (int i = 0; i < ncomp; ++i) {
-          Component &c = comp[i];
-          const int stride = c.blocks_w * 8;
-          const uint16_t *q = qt[c.tq];
-          for (int by = row0 * c.v; by < row1 * c.v; ++by)
-            for (int bx = 0; bx < c.blocks_w; ++bx)
-              idct_block(&c.plane[((size_t)by * 8) * stride + (size_t)bx * 8], stride, &c.coef[((size_t)by * c.blocks_w + bx) * 64], q);
-        }
-        {
-          std::unique_lock<std::mutex> g(S.mu);
-          S.idct_done[(size_t)b] = 1;
-          S.cv.notify_all();
-          /* colour needs the band above (its last chroma row) and the image */
-          S.cv.wait(g, [&] { return S.abort || (S.rgba_ready && (b == 0 || S.idct_done[(size_t)b - 1])); });
-          if (S.abort) return;
-        }
-        const int px0 = row0 * 8 * vmax, px1 = row1 * 8 * vmax;
-        const int y0 = b == 0 ? 0 : std::min(H, px0 - 8), y1 = (b == S.n_bands - 1) ? H : std::min(H, px1 - 8);
-        if (y1 > y0) convert_rows(*stream_img, rgb_direct, y0, y1);
-      }
-    } catch (const std::bad_alloc &) {
-      {
-        std::lock_guard<std::mutex> g(S.mu);
-        S.oom = S.abort = true;
-      }
-      S.cv.notify_all();
-    }
-  }
   bool read_scan(const uint8_t *d, size_t len) {
-    if (streamed) streamed = false; /* one more scan changes coefficients: reconstruct() does everything again from them */
-    ++scans_read;
     if (!have_sof) return fail("scan before frame header");
     if (len < 1) return fail("truncated SOS");
     const int ns = d[0];
@@ -501,36 +422,7 @@ struct Decoder {
           if (!restart()) return false;
         }
     } else {
-      /* the common file -- baseline, ONE scan with all three components, large -- is reconstructed behind this loop */
-      const int threads = reconstruct_threads();
-      bool stream = !progressive && ns == ncomp && ncomp == 3 && scans_read == 1 && threads > 1 && stream_img != nullptr &&
-                    !std::getenv("CURVIS_NO_JPEG_STREAM");
-      for (int i = 0; stream && i < ncomp; ++i) stream = qt_present[comp[i].tq];
-      Stream S;
-      struct StopWorkers { /* however this function is left, the workers are told to stop and joined */
-        Stream &s;
-        ~StopWorkers() {
-          {
-            std::lock_guard<std::mutex> g(s.mu);
-            if (!s.scan_finished) s.abort = true;
-          }
-          s.cv.notify_all();
-          for (auto &t : s.workers)
-            if (t.joinable()) t.join();
-        }
-      } stop_workers{S};
-      if (stream) {
-        for (int i = 0; i < ncomp; ++i) comp[i].plane.assign((size_t)comp[i].blocks_w * 8 * comp[i].blocks_h * 8, 0);
-        S.n_bands = (mcus_y + (int)kBandMcuRows - 1) / (int)kBandMcuRows;
-        S.idct_done.assign((size_t)S.n_bands, 0);
-        const bool rgb_direct = adobe_transform == 0 || (adobe_transform < 0 && !jfif && comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B');
-        try {
-          for (int t = 0; t < threads; ++t) S.workers.emplace_back([this, &S, rgb_direct, t] { stream_worker(S, rgb_direct, t == 0); });
-        } catch (const std::exception &) {
-          if (S.workers.empty()) stream = false; /* no thread at all: the ordinary way */
-        }
-      }
-      for (int my = 0; my < mcus_y; ++my) {
+      for (int my = 0; my < mcus_y; ++my)
         for (int mx = 0; mx < mcus_x; ++mx) {
           for (int i = 0; i < ns; ++i) {
             Component &c = comp[order[i]];
@@ -540,24 +432,6 @@ struct Decoder {
           }
           if (!restart()) return false;
         }
-        if (stream) {
-          {
-            std::lock_guard<std::mutex> g(S.mu);
-            S.mcu_rows_done = my + 1;
-          }
-          if (((my + 1) % (int)kBandMcuRows) == 0 || my + 1 == mcus_y) S.cv.notify_all();
-        }
-      }
-      if (stream) {
-        {
-          std::lock_guard<std::mutex> g(S.mu);
-          S.scan_finished = true;
-        }
-        S.cv.notify_all();
-        for (auto &t : S.workers) t.join();
-        if (S.oom) throw std::bad_alloc();
-        streamed = !S.abort;
-      }
     }
     /* leave p at the marker that ended the entropy-coded segment */
     if (hit_marker) {
@@ -717,12 +591,6 @@ struct Decoder {
   ~Decoder() { join_helpers(); }
   bool reconstruct(pngio::Image &img) {
     join_helpers();
-    if (streamed) { /* done behind the scan (stream_worker) */
-      for (int i = 0; i < ncomp; ++i) comp[i].coef.release();
-      img.w = (uint32_t)W;
-      img.h = (uint32_t)H;
-      return true;
-    }
     const int threads = reconstruct_threads();
     const bool timing = std::getenv("CURVIS_DEBUG_TIMING") != nullptr;
     double t_last = timing ? pngio::now_s() : 0.0;
@@ -845,7 +713,6 @@ struct Decoder {
 
   bool run(pngio::Image &img) {
     const double t_run0 = pngio::now_s();
-    stream_img = &img;
     if (end - p < 4 || p[0] != 0xFF || p[1] != 0xD8) return fail("not a JPEG file");
     p += 2;
     bool seen_scan = false;

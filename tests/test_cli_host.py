@@ -321,12 +321,12 @@ def test_jpeg_decoder_against_libjpeg(tmp_path):
         assert r.returncode in (0, 1), r.returncode
 
 
-def test_large_jpeg_reconstructed_behind_the_scan_equals_the_ordinary_way(tmp_path):
-    """a large baseline JPEG (one interleaved scan) is reconstructed by worker threads in bands of MCU rows WHILE the entropy
-    decoder runs (jpeg_io.h stream_worker); CURVIS_NO_JPEG_STREAM=1 takes the ordinary way (everything after the scan).  Same
-    pixels, for every subsampling, for sizes that are no multiple of a band / an MCU, with restart markers, with one worker and
-    with several; progressive and grey files do not stream and must not care; a damaged large file is an error or an image, never
-    a hang"""
+def test_large_jpeg_on_several_threads_equals_one_thread(tmp_path):
+    """a large JPEG is reconstructed on several threads (inverse DCT by block rows, upsampling + colour by pixel rows; jpeg_io.h
+    parallel_ranges): same pixels as on one thread, for every subsampling, for sizes that are no multiple of an MCU, with restart
+    markers, progressive, grey; a damaged large file is an error or an image, never a hang.  (Reconstructing a baseline file BEHIND
+    its scan was built and measured -- on the GPU box's 16-CPU quota the workers slowed the entropy decoder by more than they hid,
+    354 vs 249 ms per `curvis image` -- and taken out again; the CURVIS_NO_JPEG_STREAM switch of that build is inert now.)"""
     PIL = pytest.importorskip("PIL.Image")
 
     def decode(path, **env):

@@ -59,7 +59,7 @@ def test_image_decoders_are_clean_under_asan_and_ubsan_on_hostile_files(tmp_path
 
 
 def test_large_images_on_several_threads_are_clean_under_asan_and_ubsan(tmp_path):
-    """large files take the decoders' multi-threaded paths -- a JPEG reconstructed behind its scan by worker threads, a PNG inflated
+    """large files take the decoders' multi-threaded paths -- a JPEG reconstructed on several threads, a PNG inflated
     by one stage, reconstructed in place by a second, written as RGBA by a third -- intact and damaged, under ASan + UBSan"""
     import numpy as np
     PIL = __import__("pytest").importorskip("PIL.Image")
