@@ -1,3 +1,5 @@
 mkdir -p gpurun_out
-python tools/gpu_cli_startup.py 4 > gpurun_out/cli_startup5.txt 2>&1; grep -E '^##|^wall|jpeg|settings' gpurun_out/cli_startup5.txt | sed -n 1,40p
-echo NO_STREAM; CURVIS_NO_JPEG_STREAM=1 python tools/gpu_cli_startup.py 4 2>&1 | grep -A9 'JPEG backgrounds$' | grep -E 'wall|jpeg|settings'
+(time timeout 1200 python -m pytest tests -m gpu -x -q) > gpurun_out/s9_gpu_tests.txt 2>&1; tail -4 gpurun_out/s9_gpu_tests.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py > gpurun_out/s9_bench.json 2> gpurun_out/s9_bench.err; tail -c 200 gpurun_out/s9_bench.json
+python tools/gpu_cli_startup.py 4 > gpurun_out/cli_startup6.txt 2>&1; grep -E '^##|^wall' gpurun_out/cli_startup6.txt
