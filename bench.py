@@ -954,7 +954,8 @@ def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gp
     import shutil
     import subprocess
     import tempfile
-    from curvis_amd import paths
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refpaths  # the reference's own path_orbit.csv, committed as a data fixture (tests/golden/paths)
     exe = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
     d = tempfile.mkdtemp(prefix="curvis_e2e_")
     try:
@@ -967,7 +968,7 @@ def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gp
         # path_orbit.csv runs for 60 s; times_of_frames pushes t = 0, 1/fps, ... while t < 60 (src/rendering.rs:224-238)
         fps = n_frames / 60.0
         with open(os.path.join(d, "vid.toml"), "w") as f:
-            f.write('video_name = "e2e"\nframe_rate = %r\nfilepath_to_camera_path = "%s"\n' % (fps, paths.path_file("path_orbit.csv")))
+            f.write('video_name = "e2e"\nframe_rate = %r\nfilepath_to_camera_path = "%s"\n' % (fps, refpaths.reference_path_file("path_orbit.csv")))
         with open(os.path.join(d, "sim.toml"), "w") as f:
             f.write("escape_radius = 100.0\nray_integration_max_itarations = %d\nray_integration_step = 0.05\n"
                     "sampling_initial_nums = 100\nsampling_max_iterations = 50\n"

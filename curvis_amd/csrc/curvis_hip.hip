@@ -55,6 +55,7 @@
 #include "../../include/curvis_hip.h"
 #include "cv_device.h"
 #include "cv_efficient.h"
+#include "cv_frame_host.h"
 #include "cv_host.h"
 #include "cv_sampler.h"
 #include "host/jpeg_io.h" /* PNG + JPEG decoders shared with the curvis binary */

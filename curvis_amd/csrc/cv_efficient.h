@@ -37,13 +37,23 @@ CV_HD void mat3_identity(double *m) {
   m[6] = 0.0; m[7] = 0.0; m[8] = 1.0;
 }
 
+/* Elementary functions of the rotations below.  CvMath (cv_math.h) is what every per-ray / per-pixel evaluation uses, on
+ * the device and in its x86 twin.  The two once-per-frame host values of render_image_efficient (cam_bg, rot_bg:
+ * src/systems.rs:393-397, :411) are instead taken over the platform libm like the reference takes them -- the policy for that
+ * lives in efficient_host.h (host only). */
+struct CvMath {
+  CV_HD void sincos(double x, double *s, double *c) { cv_sincos(x, s, c); } /* CV_HD carries `static inline` */
+  CV_HD double acos(double x) { return cv_acos(x); }
+};
+
 /* nalgebra Rotation3::from_axis_angle(&Unit(axis), angle): identity iff angle == 0 (NaN is != 0) */
+template <class MT = CvMath>
 CV_HD void from_axis_angle(const double *u, double angle, double *m) {
   if (angle != 0.0) {
     const double ux = u[0], uy = u[1], uz = u[2];
     const double sqx = ux * ux, sqy = uy * uy, sqz = uz * uz;
     double sn, cs;
-    cv_sincos(angle, &sn, &cs);
+    MT::sincos(angle, &sn, &cs);
     const double omc = 1.0 - cs;
     m[0] = sqx + (1.0 - sqx) * cs;
     m[1] = ux * uy * omc - uz * sn;
@@ -60,6 +70,7 @@ CV_HD void from_axis_angle(const double *u, double angle, double *m) {
 }
 
 /* nalgebra Rotation3::rotation_between(a, b); false == None (antiparallel) */
+template <class MT = CvMath>
 CV_HD bool rotation_between(const double *a, const double *b, double *m) {
   const double an = norm3(a), bn = norm3(b);
   if (!(an <= 0.0) && !(bn <= 0.0)) { /* try_normalize(0.0) */
@@ -72,7 +83,7 @@ CV_HD bool rotation_between(const double *a, const double *b, double *m) {
     if (sq > eps * eps) {
       const double n = CV_SQRT(sq);
       const double axis[3] = {c[0] / n, c[1] / n, c[2] / n};
-      from_axis_angle(axis, cv_acos(dot3(na, nb)) * 1.0, m);
+      from_axis_angle<MT>(axis, MT::acos(dot3(na, nb)) * 1.0, m);
       return true;
     }
     if (dot3(na, nb) < 0.0) return false;
@@ -82,11 +93,12 @@ CV_HD bool rotation_between(const double *a, const double *b, double *m) {
 }
 
 /* src/algebra.rs:92-101: panics (false) when the cross product is exactly zero or nalgebra returns None */
+template <class MT = CvMath>
 CV_HD bool rotation_from_two_vectors(const double *v1, const double *v2, double *m) {
   double c[3];
   cross3(v1, v2, c);
   if (norm3(c) == 0.0) return false;
-  return rotation_between(v1, v2, m);
+  return rotation_between<MT>(v1, v2, m);
 }
 
 /* f64::rem_euclid(a, b), b > 0, general */
@@ -96,6 +108,7 @@ CV_HD double rem_euclid_general(double a, double b) {
 }
 
 /* src/algebra.rs:106-126 */
+template <class MT = CvMath>
 CV_HD void vector3_from_theta_phi(double theta, double phi, double *v) {
   if (theta < 0.0) {
     theta = CV_FABS(theta);
@@ -103,8 +116,8 @@ CV_HD void vector3_from_theta_phi(double theta, double phi, double *v) {
   }
   phi = rem_euclid_general(phi, 2.0 * CV_PI);
   double st, ct, sp, cp;
-  cv_sincos(theta, &st, &ct);
-  cv_sincos(phi, &sp, &cp);
+  MT::sincos(theta, &st, &ct);
+  MT::sincos(phi, &sp, &cp);
   v[0] = st * cp;
   v[1] = st * sp;
   v[2] = ct;

@@ -119,9 +119,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   /* step 1 (host): camera direction on the background space and the tangent->background rotation */
   std::vector<cvk::EfficientFrame> eframes(n_frames);
   for (uint32_t f = 0; f < n_frames; ++f) {
-    cvk::vector3_from_theta_phi(cams[f].pos[2], cams[f].pos[3], eframes[f].cam_bg);
-    const double ex[3] = {1.0, 0.0, 0.0};
-    if (!cvk::rotation_from_two_vectors(ex, eframes[f].cam_bg, eframes[f].rot_bg))
+    if (!cvk::efficient_frame_pose(cams[f].pos[2], cams[f].pos[3], eframes[f])) /* platform libm: cv_frame_host.h */
       return fail(ctx, CURVIS_E_PARALLEL, "v1 and v2 must not be parallel (src/algebra.rs:95-97, camera on the x axis)");
   }
 
@@ -498,9 +496,7 @@ int render_direct_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvi
   DirectParams P;
   P.metric = make_metric(*metric);
   P.cam = make_camera(*cam);
-  cvk::vector3_from_theta_phi(cam->pos[2], cam->pos[3], P.frame.cam_bg); /* src/systems.rs:393-397 */
-  const double ex[3] = {1.0, 0.0, 0.0};
-  if (!cvk::rotation_from_two_vectors(ex, P.frame.cam_bg, P.frame.rot_bg))
+  if (!cvk::efficient_frame_pose(cam->pos[2], cam->pos[3], P.frame)) /* src/systems.rs:393-397, :411 */
     return fail(ctx, CURVIS_E_PARALLEL, "v1 and v2 must not be parallel (src/algebra.rs:95-97, camera on the x axis)");
   for (int k = 0; k < 2; ++k) {
     P.sky[k].texels = (const unsigned *)ctx->d_sky[k];

@@ -190,6 +190,10 @@ void load_common(const Args &a, Common &c, const char *what) {
   std::thread second([&] { ok2 = jpegio::load_image(a.bg2, c.sky2, err2); });
   const bool ok1 = jpegio::load_image(a.bg1, c.sky1, err);
   second.join();
+  /* die() is std::exit(): it does not unwind, so JoinEarly would never run, and exit()'s handlers / the static destructors of
+   * libamdhip64 would tear the runtime down while hipInit is still executing on the helper thread (a decode error returns in
+   * microseconds, hipInit takes ~100 ms) -- join it first, the error path is not the fast path */
+  if ((!ok1 || !ok2) && early_init.joinable()) early_init.join();
   if (!ok1) die(std::string("Error in rendering ") + what + ": background image 1: " + err);
   if (!ok2) die(std::string("Error in rendering ") + what + ": background image 2: " + err2);
 }

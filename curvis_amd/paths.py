@@ -2,9 +2,16 @@
 
 The reference ships two CSV camera paths produced by small numpy scripts
 (paths/generate_path_orbit.py:4-33, paths/generate_path_through.py:3-53).  These are this
-project's own generators for the same closed forms; tests/test_paths.py checks (in the build
-container, where /root/reference exists) that the output is byte-identical to the reference's
-CSV files.  CSV format (src/csv.rs:24-62): one header line, then `t,l,theta,phi,fx,fy,fz,upx,upy,upz`.
+project's own generators for the same closed forms; they produce the BUNDLED default paths
+(`paths/path_through.csv` of a default video_settings.toml resolves to them).  Against the
+reference's files (tests/test_paths.py): path_orbit.csv is reproduced byte for byte;
+path_through.csv goes through np.exp / arctan / cos / sin, whose last bit depends on the numpy
+build, and is reproduced up to the forward vector of 29 of its 1000 rows (<= 7.8e-16, measured
+in the build container).  Everything that claims parity on configs[3] / [4] -- the tests and
+bench.py's video legs -- therefore reads the reference's own bytes, committed as data fixtures
+(tests/golden/paths/*.csv.gz, tests/refpaths.py), not these; a user who wants the reference's
+poses passes the reference's CSV, like any other camera path.
+CSV format (src/csv.rs:24-62): one header line, then `t,l,theta,phi,fx,fy,fz,upx,upy,upz`.
 """
 import os
 

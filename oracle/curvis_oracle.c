@@ -213,6 +213,7 @@ static void sincos_two_calls(double x, double *s, double *c) { /* llvm.sin.f64 a
 }
 static void sincos_glibc(double x, double *s, double *c) { sincos(x, s, c); } /* ... merged into one sincos() libcall */
 
+#define M_FRAME(name) F(name)
 #define F(name) name##_libm
 #define M_SIN sin
 #define M_COS cos
@@ -252,6 +253,8 @@ static void sincos_glibc(double x, double *s, double *c) { sincos(x, s, c); } /*
 #undef M_SINCOS
 #undef M_SIN_INL
 
+#undef M_FRAME
+#define M_FRAME(name) name##_sc /* the product's cv_frame_host.h: glibc, one sincos() per pair */
 #define F(name) name##_cv
 #define M_SIN cv_sin
 #define M_COS cv_cos
@@ -271,6 +274,7 @@ static void sincos_glibc(double x, double *s, double *c) { sincos(x, s, c); } /*
 #undef M_LOG
 #undef M_SINCOS
 #undef M_SIN_INL
+#undef M_FRAME
 
 #define DISPATCH(fl, name, ...)                                   \
   ((fl) == CVO_CV                 ? name##_cv(__VA_ARGS__)        \

@@ -8,6 +8,7 @@
 
 #include "../../curvis_amd/csrc/cv_device.h"
 #include "../../curvis_amd/csrc/cv_efficient.h"
+#include "../../curvis_amd/csrc/cv_frame_host.h"
 #include "../../curvis_amd/csrc/cv_sampler.h"
 #include "../../include/curvis_hip.h"
 
@@ -169,9 +170,7 @@ extern "C" int twin_render_efficient(const curvis_metric *m, const curvis_camera
   for (int s = 0; s < 2; ++s)
     for (int i = 0; i < 9; ++i) sky[s].inv_rot[i] = (i % 4 == 0) ? 1.0 : 0.0;
   cvk::EfficientFrame F;
-  cvk::vector3_from_theta_phi(c->pos[2], c->pos[3], F.cam_bg);
-  const double ex[3] = {1.0, 0.0, 0.0};
-  if (!cvk::rotation_from_two_vectors(ex, F.cam_bg, F.rot_bg)) return -2;
+  if (!cvk::efficient_frame_pose(c->pos[2], c->pos[3], F)) return -2; /* host values over the platform libm, as the product */
   cvs::Sampler S;
   S.a_min = -0.1 * CV_PI; S.a_max = 1.1 * CV_PI; S.n0 = alpha_nums; S.max_iterations = max_it_sampling;
   S.thr1 = thr1; S.thr2 = thr2;

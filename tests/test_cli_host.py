@@ -326,7 +326,7 @@ def test_large_jpeg_on_several_threads_equals_one_thread(tmp_path):
     parallel_ranges): same pixels as on one thread, for every subsampling, for sizes that are no multiple of an MCU, with restart
     markers, progressive, grey; a damaged large file is an error or an image, never a hang.  (Reconstructing a baseline file BEHIND
     its scan was built and measured -- on the GPU box's 16-CPU quota the workers slowed the entropy decoder by more than they hid,
-    354 vs 249 ms per `curvis image` -- and taken out again; the CURVIS_NO_JPEG_STREAM switch of that build is inert now.)"""
+    354 vs 249 ms per `curvis image` -- and taken out again.)"""
     PIL = pytest.importorskip("PIL.Image")
 
     def decode(path, **env):
@@ -346,7 +346,7 @@ def test_large_jpeg_on_several_threads_equals_one_thread(tmp_path):
                 PIL.fromarray(img).save(p, **dict({"quality": 88}, **kw))
             except TypeError:
                 continue
-            plain = decode(p, CURVIS_NO_JPEG_STREAM="1", CURVIS_DECODE_THREADS="1")
+            plain = decode(p, CURVIS_DECODE_THREADS="1")
             for threads in ("2", "5"):
                 assert np.array_equal(decode(p, CURVIS_DECODE_THREADS=threads), plain), (h, w, name, threads)
             want = np.asarray(PIL.open(p).convert("RGB"))
@@ -354,7 +354,7 @@ def test_large_jpeg_on_several_threads_equals_one_thread(tmp_path):
             assert d.max() <= 24 and d.mean() < 0.8 and (plain[..., 3] == 255).all(), (name, d.max(), d.mean())   # two conforming decoders (upsampling filters differ)
     p = tmp_path / "big_grey.jpg"
     PIL.fromarray(_jpeg_test_image(1100, 1000, seed=2)[..., 0]).save(p, quality=90)
-    assert np.array_equal(decode(p, CURVIS_DECODE_THREADS="4"), decode(p, CURVIS_NO_JPEG_STREAM="1", CURVIS_DECODE_THREADS="1"))
+    assert np.array_equal(decode(p, CURVIS_DECODE_THREADS="4"), decode(p, CURVIS_DECODE_THREADS="1"))
     blob = (tmp_path / "big_420.jpg").read_bytes()
     rng = np.random.default_rng(21)
     for k in range(24):

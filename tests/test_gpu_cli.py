@@ -10,6 +10,7 @@ import pytest
 
 import common
 import oracle_lib as O
+import refpaths
 from curvis_amd import paths, pngio, rendering
 
 pytestmark = pytest.mark.gpu
@@ -121,7 +122,7 @@ def test_video_orbit_frames_and_quirks(scene_files):
     out.mkdir()
     (out / "tmp").mkdir()
     (out / "tmp" / "stale.png").write_bytes(b"x")  # the tmp folder is deleted and recreated (src/rendering.rs:276-287)
-    orbit = paths.path_file("path_orbit.csv")
+    orbit = refpaths.reference_path_file("path_orbit.csv")
     (d / "vid.toml").write_text('video_name = "v"\nframe_rate = 0.25\nfilepath_to_camera_path = "%s"\n' % orbit)
     r = run("video", d / "pos.png", d / "neg.png", out, "-v", d / "vid.toml", "-s", d / "sim.toml", "-c", d / "cam.toml",
             "--batch", "4", "--contexts-per-device", "4", "--stats", out / "st.jsonl")
@@ -208,7 +209,7 @@ def test_video_off_by_one_panics_like_the_reference(scene_files):
     d, sp, sn = scene_files
     out = d / "out_vid2"
     out.mkdir()
-    pos, fwd, up = paths.load_path(paths.path_file("path_orbit.csv"))
+    pos, fwd, up = paths.load_path(refpaths.reference_path_file("path_orbit.csv"))
     short = d / "short.csv"
     rows = [paths.HEADER] + [",".join(repr(float(x)) for x in list(pos[i]) + list(fwd[i]) + list(up[i])) for i in range(4)]
     short.write_text("\n".join(rows))
@@ -224,7 +225,7 @@ def test_video_rccl_sky_broadcast_path(scene_files):
     """--sky-broadcast rccl (the multi-GPU default) forced on the single GPU: rank 0 uploads, the textures
     go through ncclBroadcast (curvis_ctx_bcast_skies); frames must equal those of the upload path."""
     d, sp, sn = scene_files
-    orbit = paths.path_file("path_orbit.csv")
+    orbit = refpaths.reference_path_file("path_orbit.csv")
     (d / "vid3.toml").write_text('video_name = "v"\nframe_rate = 0.1\nfilepath_to_camera_path = "%s"\n' % orbit)
     outs = []
     for tag, env_extra, flag in (("rccl", {"CURVIS_FORCE_RCCL": "1"}, "rccl"), ("upload", {}, "upload")):
@@ -292,3 +293,46 @@ def test_python_image_rendering_system_equals_the_binary(scene_files):
     oc = O.camera((0.0, 3.0, 1.3, 0.7), (-1.0, 0.2, 0.1), (0.0, 0.0, 1.0), 15.0, 43.0, (96, 54))
     want, _, _ = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), 4096, 100.0, 0.05, 100, 100, 1e-5, 2e-5)
     assert np.array_equal(pngio.read_png(path), want)
+
+
+@pytest.mark.parametrize("mode", ["efficient", "brute"])
+def test_fast_exit_drops_nothing_when_stdout_and_stats_are_pipes(scene_files, mode):
+    """main() leaves through std::_Exit after flushing (host/curvis_cli.cpp: skips the HIP runtime's exit handlers).  _Exit runs
+    no atexit handler and flushes no stdio buffer, so everything must already be out: stdout is a PIPE here (fully buffered, the
+    case in which an unflushed tail would vanish), --stats is a FIFO read by this test, and the PNG frames are re-read.  Every
+    byte that the ordinary exit (CURVIS_SLOW_EXIT=1, through the exit handlers) delivers must arrive."""
+    import threading
+    d, sp, sn = scene_files
+    orbit = refpaths.reference_path_file("path_orbit.csv")
+    got = {}
+    for how in ("fast", "slow"):
+        out = d / ("out_exit_%s_%s" % (mode, how))
+        out.mkdir()
+        (d / "vid_exit.toml").write_text('video_name = "v"\nframe_rate = 1.0\nfilepath_to_camera_path = "%s"\n' % orbit)
+        fifo = out / "st.fifo"
+        os.mkfifo(fifo)
+        records = []
+
+        def reader():
+            with open(fifo) as f:       # blocks until the binary opens its end; reads to EOF = the binary's fclose
+                records.extend(f.read().splitlines())
+        t = threading.Thread(target=reader)
+        t.start()
+        env = dict(os.environ)
+        env.pop("CURVIS_SLOW_EXIT", None)
+        if how == "slow":
+            env["CURVIS_SLOW_EXIT"] = "1"
+        r = run("video", d / "pos.png", d / "neg.png", out, "-v", d / "vid_exit.toml", "-s", d / "sim.toml", "-c", d / "cam.toml",
+                "--mode", mode, "--stats", fifo, env=env)
+        t.join(timeout=60)
+        assert not t.is_alive() and r.returncode == 0, r.stderr[-2000:]
+        recs = sorted((json.loads(ln) for ln in records), key=lambda x: x["frame"])
+        assert [x["frame"] for x in recs] == list(range(60)), (how, len(recs))
+        summ = json.loads((out / "st.fifo.summary.json").read_text())
+        assert summ["frames"] == 60
+        lines = r.stdout.splitlines()
+        assert "Rendering 60 frames..." in r.stdout and lines[-1].startswith("video: 60 frames in "), lines[-3:]
+        frames = [pngio.read_png(out / "tmp" / ("frame_%d.png" % k)) for k in range(60)]     # every file complete (CRC + Adler checked)
+        got[how] = (len(lines), [(x["frame"], x["rays"], x["steps"], x["n_pos"], x["n_neg"], x["n_none"]) for x in recs], frames)
+    assert got["fast"][0] == got["slow"][0] and got["fast"][1] == got["slow"][1]
+    assert all(np.array_equal(a, b) for a, b in zip(got["fast"][2], got["slow"][2]))

@@ -14,6 +14,7 @@ import pytest
 
 import common
 import oracle_lib as O
+import refpaths
 from curvis_amd import paths, pngio, rendering, skies
 
 pytestmark = pytest.mark.gpu
@@ -150,7 +151,7 @@ def test_video_two_devices_rccl_broadcast_against_oracle(scene_files):
     """`curvis video --mode brute --devices 2 --sky-broadcast rccl`: one process, two device threads, ncclCommInitAll,
     device 0 uploads and broadcasts, device 1 renders the odd frames from what arrived over xGMI"""
     d, sp, sn = scene_files
-    orbit = paths.path_file("path_orbit.csv")
+    orbit = refpaths.reference_path_file("path_orbit.csv")
     (d / "vid.toml").write_text('video_name = "v"\nframe_rate = 0.2\nfilepath_to_camera_path = "%s"\n' % orbit)
     out = d / "out"
     out.mkdir()

@@ -204,11 +204,9 @@ def test_sky_index_edges():
 
 def test_path_frames_and_off_by_one(tmp_path):
     """times_of_frames (src/rendering.rs:224-238) and the Interpolator off-by-one (src/interpolation.rs:76-90)."""
-    import tools_paths
-    orbit = tmp_path / "orbit.csv"
-    through = tmp_path / "through.csv"
-    tools_paths.write_orbit(orbit)
-    tools_paths.write_through(through)
+    import refpaths
+    orbit = refpaths.reference_path_file("path_orbit.csv")      # the reference's own files (tests/golden/paths)
+    through = refpaths.reference_path_file("path_through.csv")
     p = O.Path()
     assert L.cvo_load_path(str(orbit).encode(), C.byref(p)) == 0
     assert p.n == 1000

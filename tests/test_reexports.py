@@ -155,7 +155,8 @@ def test_free_functions_with_the_reference_signatures(gpu_ctx):
 def test_video_rendering_system_new_and_render_to_folder(gpu_ctx, tmp_path):
     """VideoRenderingSystem::new(metric, settings) + render (src/rendering.rs:188-327): backgrounds and camera path from
     files, <folder>/tmp recreated, frame_{k}.png per frame -- equal to the frames of the explicit constructor"""
-    from curvis_amd import images, paths, rendering
+    import refpaths
+    from curvis_amd import images, rendering
     sp, sn = common.make_skies(256, 128, "check")
     images.save_image(str(tmp_path / "pos.png"), sp[..., :3])
     images.save_image(str(tmp_path / "neg.png"), sn[..., :3])
@@ -164,7 +165,7 @@ def test_video_rendering_system_new_and_render_to_folder(gpu_ctx, tmp_path):
     (out / "tmp" / "stale.txt").write_text("x")
     st = rendering.VideoRenderingSettings(
         frame_rate=0.1, resolution_x=96, resolution_y=54, camera_diagonal=43.0, camera_focal_length=15.0,
-        filepath_to_camera_path=paths.path_file("path_orbit.csv"), filepath_to_background_image_1=str(tmp_path / "pos.png"),
+        filepath_to_camera_path=refpaths.reference_path_file("path_orbit.csv"), filepath_to_background_image_1=str(tmp_path / "pos.png"),
         filepath_to_background_image_2=str(tmp_path / "neg.png"), filepath_to_output_folder=str(out),
         max_iterations_propagation=4096, alphas_num=40, max_iterations_sampling=30, sampling_convergence_threshold_1=1e-4)
     pm = curvis_amd.EllisMetric(1.0)

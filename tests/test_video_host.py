@@ -12,11 +12,12 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+import refpaths
 from curvis_amd import paths, rendering
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORBIT = paths.path_file("path_orbit.csv")
-THROUGH = paths.path_file("path_through.csv")
+ORBIT = refpaths.reference_path_file("path_orbit.csv")      # the reference's own bytes (tests/golden/paths)
+THROUGH = refpaths.reference_path_file("path_through.csv")
 
 
 def test_interpolator_matches_oracle_including_off_by_one():
@@ -78,7 +79,7 @@ WORKER = textwrap.dedent("""
 
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    it = rendering.Interpolator.from_file(paths.path_file("path_orbit.csv"))
+    it = rendering.Interpolator.from_file(%(orbit)r)      # the reference's own path_orbit.csv (tests/golden/paths)
     ctx = StubContext()
     v = rendering.VideoRenderingSystem(None, ctx, it, 4.0, (8, 8), 43.0, 15.0, 100.0, 64, 0.05, rank=rank, world_size=world, batch=7)
     assert v.mode == "efficient"          # what the reference's video loop calls (src/rendering.rs:299-307)
@@ -105,7 +106,7 @@ def _free_port():
 
 def test_two_rank_gloo_video_sharding(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT})
+    script.write_text(WORKER % {"root": ROOT, "orbit": ORBIT})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(script)]
     env = dict(os.environ, OMP_NUM_THREADS="1")

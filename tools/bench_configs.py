@@ -11,6 +11,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import refpaths  # noqa: E402  (the reference's own camera paths: tests/golden/paths)
 import curvis_amd  # noqa: E402
 from curvis_amd import paths, rendering, skies  # noqa: E402
 
@@ -46,7 +48,7 @@ def main():
     single("config 3 (Interstellar 4K)", inter, (3840, 2160), 8192, reps=3)
 
     def video(name, metric, csv, fps, res, cap, batch, max_frames=None):
-        it = rendering.Interpolator.from_file(paths.path_file(csv))
+        it = rendering.Interpolator.from_file(refpaths.reference_path_file(csv))
         v = rendering.VideoRenderingSystem(metric, ctx, it, fps, res, 43.0, 15.0, 100.0, cap, 0.05, rank=0,
                                            world_size=args.world, batch=batch, mode="brute")
         n_total = len(v.times_of_frames())

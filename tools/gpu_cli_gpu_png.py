@@ -15,6 +15,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import refpaths  # noqa: E402  (the reference's own camera paths: tests/golden/paths)
 from curvis_amd import paths, pngio, skies  # noqa: E402
 import gpu_cli_video as V  # noqa: E402
 
@@ -43,7 +45,7 @@ def main():
     open(sim, "w").write("escape_radius = 100.0\nray_integration_max_itarations = 4096\nray_integration_step = 0.05\nsampling_initial_nums = 100\n"
                          "sampling_max_iterations = 50\nsampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 1e-5\n")
     open(cam, "w").write("resolution_x = 1920\nresolution_y = 1080\ndiagonal = 43.0\nfocal_length = 15.0\n")
-    open(vid, "w").write('video_name = "v"\nframe_rate = 40.0\nfilepath_to_camera_path = "%s"\n' % paths.path_file("path_orbit.csv"))
+    open(vid, "w").write('video_name = "v"\nframe_rate = 40.0\nfilepath_to_camera_path = "%s"\n' % refpaths.reference_path_file("path_orbit.csv"))
     print("\n## --mode efficient (the reference's renderer), ONE context on the GPU (--contexts-per-device 1), path_orbit.csv @ 40 fps = 2398 frames before the reference's own off-by-one panic, 1920x1080, Ellis")
     for tag, s_, extra in (("host writer, 16 threads", sky, ["--gpu-png", "off", "--writers", "16"]),
                            ("device front end, 16 threads", sky, ["--gpu-png", "on", "--writers", "16"]),
@@ -71,7 +73,7 @@ def main():
             eb, en = s["encode_bench"], s["encode"]
             print("    -> the pool saved %d frames in %.2f s = %.0f frames/s (%.2f ms of a writer thread per extra save)" % (
                 eb["frames"] + en["frames"], s["wall_s"], (eb["frames"] + en["frames"]) / s["wall_s"], eb["thread_ms_per_frame"]), flush=True)
-    open(vid, "w").write('video_name = "v"\nframe_rate = 4.0\nfilepath_to_camera_path = "%s"\n' % paths.path_file("path_orbit.csv"))
+    open(vid, "w").write('video_name = "v"\nframe_rate = 4.0\nfilepath_to_camera_path = "%s"\n' % refpaths.reference_path_file("path_orbit.csv"))
     print("\n## --mode brute (BASELINE configs[3]: 240 frames): the GPU is the limit either way; the host's share shrinks")
     for tag, extra in (("host writer, 16 threads", ["--gpu-png", "off"]), ("device front end, 16 threads", ["--gpu-png", "on"])):
         s = V.run(d, "br_%d" % abs(hash(tag)), sky, vid, cam, sim, ["--batch", "8", "--writers", "16"] + extra, 240)

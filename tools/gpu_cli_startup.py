@@ -17,6 +17,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import refpaths  # noqa: E402  (the reference's own camera paths: tests/golden/paths)
 from curvis_amd import paths, pngio, skies  # noqa: E402
 
 BIN = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
@@ -49,7 +51,7 @@ def main():
                              "sampling_max_iterations = 50\nsampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 1e-5\n")
         open(img, "w").write('image_name = "img"\nt = 0.0\nl = 5.0\ntheta = 1.5707963267948966\nphi = 0.0\nforward_x = -1.0\nforward_y = 0.0\nforward_z = 0.0\n'
                              'up_x = 0.0\nup_y = 0.0\nup_z = 1.0\n')
-        open(vid, "w").write('video_name = "v"\nframe_rate = 4.0\nfilepath_to_camera_path = "%s"\n' % paths.path_file("path_orbit.csv"))
+        open(vid, "w").write('video_name = "v"\nframe_rate = 4.0\nfilepath_to_camera_path = "%s"\n' % refpaths.reference_path_file("path_orbit.csv"))
         cases = [("curvis image (default mode: efficient), 1920x1080", ["image", sky[0], sky[1], os.path.join(d, "o_img"), "-i", img, "-c", cam, "-s", sim]),
                  ("curvis image --mode brute, 1920x1080 cap 4096 (configs[1])", ["image", sky[0], sky[1], os.path.join(d, "o_img"), "-i", img, "-c", cam, "-s", sim, "--mode", "brute"]),
                  ("curvis video (default mode), path_orbit.csv at 4 fps = 240 frames of 1920x1080 (configs[3])", ["video", sky[0], sky[1], os.path.join(d, "o_vid"), "-v", vid, "-c", cam, "-s", sim])]

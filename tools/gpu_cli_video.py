@@ -17,6 +17,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import refpaths  # noqa: E402  (the reference's own camera paths: tests/golden/paths)
 from curvis_amd import paths, pngio, skies  # noqa: E402
 
 BIN = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
@@ -89,7 +91,7 @@ def main():
            "sampling_max_iterations = 50\nsampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 1e-5\n")
     # ---- configs[3]: orbit, 240 frames, 1080p, Ellis
     vid = os.path.join(d, "vid.toml")
-    open(vid, "w").write('video_name = "v"\nframe_rate = 4.0\nfilepath_to_camera_path = "%s"\n' % paths.path_file("path_orbit.csv"))
+    open(vid, "w").write('video_name = "v"\nframe_rate = 4.0\nfilepath_to_camera_path = "%s"\n' % refpaths.reference_path_file("path_orbit.csv"))
     cam = os.path.join(d, "cam.toml")
     open(cam, "w").write("resolution_x = 1920\nresolution_y = 1080\ndiagonal = 43.0\nfocal_length = 15.0\n")
     open(sim, "w").write(SIM % 4096)
@@ -124,7 +126,7 @@ def main():
     # ---- configs[4]: a 24-frame shard of the 4K Interstellar video
     print("\n## configs[4], 24-frame shard: path_through.csv @ 24 fps (frames 0..23 of 480), 3840x2160, Interstellar, cap 8192 (24.9 MB raw per frame)")
     import numpy as np
-    full = open(paths.path_file("path_through.csv")).read().splitlines()
+    full = open(refpaths.reference_path_file("path_through.csv")).read().splitlines()
     # the first 50 rows of the path cover t = 0 .. 0.98 s: exactly 24 frames at 24 fps
     shard = os.path.join(d, "through_shard.csv")
     open(shard, "w").write("\n".join(full[:51]) + "\n")

@@ -14,6 +14,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import refpaths  # noqa: E402  (the reference's own camera paths: tests/golden/paths)
 from curvis_amd import paths, pngio, skies  # noqa: E402
 import gpu_cli_video as V  # noqa: E402
 
@@ -38,7 +40,7 @@ def main():
     open(sim, "w").write("escape_radius = 100.0\nray_integration_max_itarations = 4096\nray_integration_step = 0.05\nsampling_initial_nums = 100\n"
                          "sampling_max_iterations = 50\nsampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 1e-5\n")
     open(cam, "w").write("resolution_x = 1920\nresolution_y = 1080\ndiagonal = 43.0\nfocal_length = 15.0\n")
-    open(vid, "w").write('video_name = "v"\nframe_rate = 500.0\nfilepath_to_camera_path = "%s"\n' % paths.path_file("path_orbit.csv"))
+    open(vid, "w").write('video_name = "v"\nframe_rate = 500.0\nfilepath_to_camera_path = "%s"\n' % refpaths.reference_path_file("path_orbit.csv"))
     print("# curvis video --mode efficient --contexts-per-device %s --batch 32, 1920x1080, 29 970 frames per cell, ONE MI355X; sampler speculation depth "
           "(sampling_speculation, sampling_speculation_first; -1 = the library's automatic choice)" % contexts)
     res = {c: [] for c in CELLS}

@@ -32,6 +32,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import common  # noqa: E402
 import hard_cases as H  # noqa: E402
 import oracle_lib as O  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import refpaths  # noqa: E402  (the reference's own camera paths: tests/golden/paths)
 import curvis_amd  # noqa: E402
 
 NAMES = curvis_amd.Context.FAST_STEP_QUOTIENTS
@@ -163,7 +165,7 @@ def main():
     print("# fast Euler step: expected mis-rounded quotients, measured on %s" % ctx.device_info()["name"])
     print()
     default = ((0.0, 5.0, np.pi / 2, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0))
-    it = rendering.Interpolator.from_file(paths.path_file("path_through.csv"))
+    it = rendering.Interpolator.from_file(refpaths.reference_path_file("path_through.csv"))
     times = rendering.times_of_frames(it.min_time(), it.max_time(), 24.0)
     poses = [(tuple(it.camera_position(t)), tuple(it.camera_forward(t)), tuple(it.camera_up(t))) for t in times]
     ell, inter = curvis_amd.EllisMetric(1.0), curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0)

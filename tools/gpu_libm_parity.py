@@ -18,6 +18,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import common  # noqa: E402
 import oracle_lib as O  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import refpaths  # noqa: E402  (the reference's own camera paths: tests/golden/paths)
 import curvis_amd  # noqa: E402
 from curvis_amd import skies  # noqa: E402
 
@@ -189,7 +191,7 @@ def poses_main():
     print()
 
     def video_poses(csv, fps):
-        it = rendering.Interpolator.from_file(paths.path_file(csv))
+        it = rendering.Interpolator.from_file(refpaths.reference_path_file(csv))
         times = rendering.times_of_frames(it.min_time(), it.max_time(), fps)
         return [(tuple(it.camera_position(t)), tuple(it.camera_forward(t)), tuple(it.camera_up(t))) for t in times]
     orbit = video_poses("path_orbit.csv", 4.0)
