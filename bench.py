@@ -24,6 +24,9 @@ fall-back (torch's nccl broadcast, then host-staged gloo) should RCCL fail on an
 then says so in `collective.via` / `collective.fallback_from`.  Rank 0 prints ONE JSON line; for N > 1
 it also carries `cpu_baseline`, `value_single_image_rows` (ONE configs[1] image split by rows over the
 N GPUs) and `video_e2e` (`curvis video --mode brute --devices N` on a 16N-frame rendition of configs[3]).
+At N = 1 the line also carries `value_efficient`: the reference's DEFAULT renderer (render_image_efficient, what its CLI
+runs) at configs[3]'s poses -- frames/s with kernels only (one context, GPU-idle share from its HIP events) and end to end
+through `curvis video --mode efficient` on the reference's own path_orbit.csv; outside the contract's timed region.
 """
 import argparse
 import json
@@ -81,6 +84,10 @@ def parse():
                     help="length of the secondary back-to-back measurement behind `value_sustained` (clock and power "
                          "sampled during it); 0 = skip")
     ap.add_argument("--cpu-row-step", type=int, default=8)
+    ap.add_argument("--no-value-efficient", action="store_true",
+                    help="N = 1: skip value_efficient (the reference's default renderer: kernels only + `curvis video --mode efficient`)")
+    ap.add_argument("--value-efficient-frames", type=int, default=960,
+                    help="frames of the end-to-end leg of value_efficient (path_orbit.csv resampled to that many frames)")
     return ap.parse_args()
 
 
@@ -560,6 +567,13 @@ def main():
             out["distinct_gpus"] = len(set(r["pci_bus_id"] for r in per_rank))
             if sustained is not None:
                 out["value_sustained"]["all_ranks"] = round(sum(r["value_sustained"] or 0.0 for r in per_rank), 1)
+        # the reference's DEFAULT renderer (what its CLI runs): secondary figure at N = 1, outside the contract's timed region
+        if dist is None and args.metric == "ellis" and not args.no_value_efficient:
+            try:
+                out["value_efficient"] = efficient_kernels(ctx, torch, args)
+            except Exception as exc:  # noqa: BLE001 -- an extra must never cost the bench line
+                out["value_efficient"] = {"failed": short(exc)}
+            phase("value_efficient_kernels")
         # the reference's CPU path beside EVERY line (north_star: "timed on the node's own host cores in the same run"):
         # rank 0 runs it after the timed region while the other ranks wait at the barrier below
         if not args.no_cpu_baseline:
@@ -592,6 +606,21 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 out["video_e2e_efficient"] = {"failed": short(exc)}
             phase("video_e2e_both_modes")
+    if dist is None and rank == 0 and isinstance(out.get("value_efficient"), dict) and "failed" not in out["value_efficient"]:
+        # ... and end to end through the binary: `curvis video --mode efficient` on the reference's path_orbit.csv, files in -> PNG
+        # frames out (the context above is closed: the binary makes its own, 4 per GPU by default)
+        try:
+            e2e = video_e2e(args, 1, host_skies, False, mode="efficient", frames_per_gpu=args.value_efficient_frames)
+            if "failed" not in e2e:
+                dev = e2e["per_device"][0]
+                kern_s = e2e["frames"] * (dev["kernel_ms_per_frame"] + dev["gpu_png_kernel_ms_per_frame"]) / 1e3
+                e2e["gpu_idle_share"] = round(max(0.0, 1.0 - kern_s / e2e["wall_s"]), 4) if e2e["wall_s"] > 0 else None
+                e2e["gpu_idle_share_note"] = ("1 - (render + PNG kernels' HIP-event time, summed over the binary's contexts) / the binary's "
+                                              "wall time for the frames; contexts overlap on the device, so this is a lower bound of the idle share")
+            out["value_efficient"]["end_to_end"] = e2e
+        except Exception as exc:  # noqa: BLE001
+            out["value_efficient"]["end_to_end"] = {"failed": short(exc)}
+        phase("value_efficient_end_to_end")
     if dist is not None:
         dist.barrier()
         flush_c_stdio()
@@ -948,6 +977,49 @@ def rows_split_run(ctx, dist, torch, world, rank, metric, cam, args, R, DELTA, f
                         args.width, args.height, world, args.width * args.height * 3)}
 
 
+def efficient_kernels(ctx, torch, args):
+    """value_efficient, kernels only: RelativisticSystem::render_image_efficient (src/systems.rs:333-527) -- the renderer the
+    reference's CLI runs (src/rendering.rs:97-106, :299-307) -- on the 240 poses of configs[3] (the reference's own
+    path_orbit.csv at 4 fps, tests/golden/paths), args.width x args.height, cap args.max_iter, the CLI's sampler settings
+    (sampling_initial_nums = 100 for BOTH alphas_num and max_iterations_sampling, threshold_1 for both thresholds:
+    src/main.rs:91-110), ONE context, 32 frames per call, frames left in HBM.  GPU-idle share from the context's own HIP events."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refpaths
+    from curvis_amd import rendering
+    it = rendering.Interpolator.from_file(refpaths.reference_path_file("path_orbit.csv"))
+    times = rendering.times_of_frames(it.min_time(), it.max_time(), 4.0)
+    cams = [curvis_amd.Camera(tuple(it.camera_position(t)), tuple(it.camera_forward(t)), tuple(it.camera_up(t)), 15.0, 43.0,
+                              args.width, args.height) for t in times]
+    metric = curvis_amd.EllisMetric(1.0)
+    per_call = 32
+
+    def run():
+        kernel_ms = call_ms = 0.0
+        steps = 0
+        for k in range(0, len(cams), per_call):
+            _, st = ctx.render_efficient(metric, cams[k:k + per_call], args.max_iter, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
+            kernel_ms += st.kernel_ms
+            call_ms += st.total_ms
+            steps += st.steps
+        return kernel_ms, call_ms, steps
+    run()                                   # allocations, first-launch checks
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms, call_ms, steps = run()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    n = len(cams)
+    return {"unit": "%dx%d frames/s, reference's default renderer (render_image_efficient), configs[3] poses" % (args.width, args.height),
+            "kernels_only": {
+                "value": round(n / wall, 1), "frames": n, "frames_per_call": per_call, "contexts": 1,
+                "ms_per_frame": round(wall / n * 1e3, 4), "kernel_ms_per_frame": round(kernel_ms / n, 4),
+                "gpu_idle_share": round(max(0.0, 1.0 - kernel_ms / 1e3 / wall), 4),
+                "integrator_steps_per_frame": int(steps / n),
+                "note": "one context, frames stay in HBM; wall time includes the host side of the adaptive sampler "
+                        "(src/sampling.rs:46-195: the rounds are host-paced); gpu_idle_share = 1 - kernels' HIP-event time / wall; "
+                        "several contexts on host threads hide the idle share (end_to_end uses the binary's default of 4)"}}
+
+
 def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gpu=None):
     """`curvis video --mode brute --devices N --stats` on a 16N-frame rendition of configs[3] (Ellis, path_orbit.csv,
     1920x1080, cap 4096): files in, PNG frames out, the binary's own per-device table back."""
@@ -1094,7 +1166,7 @@ def live_traffic(args, kernel_name, steps_per_launch):
              "--width", str(args.width), "--height", str(args.height), "--max-iter", str(args.max_iter),
              "--metric", args.metric, "--sky", str(args.sky), "--variant", str(args.variant),
              "--fast-math", str(args.fast_math), "--fuse-shade", str(args.fuse_shade), "--multi-frame", "0",
-             "--sustained-seconds", "0", "--no-traffic", "--no-live-traffic", "--no-cpu-baseline"]
+             "--sustained-seconds", "0", "--no-traffic", "--no-live-traffic", "--no-cpu-baseline", "--no-value-efficient"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CURVIS_BENCH_FORCE_DIST")}
     env["TMPDIR"] = "/tmp"
     SQ = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE")
@@ -1183,6 +1255,16 @@ def cpu_baseline(args, host_skies):
     om = O.ellis(1.0) if args.metric == "ellis" else O.interstellar(0.1, 1e-4, 1.0)
     oc = O.camera(res=(args.width, args.height))
     sp, sn = O.sky(host_skies[0]), O.sky(host_skies[1])
+    # the LITERAL Euler step: every r(l) / r_squared(l) / r_derivative(l) call the reference makes per step (the tests run the
+    # oracle with each evaluated once -- identical bits, fewer libm calls; a timed baseline must not)
+    O.lib().cvo_set_metric_memo(0)
+    try:
+        return _cpu_baseline_timed(args, O, om, oc, sp, sn)
+    finally:
+        O.lib().cvo_set_metric_memo(1)
+
+
+def _cpu_baseline_timed(args, O, om, oc, sp, sn):
     t0 = time.perf_counter()
     _, _, st = O.render_image(O.LIBM, om, oc, sp, sn, args.max_iter, 100.0, 0.05, row_begin=0,
                               row_step=args.cpu_row_step)
@@ -1248,6 +1330,7 @@ def cpu_baseline(args, host_skies):
         "unit": "Mray-steps/s (executed)",
         "cores": 1,
         "kind": "port",
+        "step": "literal (oracle/curvis_oracle_impl.inc update: the reference's calls, one for one; cvo_set_metric_memo(0))",
         "sample": "every %dth row of the same %dx%d frame: %d rays, %d Euler steps, %.1f s" % (
             args.cpu_row_step, args.width, args.height, st.rays, st.steps, dt),
         "host_cpu": model,

@@ -905,8 +905,6 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->fast_math = (int)value;
   else if (k == "fuse_shade")
     ctx->fuse_shade = (int)value;
-  else if (k == "png_path")
-    ctx->png_path = value != 0 ? 1 : 0;
   else if (k == "sampling_speculation")
     ctx->sampling_speculation = (int)value;
   else if (k == "sampling_speculation_first")
@@ -951,12 +949,6 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = (int64_t)ctx->relay_verified.size();
   else if (k == "relay_checks")
     *value = (int64_t)ctx->relay_checks;
-  else if (k == "last_png_direct_blocks")
-    *value = (int64_t)ctx->last_png_direct_blocks;
-  else if (k == "png_path")
-    *value = ctx->png_path;
-  else if (k == "last_png_passes")
-    *value = ctx->last_png_passes;
   else if (k == "last_png_stream_bytes")
     *value = (int64_t)ctx->last_png_stream_bytes;
   else if (k == "relay_recheck_every")

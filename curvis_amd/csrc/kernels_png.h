@@ -7,18 +7,28 @@
  * and distance-1 matches for runs of zero bytes -- the format of the host writer (host/png_io.h encode_rgb8_fast) with one
  * difference: a thread tokenises 64 image bytes, so a zero run is cut every 64 bytes (matches of 3..63 instead of 3..258).
  *
- *   png_hist_kernel   pass 1: token histogram (286 symbols) per frame, Adler-32 partial sums of the filtered bytes
- *   (host)            code lengths (<= 12 bits) and canonical codes from the histograms: 286 symbols per frame, microseconds
- *   png_count_kernel  pass 2: bits per workgroup
- *   png_scan_kernel   exclusive scan of the workgroup totals of every frame, total stream length
- *   png_zero_kernel   zeroes exactly the words the stream will occupy
- *   png_emit_kernel   pass 3: every thread writes its codes at its bit offset -- assembled in LDS per workgroup (ds_or), written
- *                     out as whole words (the first and last word of a workgroup's span are shared with its neighbours: atomicOr)
+ *   png_hist2_kernel      pass 1: token histogram (286 symbols) per frame AND per workgroup, Adler-32 partial sums
+ *   (host)                code lengths (<= 12 bits) and canonical codes from the histograms: 286 symbols per frame, microseconds
+ *   png_blockbits_kernel  bits per workgroup = its token counts . bits per symbol (no pass over the pixels)
+ *   png_offsets_kernel    exclusive scan of the workgroup totals of every frame, total stream length; headers; the few words
+ *                         the emit pass ORs into are cleared
+ *   png_emit2_kernel      pass 2: every thread counts its bits, the workgroup scans them, every thread writes its codes at its
+ *                         bit offset -- assembled in LDS per workgroup (ds_or), written out as whole words (the first and last
+ *                         word of a workgroup's span are shared with its neighbours: atomicOr)
+ *   png_crc_kernel        CRC-32 of the PNG chunk ("IDAT" + stream)
  *
- * Byte work, no floating point.  Each pass reads the frame once -- current row and row above, the latter out of the XCD's own
- * L2 thanks to the workgroup order (png_logical_block) --, stages the filtered bytes in LDS with coalesced 16-byte loads
- * (png_stage) and then tokenises 64 bytes per thread; pass 3 writes the stream.  Algorithmic bytes per frame: W*H*3 read +
- * stream written.  What bounds the passes is the byte-serial tokeniser (divergent branches per byte), not HBM: DESIGN.md 8.
+ * Byte work, no floating point.  TWO reads of the frames: the bits a workgroup's tokens take are  sum over the symbols of
+ * count x bits(symbol), and pass 1 already counts the tokens -- so it also leaves its 288 counts PER WORKGROUP (576 B per
+ * 16 KiB of pixels) and the bit offsets follow without a counting pass.  (Rounds 3-5 also carried the original three-pass
+ * kernels -- histogram, count, emit, with a byte-serial tokeniser -- for frames whose rows are no multiple of 64 bytes and as the
+ * checker of this path; round 6 taught the staging ragged rows (png_stage_ragged) and removed them: one path for every width.)
+ * Each pass reads the frame once -- current row and row above, the latter out of the XCD's own L2 thanks to the workgroup order
+ * (png_logical_block) --, stages the FILTERED bytes in LDS (png_stage: coalesced 16-byte loads when the rows are a multiple of
+ * 64 bytes, i.e. every common video size) and tokenises 64 bytes per thread word-parallel: a thread holds its 64 filtered
+ * bytes in 16 registers, classifies them four at a time (zero / +1 / -1 / other with carry-free byte tricks), builds the 64-bit
+ * map of its zero bytes and walks the RUNS of that map (one iteration per run, not per byte).  The hottest symbols (literal 0,
+ * 1, 255 and the match of a whole zero chunk) are counted in registers and reduced across the wave before they touch LDS.
+ * Algorithmic bytes per frame: W*H*3 read + stream written.
  * Part of the ONE translation unit curvis_hip.hip (included there, nowhere else). */
 #pragma once
 
@@ -29,29 +39,25 @@ constexpr unsigned kPngBlock = 256;  /* threads per workgroup */
 constexpr unsigned kPngBins = 288;   /* 286 literal/length symbols, padded */
 constexpr unsigned kPngCodes = 256 + 64; /* per frame: literal entries [0, 256), match entries for lengths [0, 64) */
 constexpr unsigned kPngCodeBits = 12;    /* longest literal/length code */
-/* LDS image of a workgroup's piece of the stream: 8 KiB = 256 bits per thread on average, i.e. frames that compress at least
- * 2 x; a workgroup whose codes need more (at most 65 literals of 12 bits per thread = 780 bits) ORs them into global memory */
-constexpr unsigned kPngLdsWords = 2048;
 constexpr unsigned kPngHeaderWords = 44; /* zlib header (16 bits) + dynamic block header (<= 1222 bits) + slack: 176 bytes */
 
 struct PngParams {
   const unsigned char *fb;        /* n_frames frames of H rows of row_bytes bytes, back to back */
   size_t frame_bytes;
   unsigned W, H, row_bytes, chunks_per_row, chunks_per_frame, blocks_per_frame, n_frames;
-  int aligned;                    /* row_bytes % 16 == 0: 16-byte loads */
-  int staged;                     /* row_bytes % 64 == 0: every chunk is full; workgroups stage their filtered bytes in LDS */
+  int aligned;                    /* row_bytes % 4 == 0: a ragged frame's chunks are read four bytes at a time (else byte by byte) */
+  int staged;                     /* row_bytes % 64 == 0: every chunk is full and a workgroup's 256 chunks are 16 KiB of consecutive
+                                     bytes (png_stage); else the last chunk of a row is partial (png_stage_ragged) */
   unsigned grid_x;                /* 8 * ceil(blocks_per_frame / 8): see png_logical_block */
   unsigned *hist;                 /* [n_frames][kPngBins] */
   unsigned long long *adler;      /* [n_frames][2]: sum of the filtered bytes; sum of (n - i) * byte_i; both mod 65521 per workgroup */
   const unsigned *codes;          /* [n_frames][kPngCodes]: bits | n_bits << 24 */
   unsigned long long *block_bits; /* [n_frames][blocks_per_frame]: bits per workgroup, then (in place) exclusive prefix */
-  unsigned short *thread_bits;    /* [n_frames][blocks_per_frame * 256]: bits per thread (<= 798), pass 2 -> pass 3 */
   const unsigned *start_bit;      /* [n_frames]: where the token stream starts (after the zlib and the block header) */
   unsigned long long *frame_bits; /* [n_frames]: end of the stream in bits (start offset, tokens, end-of-block code) */
-  unsigned *direct_blocks;        /* [1]: workgroups of pass 3 whose codes did not fit their LDS image (diagnostics, tests) */
-  unsigned short *block_hist;     /* two-pass path: [n_frames][blocks_per_frame][kPngBins] token counts per workgroup (<= 16 641 each) */
-  const unsigned *sym_bits;       /* two-pass path: [n_frames][kPngBins] bits a token of each symbol takes (code + extra + distance) */
-  const unsigned *header;         /* two-pass path: [n_frames][kPngHeaderWords] zlib + block header bits (zero from start_bit on) */
+  unsigned short *block_hist;     /* [n_frames][blocks_per_frame][kPngBins] token counts per workgroup (<= 16 641 each) */
+  const unsigned *sym_bits;       /* [n_frames][kPngBins] bits a token of each symbol takes (code + extra + distance) */
+  const unsigned *header;         /* [n_frames][kPngHeaderWords] zlib + block header bits (zero from start_bit on) */
   const unsigned *crc_tables;     /* [4][256] slice-by-4 tables of CRC-32 (reflected 0xEDB88320), then x^(8 d 16^i) mod p, [i = 0..7][d = 0..15] */
   unsigned *crc;                  /* [n_frames]: XOR of the threads' contributions = CRC state after "IDAT" + the frame's stream */
   unsigned *out;                  /* [n_frames][out_words] */
@@ -110,126 +116,49 @@ __device__ __forceinline__ void png_stage(const PngParams &P, unsigned frame, un
   }
 }
 
-/* The tokens of chunk `chunk` of row `row` of frame `frame`, in stream order: sink.lit(value) for a literal byte,
- * sink.match(len) for `len` (3..63) further zero bytes after a literal zero.  Chunk 0 of a row starts with the row's
- * filter-type byte (2 = Up).  s_chunk: this thread's 64 filtered bytes in LDS (staged frames), or NULL: read and filter from
- * global memory.  Written as ONE rolled loop over the words of the chunk with two small emission sites: the sinks' state has to
- * stay in registers (an earlier version with a lambda call per byte, 64 sites, was not inlined and ran out of scratch memory). */
-template <typename Sink>
-__device__ __forceinline__ void png_tokens(const PngParams &P, const unsigned char *s_chunk, unsigned frame, unsigned row, unsigned chunk, Sink &sink) {
-  const unsigned x0 = chunk * kPngChunk;
-  const unsigned nb = min(kPngChunk, P.row_bytes - x0);
-  const unsigned char *cur = P.fb + (size_t)frame * P.frame_bytes + (size_t)row * P.row_bytes + x0;
-  const unsigned char *up = cur - P.row_bytes; /* row 0: treated as zeros, never read */
-  if (chunk == 0u) sink.lit(2u);
-  unsigned run = 0;
-#define PNG_FLUSH_RUN()                                \
-  do {                                                 \
-    if (run) {                                         \
-      const unsigned n_lit = run <= 3u ? run : 1u;     \
-      for (unsigned k_ = 0; k_ < n_lit; ++k_) sink.lit(0u); \
-      if (run > 3u) sink.match(run - 1u);              \
-      run = 0u;                                        \
-    }                                                  \
-  } while (0)
-#define PNG_WORD(word)                                 \
-  do {                                                 \
-    unsigned d_ = (word);                              \
-    if (d_ == 0u) {                                    \
-      run += 4u;                                       \
-    } else {                                           \
-      _Pragma("unroll 1") for (unsigned b_ = 0; b_ < 4u; ++b_) { \
-        const unsigned v_ = d_ & 0xffu;                \
-        d_ >>= 8;                                      \
-        if (v_ == 0u) {                                \
-          ++run;                                       \
-        } else {                                       \
-          PNG_FLUSH_RUN();                             \
-          sink.lit(v_);                                \
-        }                                              \
-      }                                                \
-    }                                                  \
-  } while (0)
-  if (s_chunk) { /* staged: 64 filtered bytes in LDS, 16 at a time; zero runs of 16 cost one read and one compare */
-#pragma unroll 1
-    for (unsigned q = 0; q < kPngChunk; q += 16u) {
-      const uint4 d4 = *reinterpret_cast<const uint4 *>(s_chunk + q);
-      if ((d4.x | d4.y | d4.z | d4.w) == 0u) {
-        run += 16u;
-        continue;
-      }
-      PNG_WORD(d4.x);
-      PNG_WORD(d4.y);
-      PNG_WORD(d4.z);
-      PNG_WORD(d4.w);
-    }
-    PNG_FLUSH_RUN();
-    return;
+/* Ragged frames (rows that are no multiple of 64 bytes: the last chunk of every row is partial, chunks do not tile the frame):
+ * every thread reads and filters its OWN chunk -- four bytes at a time when the rows are a multiple of 4 bytes, else byte by
+ * byte -- and leaves it in its LDS slot, zero-padded to 64 bytes; the tokeniser masks the map of zero bytes to the chunk's
+ * length (png_chunk_load), so the padding produces no token.  Uncoalesced (64-byte stride between lanes): such sizes are test
+ * images and odd still frames, not video. */
+__device__ __forceinline__ void png_stage_ragged(const PngParams &P, unsigned frame, unsigned block, unsigned char *s_f) {
+  const unsigned g = block * kPngBlock + threadIdx.x;
+  unsigned *dst = reinterpret_cast<unsigned *>(s_f + threadIdx.x * kPngLdsStride);
+  unsigned nb = 0u;
+  const unsigned char *cur = nullptr;
+  bool has_up = false;
+  if (g < P.chunks_per_frame) {
+    const unsigned row = g / P.chunks_per_row, chunk = g - row * P.chunks_per_row, x0 = chunk * kPngChunk;
+    nb = min(kPngChunk, P.row_bytes - x0);
+    cur = P.fb + (size_t)frame * P.frame_bytes + (size_t)row * P.row_bytes + x0;
+    has_up = row != 0u; /* row 0: the row above is treated as zeros, never read */
   }
-  const unsigned n_words = (nb + 3u) >> 2;
 #pragma unroll 1
-  for (unsigned w = 0; w < n_words; ++w) {
-    unsigned d;
-    if (P.aligned) {
-      const unsigned c = *reinterpret_cast<const unsigned *>(cur + 4u * w);
-      d = png_sub4(c, row != 0u ? *reinterpret_cast<const unsigned *>(up + 4u * w) : 0u);
-    } else {
-      d = 0u;
-      for (unsigned b = 0; b < 4u && 4u * w + b < nb; ++b)
-        d |= (((unsigned)cur[4u * w + b] - (row != 0u ? (unsigned)up[4u * w + b] : 0u)) & 0xffu) << (8u * b);
-    }
-    const unsigned in_word = min(4u, nb - 4u * w);
-    if (d == 0u) { /* four zero bytes at once (fewer in the ragged last word) */
-      run += in_word;
-      continue;
-    }
-#pragma unroll 1
-    for (unsigned b = 0; b < in_word; ++b) {
-      const unsigned v = d & 0xffu;
-      d >>= 8;
-      if (v == 0u) {
-        ++run;
-        continue;
+  for (unsigned w = 0; w < kPngChunk / 4u; ++w) {
+    unsigned d = 0u;
+    if (4u * w < nb) {
+      if (P.aligned) { /* nb is a multiple of 4 then */
+        const unsigned c = *reinterpret_cast<const unsigned *>(cur + 4u * w);
+        d = png_sub4(c, has_up ? *reinterpret_cast<const unsigned *>(cur - P.row_bytes + 4u * w) : 0u);
+      } else {
+        for (unsigned b = 0; b < 4u && 4u * w + b < nb; ++b)
+          d |= (((unsigned)cur[4u * w + b] - (has_up ? (unsigned)cur[4u * w + b - P.row_bytes] : 0u)) & 0xffu) << (8u * b);
       }
-      PNG_FLUSH_RUN();
-      sink.lit(v);
     }
+    dst[w] = d;
   }
-  PNG_FLUSH_RUN();
-#undef PNG_WORD
-#undef PNG_FLUSH_RUN
 }
+__device__ __forceinline__ void png_stage_any(const PngParams &P, unsigned frame, unsigned block, unsigned char *s_f) {
+  if (P.staged) /* uniform over the launch */
+    png_stage(P, frame, block, s_f);
+  else
+    png_stage_ragged(P, frame, block, s_f);
+}
+/* bytes of chunk `chunk` of a row (64, or what is left of a ragged row) */
+__device__ __forceinline__ unsigned png_chunk_bytes(const PngParams &P, unsigned chunk) { return min(kPngChunk, P.row_bytes - chunk * kPngChunk); }
 
-struct PngHistSink { /* pass 1 */
-  unsigned *hist; /* LDS */
-  unsigned k;     /* index of the next filtered byte, counted from the thread's first (<= 65) */
-  unsigned a, kv; /* Adler-32 partial sums in 32 bits: sum of bytes (<= 65 * 255), sum of k * byte_k (<= 65 * 65 * 255) */
-  unsigned zeros; /* literal zeros are the hottest bin by far: counted in a register, added once (doing the same for +1 and -1,
-                     the next hottest after the Up filter, was measured SLOWER: 112 vs 86 us -- two more branches per literal) */
-  __device__ __forceinline__ void lit(unsigned v) {
-    if (v == 0u) {
-      ++zeros;
-    } else {
-      atomicAdd(&hist[v], 1u);
-      a += v;
-      kv += k * v;
-    }
-    ++k;
-  }
-  __device__ __forceinline__ void match(unsigned len) {
-    atomicAdd(&hist[png_len_symbol(len)], 1u);
-    k += len;
-  }
-};
-
-struct PngCountSink { /* pass 2 */
-  const unsigned *codes; /* LDS */
-  unsigned bits;
-  __device__ __forceinline__ void lit(unsigned v) { bits += codes[v] >> 24; }
-  __device__ __forceinline__ void match(unsigned len) { bits += codes[256u + len] >> 24; }
-};
-
-struct PngEmitSink { /* pass 3: codes ORed into the workgroup's LDS image of the stream */
+/* codes ORed into the workgroup's LDS image of the stream */
+struct PngEmitSink {
   const unsigned *codes; /* LDS */
   unsigned *out;         /* LDS */
   unsigned w, fill;
@@ -244,194 +173,11 @@ struct PngEmitSink { /* pass 3: codes ORed into the workgroup's LDS image of the
       fill -= 32u;
     }
   }
-  __device__ __forceinline__ void lit(unsigned v) { put(codes[v]); }
-  __device__ __forceinline__ void match(unsigned len) { put(codes[256u + len]); }
 };
-
-__global__ __launch_bounds__(kPngBlock) void png_hist_kernel(const PngParams P) {
-  __shared__ unsigned s_hist[kPngBins];
-  __shared__ unsigned long long s_sum[2];
-  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
-  const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
-  if (block >= P.blocks_per_frame) return; /* the whole workgroup */
-  const unsigned g = block * kPngBlock + threadIdx.x;
-  for (unsigned k = threadIdx.x; k < kPngBins; k += kPngBlock) s_hist[k] = 0u;
-  if (threadIdx.x < 2u) s_sum[threadIdx.x] = 0ull;
-  if (P.staged) png_stage(P, frame, block, s_f);
-  __syncthreads();
-  if (g < P.chunks_per_frame) {
-    const unsigned row = g / P.chunks_per_row, chunk = g - row * P.chunks_per_row;
-    const unsigned long long n = (unsigned long long)P.H * (P.row_bytes + 1u);
-    /* index of this thread's first filtered byte in the frame's stream (the filter-type byte leads every row) */
-    const unsigned long long i0 = (unsigned long long)row * (P.row_bytes + 1u) + (chunk == 0u ? 0u : 1u + chunk * kPngChunk);
-    PngHistSink sink{s_hist, 0u, 0u, 0u, 0u};
-    png_tokens(P, P.staged ? s_f + threadIdx.x * kPngLdsStride : nullptr, frame, row, chunk, sink);
-    if (sink.zeros) atomicAdd(&s_hist[0], sink.zeros);
-    /* Adler-32: s2 = n + sum over the stream of (n - i) * byte_i; this thread's bytes sit at i = i0 + k */
-    const unsigned long long a = sink.a, b = (n - i0) * a - sink.kv;
-    atomicAdd(&s_sum[0], a % 65521ull);
-    atomicAdd(&s_sum[1], b % 65521ull);
-  }
-  __syncthreads();
-  for (unsigned k = threadIdx.x; k < kPngBins; k += kPngBlock)
-    if (s_hist[k]) atomicAdd(&P.hist[(size_t)frame * kPngBins + k], s_hist[k]);
-  if (threadIdx.x < 2u) atomicAdd(&P.adler[(size_t)frame * 2 + threadIdx.x], s_sum[threadIdx.x] % 65521ull);
-}
-
-/* bits this thread's tokens take with the frame's code (+ the end-of-block code after the last chunk of the frame) */
-__device__ __forceinline__ unsigned png_thread_bits(const PngParams &P, const unsigned *s_codes, const unsigned char *s_chunk, unsigned frame, unsigned g) {
-  unsigned bits = 0;
-  if (g < P.chunks_per_frame) {
-    const unsigned row = g / P.chunks_per_row, chunk = g - row * P.chunks_per_row;
-    PngCountSink sink{s_codes, 0u};
-    png_tokens(P, s_chunk, frame, row, chunk, sink);
-    bits = sink.bits;
-    if (g == P.chunks_per_frame - 1u) bits += s_codes[256u] >> 24; /* end of block: stored in the unused slot "match of length 0" */
-  }
-  return bits;
-}
-
-__global__ __launch_bounds__(kPngBlock) void png_count_kernel(const PngParams P) {
-  __shared__ unsigned s_codes[kPngCodes];
-  __shared__ unsigned s_total;
-  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
-  const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
-  if (block >= P.blocks_per_frame) return;
-  const unsigned g = block * kPngBlock + threadIdx.x;
-  for (unsigned k = threadIdx.x; k < kPngCodes; k += kPngBlock) s_codes[k] = P.codes[(size_t)frame * kPngCodes + k];
-  if (threadIdx.x == 0u) s_total = 0u;
-  if (P.staged) png_stage(P, frame, block, s_f);
-  __syncthreads();
-  unsigned bits = png_thread_bits(P, s_codes, P.staged ? s_f + threadIdx.x * kPngLdsStride : nullptr, frame, g);
-  P.thread_bits[((size_t)frame * P.blocks_per_frame + block) * kPngBlock + threadIdx.x] = (unsigned short)bits;
-  for (int off = 32; off > 0; off >>= 1) bits += __shfl_down(bits, off, 64);
-  if ((threadIdx.x & 63u) == 0u) atomicAdd(&s_total, bits);
-  __syncthreads();
-  if (threadIdx.x == 0u) P.block_bits[(size_t)frame * P.blocks_per_frame + block] = s_total;
-}
-
-/* one workgroup per frame: block_bits -> exclusive prefix (in place), frame_bits = start + total */
-__global__ __launch_bounds__(kPngBlock) void png_scan_kernel(const PngParams P) {
-  __shared__ unsigned long long s_part[kPngBlock];
-  const unsigned frame = blockIdx.x, nb = P.blocks_per_frame;
-  unsigned long long *v = P.block_bits + (size_t)frame * nb;
-  const unsigned per = (nb + kPngBlock - 1u) / kPngBlock;
-  const unsigned lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
-  unsigned long long sum = 0ull;
-  for (unsigned k = lo; k < hi; ++k) sum += v[k];
-  s_part[threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0u) { /* 256 partial sums: a serial pass is as fast as anything here */
-    unsigned long long run = 0ull;
-    for (unsigned k = 0; k < kPngBlock; ++k) {
-      const unsigned long long t = s_part[k];
-      s_part[k] = run;
-      run += t;
-    }
-    P.frame_bits[frame] = (unsigned long long)P.start_bit[frame] + run;
-  }
-  __syncthreads();
-  unsigned long long run = s_part[threadIdx.x];
-  for (unsigned k = lo; k < hi; ++k) {
-    const unsigned long long t = v[k];
-    v[k] = run;
-    run += t;
-  }
-}
-
-/* zero the words [0, ceil(frame_bits / 32)] of every frame's output (the emit pass ORs into them) */
-__global__ __launch_bounds__(kPngBlock) void png_zero_kernel(const PngParams P) {
-  const unsigned frame = blockIdx.y;
-  const size_t words = min(P.out_words, (size_t)(P.frame_bits[frame] >> 5) + 2u);
-  uint4 *dst = reinterpret_cast<uint4 *>(P.out + (size_t)frame * P.out_words);
-  const size_t quads = (words + 3u) / 4u; /* out_words is a multiple of 4 */
-  for (size_t k = (size_t)blockIdx.x * kPngBlock + threadIdx.x; k < quads; k += (size_t)gridDim.x * kPngBlock) dst[k] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-__global__ __launch_bounds__(kPngBlock) void png_emit_kernel(const PngParams P) {
-  __shared__ unsigned s_codes[kPngCodes];
-  __shared__ unsigned s_wave[kPngBlock / 64];
-  __shared__ unsigned s_out[kPngLdsWords];
-  __shared__ __attribute__((aligned(16))) unsigned char s_f[kPngBlock * kPngLdsStride];
-  const unsigned frame = blockIdx.y, block = png_logical_block(blockIdx.x, P.blocks_per_frame);
-  if (block >= P.blocks_per_frame) return;
-  const unsigned g = block * kPngBlock + threadIdx.x;
-  for (unsigned k = threadIdx.x; k < kPngCodes; k += kPngBlock) s_codes[k] = P.codes[(size_t)frame * kPngCodes + k];
-  if (P.staged) png_stage(P, frame, block, s_f);
-  const unsigned mine = P.thread_bits[((size_t)frame * P.blocks_per_frame + block) * kPngBlock + threadIdx.x]; /* counted by pass 2 */
-  /* exclusive scan over the workgroup: inside the wave by shuffles, across the four waves through LDS */
-  unsigned incl = mine;
-  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned t = __shfl_up(incl, off, 64);
-    if ((int)lane >= off) incl += t;
-  }
-  if (lane == 63u) s_wave[wave] = incl;
-  __syncthreads();
-  unsigned before = 0, total = 0;
-  for (unsigned w = 0; w < kPngBlock / 64; ++w) {
-    if (w < wave) before += s_wave[w];
-    total += s_wave[w];
-  }
-  const unsigned long long base = (unsigned long long)P.start_bit[frame] + P.block_bits[(size_t)frame * P.blocks_per_frame + block];
-  const unsigned shift = (unsigned)(base & 31ull);
-  const unsigned words = (shift + total + 31u) >> 5; /* what this workgroup's codes occupy */
-  unsigned *dst = P.out + (size_t)frame * P.out_words + (size_t)(base >> 5);
-  const bool in_lds = words <= kPngLdsWords; /* the same for the whole workgroup */
-  if (in_lds)
-    for (unsigned k = threadIdx.x; k < words; k += kPngBlock) s_out[k] = 0u;
-  __syncthreads();
-  const unsigned pos = shift + before + (incl - mine); /* bit position of this thread's first code in the workgroup's piece */
-  if (g < P.chunks_per_frame) {
-    const unsigned row = g / P.chunks_per_row, chunk = g - row * P.chunks_per_row;
-    const unsigned char *s_chunk = P.staged ? s_f + threadIdx.x * kPngLdsStride : nullptr;
-    if (in_lds) {
-      PngEmitSink sink{s_codes, s_out, pos >> 5, pos & 31u, 0ull};
-      png_tokens(P, s_chunk, frame, row, chunk, sink);
-      if (g == P.chunks_per_frame - 1u) sink.put(s_codes[256u]);
-      if (sink.fill) atomicOr(&s_out[sink.w], (unsigned)sink.acc);
-    } else { /* rare (frames that hardly compress): straight into the zeroed stream */
-      PngEmitSink sink{s_codes, dst, pos >> 5, pos & 31u, 0ull};
-      png_tokens(P, s_chunk, frame, row, chunk, sink);
-      if (g == P.chunks_per_frame - 1u) sink.put(s_codes[256u]);
-      if (sink.fill) atomicOr(&dst[sink.w], (unsigned)sink.acc);
-    }
-  }
-  if (!in_lds) {
-    if (threadIdx.x == 0u) atomicAdd(P.direct_blocks, 1u);
-    return;
-  }
-  __syncthreads();
-  for (unsigned k = threadIdx.x; k < words; k += kPngBlock) {
-    const unsigned v = s_out[k];
-    if (!v) continue;
-    if (k == 0u || k + 1u == words)
-      atomicOr(&dst[k], v); /* shared with the neighbouring workgroups' spans */
-    else
-      dst[k] = v;
-  }
-}
-
-/* =====================================================================================================================
- * Two-pass path (round 5; frames whose rows are a multiple of 64 bytes -- every common video size).
- *
- * The three-pass path above reads the frames three times because the bit offset of a workgroup's codes is known only after a
- * pass that counted them.  But the bits a workgroup's tokens take are  sum over the symbols of  count x bits(symbol)  -- and
- * the first pass already counts the tokens.  So pass 1 also leaves its 288 counts PER WORKGROUP (576 B per 16 KiB of
- * pixels), the scan turns them into bit offsets with the frame's code lengths (png_scan2_kernel), and ONE more pass over
- * the pixels counts each thread's bits, scans them inside the workgroup and writes the codes: two reads of the frames.
- *
- * Both passes use a word-parallel tokeniser instead of the byte-serial one: a thread holds its 64 filtered bytes in 16
- * registers, classifies them four at a time (zero / +1 / -1 / other with carry-free byte tricks), builds the 64-bit map of
- * its zero bytes and walks the RUNS of that map (one iteration per run, not per byte).  The hottest symbols (literal 0, 1,
- * 255 and the match of a whole zero chunk) are counted in registers and reduced across the wave before they touch LDS --
- * they were what serialised the LDS atomics of the first version.  Same tokens, same codes, same stream, bit for bit
- * (tests/test_gpu_png.py compares the two paths).
- * ===================================================================================================================== */
 
 constexpr unsigned kPngHistReplicas = 4;   /* LDS histogram copies (lane & 3): same-value literals of neighbouring lanes do not collide */
 constexpr unsigned kPngMatchReplicas = 16; /* copies of the 32 bins from 256 on (lane & 15): neighbouring chunks tend to hold runs of the SAME length */
-constexpr unsigned kPngImageWords = 6272;  /* LDS image of a workgroup's piece of the stream in the two-pass emit: the worst case --
+constexpr unsigned kPngImageWords = 6272;  /* LDS image of a workgroup's piece of the stream in the emit pass: the worst case --
                                               65 literals of 12 bits per thread = 780 bits x 256 threads = 6240 words -- fits */
 static_assert(kPngImageWords * 4u >= kPngBlock * kPngLdsStride, "the stream image re-uses the staging buffer");
 
@@ -451,7 +197,7 @@ struct PngChunk {
   unsigned d[16];
   unsigned long long Z; /* bit i: byte i is zero */
 };
-__device__ __forceinline__ void png_chunk_load(const unsigned char *s_chunk, PngChunk &c) {
+__device__ __forceinline__ void png_chunk_load(const unsigned char *s_chunk, unsigned nb, PngChunk &c) { /* nb: bytes of the chunk (1..64) */
 #pragma unroll
   for (unsigned q = 0; q < 4u; ++q) {
     const uint4 v = *reinterpret_cast<const uint4 *>(s_chunk + 16u * q);
@@ -463,6 +209,7 @@ __device__ __forceinline__ void png_chunk_load(const unsigned char *s_chunk, Png
 #pragma unroll
   for (unsigned w = 0; w < 8u; ++w) hi |= png_flags_nibble(png_zero_flags(c.d[8u + w])) << (4u * w);
   c.Z = ((unsigned long long)hi << 32) | lo;
+  if (nb < kPngChunk) c.Z &= (1ull << nb) - 1ull; /* ragged rows: the zero padding behind a partial chunk is not part of the stream */
 }
 /* length of the run of ones of Z that starts at bit s (Z has bit s set) */
 __device__ __forceinline__ unsigned png_run_length(unsigned long long Z, unsigned s) {
@@ -470,7 +217,7 @@ __device__ __forceinline__ unsigned png_run_length(unsigned long long Z, unsigne
   return (unsigned)__ffsll((long long)t) - 1u;   /* s > 0: bit 64 - s of t is set.  s == 0 and Z all ones: t == 0 -> ffs = 0 -> handled by the caller */
 }
 /* zero runs of a chunk in stream order: f(start, length); a run of L <= 3 zeros is L literals, a longer one a literal zero and a
- * distance-1 match of L - 1 (3..63) -- exactly PNG_FLUSH_RUN of the byte-serial tokeniser */
+ * distance-1 match of L - 1 (3..63) -- the host writer's rule (host/png_io.h encode_rgb8_fast), cut at the chunk's end */
 template <typename F>
 __device__ __forceinline__ void png_for_runs(unsigned long long Z, F f) {
   if (Z == ~0ull) {
@@ -485,7 +232,7 @@ __device__ __forceinline__ void png_for_runs(unsigned long long Z, F f) {
   }
 }
 
-/* pass 1 of the two-pass path: token histogram per frame AND per workgroup, Adler-32 partial sums */
+/* pass 1: token histogram per frame AND per workgroup, Adler-32 partial sums */
 __global__ __launch_bounds__(kPngBlock) void png_hist2_kernel(const PngParams P) {
   __shared__ unsigned s_hist[kPngHistReplicas][kPngBins];
   __shared__ unsigned s_match[kPngMatchReplicas][32];
@@ -497,7 +244,7 @@ __global__ __launch_bounds__(kPngBlock) void png_hist2_kernel(const PngParams P)
   for (unsigned k = threadIdx.x; k < kPngHistReplicas * kPngBins; k += kPngBlock) (&s_hist[0][0])[k] = 0u;
   for (unsigned k = threadIdx.x; k < kPngMatchReplicas * 32u; k += kPngBlock) (&s_match[0][0])[k] = 0u;
   if (threadIdx.x < 2u) s_sum[threadIdx.x] = 0ull;
-  png_stage(P, frame, block, s_f);
+  png_stage_any(P, frame, block, s_f);
   __syncthreads();
   unsigned *my_hist = s_hist[threadIdx.x & (kPngHistReplicas - 1u)];
   unsigned *my_match = s_match[threadIdx.x & (kPngMatchReplicas - 1u)];
@@ -506,7 +253,7 @@ __global__ __launch_bounds__(kPngBlock) void png_hist2_kernel(const PngParams P)
   if (g < P.chunks_per_frame) {
     const unsigned row = g / P.chunks_per_row, chunk = g - row * P.chunks_per_row;
     PngChunk c;
-    png_chunk_load(s_f + threadIdx.x * kPngLdsStride, c);
+    png_chunk_load(s_f + threadIdx.x * kPngLdsStride, png_chunk_bytes(P, chunk), c);
     const unsigned off = chunk == 0u ? 1u : 0u; /* chunk 0 of a row starts with the filter-type byte (2 = Up): stream index 0 */
     unsigned kv = 0u;
     if (off) {
@@ -597,7 +344,7 @@ __global__ __launch_bounds__(kPngBlock) void png_blockbits_kernel(const PngParam
 }
 
 /* one workgroup per frame: block_bits -> exclusive prefix (in place), frame_bits = start + total; and the ONLY zeroing the
- * two-pass emit needs: a workgroup of png_emit2_kernel stores every word strictly inside its span and ORs into the first and
+ * emit pass needs: a workgroup of png_emit2_kernel stores every word strictly inside its span and ORs into the first and
  * the last one, which it shares with its neighbours -- so the first word of every span and the last word of the stream are
  * cleared here, and the words before the first span receive the zlib and block headers
  * (a few KB per frame instead of a pass over the whole stream) */
@@ -640,7 +387,7 @@ __global__ __launch_bounds__(kPngBlock) void png_offsets_kernel(const PngParams 
   }
 }
 
-/* pass 2 of the two-pass path: count this thread's bits, scan inside the workgroup, write the codes */
+/* pass 2: count this thread's bits, scan inside the workgroup, write the codes */
 __global__ __launch_bounds__(kPngBlock) void png_emit2_kernel(const PngParams P) {
   __shared__ unsigned s_codes[kPngCodes];
   __shared__ unsigned s_wave[kPngBlock / 64];
@@ -649,7 +396,7 @@ __global__ __launch_bounds__(kPngBlock) void png_emit2_kernel(const PngParams P)
   if (block >= P.blocks_per_frame) return;
   const unsigned g = block * kPngBlock + threadIdx.x;
   for (unsigned k = threadIdx.x; k < kPngCodes; k += kPngBlock) s_codes[k] = P.codes[(size_t)frame * kPngCodes + k];
-  png_stage(P, frame, block, reinterpret_cast<unsigned char *>(s_image));
+  png_stage_any(P, frame, block, reinterpret_cast<unsigned char *>(s_image));
   __syncthreads();
   const bool live = g < P.chunks_per_frame;
   const bool first = live && (g % P.chunks_per_row) == 0u, last = g + 1u == P.chunks_per_frame;
@@ -658,7 +405,7 @@ __global__ __launch_bounds__(kPngBlock) void png_emit2_kernel(const PngParams P)
   unsigned long long ZL = 0ull, MS = 0ull; /* zero bytes that are emitted as literals; of those, the ones a match follows */
   unsigned mine = 0u;
   if (live) {
-    png_chunk_load(reinterpret_cast<const unsigned char *>(s_image) + threadIdx.x * kPngLdsStride, c);
+    png_chunk_load(reinterpret_cast<const unsigned char *>(s_image) + threadIdx.x * kPngLdsStride, png_chunk_bytes(P, g % P.chunks_per_row), c);
     if (first) mine += s_codes[2] >> 24;
     if (c.Z != ~0ull) {
 #pragma unroll

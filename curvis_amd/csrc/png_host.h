@@ -1,4 +1,4 @@
-/* png_host.h -- host side of the device PNG front end (kernels_png.h): scratch layout, the two launches around the host's
+/* png_host.h -- host side of the device PNG front end (kernels_png.h): scratch layout, the launches around the host's
  * Huffman-code construction, assembly of one zlib stream per frame in the caller's buffer.
  * Part of the ONE translation unit curvis_hip.hip (included there, nowhere else). */
 #pragma once
@@ -6,7 +6,7 @@
 namespace {
 
 struct PngScratch { /* one allocation, carved */
-  size_t hist, adler, direct_blocks, crc, codes, block_bits, thread_bits, start_bit, frame_bits, block_hist, sym_bits, header, crc_tables, out, total;
+  size_t hist, adler, crc, codes, block_bits, start_bit, frame_bits, block_hist, sym_bits, header, crc_tables, out, total;
   size_t out_words;
 };
 
@@ -21,21 +21,17 @@ PngScratch png_scratch_layout(const PngParams &P) {
   off = up(off + (size_t)P.n_frames * kPngBins * sizeof(unsigned));
   L.adler = off;
   off = up(off + (size_t)P.n_frames * 2 * sizeof(unsigned long long));
-  L.direct_blocks = off;
-  off = up(off + sizeof(unsigned));
   L.crc = off; /* cleared with the histograms */
   off = up(off + (size_t)P.n_frames * sizeof(unsigned));
   L.codes = off;
   off = up(off + (size_t)P.n_frames * kPngCodes * sizeof(unsigned));
   L.block_bits = off;
   off = up(off + (size_t)P.n_frames * P.blocks_per_frame * sizeof(unsigned long long));
-  L.thread_bits = off;
-  off = up(off + (size_t)P.n_frames * P.blocks_per_frame * kPngBlock * sizeof(unsigned short));
   L.start_bit = off;
   off = up(off + (size_t)P.n_frames * sizeof(unsigned));
   L.frame_bits = off;
   off = up(off + (size_t)P.n_frames * sizeof(unsigned long long));
-  L.block_hist = off; /* two-pass path: token counts per workgroup */
+  L.block_hist = off; /* token counts per workgroup */
   off = up(off + (size_t)P.n_frames * P.blocks_per_frame * kPngBins * sizeof(unsigned short));
   L.sym_bits = off;
   off = up(off + (size_t)P.n_frames * kPngBins * sizeof(unsigned));
@@ -85,7 +81,8 @@ const std::array<unsigned, 1024 + 128> &png_crc_tables() {
 }
 
 /* frames [0, n_frames) of W x H RGB8 in ctx->d_fb -> zlib streams, back to back in `out`; offsets[f] .. offsets[f + 1] is
- * frame f's stream.  kernel_ms: HIP-event time of the five launches (the host's code construction between them excluded). */
+ * frame f's stream.  kernel_ms: HIP-event time of the five launches (histogram; workgroup bits, offsets, emit, CRC), the
+ * host's code construction between the first and the rest excluded. */
 int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_frames, uint8_t *out, size_t out_cap, size_t *offsets,
                         double *kernel_ms, uint32_t *idat_crc = nullptr, int *crc_valid = nullptr) {
   if (crc_valid) *crc_valid = 0;
@@ -106,7 +103,7 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   P.chunks_per_frame = (unsigned)cpf;
   P.blocks_per_frame = (P.chunks_per_frame + kPngBlock - 1) / kPngBlock;
   P.n_frames = n_frames;
-  P.aligned = (P.row_bytes % 16u) == 0u ? 1 : 0;
+  P.aligned = (P.row_bytes % 4u) == 0u ? 1 : 0;
   P.staged = (P.row_bytes % kPngChunk) == 0u ? 1 : 0;
   P.grid_x = 8u * ((P.blocks_per_frame + 7u) / 8u);
   const PngScratch L = png_scratch_layout(P);
@@ -115,10 +112,8 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   unsigned char *base = ctx->d_png;
   P.hist = (unsigned *)(base + L.hist);
   P.adler = (unsigned long long *)(base + L.adler);
-  P.direct_blocks = (unsigned *)(base + L.direct_blocks);
   P.codes = (const unsigned *)(base + L.codes);
   P.block_bits = (unsigned long long *)(base + L.block_bits);
-  P.thread_bits = (unsigned short *)(base + L.thread_bits);
   P.start_bit = (const unsigned *)(base + L.start_bit);
   P.frame_bits = (unsigned long long *)(base + L.frame_bits);
   P.block_hist = (unsigned short *)(base + L.block_hist);
@@ -128,20 +123,13 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   P.crc = (unsigned *)(base + L.crc);
   P.out = (unsigned *)(base + L.out);
   P.out_words = L.out_words;
-  /* two reads of the frames instead of three (kernels_png.h, "two-pass path"): frames whose rows are a multiple of 64 bytes,
-   * unless the option "png_path" = 0 asks for the three-pass kernels (kept for ragged widths, and as the checker of the new ones) */
-  const bool two_pass = P.staged && ctx->png_path != 0;
-  ctx->last_png_passes = two_pass ? 2 : 3;
   const dim3 grid(P.grid_x, n_frames), block(kPngBlock); /* the 8 XCDs take contiguous eighths of a frame: png_logical_block */
   float ms_a = 0.f, ms_b = 0.f;
 
   /* pass 1: histograms + Adler sums */
-  HIP_TRY(ctx, hipMemsetAsync(base + L.hist, 0, L.codes - L.hist, ctx->stream)); /* hist, adler and the diagnostics counter are adjacent */
+  HIP_TRY(ctx, hipMemsetAsync(base + L.hist, 0, L.codes - L.hist, ctx->stream)); /* hist, adler and the CRC words are adjacent */
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  if (two_pass)
-    hipLaunchKernelGGL(png_hist2_kernel, grid, block, 0, ctx->stream, P);
-  else
-    hipLaunchKernelGGL(png_hist_kernel, grid, block, 0, ctx->stream, P);
+  hipLaunchKernelGGL(png_hist2_kernel, grid, block, 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   std::vector<unsigned> hist((size_t)n_frames * kPngBins);
@@ -185,43 +173,29 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   }
   HIP_TRY(ctx, hipMemcpyAsync(base + L.codes, codes.data(), codes.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(base + L.start_bit, start_bit.data(), start_bit.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-  std::vector<unsigned> header_words;
-  if (two_pass) {
-    HIP_TRY(ctx, hipMemcpyAsync(base + L.sym_bits, sym_bits.data(), sym_bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-    /* the headers go to the device too: the stream it leaves is then complete (but for the Adler-32 trailer), which is what
-     * lets it compute the PNG chunk's CRC-32 as well */
-    header_words.assign((size_t)n_frames * kPngHeaderWords, 0u);
-    for (uint32_t f = 0; f < n_frames; ++f) std::memcpy(header_words.data() + (size_t)f * kPngHeaderWords, header[f].data(), sizeof header[f]);
-    static_assert(sizeof(std::array<uint8_t, 176>) == kPngHeaderWords * sizeof(unsigned), "header staging");
-    HIP_TRY(ctx, hipMemcpyAsync(base + L.header, header_words.data(), header_words.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(base + L.crc_tables, png_crc_tables().data(), sizeof(unsigned) * (1024 + 128), hipMemcpyHostToDevice, ctx->stream));
-  }
+  HIP_TRY(ctx, hipMemcpyAsync(base + L.sym_bits, sym_bits.data(), sym_bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+  /* the headers go to the device too: the stream it leaves is then complete (but for the Adler-32 trailer), which is what
+   * lets it compute the PNG chunk's CRC-32 as well */
+  std::vector<unsigned> header_words((size_t)n_frames * kPngHeaderWords, 0u);
+  for (uint32_t f = 0; f < n_frames; ++f) std::memcpy(header_words.data() + (size_t)f * kPngHeaderWords, header[f].data(), sizeof header[f]);
+  static_assert(sizeof(std::array<uint8_t, 176>) == kPngHeaderWords * sizeof(unsigned), "header staging");
+  HIP_TRY(ctx, hipMemcpyAsync(base + L.header, header_words.data(), header_words.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(base + L.crc_tables, png_crc_tables().data(), sizeof(unsigned) * (1024 + 128), hipMemcpyHostToDevice, ctx->stream));
 
-  /* passes 2 and 3 */
+  /* offsets from the workgroups' token counts, then ONE more pass over the pixels, then the chunk's CRC over the stream */
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  if (two_pass) { /* offsets from the workgroups' token counts, then ONE more pass over the pixels */
-    hipLaunchKernelGGL(png_blockbits_kernel, dim3((P.blocks_per_frame + 3u) / 4u, n_frames), block, 0, ctx->stream, P);
-    hipLaunchKernelGGL(png_offsets_kernel, dim3(n_frames), block, 0, ctx->stream, P);
-    hipLaunchKernelGGL(png_emit2_kernel, grid, block, 0, ctx->stream, P);
-    hipLaunchKernelGGL(png_crc_kernel, dim3((unsigned)((P.out_words * 4 + kPngBlock * 64 - 1) / (kPngBlock * 64)), n_frames), block, 0, ctx->stream, P);
-  } else {
-    hipLaunchKernelGGL(png_count_kernel, grid, block, 0, ctx->stream, P);
-    hipLaunchKernelGGL(png_scan_kernel, dim3(n_frames), block, 0, ctx->stream, P);
-    hipLaunchKernelGGL(png_zero_kernel, dim3(64, n_frames), block, 0, ctx->stream, P);
-    hipLaunchKernelGGL(png_emit_kernel, grid, block, 0, ctx->stream, P);
-  }
+  hipLaunchKernelGGL(png_blockbits_kernel, dim3((P.blocks_per_frame + 3u) / 4u, n_frames), block, 0, ctx->stream, P);
+  hipLaunchKernelGGL(png_offsets_kernel, dim3(n_frames), block, 0, ctx->stream, P);
+  hipLaunchKernelGGL(png_emit2_kernel, grid, block, 0, ctx->stream, P);
+  hipLaunchKernelGGL(png_crc_kernel, dim3((unsigned)((P.out_words * 4 + kPngBlock * 64 - 1) / (kPngBlock * 64)), n_frames), block, 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   std::vector<unsigned long long> frame_bits(n_frames);
   HIP_TRY(ctx, hipMemcpyAsync(frame_bits.data(), base + L.frame_bits, frame_bits.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ctx->stream));
-  unsigned direct_blocks = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&direct_blocks, base + L.direct_blocks, sizeof direct_blocks, hipMemcpyDeviceToHost, ctx->stream));
   std::vector<unsigned> crc_state(n_frames, 0u);
-  if (two_pass)
-    HIP_TRY(ctx, hipMemcpyAsync(crc_state.data(), base + L.crc, crc_state.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(crc_state.data(), base + L.crc, crc_state.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->last_png_direct_blocks = direct_blocks;
   HIP_TRY(ctx, hipEventElapsedTime(&ms_b, ctx->ev0, ctx->ev1));
 
   /* streams to the host: deflate bytes, then the Adler-32 of the filtered scanlines.  Sizes first, copies after: a call that
@@ -247,7 +221,7 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   for (uint32_t f = 0; f < n_frames; ++f) {
     uint8_t *z = out + offsets[f];
     const size_t hb = (start_bit[f] + 7) / 8;
-    for (size_t k = 0; k < hb; ++k) z[k] |= header[f][k]; /* the device wrote from bit start_bit on, into zeroed words */
+    for (size_t k = 0; k < hb; ++k) z[k] |= header[f][k]; /* (png_offsets_kernel wrote them already; idempotent) */
     const unsigned long long s1 = (1ull + adler[(size_t)f * 2]) % 65521ull, s2 = (n % 65521ull + adler[(size_t)f * 2 + 1]) % 65521ull;
     uint8_t *a = out + offsets[f + 1] - 4;
     a[0] = (uint8_t)(s2 >> 8);
@@ -255,9 +229,9 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
     a[2] = (uint8_t)(s1 >> 8);
     a[3] = (uint8_t)s1;
     /* CRC-32 of the PNG chunk: the device's register after "IDAT" + stream, finalised, continued over the four trailer bytes */
-    if (two_pass && idat_crc) idat_crc[f] = (uint32_t)crc32((uLong)(crc_state[f] ^ 0xFFFFFFFFu), a, 4);
+    if (idat_crc) idat_crc[f] = (uint32_t)crc32((uLong)(crc_state[f] ^ 0xFFFFFFFFu), a, 4);
   }
-  if (two_pass && crc_valid) *crc_valid = 1;
+  if (crc_valid) *crc_valid = 1;
   if (kernel_ms) *kernel_ms = (double)ms_a + (double)ms_b;
   ctx->last_png_ms = (double)ms_a + (double)ms_b;
   return CURVIS_OK;

@@ -43,11 +43,8 @@ struct curvis_ctx {
   size_t verify_cap = 0;
   unsigned char *d_png = nullptr;    /* scratch of the device PNG front end (kernels_png.h): histograms, codes, offsets, streams */
   size_t png_cap = 0;
-  uint32_t last_png_direct_blocks = 0; /* workgroups of the last deflate whose codes went straight to global memory */
   double last_png_ms = 0.0;          /* HIP-event time of the last curvis_ctx_deflate_frames */
   size_t last_png_stream_bytes = 0;  /* bytes the streams of the last curvis_ctx_deflate_frames take (also when it failed for want of room) */
-  int png_path = 1;                  /* 1: two reads of the frames (word-parallel tokeniser) where the rows allow it; 0: the three-pass kernels */
-  int last_png_passes = 0;           /* passes over the pixels the last curvis_ctx_deflate_frames made (2 or 3) */
   int relay_segment = 0;            /* steps between two hand-over points; 0 = automatic */
   int relay_max_hops = 0;           /* hand-overs per tile at most; 0 = no limit */
   int relay_max_parks = 0;          /* hand-overs per launch at most; 0 = no limit */

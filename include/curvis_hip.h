@@ -300,8 +300,8 @@ int curvis_ctx_deflate_frames(curvis_ctx *ctx, uint32_t res_x, uint32_t res_y, u
                               size_t *offsets, double *kernel_ms);
 int curvis_image_save_zlib_rgb8(const char *path, const uint8_t *zlib_stream, size_t len, uint32_t w, uint32_t h);
 /* the same with the PNG chunk's CRC-32 from the device: idat_crc[f] = CRC-32 of "IDAT" + frame f's stream (Adler-32 trailer
- * included), *crc_valid = 1 when the path taken computed it (frames whose rows are a multiple of 64 bytes), else 0 and
- * idat_crc is untouched.  curvis_image_save_zlib_rgb8_crc then writes the file without reading the stream again: what is left
+ * included), *crc_valid = 1 on success (always, since round 6: one device path for every frame width; the flag stays in the
+ * signature -- until round 5 frames whose rows were no multiple of 64 bytes left it 0 and idat_crc untouched).  curvis_image_save_zlib_rgb8_crc then writes the file without reading the stream again: what is left
  * to a writer thread is the write itself. */
 int curvis_ctx_deflate_frames_crc(curvis_ctx *ctx, uint32_t res_x, uint32_t res_y, uint32_t n_frames, uint8_t *zlib_out, size_t out_cap,
                                   size_t *offsets, double *kernel_ms, uint32_t *idat_crc, int *crc_valid);

@@ -213,6 +213,13 @@ static void sincos_two_calls(double x, double *s, double *c) { /* llvm.sin.f64 a
 }
 static void sincos_glibc(double x, double *s, double *c) { sincos(x, s, c); } /* ... merged into one sincos() libcall */
 
+/* 1 (default): the render loops step with update_memo (every metric function once per step: identical bits, 2-3 x fewer libm
+ * calls for the Interstellar metric); 0: with the literal update, call for call what the reference executes.  See
+ * curvis_oracle_impl.inc.  Not for use while renders are running on other threads. */
+static int g_metric_memo = 1;
+void cvo_set_metric_memo(int on) { g_metric_memo = on != 0; }
+int cvo_get_metric_memo(void) { return g_metric_memo; }
+
 #define M_FRAME(name) F(name)
 #define F(name) name##_libm
 #define M_SIN sin
@@ -332,8 +339,11 @@ double cvo_metric_r_derivative(int fl, const cvo_metric *m, double l) { return D
 void cvo_new_photon(int fl, const cvo_metric *m, const double pos[4], const double dir[3], double x[4], double p[4]) {
   DISPATCH(fl, new_photon, m, pos, dir, x, p);
 }
-void cvo_update(int fl, const cvo_metric *m, double x[4], double p[4], double delta) {
+void cvo_update(int fl, const cvo_metric *m, double x[4], double p[4], double delta) { /* always the literal step */
   DISPATCH(fl, update, m, x, p, delta);
+}
+void cvo_update_memo(int fl, const cvo_metric *m, double x[4], double p[4], double delta) { /* every metric function once */
+  DISPATCH(fl, update_memo, m, x, p, delta);
 }
 int cvo_escape_photon(int fl, const cvo_metric *m, double x[4], double p[4], double delta, uint32_t max_iter,
                       double max_radius, uint32_t *steps) {

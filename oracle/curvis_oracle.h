@@ -110,7 +110,12 @@ double cvo_metric_r(int fl, const cvo_metric *m, double l);
 double cvo_metric_r_squared(int fl, const cvo_metric *m, double l);
 double cvo_metric_r_derivative(int fl, const cvo_metric *m, double l);
 void cvo_new_photon(int fl, const cvo_metric *m, const double pos[4], const double dir[3], double x[4], double p[4]);
-void cvo_update(int fl, const cvo_metric *m, double x[4], double p[4], double delta);
+void cvo_update(int fl, const cvo_metric *m, double x[4], double p[4], double delta); /* literal: call for call the reference's */
+/* the same step with r(l), r_squared(l), r_derivative(l) evaluated once each (pure functions: identical bits); what the render
+ * loops use unless cvo_set_metric_memo(0) -- bench.py's cpu_baseline times the literal step */
+void cvo_update_memo(int fl, const cvo_metric *m, double x[4], double p[4], double delta);
+void cvo_set_metric_memo(int on);
+int cvo_get_metric_memo(void);
 int cvo_escape_photon(int fl, const cvo_metric *m, double x[4], double p[4], double delta, uint32_t max_iter,
                       double max_radius, uint32_t *steps);
 void cvo_vector_to_direction(int fl, const cvo_metric *m, const double p_cov[4], const double x[4], double dir[3]);

@@ -141,10 +141,8 @@ def share_env(n_devices, **extra):
     return env
 
 
-def host_threads(cap=128):
-    """threads worth starting for the striped oracle renders: the container's CPU quota when the cgroup sets one (the
-    GPU boxes show 256 logical CPUs behind a 16-CPU quota; more threads than that only add throttling), else the CPUs
-    of the affinity mask"""
+def host_cpus():
+    """(cgroup CPU quota or None, CPUs in the affinity mask, logical CPUs of the machine)"""
     quota = None
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:
@@ -158,8 +156,77 @@ def host_threads(cap=128):
         except (OSError, ValueError):
             pass
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return quota, usable, os.cpu_count() or 1
+
+
+_reported = False
+
+
+def host_threads(cap=128):
+    """threads worth starting for the striped oracle renders: the container's CPU quota when the cgroup sets one (the
+    GPU boxes show 256 logical CPUs behind a 16-CPU quota; more threads than that only add throttling), else the CPUs
+    of the affinity mask.  The first call says what it found (pytest shows it with -s, and in the captured output of a
+    failing test): the GPU tests' wall time is oracle time, i.e. proportional to 1 / this number."""
+    global _reported
+    quota, usable, logical = host_cpus()
     n = int(quota + 0.5) if quota else usable
-    return max(1, min(cap, n, usable))
+    n = max(1, min(n, usable))
+    if not _reported:
+        _reported = True
+        print("[host] cgroup CPU quota %s, %d CPUs in the affinity mask, %d logical CPUs -> %d oracle threads" % (
+            "%.2f" % quota if quota else "none", usable, logical, n), flush=True)
+    return max(1, min(cap, n))
+
+
+# ---- oracle time: memo of repeated renders, and a budget that fails FAST instead of being killed by the driver's limit ----
+_memo = {}
+
+
+def oracle_memo(key, make):
+    """session-wide memo of an oracle result several tests need (key = everything the result depends on: flavour, scene,
+    size, cap, sky); the first caller pays"""
+    if key not in _memo:
+        _memo[key] = make()
+    return _memo[key]
+
+
+_rate = {}
+_oracle_seconds = [0.0]   # projected oracle wall time of the heavy tests that have asked so far
+
+
+def oracle_rate(kind, fl):
+    """Euler steps per second of ONE oracle thread on this host (measured once per metric kind and flavour on a 64x36 frame)"""
+    import time
+    if (kind, fl) not in _rate:
+        om, oc, _, _ = scene(kind, res=(64, 36))
+        sp, sn = make_skies(64, 32, "check")
+        t0 = time.perf_counter()
+        _, _, st = O.render_image(fl, om, oc, O.sky(sp), O.sky(sn), 8192, 100.0, 0.05)
+        _rate[(kind, fl)] = st.steps / max(time.perf_counter() - t0, 1e-6)
+    return _rate[(kind, fl)]
+
+
+def oracle_budget(what, kind, fl, n_steps, threads=None):
+    """Called by a test BEFORE an oracle render of ~n_steps Euler steps: projects its wall time from the measured single-thread
+    rate and the threads this lease really gives, prints it, and fails the test at once -- with the numbers -- when that one
+    render would take longer than CURVIS_TEST_ORACLE_LIMIT_S (default 420 s) or the heavy renders of the session together
+    longer than CURVIS_TEST_ORACLE_TOTAL_S (default 1000 s; the driver kills the GPU suite at 1200 s, and a green product must
+    not read as `killed_at_limit` because the lease had a small CPU quota)."""
+    import pytest
+    T = threads or host_threads(64)
+    rate = oracle_rate(kind, fl)
+    projected = n_steps / (rate * T * 0.85)      # 0.85: what striping over T threads of a throttled cgroup delivers
+    _oracle_seconds[0] += projected
+    quota, usable, _ = host_cpus()
+    line = "[oracle budget] %s: %.3g steps at %.1f Msteps/s/thread x %d threads (quota %s) -> ~%.0f s; heavy renders so far ~%.0f s" % (
+        what, n_steps, rate / 1e6, T, "%.1f" % quota if quota else "none", projected, _oracle_seconds[0])
+    print(line, flush=True)
+    limit, total = float(os.environ.get("CURVIS_TEST_ORACLE_LIMIT_S", 420)), float(os.environ.get("CURVIS_TEST_ORACLE_TOTAL_S", 1000))
+    if projected > limit or _oracle_seconds[0] > total:
+        pytest.fail("oracle time over budget on this host, not a product failure -- " + line +
+                    " (limits: %.0f s per render, %.0f s per session; raise CURVIS_TEST_ORACLE_LIMIT_S / _TOTAL_S or run on a "
+                    "lease with more CPUs)" % (limit, total), pytrace=False)
+    return projected
 
 
 def oracle_full_frame(fl, om, oc, sky_pos, sky_neg, cap, threads=None):

@@ -24,3 +24,16 @@ def gpu_ctx():
     ctx = curvis_amd.Context(0)  # raises loudly if the HIP library or the GPU is missing
     yield ctx
     ctx.close()
+
+
+def pytest_sessionstart(session):
+    """what the oracle-bound tests will get on this host: printed even with -q (the GPU suite's wall time is oracle time)"""
+    tr = session.config.pluginmanager.get_plugin("terminalreporter")
+    try:
+        import common
+        quota, usable, logical = common.host_cpus()
+        line = "host CPUs: cgroup quota %s, %d in the affinity mask, %d logical" % ("%.2f" % quota if quota else "none", usable, logical)
+    except Exception as exc:  # never fatal: a report line
+        line = "host CPUs: unknown (%s)" % exc
+    if tr is not None:
+        tr.write_line(line)

@@ -91,6 +91,9 @@ def lib():
     sig("cvo_metric_r_derivative", d, [i32, MP, d])
     sig("cvo_new_photon", None, [i32, MP, dp, dp, dp, dp])
     sig("cvo_update", None, [i32, MP, dp, dp, d])
+    sig("cvo_update_memo", None, [i32, MP, dp, dp, d])
+    sig("cvo_set_metric_memo", None, [i32])
+    sig("cvo_get_metric_memo", i32, [])
     sig("cvo_escape_photon", i32, [i32, MP, dp, dp, d, u32, d, C.POINTER(u32)])
     sig("cvo_vector_to_direction", None, [i32, MP, dp, dp, dp])
     sig("cvo_squared_norm_cov", d, [i32, MP, dp, dp])

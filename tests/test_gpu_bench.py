@@ -142,6 +142,17 @@ def test_default_line_clock_agrees_with_itself_and_carries_the_download_figure()
     ov = dl["overlapped"]                                   # option async_download: the DMA of frame k under the kernel of frame k + 1
     assert "failed" not in ov, ov
     assert ov["value"] >= dl["value"] * 0.99 and 0.5 < ov["fraction_of_value"] <= 1.03, (ov, dl)
+    # the reference's DEFAULT renderer on the default N = 1 line -- 1080p frames/s with kernels only (one context,
+    # GPU-idle share from its own HIP events) and end to end through `curvis video --mode efficient` on the reference's path_orbit.csv
+    ve = out["value_efficient"]
+    assert "failed" not in ve, ve
+    ko = ve["kernels_only"]
+    assert ko["frames"] == 240 and ko["contexts"] == 1 and ko["value"] > 100 and 0 < ko["kernel_ms_per_frame"] < ko["ms_per_frame"] * 1.001
+    assert 0.0 <= ko["gpu_idle_share"] < 1.0 and abs(ko["gpu_idle_share"] - (1 - ko["kernel_ms_per_frame"] / ko["ms_per_frame"])) < 2e-3
+    ee = ve["end_to_end"]
+    assert "failed" not in ee, ee
+    assert ee["frames"] == ee["frames_on_disk"] == 960 and ee["frames_per_s"] > 100 and ee["gpu_png"] is True and 0.0 <= ee["gpu_idle_share"] < 1.0
+    assert "--mode efficient" in ee["command"] and "path_orbit.csv" in ee["command"]
 
 
 def test_single_rank_over_rccl_takes_the_multi_gpu_code_path():

@@ -52,7 +52,14 @@ def metrics_of(name):
 
 
 def oracle_frames(om, poses, res, sp, sn, cap):
-    """oracle (cv flavour) render of every pose, frames spread over the host threads: [(rgb, Stats)]"""
+    """oracle (cv flavour) render of every pose, frames spread over the host threads: [(rgb, Stats)]; memoised for the session --
+    the small-frame test and the test through the binary need the same 240 / 480 frames"""
+    import hashlib
+    key = ("oracle_frames", om.kind, om.rho, om.m, om.a, tuple(poses), tuple(res), hashlib.sha1(sp.tobytes() + sn.tobytes()).hexdigest(), cap)
+    return common.oracle_memo(key, lambda: _oracle_frames(om, poses, res, sp, sn, cap))
+
+
+def _oracle_frames(om, poses, res, sp, sn, cap):
     osp, osn = O.sky(sp), O.sky(sn)
 
     def work(p):
@@ -140,6 +147,7 @@ def test_video_config_full_size_frames(gpu_ctx, video):
     rgb, st = gpu_ctx.render_brute(pm, cams, cap, 100.0, 0.05)
     per = gpu_ctx.frame_stats()
     assert len(per) == len(sel)
+    common.oracle_budget("%s: %d full-size frames, cv flavour" % (video, len(sel)), metric, O.CV, float(st.steps), threads=THREADS)
     for j, i in enumerate(sel):
         oc = O.camera(poses[i][0], poses[i][1], poses[i][2], 15.0, 43.0, res)
         want_rgb, want = common.oracle_full_frame_stats(O.CV, om, oc, sp, sn, cap, threads=THREADS)
@@ -195,6 +203,8 @@ def test_video_config_every_frame_against_glibc(gpu_ctx, video):
     def work(p):
         oc = O.camera(p[0], p[1], p[2], 15.0, 43.0, res)
         return [O.render_image(fl, om, oc, osp, osn, cap, 100.0, 0.05, debug=True)[:2] for fl in O.GLIBC_FLAVOURS]
+    common.oracle_budget("%s: %d poses at %dx%d, three glibc flavours" % (video, n_frames, res[0], res[1]), metric, O.LIBM,
+                         3.0 * n_frames * res[0] * res[1] * 2000, threads=THREADS)
     with ThreadPoolExecutor(THREADS) as ex:
         want = list(ex.map(work, poses))
     worst = {fl: dict(pixels=1.0, le1=1.0, texel=1.0, steps=1.0, code=1.0) for fl in O.GLIBC_FLAVOURS}
@@ -235,6 +245,8 @@ def test_video_config_full_size_frames_against_glibc(gpu_ctx, video):
     gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
     W, H = res
     T = common.host_threads(64)
+    common.oracle_budget("%s: every 8th row of %d full-size frames, glibc" % (video, len(sel)), metric, O.LIBM_SINCOS_INL,
+                         len(sel) * W * (H // 8) * 2000.0, threads=T)
     for i in sel:
         p = poses[i]
         cam = curvis_amd.Camera(p[0], p[1], p[2], 15.0, 43.0, W, H)

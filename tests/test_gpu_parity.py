@@ -163,6 +163,7 @@ def test_full_size_frame_bit_exact(gpu_ctx, metric, res, cap):
     the fast (shared-reciprocal) and the strict (compiler IEEE) kernels, persistent and static."""
     sp, sn = common.make_skies(2048, 1024, "check")
     om, oc, pm, pc = common.scene(metric, res=res)
+    common.oracle_budget("%s %dx%d: cv flavour + three glibc flavours" % ((metric,) + res), metric, O.LIBM, 4.0 * res[0] * res[1] * 2000)
     want_rgb, want_dbg, steps = oracle_full_frame(O.CV, om, oc, sp, sn, cap)
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
                                          context=gpu_ctx)
@@ -337,6 +338,8 @@ def test_config3_full_size_4k_interstellar(gpu_ctx):
     # just slower (1.6e10 steps at ~25 M steps/s per core); the GPU boxes have 128+ cores.
     sp, sn = common.make_skies(2048, 1024, "check")
     om, oc, pm, pc = common.scene("interstellar", res=(3840, 2160))
+    common.oracle_budget("configs[2], 3840x2160 Interstellar: cv flavour in full + every 8th row in glibc", "interstellar", O.CV,
+                         (1.0 + 1.0 / 8) * 3840 * 2160 * 2000, threads=common.host_threads(128))
     want_rgb, want_dbg, steps = oracle_full_frame(O.CV, om, oc, sp, sn, 8192, threads=common.host_threads(128))
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
                                          context=gpu_ctx)

@@ -31,6 +31,98 @@ def product_decode(path):
         _abi.lib().curvis_image_free(p)
 
 
+_LEN_BASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+_LEN_EXTRA = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0]
+_CL_ORDER = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+
+
+def deflate_tokens(z):
+    """The TOKENS of a zlib stream holding one final dynamic-Huffman block (RFC 1951), read by a decoder written for this test:
+    literal v -> v, match of length L at distance 1 -> 1000 + L (any other distance fails).  The independent checker of WHAT the
+    device emitted, not only of what it decodes to (until round 5 the three-pass kernels played that part)."""
+    data = int.from_bytes(z[2:-4], "little")
+    pos = 0
+
+    def bits(n):
+        nonlocal pos
+        v = (data >> pos) & ((1 << n) - 1)
+        pos += n
+        return v
+
+    def table(lengths):
+        code, out = 0, {}
+        for ln in range(1, 16):
+            for sym, l in enumerate(lengths):
+                if l == ln:
+                    out[(ln, code)] = sym
+                    code += 1
+            code <<= 1
+        return out
+
+    def symbol(t):
+        code = 0
+        for ln in range(1, 16):
+            code = (code << 1) | bits(1)
+            if (ln, code) in t:
+                return t[(ln, code)]
+        raise AssertionError("bad code")
+    assert z[:2] == b"\x78\x01" and bits(1) == 1 and bits(2) == 2          # final block, dynamic Huffman
+    hlit, hdist, hclen = bits(5) + 257, bits(5) + 1, bits(4) + 4
+    cl = [0] * 19
+    for k in range(hclen):
+        cl[_CL_ORDER[k]] = bits(3)
+    clt, lens = table(cl), []
+    while len(lens) < hlit + hdist:
+        sy = symbol(clt)
+        if sy < 16:
+            lens.append(sy)
+        elif sy == 16:
+            lens += [lens[-1]] * (3 + bits(2))
+        elif sy == 17:
+            lens += [0] * (3 + bits(3))
+        else:
+            lens += [0] * (11 + bits(7))
+    lt, dt = table(lens[:hlit]), table(lens[hlit:])
+    toks = []
+    while True:
+        sy = symbol(lt)
+        if sy < 256:
+            toks.append(sy)
+        elif sy == 256:
+            break
+        else:
+            ln = _LEN_BASE[sy - 257] + bits(_LEN_EXTRA[sy - 257])
+            assert symbol(dt) == 0, "only distance 1 is ever emitted"
+            toks.append(1000 + ln)
+    assert (len(z) - 6) * 8 - pos < 8, "the stream ends with the end-of-block code"
+    return toks
+
+
+def model_tokens(frame):
+    """the stream format of kernels_png.h, restated: filter Up on every row (type byte 2 leads the row), every 64 image bytes of a
+    row tokenised on their own -- a run of L zeros is L literals when L <= 3, else one literal zero and a distance-1 match of L - 1"""
+    h, w, _ = frame.shape
+    rows = frame.reshape(h, w * 3).astype(np.int16)
+    filt = rows.copy()
+    filt[1:] -= rows[:-1]
+    filt = (filt & 255).astype(np.uint8)
+    toks = []
+    for r in range(h):
+        toks.append(2)
+        for x0 in range(0, w * 3, 64):
+            run = 0
+            for v in filt[r, x0:x0 + 64].tolist() + [None]:
+                if v == 0:
+                    run += 1
+                    continue
+                if run:
+                    toks += [0] * run if run <= 3 else [0, 1000 + run - 1]
+                    run = 0
+                if v is not None:
+                    toks.append(v)
+    return toks
+
+
 def check_streams(ctx, tmp_path, frames, w, h, tag):
     streams, ms = ctx.deflate_frames(w, h, len(frames))
     assert ms > 0 and len(streams) == len(frames)
@@ -45,37 +137,28 @@ def check_streams(ctx, tmp_path, frames, w, h, tag):
         assert np.array_equal(pngio.read_png(path), want), (tag, k)              # decoder 1: tests' own (zlib + unfilter)
         got = product_decode(path)                                               # decoder 2: the product's (host/png_io.h)
         assert np.array_equal(got[..., :3], want) and (got[..., 3] == 255).all(), (tag, k)
-    # the two-pass path (word-parallel tokeniser, offsets from per-workgroup token counts) and the three-pass kernels it
-    # replaced must produce the SAME stream, bit for bit: same tokens, same codes, same offsets
-    passes = ctx.get_option("last_png_passes")
-    assert passes == (2 if (w * 3) % 64 == 0 else 3), (tag, passes)
-    if passes == 2:
-        ctx.set_option("png_path", 0)
-        try:
-            old, _ = ctx.deflate_frames(w, h, len(frames))
-            assert ctx.get_option("last_png_passes") == 3
-        finally:
-            ctx.set_option("png_path", 1)
-        assert old == streams, (tag, [i for i, (a, b) in enumerate(zip(old, streams)) if a != b])
-        ctx.deflate_frames(w, h, len(frames))                          # leave the context's "last_*" options describing the default path
+    # WHAT was emitted, token by token, against the restated format (small frames: the checker is a Python loop per token).
+    # One device path serves every width since round 6 (rows that are a multiple of 64 bytes are staged with coalesced loads,
+    # ragged rows chunk by chunk); until then the three-pass kernels were compared bit for bit here.
+    if w * h * 3 <= 160_000:
+        for k, (z, want) in enumerate(zip(streams, frames)):
+            assert deflate_tokens(z) == model_tokens(want), (tag, k)
     # the PNG chunk's CRC-32 ("IDAT" + stream) from the device: equal to zlib's over the same bytes, for every frame; the file
     # written with it is byte-identical to the one whose CRC the host computed
     s2, _, crcs = ctx.deflate_frames_crc(w, h, len(frames))
     assert s2 == streams
-    if passes == 2:
-        assert crcs is not None and [zlib.crc32(b"IDAT" + z) for z in streams] == crcs, tag
-        buf = np.frombuffer(streams[0], np.uint8)
-        pa, pb = tmp_path / ("%s_crc_dev.png" % tag), tmp_path / ("%s_0.png" % tag)
-        _abi.check(_abi.lib().curvis_image_save_zlib_rgb8_crc(str(pa).encode(), buf.ctypes.data, buf.size, w, h, crcs[0]))
-        assert pa.read_bytes() == pb.read_bytes()
-    else:
-        assert crcs is None                                            # three-pass kernels: the host computes it
+    assert crcs is not None and [zlib.crc32(b"IDAT" + z) for z in streams] == crcs, tag
+    buf = np.frombuffer(streams[0], np.uint8)
+    pa, pb = tmp_path / ("%s_crc_dev.png" % tag), tmp_path / ("%s_0.png" % tag)
+    _abi.check(_abi.lib().curvis_image_save_zlib_rgb8_crc(str(pa).encode(), buf.ctypes.data, buf.size, w, h, crcs[0]))
+    assert pa.read_bytes() == pb.read_bytes()
     return streams, ms
 
 
 @pytest.mark.parametrize("metric,res", [("ellis", (96, 54)), ("interstellar", (64, 36)), ("ellis", (50, 31)), ("ellis", (7, 3)), ("ellis", (341, 17))])
 def test_brute_frames_round_trip(gpu_ctx, tmp_path, metric, res):
-    """aligned rows (16-byte loads) and ragged ones (50, 7, 341 pixels: byte loads, a last chunk of 22 / 21 / 63 bytes)"""
+    """rows that are a multiple of 64 bytes (staged: coalesced 16-byte loads), of 4 bytes (96, 64 pixels... 288-byte rows: a ragged last
+    chunk read word by word) and of neither (50, 7, 341 pixels: byte loads, a last chunk of 22 / 21 / 63 bytes)"""
     sp, sn = common.make_skies(512, 256, "check")
     gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
     gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
@@ -104,9 +187,9 @@ def test_batch_of_frames_and_black_frame(gpu_ctx, tmp_path):
 
 
 def test_frames_that_do_not_compress(gpu_ctx, tmp_path):
-    """white-noise skies: every pixel differs from its neighbours, literals cost ~8 bits each, a workgroup's codes no longer fit
-    its LDS image of the stream (> 256 bits per thread) and go straight to global memory -- same decoded pixels; the stream
-    is about as long as the raw frame"""
+    """white-noise skies: every pixel differs from its neighbours, literals cost ~8 bits each; the emit pass's LDS image of a
+    workgroup's piece of the stream holds the worst case (65 literals of 12 bits per thread) -- same decoded pixels; the stream is
+    about as long as the raw frame"""
     rng = np.random.default_rng(11)
     skies_ = []
     for _ in range(2):
@@ -115,15 +198,12 @@ def test_frames_that_do_not_compress(gpu_ctx, tmp_path):
         skies_.append(t)
     gpu_ctx.set_sky(0, curvis_amd.SphericalImage(skies_[0]))
     gpu_ctx.set_sky(1, curvis_amd.SphericalImage(skies_[1]))
-    for res in ((256, 144), (200, 77)):            # staged (768-byte rows) and direct (600-byte rows: 16-byte loads, ragged last chunk)
+    for res in ((256, 144), (200, 77)):            # staged (768-byte rows) and ragged (600-byte rows: word loads, a last chunk of 24 bytes)
         _, _, pm, pc = common.scene("ellis", res=res)
         rgb, _ = gpu_ctx.render_brute(pm, [pc, pc], 4096, 100.0, 0.05)
         streams, _ = check_streams(gpu_ctx, tmp_path, list(rgb), res[0], res[1], "noise%d" % res[0])
         ratios = [len(z) / (res[0] * res[1] * 3) for z in streams]
         assert all(r > 0.4 for r in ratios), ratios                      # measured 0.48: noise outside the throat, flat inside
-        # three-pass kernels (the ragged width): workgroups in the noisy rows took the global path; the two-pass path's LDS image
-        # holds the worst case (65 literals of 12 bits per thread), nothing leaves it
-        assert (gpu_ctx.get_option("last_png_direct_blocks") > 0) == (res[0] * 3 % 64 != 0)
 
 
 def test_efficient_frames_and_full_hd(gpu_ctx, tmp_path):
@@ -139,7 +219,6 @@ def test_efficient_frames_and_full_hd(gpu_ctx, tmp_path):
     want, _ = gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
     gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
     streams, ms = check_streams(gpu_ctx, tmp_path, list(want), 1920, 1080, "eff")
-    assert gpu_ctx.get_option("last_png_direct_blocks") == 0 and gpu_ctx.get_option("last_png_passes") == 2
     assert all(len(z) < 1920 * 1080 * 3 // 4 for z in streams)
     print("device PNG front end: 3 x 1080p in %.3f ms, streams %s bytes" % (ms, [len(z) for z in streams]))
 
@@ -158,12 +237,13 @@ def test_errors(gpu_ctx):
     assert e.value.code == _abi.E_INVALID and "too small" in str(e.value)
 
 
-@pytest.mark.parametrize("w,h", [(64, 5), (192, 33), (320, 47), (1280, 9), (960, 235), (512, 143)])
-def test_two_pass_path_on_synthetic_contents(gpu_ctx, tmp_path, w, h):
-    """the word-parallel tokeniser against the byte-serial one on contents chosen to hit its cases: runs of every length at
+@pytest.mark.parametrize("w,h", [(64, 5), (192, 33), (320, 47), (1280, 9), (960, 235), (512, 143), (100, 41), (85, 23), (23, 90), (1, 7), (277, 3)])
+def test_tokeniser_on_synthetic_contents(gpu_ctx, tmp_path, w, h):
+    """the word-parallel tokeniser -- staged widths and ragged ones (300 / 255 / 69 / 3 / 831-byte rows: partial last chunks of 44,
+    63, 5, 3 and 63 bytes, word and byte loads) -- on contents chosen to hit its cases: runs of every length at
     every alignment (1..70 zeros between non-zero bytes), bytes 1 / 255 / others in every position of a word, whole zero
     chunks, rows that differ from the row above in one byte only, white noise; frames put into the context's framebuffer
-    with curvis_ctx_upload -- streams identical to the three-pass kernels', decoded pixels identical"""
+    with curvis_ctx_upload -- tokens identical to the restated format's (small frames), decoded pixels identical"""
     rng = np.random.default_rng(w * 1000 + h)
     frames = []
     n = w * h * 3

@@ -499,3 +499,38 @@ def test_llvm_merges_sin_and_cos_of_the_update_shape_into_sincos():
     for part in (inl, sep):
         calls = [ln.split()[-1] for ln in part.splitlines() if "call" in ln]
         assert calls == ["sincos@PLT"], calls
+
+
+def test_memoised_step_is_the_literal_step_bit_for_bit():
+    """cvo_update_memo (what the render loops run by default: r, r_squared, r_derivative once per step) against cvo_update (the
+    literal step: 3 x r_squared + r + r_derivative, as src/metrics.rs:223-270 calls them) -- every flavour, every metric, the
+    Interstellar branch |l| <= a included, random states AND whole trajectories; then whole renders with the switch on and off."""
+    rng = np.random.default_rng(5)
+    metrics = [O.ellis(1.0), O.ellis(0.3), O.interstellar(0.1, 1e-4, 1.0), O.interstellar(0.7, 1.5, 2.0), O.flat()]
+    for fl in (O.CV,) + tuple(O.GLIBC_FLAVOURS):
+        for m in metrics:
+            for _ in range(200):
+                x = np.array([0.0, rng.uniform(-6, 6) * rng.choice([1.0, 1e-3, 1e-5]), rng.uniform(0.05, 3.1), rng.uniform(0, 6.28)])
+                p = np.array([1.0, rng.normal(), rng.normal() * 3, rng.normal() * 3])
+                xa, pa, xb, pb = x.copy(), p.copy(), x.copy(), p.copy()
+                for _ in range(25):
+                    L.cvo_update(fl, C.byref(m), O._dp(xa), O._dp(pa), 0.05)
+                    L.cvo_update_memo(fl, C.byref(m), O._dp(xb), O._dp(pb), 0.05)
+                    assert xa.tobytes() == xb.tobytes() and pa.tobytes() == pb.tobytes(), (fl, m.kind)
+    assert L.cvo_get_metric_memo() == 1
+    import common
+    sp, sn = common.make_skies(256, 128, "check")
+    try:
+        for metric, cap in (("ellis", 4096), ("interstellar", 8192)):
+            om, oc, _, _ = common.scene(metric, res=(48, 27), pos=(0.0, 3.0, common.HALF_PI, 0.4))
+            for fl in (O.CV, O.LIBM_SINCOS_INL):
+                L.cvo_set_metric_memo(1)
+                a = O.render_image(fl, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, debug=True)
+                ea = O.render_image_efficient(fl, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+                L.cvo_set_metric_memo(0)
+                b = O.render_image(fl, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, debug=True)
+                eb = O.render_image_efficient(fl, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+                assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and a[2].steps == b[2].steps
+                assert ea[0].tobytes() == eb[0].tobytes() and all(ea[1][k].tobytes() == eb[1][k].tobytes() for k in "aes")
+    finally:
+        L.cvo_set_metric_memo(1)

@@ -3,14 +3,18 @@
 bytes, 16-byte-aligned rows, ragged rows; 1-pixel frames up to 1000 pixels wide), 1-6 frames per call, skies of white noise /
 hash checker / smooth gradient (streams from ~1.0 x down to ~0.01 x of the pixels), cap 0 (black frame) now and then.
 Every stream must inflate (Adler-32 checked by zlib) to the Up-filtered scanlines of the frame a download returns.
-Staged frames go through the two-pass path (round 5) AND the three-pass kernels: the two streams must be identical.
-python tools/gpu_png_fuzz.py [cases] [seed]   -> profiles/round5_png_fuzz.txt"""
+Since round 6 ONE device path serves every width (the three-pass kernels that ragged widths took, and that staged frames were
+compared with, are gone); frames of up to 120 000 bytes are also checked TOKEN BY TOKEN against the restated stream format
+(tests/test_gpu_png.py deflate_tokens / model_tokens), and every chunk CRC-32 against zlib's.
+python tools/gpu_png_fuzz.py [cases] [seed]   -> profiles/round6_png_fuzz.txt"""
 import os, sys, time, zlib
 import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, "tests"))
 import curvis_amd
 from curvis_amd import skies
+import test_gpu_png as T
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 ctx = curvis_amd.Context(0)
@@ -18,7 +22,7 @@ noise = []
 for _ in range(2):
     t = rng.integers(0, 256, (1024, 2048, 4), dtype=np.uint8); t[..., 3] = 255; noise.append(t)
 SKIES = {"noise": noise, "check": [skies.checker(1024, 512, 3), skies.checker(1024, 512, 4)], "smooth": [skies.smooth(2048, 1024, 128), skies.smooth(2048, 1024, 32)]}
-bad = 0; two_pass = 0; t0 = time.time(); kinds = {"staged": 0, "aligned": 0, "ragged": 0}; direct = 0; ratio_min, ratio_max = 9.0, 0.0
+bad = 0; token_checked = 0; t0 = time.time(); kinds = {"staged": 0, "aligned": 0, "ragged": 0}; ratio_min, ratio_max = 9.0, 0.0
 for it in range(N):
     mode = it % 3
     if mode == 0: w = int(rng.choice([64, 128, 192, 256, 320, 448, 640, 960]))                                                          # 3w % 64 == 0
@@ -35,16 +39,17 @@ for it in range(N):
     cap = 0 if rng.random() < 0.05 else 3000
     rgb, _ = ctx.render_brute(m, cams, cap, 100.0, 0.05)
     streams, _, crcs = ctx.deflate_frames_crc(w, h, nf)
-    if crcs is not None and crcs != [zlib.crc32(b"IDAT" + z) for z in streams]:   # the chunk CRC-32 the device computed (two-pass path)
+    if crcs is None or crcs != [zlib.crc32(b"IDAT" + z) for z in streams]:   # the chunk CRC-32 the device computed
         bad += 1; print("CRC DIFFERS case %d: %dx%d x%d" % (it, w, h, nf), flush=True)
-    direct += ctx.get_option("last_png_direct_blocks") > 0
-    if ctx.get_option("last_png_passes") == 2:   # the same frames through the three-pass kernels: identical streams
-        two_pass += 1
-        ctx.set_option("png_path", 0)
-        old, _ = ctx.deflate_frames(w, h, nf)
-        ctx.set_option("png_path", 1)
-        if old != streams:
-            bad += 1; print("PATHS DIFFER case %d: %dx%d x%d %s cap %d" % (it, w, h, nf, sk, cap), flush=True)
+    if w * h * 3 <= 120_000:
+        token_checked += 1
+        for k in range(nf):
+            try:
+                same = T.deflate_tokens(streams[k]) == T.model_tokens(rgb[k])
+            except AssertionError as exc:
+                same = False; print("TOKEN READER:", exc)
+            if not same:
+                bad += 1; print("TOKENS DIFFER case %d frame %d: %dx%d x%d %s cap %d" % (it, k, w, h, nf, sk, cap), flush=True)
     for k in range(nf):
         try:
             raw = np.frombuffer(zlib.decompress(streams[k]), np.uint8).reshape(h, 3 * w + 1)
@@ -55,6 +60,6 @@ for it in range(N):
         if w * h > 20000: ratio_min, ratio_max = min(ratio_min, r), max(ratio_max, r)
         if not ok:
             bad += 1; print("MISMATCH case %d frame %d: %dx%d x%d %s cap %d" % (it, k, w, h, nf, sk, cap), flush=True)
-print("cases %d (%s; %d through the two-pass path and, for comparison, the three-pass kernels), calls with workgroups on the global-memory path %d, stream / pixels between %.4f and %.3f (frames > 20 000 pixels), mismatches %d, %.0f s" % (
-    N, ", ".join("%s %d" % kv for kv in kinds.items()), two_pass, direct, ratio_min, ratio_max, bad, time.time() - t0))
+print("cases %d (%s; %d of them also token by token), stream / pixels between %.4f and %.3f (frames > 20 000 pixels), mismatches %d, %.0f s" % (
+    N, ", ".join("%s %d" % kv for kv in kinds.items()), token_checked, ratio_min, ratio_max, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
