@@ -133,16 +133,17 @@ __device__ __forceinline__ void png_stage_ragged(const PngParams &P, unsigned fr
     cur = P.fb + (size_t)frame * P.frame_bytes + (size_t)row * P.row_bytes + x0;
     has_up = row != 0u; /* row 0: the row above is treated as zeros, never read */
   }
+  const unsigned char *up = cur - P.row_bytes; /* a POINTER one row up: an unsigned index `4 w + b - row_bytes` would wrap */
 #pragma unroll 1
   for (unsigned w = 0; w < kPngChunk / 4u; ++w) {
     unsigned d = 0u;
     if (4u * w < nb) {
       if (P.aligned) { /* nb is a multiple of 4 then */
         const unsigned c = *reinterpret_cast<const unsigned *>(cur + 4u * w);
-        d = png_sub4(c, has_up ? *reinterpret_cast<const unsigned *>(cur - P.row_bytes + 4u * w) : 0u);
+        d = png_sub4(c, has_up ? *reinterpret_cast<const unsigned *>(up + 4u * w) : 0u);
       } else {
         for (unsigned b = 0; b < 4u && 4u * w + b < nb; ++b)
-          d |= (((unsigned)cur[4u * w + b] - (has_up ? (unsigned)cur[4u * w + b - P.row_bytes] : 0u)) & 0xffu) << (8u * b);
+          d |= (((unsigned)cur[4u * w + b] - (has_up ? (unsigned)up[4u * w + b] : 0u)) & 0xffu) << (8u * b);
       }
     }
     dst[w] = d;

@@ -84,7 +84,7 @@ def test_two_ranks_agree_on_the_fallback_when_rccl_fails_on_one_of_them():
     r = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--sustained-seconds", "0", "--no-cpu-baseline", "--no-video-e2e",
                    "--no-rows-split", "--multi-frame", "0"] + QUICK,
                   {"CURVIS_BENCH_SHARE_DEVICE": "1", "CURVIS_BENCH_TRY_RCCL": "1", "CURVIS_BENCH_TEST_RCCL_FAIL": "1",
-                   "CURVIS_BENCH_RCCL_INIT_TIMEOUT": "20"})
+                   "CURVIS_BENCH_RCCL_INIT_TIMEOUT": "8"})
     out = the_line(r)
     col = out["collective"]
     assert out["n_gpus"] == 2 and col["backend"] == "gloo" and col["readback_verified_on_every_rank"] is True
