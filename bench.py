@@ -985,6 +985,7 @@ def efficient_kernels(ctx, torch, args):
     src/main.rs:91-110), ONE context, 32 frames per call, frames left in HBM.  GPU-idle share from the context's own HIP events."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import refpaths
+    import curvis_amd
     from curvis_amd import rendering
     it = rendering.Interpolator.from_file(refpaths.reference_path_file("path_orbit.csv"))
     times = rendering.times_of_frames(it.min_time(), it.max_time(), 4.0)

@@ -452,7 +452,10 @@ struct Decoder {
        * ((dc q 16384 + 65536 + (128 << 17)) >> 17 in every position), without making them */
       uint64_t ac[16];
       std::memcpy(ac, coef, sizeof ac);
-      uint64_t any = ac[0] & ~(uint64_t)0xFFFF; /* little endian: coef[0] is the low 16 bits */
+#if !defined(__BYTE_ORDER__) || __BYTE_ORDER__ != __ORDER_LITTLE_ENDIAN__
+#error "the DC-only test below takes coef[0] for the LOW 16 bits of the first 64-bit word: little-endian hosts only"
+#endif
+      uint64_t any = ac[0] & ~(uint64_t)0xFFFF; /* little endian (checked above): coef[0] is the low 16 bits */
       for (int i = 1; i < 16; ++i) any |= ac[i];
       if (!any) {
         idct_t x = (idct_t)coef[0] * (idct_t)q[0];

@@ -213,8 +213,9 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
   uint32_t W = 0, H = 0;
   int depth = 0, ctype = 0, interlace = 0;
   std::vector<uint8_t> plte, trns;
-  /* the IDAT chunks stay where they are in the file: (data, length, CRC field) -- inflated span by span, their CRC-32s checked
-   * by a helper thread meanwhile (a 36 MB star map: 95 ms of copying and checksumming before the first byte was inflated) */
+  /* the IDAT chunks are first only NOTED where they are in the file: (data, length, CRC field); before inflating they are copied
+   * into ONE contiguous, padded buffer (inflate_fast.h reads a few bytes ahead), and their CRC-32s are checked by a helper
+   * thread meanwhile (a 36 MB star map: 95 ms of checksumming before the first byte was inflated when it ran first) */
   struct Span { const uint8_t *data; uint32_t len; const uint8_t *type; };
   std::vector<Span> idat;
   bool have_ihdr = false;
@@ -295,8 +296,9 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
   const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
   /* fast path: 8-bit RGB / RGBA, not interlaced, no transparent colour -- every sky texture in practice.  Scanlines are
    * reconstructed IN PLACE in the inflated buffer and go to the RGBA image a row at a time (cache-hot), by a second thread
-   * that follows the inflater: zlib is called for 1 MiB of output at a time and the rows a finished call has completed
-   * are handed over -- a call reads back only its own output and zlib's private window, so rewriting earlier rows is safe.
+   * that follows the inflater.  What makes rewriting earlier rows safe is inflate_fast.h's Progress contract: the output
+   * buffer IS the window, the inflater never reads or writes below op - 32768, and Progress publishes settled = have - 32 KiB
+   * to the follower, which touches nothing above that bound.
    * An 8192x4096 background: 0.80 s -> 0.23 s (smooth), 1.3 s -> 0.7 s (noisy, inflate-bound). */
   const bool fast = !interlace && depth == 8 && (ctype == 6 || (ctype == 2 && trns.size() < 6));
   const size_t fstride = (size_t)W * (size_t)channels;
@@ -304,7 +306,20 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
   std::condition_variable fcv;
   size_t f_have = 0;      /* inflated bytes the follower may touch (guarded by fmu) */
   bool f_done = false;    /* the inflater has stopped (end of stream or error) */
-  bool f_bad_filter = false, f_oom = false;
+  bool f_bad_filter = false, f_oom = false, f_no_thread = false;
+  /* declared BEFORE the follower and its guard: locals die in reverse order, and the follower / converter threads read and write
+   * raw.data() until the guard has joined them */
+  struct RawBuffer { /* the inflated scanlines: NOT zero-filled (a vector's resize would write 134 MB that the inflater overwrites) */
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    uint8_t *data() const { return p.get(); }
+    size_t size() const { return n; }
+    void resize(size_t bytes) { /* grows once, from empty; afterwards only shrinks */
+      if (!p) p.reset(new uint8_t[bytes]);
+      n = bytes;
+    }
+  } raw;
+  uint32_t follower_adler = 1; /* Adler-32 of the scanlines the follower has taken (it sums a row before it rewrites it) */
   std::thread follower;
   struct FollowerGuard { /* however decode() is left -- an exception included -- the follower is told to stop and joined first */
     std::thread &t;
@@ -324,17 +339,6 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
   img.w = W;
   img.h = H;
   /* inflate (inflate_fast.h: the stream contiguous in memory, the output buffer its own window) */
-  struct RawBuffer { /* the inflated scanlines: NOT zero-filled (a vector's resize would write 134 MB that the inflater overwrites) */
-    std::unique_ptr<uint8_t[]> p;
-    size_t n = 0;
-    uint8_t *data() const { return p.get(); }
-    size_t size() const { return n; }
-    void resize(size_t bytes) { /* grows once, from empty; afterwards only shrinks */
-      if (!p) p.reset(new uint8_t[bytes]);
-      n = bytes;
-    }
-  } raw;
-  uint32_t follower_adler = 1; /* Adler-32 of the scanlines the follower has taken (it sums a row before it rewrites it) */
   {
     size_t zbytes = 0;
     for (const Span &sp : idat) zbytes += sp.len;
@@ -407,8 +411,8 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
               }
             }
           });
-        } catch (const std::exception &) { /* no thread to be had: this stage cannot run */
-          f_oom = true;
+        } catch (const std::exception &) { /* no thread to be had: this stage cannot run -- said as such, not as "out of memory" */
+          f_no_thread = true;
           return;
         }
         auto hand_over = [&](size_t rows, bool last) {
@@ -483,7 +487,7 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
     raw.resize(have);
     /* Adler-32 of the inflated data (RFC 1950), as zlib checks it: the follower has summed the rows it took before it rewrote
      * them; whatever it did not take is still as inflated */
-    if (!f_bad_filter && !f_oom) {
+    if (!f_bad_filter && !f_oom && !f_no_thread) {
       uLong adler = 1;
       size_t from = 0;
       if (fast) {
@@ -502,6 +506,7 @@ inline bool decode(const std::vector<uint8_t> &file, Image &img, std::string &er
   mark(fast ? "inflate (+ unfilter, RGBA)" : "inflate");
   if (fast) {
     if (f_oom) throw std::bad_alloc(); /* in THIS thread, where the callers expect it */
+    if (f_no_thread) { err = "could not start a PNG decoder thread (std::system_error: resource unavailable)"; return false; }
     if (f_bad_filter || raw.size() < (size_t)H * (fstride + 1)) { err = "corrupt PNG scanlines"; return false; }
     return true;
   }

@@ -185,11 +185,19 @@ int fb_download(curvis_ctx *ctx, unsigned char *rgb_out, size_t bytes) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fb, ctx->stream));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_fb, 0));
   HIP_TRY(ctx, hipMemcpyAsync(rgb_out, ctx->d_fb, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_dl, ctx->copy_stream));
+  /* from here on a copy into the caller's buffer is in flight: it is tracked BEFORE anything else can fail, and a failure of
+   * one of the remaining calls drains the copy stream before it is reported -- no error return with rgb_out still being written */
   ctx->dl_pending = true;
   ctx->dl_src = ctx->d_fb;
   ctx->downloads_overlapped++;
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* kernels, counters, debug dump: done (the frames are still on their way) */
+  hipError_t e = hipEventRecord(ctx->ev_dl, ctx->copy_stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); /* kernels, counters, debug dump: done (the frames are still on their way) */
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    ctx->dl_pending = false;
+    ctx->dl_src = nullptr;
+    return fail(ctx, CURVIS_E_HIP, std::string("asynchronous frame download: ") + hipGetErrorString(e));
+  }
   return CURVIS_OK;
 }
 

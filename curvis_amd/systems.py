@@ -286,6 +286,8 @@ class Context:
         check(lib().curvis_ctx_create(int(device), C.byref(self._h)))
         self.device = device
         self._sky_objs = [None, None]  # strong refs: identity check must not suffer id() reuse
+        self._async_download = False
+        self._dl_keep = None  # the array the last download went (or is still going) into: see _downloaded
 
     def close(self):
         if self._h:
@@ -393,6 +395,23 @@ class Context:
 
     def set_option(self, key, value):
         check(lib().curvis_ctx_set_option(self._h, key.encode(), int(value)), self._h)
+        if key == "async_download":
+            self._async_download = bool(int(value))
+            if not self._async_download:
+                self._dl_keep = None  # (the library drains a pending copy when the option is switched off)
+
+    def _downloaded(self, array, callers_buffer):
+        """after a render call that was given a host buffer.  With option "async_download" = 1 the copy into `array` may still be
+        in flight when the call returns: the context keeps a reference to it until the next download or download_wait -- a
+        caller dropping the returned array must not leave the DMA writing into freed memory -- and when the array is one this
+        wrapper allocated itself (pageable np.empty, handed straight back to the caller) the copy is waited for right here:
+        overlapping it is only meaningful into a caller-owned page-locked buffer, and nobody expects to call download_wait
+        for an array they were just handed."""
+        if not self._async_download or array is None:
+            return
+        self._dl_keep = array
+        if not callers_buffer:
+            self.download_wait()
 
     def get_option(self, key):
         v = C.c_int64(0)
@@ -413,6 +432,7 @@ class Context:
         """curvis_ctx_download_wait: with option "async_download" = 1, the frames of the last render call that was given
         an output buffer are in host memory when this returns (they also are once the NEXT such call has returned)"""
         check(lib().curvis_ctx_download_wait(self._h), self._h)
+        self._dl_keep = None
 
     def download_frames(self, width, height, n_frames=1):
         """curvis_ctx_download: the frames the last render call left in HBM as an n x H x W x 3 uint8 array"""
@@ -437,6 +457,7 @@ class Context:
             download = True
         else:
             rgb = np.empty((n, H, W, 3), dtype=np.uint8) if download else None
+        callers_buffer = out is not None
         out = rgb.ctypes.data if download else None
         if debug:
             if n != 1:
@@ -444,9 +465,11 @@ class Context:
             dbg = np.zeros((H, W), dtype=_abi.RAY_DEBUG)
             check(lib().curvis_render_brute_debug(self._h, C.byref(m), arr, max_iterations, max_radius, delta, out,
                                                   dbg.ctypes.data, C.byref(st)), self._h)
+            self._downloaded(rgb, callers_buffer)
             return (rgb[0] if download else None), st, dbg
         check(lib().curvis_render_brute_batch(self._h, C.byref(m), arr, n, max_iterations, max_radius, delta, out,
                                               C.byref(st)), self._h)
+        self._downloaded(rgb, callers_buffer)
         if download and single:
             rgb = rgb[0]
         return rgb, st
@@ -460,6 +483,7 @@ class Context:
         check(lib().curvis_render_brute_rows(self._h, C.byref(m), C.byref(camera._c), row_begin, row_count, max_iterations,
                                              max_radius, delta, rgb.ctypes.data if download else None, C.byref(st)),
               self._h)
+        self._downloaded(rgb, False)
         return rgb, st
 
     def render_efficient(self, metric, cameras, max_iterations_propagation, max_radius, delta, alpha_nums,
@@ -482,6 +506,7 @@ class Context:
         check(lib().curvis_render_efficient_batch(self._h, C.byref(m), arr, n, max_iterations_propagation, max_radius,
                                                   delta, alpha_nums, max_iterations_sampling, thr1, thr2,
                                                   rgb.ctypes.data if download else None, C.byref(st)), self._h)
+        self._downloaded(rgb, out is not None)
         if download and single:
             rgb = rgb[0]
         return rgb, st
@@ -500,6 +525,7 @@ class Context:
             rgb = np.empty((H, W, 3), dtype=np.uint8) if download else None
         check(lib().curvis_render_direct(self._h, C.byref(m), C.byref(camera._c), max_iterations, max_radius, delta,
                                          rgb.ctypes.data if download else None, C.byref(st)), self._h)
+        self._downloaded(rgb, out is not None)
         return rgb, st
 
     def frame_stats(self, frame=None):

@@ -162,3 +162,35 @@ def test_context_destroyed_with_a_download_in_flight():
     c.close()                                                          # waits for the copy engine before freeing the frame buffers
     assert np.array_equal(buf.array.reshape(H, W, 3), want)
     buf.close()
+
+
+def test_wrapper_arrays_are_complete_and_kept_alive(ctx):
+    """with the option on, a render call WITHOUT a caller's buffer hands back an array the wrapper allocated itself
+    (pageable): it must be complete on return -- nobody calls download_wait for an array they were just handed -- and a caller's
+    buffer whose only other reference is dropped must stay alive (the context keeps it) until the copy has been waited for."""
+    import gc
+    import weakref
+    c, sp, sn = ctx
+    _, _, pm, pc = common.scene("ellis", (W, H))
+    want, _ = c.render_brute(pm, pc, CAP, R, DELTA)
+    c.set_option("async_download", 1)
+    try:
+        for _ in range(3):
+            got, _ = c.render_brute(pm, pc, CAP, R, DELTA)                 # no `out`: waited for inside the wrapper
+            assert c.get_option("download_pending") == 0 and np.array_equal(got, want)
+            eff, _ = c.render_efficient(pm, pc, CAP, R, DELTA, 100, 50, 1e-5, 1e-5)
+            assert c.get_option("download_pending") == 0 and eff.shape == want.shape
+        buf = np.empty(W * H * 3, np.uint8)                               # a caller's (pageable) buffer, dropped right after the call
+        ref = weakref.ref(buf)
+        c.render_brute(pm, pc, CAP, R, DELTA, out=buf)
+        del buf
+        gc.collect()
+        assert ref() is not None                                           # the context holds it while the copy may be in flight
+        kept = ref()
+        c.download_wait()
+        assert np.array_equal(kept.reshape(H, W, 3), want)
+        del kept
+        gc.collect()
+        assert ref() is None                                               # ... and lets go afterwards
+    finally:
+        c.set_option("async_download", 0)
