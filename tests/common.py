@@ -180,14 +180,59 @@ def host_threads(cap=128):
 
 # ---- oracle time: memo of repeated renders, and a budget that fails FAST instead of being killed by the driver's limit ----
 _memo = {}
+_memo_lock = None
+_prefetch_thread = None
+
+
+def _memo_slot(key):
+    import threading
+    global _memo_lock
+    if _memo_lock is None:
+        _memo_lock = threading.Lock()
+    with _memo_lock:
+        if key not in _memo:
+            _memo[key] = {"lock": threading.Lock(), "done": False, "value": None}
+        return _memo[key]
 
 
 def oracle_memo(key, make):
     """session-wide memo of an oracle result several tests need (key = everything the result depends on: flavour, scene,
-    size, cap, sky); the first caller pays"""
-    if key not in _memo:
-        _memo[key] = make()
-    return _memo[key]
+    size, cap, sky); the first caller pays -- or the background prefetcher already has (oracle_prefetch): a test that asks
+    for a result being computed there waits for it instead of computing it twice"""
+    slot = _memo_slot(key)
+    with slot["lock"]:
+        if not slot["done"]:
+            slot["value"] = make()
+            slot["done"] = True
+    return slot["value"]
+
+
+def prefetch_threads():
+    """threads the background prefetcher may use: the quota minus six, so that the tests running meanwhile (the bench and CLI
+    tests: subprocesses that mostly wait for the GPU and RCCL, but whose timing assertions must not be disturbed) keep CPUs and
+    the cgroup stays under its quota -- CFS throttles EVERY thread of a cgroup that exceeds it"""
+    return max(1, host_threads(64) - 6)
+
+
+def oracle_prefetch(thunks):
+    """Run `thunks` (callables that end in an oracle_memo call), one after the other, on ONE background thread, starting now.
+    The GPU suite runs its files in alphabetical order: async download, bench and CLI tests come first and leave the host's
+    CPUs idle for ~100 s, while the tests that need the heaviest oracle renders (full-size frames of the video configs, the 4K
+    frame of configs[2]) come later and used to compute them while the GPU sat idle.  The renders start here instead; nothing
+    about WHAT is computed or asserted changes.  A thunk that fails is dropped: the test then computes (and fails) itself."""
+    import threading
+    global _prefetch_thread
+    if _prefetch_thread is not None or not thunks or os.environ.get("CURVIS_TEST_NO_PREFETCH"):
+        return
+
+    def run():
+        for t in thunks:
+            try:
+                t()
+            except Exception as exc:  # noqa: BLE001
+                print("[oracle prefetch] dropped a job: %s" % exc, flush=True)
+    _prefetch_thread = threading.Thread(target=run, name="oracle-prefetch", daemon=True)
+    _prefetch_thread.start()
 
 
 _rate = {}

@@ -37,3 +37,22 @@ def pytest_sessionstart(session):
         line = "host CPUs: unknown (%s)" % exc
     if tr is not None:
         tr.write_line(line)
+
+
+def pytest_collection_finish(session):
+    """the heaviest oracle renders of the selected GPU tests start NOW, on a background thread (tests/common.py oracle_prefetch):
+    test modules that have such renders name them in ORACLE_PREFETCH(selected node ids)"""
+    names = [item.nodeid for item in session.items]
+    if not any("test_gpu_" in n for n in names) or session.config.option.collectonly:
+        return
+    thunks = []
+    for mod in sorted({item.module for item in session.items if hasattr(item, "module")}, key=lambda m: m.__name__):   # the order the files run in
+        make = getattr(mod, "ORACLE_PREFETCH", None)
+        if make is not None:
+            try:
+                thunks += list(make(names))
+            except Exception as exc:  # noqa: BLE001 -- prefetching is an optimisation, never a reason to fail collection
+                print("[oracle prefetch] %s: %s" % (getattr(mod, "__name__", mod), exc))
+    if thunks:
+        import common
+        common.oracle_prefetch(thunks)

@@ -129,6 +129,30 @@ def full_size_frames(video, n_frames, poses):
     return [0] + near
 
 
+def full_size_oracle_frame(video, i, threads=None):
+    """oracle (cv flavour) render of frame i of a video config at FULL size on the 2048x1024 checker skies: (rgb, counters);
+    memoised -- the background prefetcher (ORACLE_PREFETCH below, started by conftest) computes the fly-through's frames while
+    the first test files run"""
+    metric, csv, fps, n_frames, _, res, cap = VIDEOS[video]
+
+    def make():
+        _, poses = video_poses(csv, fps)
+        om, _ = metrics_of(metric)
+        sp, sn = common.make_skies(2048, 1024, "check")
+        oc = O.camera(poses[i][0], poses[i][1], poses[i][2], 15.0, 43.0, res)
+        return common.oracle_full_frame_stats(O.CV, om, oc, sp, sn, cap, threads=threads or THREADS)
+    return common.oracle_memo(("full_size_oracle_frame", video, i), make)
+
+
+def ORACLE_PREFETCH(selected):
+    """jobs for common.oracle_prefetch: the three full-size fly-through frames (~60 s of 16 CPUs) when their test is selected"""
+    if not any("test_video_config_full_size_frames[through]" in n for n in selected):
+        return []
+    _, poses = video_poses(VIDEOS["through"][1], VIDEOS["through"][2])
+    T = common.prefetch_threads()
+    return [lambda i=i: full_size_oracle_frame("through", i, threads=T) for i in full_size_frames("through", VIDEOS["through"][3], poses)]
+
+
 @pytest.mark.parametrize("video", ["orbit", "through"])
 def test_video_config_full_size_frames(gpu_ctx, video):
     """frames {0, 60, 120, 239} of the orbit at 1920x1080 cap 4096; frame 0 (l = -4) and the two frames nearest
@@ -149,8 +173,7 @@ def test_video_config_full_size_frames(gpu_ctx, video):
     assert len(per) == len(sel)
     common.oracle_budget("%s: %d full-size frames, cv flavour" % (video, len(sel)), metric, O.CV, float(st.steps), threads=THREADS)
     for j, i in enumerate(sel):
-        oc = O.camera(poses[i][0], poses[i][1], poses[i][2], 15.0, 43.0, res)
-        want_rgb, want = common.oracle_full_frame_stats(O.CV, om, oc, sp, sn, cap, threads=THREADS)
+        want_rgb, want = full_size_oracle_frame(video, i)
         assert want[0] == res[0] * res[1]
         assert stats_tuple(per[j]) == want, "frame %d: %s vs %s" % (i, stats_tuple(per[j]), want)
         assert np.array_equal(rgb[j], want_rgb), "frame %d pixels" % i

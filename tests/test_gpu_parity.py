@@ -329,6 +329,22 @@ def test_efficient_default_960x540_vs_oracle(gpu_ctx):
         assert d.max() == 0, O.FLAVOUR_NAMES[fl]  # measured: 518 400 of 518 400 pixels identical (profiles/round3_libm_parity.txt)
 
 
+def config3_oracle_frame(threads=None):
+    """oracle (cv flavour) render of BASELINE configs[2] at full size with the per-ray dump; memoised -- the background
+    prefetcher (ORACLE_PREFETCH, started by conftest) computes it while the first test files run"""
+    def make():
+        sp, sn = common.make_skies(2048, 1024, "check")
+        om, oc, _, _ = common.scene("interstellar", res=(3840, 2160))
+        return oracle_full_frame(O.CV, om, oc, sp, sn, 8192, threads=threads or common.host_threads(128))
+    return common.oracle_memo(("config3_oracle_frame",), make)
+
+
+def ORACLE_PREFETCH(selected):
+    if not any("test_config3_full_size_4k_interstellar" in n for n in selected):
+        return []
+    return [lambda: config3_oracle_frame(threads=common.prefetch_threads())]
+
+
 def test_config3_full_size_4k_interstellar(gpu_ctx):
     """BASELINE configs[2] at full size: Interstellar (m=0.1, a=1e-4, rho=1), 3840x2160, cap 8192 --
     8 294 400 rays, 1.6e10 Euler steps -- pixels, step total and escape counts bit-exact against the oracle
@@ -340,7 +356,7 @@ def test_config3_full_size_4k_interstellar(gpu_ctx):
     om, oc, pm, pc = common.scene("interstellar", res=(3840, 2160))
     common.oracle_budget("configs[2], 3840x2160 Interstellar: cv flavour in full + every 8th row in glibc", "interstellar", O.CV,
                          (1.0 + 1.0 / 8) * 3840 * 2160 * 2000, threads=common.host_threads(128))
-    want_rgb, want_dbg, steps = oracle_full_frame(O.CV, om, oc, sp, sn, 8192, threads=common.host_threads(128))
+    want_rgb, want_dbg, steps = config3_oracle_frame()
     sys_ = curvis_amd.RelativisticSystem(pm, curvis_amd.SphericalImage(sp), curvis_amd.SphericalImage(sn), pc,
                                          context=gpu_ctx)
     got = sys_.render_image(8192, 100.0, 0.05)
