@@ -58,6 +58,7 @@
 #include "cv_frame_host.h"
 #include "cv_host.h"
 #include "cv_sampler.h"
+#include "cv_sampler_dev.h"
 #include "host/jpeg_io.h" /* PNG + JPEG decoders shared with the curvis binary */
 
 #pragma clang fp contract(off)
@@ -644,6 +645,10 @@ int curvis_ctx_frame_stats(const curvis_ctx *ctx, uint32_t frame, curvis_stats *
 int curvis_ctx_samples(const curvis_ctx *ctx, uint32_t frame, double *alpha, double *escape_angle,
                        double *escape_space, size_t cap) {
   if (!ctx || frame >= ctx->last_samples.size()) return CURVIS_E_INVALID;
+  /* device-resident sampler: the tables stayed in HBM; this frame's is fetched now (the context is the caller's to mutate: a
+   * context is not thread-safe, and the const in the signature promises nothing about caches) */
+  const int frc = fetch_device_samples(const_cast<curvis_ctx *>(ctx), frame);
+  if (frc != CURVIS_OK) return frc;
   const auto &pts = ctx->last_samples[frame];
   if (cap < pts.size()) return CURVIS_E_INVALID;
   for (size_t i = 0; i < pts.size(); ++i) {
@@ -905,6 +910,10 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
     ctx->fast_math = (int)value;
   else if (k == "fuse_shade")
     ctx->fuse_shade = (int)value;
+  else if (k == "device_sampler")
+    ctx->device_sampler = (int)value;
+  else if (k == "device_sampler_min_frames")
+    ctx->device_sampler_min_frames = value < 1 ? 1 : (int)value;
   else if (k == "sampling_speculation")
     ctx->sampling_speculation = (int)value;
   else if (k == "sampling_speculation_first")
@@ -978,6 +987,12 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->sampling_speculation;
   else if (k == "sampling_speculation_first")
     *value = ctx->sampling_speculation_first;
+  else if (k == "device_sampler")
+    *value = ctx->device_sampler;
+  else if (k == "device_sampler_min_frames")
+    *value = ctx->device_sampler_min_frames;
+  else if (k == "last_sampler_path")
+    *value = ctx->last_sampler_path;
   else if (k == "last_sampling_launches")
     *value = ctx->last_sampling_launches;
   else if (k == "last_sampling_evaluated")

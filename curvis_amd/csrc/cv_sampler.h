@@ -14,6 +14,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "cv_sampler_dev.h"
+
 namespace cvs {
 
 struct BiPoint {
@@ -77,12 +79,9 @@ struct Sampler {
     size_t i = 0;
     while (i < n - 2) {
       const BiPoint &b1 = pts[i], &b2 = pts[(i + 1) % n], &b3 = pts[(i + 2) % n];
-      const double area1 =
-          std::fabs((b1.a * b2.e + b2.a * b3.e + b3.a * b1.e) - (b1.e * b2.a + b2.e * b3.a + b3.e * b1.a));
-      const double area2 =
-          std::fabs((b1.a * b2.s + b2.a * b3.s + b3.a * b1.s) - (b1.s * b2.a + b2.s * b3.a + b3.s * b1.a));
       visit.push_back(i);
-      if (!(area1 > thr1 || area2 > thr2)) {
+      /* the two shoelace areas: cvk::sampler_refine, shared with the device-resident sampler (cv_sampler_dev.h) */
+      if (!cvk::sampler_refine(b1.a, b1.e, b1.s, b2.a, b2.e, b2.s, b3.a, b3.e, b3.s, thr1, thr2)) {
         refined.push_back(0);
         i += 1;
       } else {

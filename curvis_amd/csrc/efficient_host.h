@@ -29,6 +29,7 @@ int eval_escape_batch(curvis_ctx *ctx, const curvis_metric *metric, const cvk::M
   steps.resize(n);
   status.resize(n);
   if (n == 0) return CURVIS_OK;
+  ctx->dev_samples.valid = false; /* the scratch is about to be reused */
   /* layout: alpha | l | angle | space (f64) | steps (u32) | status (i32) */
   const size_t bytes = n * (4 * sizeof(double) + sizeof(unsigned) + sizeof(int));
   int rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, bytes);
@@ -93,6 +94,245 @@ int eval_escape_batch(curvis_ctx *ctx, const curvis_metric *metric, const cvk::M
   return CURVIS_OK;
 }
 
+
+/* ---- efficient mode with the DEVICE-RESIDENT sampler (kernels_efficient.h sampler_kernel) ------------------------------------
+ * One launch samples every frame of the call -- a workgroup per distinct camera radius, rounds and all --, the per-pixel kernel
+ * follows on the same stream and reads the tables where the sampler left them: no host round trip per refinement round, no
+ * evaluation cache, no table building on the host.  What comes back is 32 bytes per job (counts and status) and the frame
+ * counters; the sample tables themselves are fetched only if curvis_ctx_samples asks for them.
+ * Returns CURVIS_OK, an error, or kSamplerFallback: a table outgrew the kernel's fixed arrays (cv_sampler_dev.h kSamplerCap) --
+ * the caller then runs the host-paced sampler, which has no such bound. */
+constexpr int kSamplerFallback = 1;
+
+template <int KIND>
+int launch_sampler_kind(curvis_ctx *ctx, bool fast, const SamplerParams &P) {
+  if (fast)
+    hipLaunchKernelGGL((sampler_kernel<KIND, true>), dim3(P.n_jobs), dim3(kSamplerThreads), 0, ctx->stream, P);
+  else
+    hipLaunchKernelGGL((sampler_kernel<KIND, false>), dim3(P.n_jobs), dim3(kSamplerThreads), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  return CURVIS_OK;
+}
+
+int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const cvk::MetricParams &MP, const curvis_camera *cams,
+                            uint32_t n_frames, const std::vector<cvk::EfficientFrame> &eframes, uint32_t max_iter, double max_radius,
+                            double delta, uint32_t alpha_nums, uint32_t max_iterations_sampling, double thr1, double thr2,
+                            uint8_t *rgb_out, curvis_stats *stats, std::chrono::steady_clock::time_point t_begin) {
+  const uint32_t W = cams[0].res_x, H = cams[0].res_y;
+  const size_t npix = (size_t)W * H;
+  if (npix > 0xFFFFFFFFull || n_frames > 65535u) return fail(ctx, CURVIS_E_INVALID, "frame or batch too large");
+  /* jobs: one per distinct radial coordinate of the cameras (bit pattern) */
+  std::vector<unsigned> job_of_frame(n_frames);
+  std::vector<double> l_job;
+  {
+    std::map<uint64_t, unsigned> seen;
+    for (uint32_t f = 0; f < n_frames; ++f) {
+      uint64_t key;
+      std::memcpy(&key, &cams[f].pos[1], sizeof key);
+      auto it = seen.find(key);
+      if (it == seen.end()) {
+        it = seen.emplace(key, (unsigned)l_job.size()).first;
+        l_job.push_back(cams[f].pos[1]);
+      }
+      job_of_frame[f] = it->second;
+    }
+  }
+  const unsigned n_jobs = (unsigned)l_job.size();
+  const size_t T = (size_t)n_jobs * cvk::kSamplerCap;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  /* staged from the host in one copy ... */
+  const size_t o_cams = carve(sizeof(cvk::CameraParams) * n_frames), o_fr = carve(sizeof(cvk::EfficientFrame) * n_frames),
+               o_to = carve(sizeof(unsigned) * n_frames), o_jf = carve(sizeof(unsigned) * n_frames), o_l = carve(sizeof(double) * n_jobs);
+  const size_t staged = off;
+  /* ... written by the sampler kernel */
+  const size_t o_tn = carve(sizeof(unsigned) * n_frames), o_res = carve(sizeof(cvk::SamplerResult) * n_jobs);
+  size_t o_tab[7];
+  for (size_t &o : o_tab) o = carve(sizeof(double) * T);
+  int rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, off);
+  if (rc) return rc;
+  const size_t res_bytes = sizeof(cvk::SamplerResult) * n_jobs;
+  const size_t pinned = staged + ((res_bytes + 255) & ~(size_t)255);
+  if (ctx->h_eff_cap < pinned) {
+    if (ctx->h_eff) HIP_TRY(ctx, hipHostFree(ctx->h_eff));
+    ctx->h_eff = nullptr;
+    ctx->h_eff_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_eff, pinned + pinned / 2));
+    ctx->h_eff_cap = pinned + pinned / 2;
+  }
+  unsigned char *stage = ctx->h_eff;
+  {
+    auto *cp = reinterpret_cast<cvk::CameraParams *>(stage + o_cams);
+    for (uint32_t f = 0; f < n_frames; ++f) cp[f] = make_camera(cams[f]);
+    std::memcpy(stage + o_fr, eframes.data(), sizeof(cvk::EfficientFrame) * n_frames);
+    auto *to = reinterpret_cast<unsigned *>(stage + o_to);
+    for (uint32_t f = 0; f < n_frames; ++f) to[f] = job_of_frame[f] * cvk::kSamplerCap;
+    std::memcpy(stage + o_jf, job_of_frame.data(), sizeof(unsigned) * n_frames);
+    std::memcpy(stage + o_l, l_job.data(), sizeof(double) * n_jobs);
+  }
+  const size_t fb_bytes = npix * 3 * n_frames;
+  rc = fb_begin_write(ctx, fb_bytes);
+  if (rc) return rc;
+  ctx->fb_bytes = fb_bytes;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eff, stage, staged, hipMemcpyHostToDevice, ctx->stream));
+  SamplerParams SP;
+  SP.metric = MP;
+  SP.l_cam = (const double *)(ctx->d_eff + o_l);
+  SP.n_jobs = n_jobs;
+  SP.n_frames = n_frames;
+  SP.job_of_frame = (const unsigned *)(ctx->d_eff + o_jf);
+  SP.tab_n = (unsigned *)(ctx->d_eff + o_tn);
+  SP.n0 = alpha_nums;
+  SP.max_iterations = max_iterations_sampling;
+  SP.max_iter = max_iter;
+  SP.a_min = -0.1 * CV_PI; /* src/systems.rs:437-438 */
+  SP.a_max = 1.1 * CV_PI;
+  SP.thr1 = thr1;
+  SP.thr2 = thr2;
+  SP.max_radius = max_radius;
+  SP.delta = delta;
+  SP.fast_ok = cvk::metric_fast_ok(metric->kind, MP, max_radius) ? 1 : 0;
+  SP.sx = (double *)(ctx->d_eff + o_tab[0]);
+  SP.se = (double *)(ctx->d_eff + o_tab[1]);
+  SP.ss = (double *)(ctx->d_eff + o_tab[2]);
+  SP.m_e = (double *)(ctx->d_eff + o_tab[3]);
+  SP.c_e = (double *)(ctx->d_eff + o_tab[4]);
+  SP.m_s = (double *)(ctx->d_eff + o_tab[5]);
+  SP.c_s = (double *)(ctx->d_eff + o_tab[6]);
+  SP.res = (cvk::SamplerResult *)(ctx->d_eff + o_res);
+  const bool fast = ctx->fast_math != 0;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  switch (metric->kind) {
+    case CURVIS_METRIC_ELLIS: rc = launch_sampler_kind<cvk::METRIC_ELLIS>(ctx, fast, SP); break;
+    case CURVIS_METRIC_INTERSTELLAR: rc = launch_sampler_kind<cvk::METRIC_INTERSTELLAR>(ctx, fast, SP); break;
+    default: rc = launch_sampler_kind<cvk::METRIC_FLAT>(ctx, fast, SP); break;
+  }
+  if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  FrameCounters FC;
+  rc = prepare_counters(ctx, n_frames, FC, 64u);
+  if (rc) return rc;
+  const size_t cnt_words = counter_words(n_frames, FC.slots);
+  EfficientPixelParams Q;
+  for (int k = 0; k < 2; ++k) {
+    Q.sky[k].texels = (const unsigned *)ctx->d_sky[k];
+    Q.sky[k].w = ctx->sky_w[k];
+    Q.sky[k].h = ctx->sky_h[k];
+    for (int i = 0; i < 9; ++i) Q.sky[k].inv_rot[i] = ctx->sky_inv_rot[k][i];
+  }
+  Q.cams = (const cvk::CameraParams *)(ctx->d_eff + o_cams);
+  Q.frames = (const cvk::EfficientFrame *)(ctx->d_eff + o_fr);
+  Q.tab_off = (const unsigned *)(ctx->d_eff + o_to);
+  Q.tab_n = SP.tab_n;
+  Q.sx = SP.sx;
+  Q.m_e = SP.m_e;
+  Q.c_e = SP.c_e;
+  Q.m_s = SP.m_s;
+  Q.c_s = SP.c_s;
+  Q.n_frames = n_frames;
+  Q.W = W;
+  Q.H = H;
+  Q.fb = ctx->d_fb;
+  Q.counters = FC;
+  hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)((npix + 255) / 256), n_frames), dim3(256), 0, ctx->stream, Q);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words, hipMemcpyDeviceToHost, ctx->stream));
+  auto *h_res = reinterpret_cast<const cvk::SamplerResult *>(stage + staged);
+  HIP_TRY(ctx, hipMemcpyAsync(stage + staged, ctx->d_eff + o_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* the statuses decide whether the frames may leave */
+  bool overflow = false, panic = false;
+  for (unsigned j = 0; j < n_jobs; ++j) {
+    overflow = overflow || h_res[j].status == cvk::SAMPLER_OVERFLOW;
+    panic = panic || h_res[j].status == cvk::SAMPLER_PANIC;
+  }
+  if (overflow) return kSamplerFallback;
+  float sample_ms = 0.f, ms = 0.f;
+  HIP_TRY(ctx, hipEventElapsedTime(&sample_ms, ctx->ev0, ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
+  ctx->last_sampling_launches = 1;
+  uint64_t total_steps = 0, evaluated = 0;
+  ctx->last_samples.assign(n_frames, {});
+  ctx->last_sampling_info.assign(n_frames, curvis_sampling_info{});
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const cvk::SamplerResult &r = h_res[job_of_frame[f]];
+    curvis_sampling_info &si = ctx->last_sampling_info[f];
+    si.n_samples = r.n;
+    si.rounds = r.rounds;
+    si.calls = r.calls; /* what the reference's sampler of THIS frame calls and steps, whether or not frames shared the work */
+    si.steps = r.steps;
+    si.warned_max_iterations = r.warned;
+    total_steps += r.steps;
+  }
+  for (unsigned j = 0; j < n_jobs; ++j) evaluated += h_res[j].calls;
+  ctx->last_sampling_evaluated = evaluated;
+  ctx->dev_samples.valid = !panic;
+  ctx->dev_samples.job_of_frame = job_of_frame;
+  ctx->dev_samples.off_a = o_tab[0];
+  ctx->dev_samples.off_e = o_tab[1];
+  ctx->dev_samples.off_s = o_tab[2];
+  if (panic)
+    return fail(ctx, CURVIS_E_SAMPLING,
+                "sampler panic: fewer than 3 finite samples (src/sampling.rs:155-157) or undefined tangent rotation "
+                "(src/algebra.rs:95-97)");
+  if (rgb_out) {
+    rc = fb_download(ctx, rgb_out, fb_bytes);
+    if (rc) return rc;
+  }
+  uint64_t tot[FC_N] = {0};
+  ctx->last_frame_stats.assign(n_frames, curvis_stats{});
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    uint64_t fc[FC_N];
+    sum_frame_counters(ctx->h_counters, FC.slots, f, fc);
+    for (int k = 0; k < FC_N; ++k) tot[k] += fc[k];
+    curvis_stats &fs = ctx->last_frame_stats[f];
+    fs.rays = (uint64_t)npix;
+    fs.steps = ctx->last_sampling_info[f].steps;
+    fs.n_pos = fc[FC_POS];
+    fs.n_neg = fc[FC_NEG];
+    fs.n_none = fc[FC_NONE];
+    fs.n_oob = fc[FC_OOB];
+    fs.integrate_ms = sample_ms / n_frames;
+    fs.shade_ms = ms / n_frames;
+    fs.kernel_ms = fs.integrate_ms + fs.shade_ms;
+    fs.total_ms = fs.kernel_ms;
+  }
+  if (stats) {
+    stats->rays = (uint64_t)npix * n_frames;
+    stats->steps = total_steps;
+    stats->n_pos = tot[FC_POS];
+    stats->n_neg = tot[FC_NEG];
+    stats->n_none = tot[FC_NONE];
+    stats->n_oob = tot[FC_OOB];
+    stats->integrate_ms = sample_ms;
+    stats->shade_ms = ms;
+    stats->kernel_ms = sample_ms + ms;
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return CURVIS_OK;
+}
+
+/* the sample table of frame `frame` of the last render_efficient call that used the device-resident sampler: fetched from the
+ * context's scratch on demand (curvis_ctx_samples), once per frame asked for */
+int fetch_device_samples(curvis_ctx *ctx, uint32_t frame) {
+  if (!ctx->dev_samples.valid || frame >= ctx->dev_samples.job_of_frame.size()) return CURVIS_OK;
+  if (!ctx->last_samples[frame].empty() || ctx->last_sampling_info[frame].n_samples == 0) return CURVIS_OK;
+  const size_t n = ctx->last_sampling_info[frame].n_samples, o = (size_t)ctx->dev_samples.job_of_frame[frame] * cvk::kSamplerCap * sizeof(double);
+  std::vector<double> a(n), e(n), s(n);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpy(a.data(), ctx->d_eff + ctx->dev_samples.off_a + o, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(e.data(), ctx->d_eff + ctx->dev_samples.off_e + o, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(s.data(), ctx->d_eff + ctx->dev_samples.off_s + o, n * sizeof(double), hipMemcpyDeviceToHost));
+  auto &pts = ctx->last_samples[frame];
+  pts.resize(n);
+  for (size_t i = 0; i < n; ++i) pts[i] = cvs::BiPoint{a[i], e[i], s[i]};
+  return CURVIS_OK;
+}
+
 int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cams, uint32_t n_frames,
                           uint32_t max_iter, double max_radius, double delta, uint32_t alpha_nums,
                           uint32_t max_iterations_sampling, double thr1, double thr2, uint8_t *rgb_out,
@@ -123,7 +363,22 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
       return fail(ctx, CURVIS_E_PARALLEL, "v1 and v2 must not be parallel (src/algebra.rs:95-97, camera on the x axis)");
   }
 
-  /* step 3: one sampler per frame, advanced in lock step; every round is ONE kernel launch */
+  ctx->dev_samples.valid = false;
+  /* step 3 on the device (sampler_kernel: no host in the refinement loop) for calls of `device_sampler_min_frames` frames and
+   * more -- its latency is rounds x one Euler chain, about three times the speculating host-paced sampler's below, and what it
+   * saves is host time and launches per frame, so single images stay on the host-paced path; option "device_sampler": 1 always,
+   * 0 never, -1 (default) by that threshold */
+  const bool want_device = ctx->device_sampler > 0 || (ctx->device_sampler < 0 && n_frames >= (uint32_t)ctx->device_sampler_min_frames);
+  if (want_device && alpha_nums <= cvk::kSamplerCap && alpha_nums <= cvk::kSamplerPendCap) {
+    rc = render_efficient_device(ctx, metric, MP, cams, n_frames, eframes, max_iter, max_radius, delta, alpha_nums, max_iterations_sampling,
+                                 thr1, thr2, rgb_out, stats, t_begin);
+    ctx->last_sampler_path = rc == kSamplerFallback ? 2 : 1;
+    if (rc != kSamplerFallback) return rc;
+    ctx->dev_samples.valid = false; /* a table outgrew the kernel's arrays: the host-paced sampler takes the call */
+  } else {
+    ctx->last_sampler_path = 0;
+  }
+  /* step 3 on the host: one sampler per frame, advanced in lock step; every round is ONE kernel launch */
   std::vector<cvs::Sampler> smp(n_frames);
   for (uint32_t f = 0; f < n_frames; ++f) {
     smp[f].a_min = -0.1 * CV_PI; /* src/systems.rs:437-438 */

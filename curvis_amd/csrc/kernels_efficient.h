@@ -21,33 +21,29 @@ struct EscapeAngleParams {
   int fast_ok;
 };
 
-/* K2: compute_escape_angle (src/systems.rs:203-261) for a batch of alphas: photon at (0, l, pi/2, 0)
- * with tangent direction (cos a, 0, sin a), Euler loop WITH phi, world direction, angle. */
+/* compute_escape_angle (src/systems.rs:203-261) for ONE alpha on one lane: photon at (0, l, pi/2, 0) with tangent direction
+ * (cos a, 0, sin a), Euler loop WITH phi, world direction, angle.  Every lane of the wave that is active here must have entered
+ * together (the step counter is wave-uniform). */
 template <int KIND, bool FAST>
-__global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParams P) {
-  __shared__ MathTablesLds<KIND> s_tab;
-  cvk::MetricParams M = P.metric;
-  load_math_tables<KIND>(s_tab, M);
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.n) return;
-  const double alpha = P.alpha[i];
+__device__ __forceinline__ void escape_angle_lane(const cvk::MetricParams &M, double alpha, double l_cam, unsigned max_iter, double max_radius,
+                                                  double delta, int fast_ok, double &angle, double &space, unsigned &steps_out, int &status) {
   double sa, ca;
   cv_sincos(alpha, &sa, &ca);
-  const double pos[4] = {0.0, P.l_cam[i], CV_PI / 2.0, 0.0};
+  const double pos[4] = {0.0, l_cam, CV_PI / 2.0, 0.0};
   cvk::Ray q;
   cvk::ray_init_dir<KIND>(M, pos, ca, 0.0, sa, q);
-  const bool lane_ok = FAST && P.fast_ok && cvk::ray_fast_ok(q);
+  const bool lane_ok = FAST && fast_ok && cvk::ray_fast_ok(q);
   /* same loop shape as geodesic_static: wave-uniform step counter (all lanes start together), one escape compare,
    * the per-lane step count captured under a scalar branch in the iterations in which some lane escapes */
-  unsigned steps = P.max_iter;
+  unsigned steps = max_iter;
   int code = cvk::CODE_NONE;
-  if (P.max_iter != 0) {
+  if (max_iter != 0) {
     const unsigned lane = threadIdx.x & 63u;
     unsigned k = 0;
     for (;;) {
       ++k;
-      one_step<KIND, true, FAST, true>(M, P.delta, q, lane_ok); /* equatorial photons: see ray_step_fast */
-      const bool esc = ray_escaped(q.l, P.max_radius);
+      one_step<KIND, true, FAST, true>(M, delta, q, lane_ok); /* equatorial photons: see ray_step_fast */
+      const bool esc = ray_escaped(q.l, max_radius);
       const unsigned long long em = __builtin_amdgcn_ballot_w64(esc);
       if (em) {
         unsigned kv;
@@ -55,15 +51,16 @@ __global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParam
         if ((em >> lane) & 1ull) steps = kv;
       }
       if (esc) break;
-      if (k >= P.max_iter) break;
+      if (k >= max_iter) break;
     }
-    if (ray_escaped(q.l, P.max_radius)) code = escape_code(q.l);
+    if (ray_escaped(q.l, max_radius)) code = escape_code(q.l);
   } else {
     steps = 0;
   }
   const double nan = __builtin_nan("");
-  double angle = nan, space = nan;
-  int status = code;
+  angle = nan;
+  space = nan;
+  status = code;
   if (code != cvk::CODE_NONE) {
     if (cvk::escape_angle_of<KIND>(M, q, angle)) {
       space = (code == cvk::CODE_POS) ? 1.0 : -1.0;
@@ -72,10 +69,124 @@ __global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParam
       status = cvk::ESC_PANIC;
     }
   }
+  steps_out = steps;
+}
+
+/* K2: compute_escape_angle for a batch of alphas (the host-paced sampler's launches: efficient_host.h eval_escape_batch) */
+template <int KIND, bool FAST>
+__global__ __launch_bounds__(64) void escape_angle_kernel(const EscapeAngleParams P) {
+  __shared__ MathTablesLds<KIND> s_tab;
+  cvk::MetricParams M = P.metric;
+  load_math_tables<KIND>(s_tab, M);
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  double angle, space;
+  unsigned steps;
+  int status;
+  escape_angle_lane<KIND, FAST>(M, P.alpha[i], P.l_cam[i], P.max_iter, P.max_radius, P.delta, P.fast_ok, angle, space, steps, status);
   P.angle[i] = angle;
   P.space[i] = space;
   P.steps[i] = steps;
   P.status[i] = status;
+}
+
+/* K2': the reference's adaptive sampler (doubly_sample_function, src/sampling.rs:46-195, called at src/systems.rs:437-486) as the
+ * job of ONE WORKGROUP, start to finish, with no host in the loop.  Table, plan and counters live in LDS (cv_sampler_dev.h
+ * SamplerState, 82 KB); lane 0 plans a round (the walk over the triples is sequential by definition: `i += 1` or `i += 2`
+ * depending on the triple just seen), every lane integrates one of the round's new alphas -- a 2000-step dependency chain per
+ * round is what a job costs, however many lanes take part --, lane 0 assembles, and round again.  When the table has settled, all
+ * lanes write it out together with interp 1.0.3's slopes and intercepts over it (the per-pixel kernel's inputs: m = dy / dx,
+ * c = y - x m, IEEE division and unfused multiply-subtract like the host's cvs::interp_tables) and the sample count of every
+ * frame that uses this job.  Frames whose cameras share the radial coordinate l share a job: compute_escape_angle(l, alpha) sees
+ * nothing else of the camera (src/systems.rs:473-485), so their tables are the same table.
+ * One job per workgroup, one workgroup per CU (LDS): a launch of up to 256 jobs runs them all at once; what bounds a launch is
+ * the latency of the longest job (rounds x ~2000 steps x ~600 cycles), not the number of jobs. */
+struct SamplerParams {
+  cvk::MetricParams metric;
+  const double *l_cam;            /* n_jobs */
+  unsigned n_jobs, n_frames;
+  const unsigned *job_of_frame;   /* n_frames */
+  unsigned *tab_n;                /* n_frames: samples in the table of the frame's job (read by efficient_pixel_kernel) */
+  unsigned n0, max_iterations, max_iter;
+  double a_min, a_max, thr1, thr2, max_radius, delta;
+  int fast_ok;
+  double *sx, *se, *ss, *m_e, *c_e, *m_s, *c_s; /* n_jobs x kSamplerCap each */
+  cvk::SamplerResult *res;        /* n_jobs */
+};
+constexpr unsigned kSamplerThreads = 256;
+
+template <int KIND, bool FAST>
+__global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(const SamplerParams P) {
+  __shared__ MathTablesLds<KIND> s_tab;
+  __shared__ cvk::SamplerState S;
+  __shared__ int s_panic;
+  cvk::MetricParams M = P.metric;
+  if (threadIdx.x == 0u) {
+    cvk::sampler_reset(S);
+    s_panic = 0;
+  }
+  load_math_tables<KIND>(s_tab, M); /* ends with a barrier */
+  const unsigned job = blockIdx.x;
+  const double l_cam = P.l_cam[job];
+  for (;;) {
+    if (threadIdx.x == 0u) S.go = cvk::sampler_plan(S, P.n0, P.max_iterations, P.a_min, P.a_max, P.thr1, P.thr2) ? 1 : 0;
+    __syncthreads();
+    if (!S.go) break; /* uniform: read between this barrier and the next, written only after the one that follows */
+    const unsigned np = S.n_pend;
+    for (unsigned base = 0; base < np; base += kSamplerThreads) {
+      const unsigned t = base + threadIdx.x;
+      if (t < np) {
+        double angle, space;
+        unsigned steps;
+        int status;
+        escape_angle_lane<KIND, FAST>(M, S.pend_a[t], l_cam, P.max_iter, P.max_radius, P.delta, P.fast_ok, angle, space, steps, status);
+        cvk::sampler_store(S, t, angle, space);
+        atomicAdd(&S.steps, (unsigned long long)steps);
+        if (status == cvk::ESC_PANIC) s_panic = 1;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) cvk::sampler_consume(S, P.max_iterations);
+    __syncthreads();
+  }
+  /* the finished table and the interpolation tables over it; slot max(n, 1) - 1 is padding (zeros), as on the host */
+  const unsigned n = S.n, cur = S.cur;
+  const size_t o = (size_t)job * cvk::kSamplerCap;
+  const double *A = S.a[cur], *E = S.e[cur], *Z = S.s[cur];
+  const unsigned slots = n ? n : 1u;
+  for (unsigned i = threadIdx.x; i < slots; i += kSamplerThreads) {
+    const bool have = i < n;
+    P.sx[o + i] = have ? A[i] : 0.0;
+    P.se[o + i] = have ? E[i] : 0.0;
+    P.ss[o + i] = have ? Z[i] : 0.0;
+    double me = 0.0, ce = 0.0, ms = 0.0, cs = 0.0;
+    if (n == 1u) { /* interp 1.0.3 with one point: the "intercept" is y[0] */
+      ce = E[0];
+      cs = Z[0];
+    } else if (i + 1u < n) {
+      const double dx = A[i + 1u] - A[i];
+      me = (E[i + 1u] - E[i]) / dx;
+      ce = E[i] - A[i] * me;
+      ms = (Z[i + 1u] - Z[i]) / dx;
+      cs = Z[i] - A[i] * ms;
+    }
+    P.m_e[o + i] = me;
+    P.c_e[o + i] = ce;
+    P.m_s[o + i] = ms;
+    P.c_s[o + i] = cs;
+  }
+  for (unsigned f = threadIdx.x; f < P.n_frames; f += kSamplerThreads)
+    if (P.job_of_frame[f] == job) P.tab_n[f] = n;
+  if (threadIdx.x == 0u) {
+    cvk::SamplerResult r;
+    r.n = n;
+    r.rounds = S.rounds;
+    r.calls = S.calls;
+    r.steps = S.steps;
+    r.warned = S.warned;
+    r.status = S.overflow ? cvk::SAMPLER_OVERFLOW : (S.panicked || s_panic) ? cvk::SAMPLER_PANIC : cvk::SAMPLER_OK;
+    P.res[job] = r;
+  }
 }
 
 struct EfficientPixelParams {

@@ -54,7 +54,7 @@ def twin():
                                             C.c_double, C.c_uint, C.c_uint, C.c_double, C.c_double, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
-                                            C.c_int]
+                                            C.c_int, C.c_int]
         _twin = L
     return _twin
 
@@ -108,7 +108,8 @@ def assert_debug_equal(got, want, check_t=True):
 
 
 def twin_render_efficient(pm, pc, sky_pos, sky_neg, max_iter, max_radius, delta, alpha_nums, max_it_sampling, thr1, thr2,
-                          fast=0, cap=8192):
+                          fast=0, cap=8192, dev_sampler=0):
+    """dev_sampler=1: the control flow of the device-resident sampler (cv_sampler_dev.h) instead of cv_sampler.h's"""
     W, H = pc.resolution_width, pc.resolution_height
     rgb = np.zeros((H, W, 3), np.uint8)
     a, e, s = np.zeros(cap), np.zeros(cap), np.zeros(cap)
@@ -118,7 +119,7 @@ def twin_render_efficient(pm, pc, sky_pos, sky_neg, max_iter, max_radius, delta,
                                       sky_neg.ctypes.data, sky_neg.shape[1], sky_neg.shape[0], max_iter, max_radius,
                                       delta, alpha_nums, max_it_sampling, thr1, thr2, rgb.ctypes.data, a.ctypes.data,
                                       e.ctypes.data, s.ctypes.data, cap, C.byref(n), C.byref(calls), C.byref(steps),
-                                      int(fast))
+                                      int(fast), int(dev_sampler))
     if rc != 0:
         raise RuntimeError("twin efficient render failed: %d" % rc)
     k = n.value

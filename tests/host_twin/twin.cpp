@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstring>
 
+#include <memory>
 #include <vector>
 
 #include "../../curvis_amd/csrc/cv_device.h"
@@ -156,7 +157,7 @@ extern "C" int twin_render_efficient(const curvis_metric *m, const curvis_camera
                                      unsigned hp, const uint8_t *sky_neg, unsigned wn, unsigned hn, unsigned max_iter,
                                      double R, double delta, unsigned alpha_nums, unsigned max_it_sampling, double thr1,
                                      double thr2, uint8_t *rgb, double *sa, double *se, double *ss, size_t cap,
-                                     size_t *n_out, uint64_t *calls, uint64_t *steps_out, int fast) {
+                                     size_t *n_out, uint64_t *calls, uint64_t *steps_out, int fast, int dev_sampler) {
   cvk::MetricParams M;
   M.rho = m->rho; M.rho2 = m->rho * m->rho; M.m = m->m; M.a = m->a; M.pim = CV_PI * m->m; M.inv_pim = 1.0 / M.pim; M.two_o_pi = 2.0 / CV_PI; M.T = cv_sc_table(); M.LT = cv_log_table(); M.AT = cv_atan_table();
   cvk::CameraParams C;
@@ -177,13 +178,34 @@ extern "C" int twin_render_efficient(const curvis_metric *m, const curvis_camera
   bool panic = false;
   std::vector<double> e, s;
   std::vector<uint32_t> st;
-  while (S.plan()) {
-    const size_t n = S.pending.size();
-    e.resize(n); s.resize(n); st.resize(n);
-    for (size_t k = 0; k < n; ++k)
-      if (escape_angle_any(m->kind, M, c->pos[1], S.pending[k], delta, max_iter, R, fast, e[k], s[k], st[k]) == cvk::ESC_PANIC)
-        panic = true;
-    S.consume(e.data(), s.data(), st.data());
+  if (dev_sampler) {
+    /* the DEVICE-resident sampler's control flow (cv_sampler_dev.h: what lane 0 of sampler_kernel runs) around a serial
+     * evaluation; its result is poured into S so that everything downstream is shared */
+    std::unique_ptr<cvk::SamplerState> D(new cvk::SamplerState);
+    cvk::sampler_reset(*D);
+    while (cvk::sampler_plan(*D, alpha_nums, max_it_sampling, S.a_min, S.a_max, thr1, thr2)) {
+      for (unsigned t = 0; t < D->n_pend; ++t) {
+        double ee, sp_;
+        uint32_t stp;
+        if (escape_angle_any(m->kind, M, c->pos[1], D->pend_a[t], delta, max_iter, R, fast, ee, sp_, stp) == cvk::ESC_PANIC) panic = true;
+        D->steps += stp;
+        cvk::sampler_store(*D, t, ee, sp_);
+      }
+      cvk::sampler_consume(*D, max_it_sampling);
+    }
+    if (D->overflow) return -4;
+    S.pts.resize(D->n);
+    for (unsigned i = 0; i < D->n; ++i) S.pts[i] = cvs::BiPoint{D->a[D->cur][i], D->e[D->cur][i], D->s[D->cur][i]};
+    S.calls = D->calls; S.steps = D->steps; S.rounds = D->rounds; S.panicked = D->panicked != 0; S.warned = D->warned != 0;
+  } else {
+    while (S.plan()) {
+      const size_t n = S.pending.size();
+      e.resize(n); s.resize(n); st.resize(n);
+      for (size_t k = 0; k < n; ++k)
+        if (escape_angle_any(m->kind, M, c->pos[1], S.pending[k], delta, max_iter, R, fast, e[k], s[k], st[k]) == cvk::ESC_PANIC)
+          panic = true;
+      S.consume(e.data(), s.data(), st.data());
+    }
   }
   if (panic || S.panicked) return -2;
   *n_out = S.pts.size();

@@ -15,14 +15,15 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("dev_sampler", [0, 1], ids=["host-sampler", "device-sampler-control-flow"])
 @pytest.mark.parametrize("fast", [0, 1])
 @pytest.mark.parametrize("metric,pos,fwd,cap,n0", CASES)
-def test_twin_efficient_equals_oracle(metric, pos, fwd, cap, n0, fast):
+def test_twin_efficient_equals_oracle(metric, pos, fwd, cap, n0, fast, dev_sampler):
     sp, sn = common.make_skies(256, 128, "check")
     om, oc, pm, pc = common.scene(metric, res=(48, 27), pos=pos, fwd=fwd)
     # the reference wires max_iterations_sampling to sampling_initial_nums (src/main.rs:47,107)
     want_rgb, want, st = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, n0, n0, 1e-5, 1e-5)
-    got_rgb, got = common.twin_render_efficient(pm, pc, sp, sn, cap, 100.0, 0.05, n0, n0, 1e-5, 1e-5, fast=fast)
+    got_rgb, got = common.twin_render_efficient(pm, pc, sp, sn, cap, 100.0, 0.05, n0, n0, 1e-5, 1e-5, fast=fast, dev_sampler=dev_sampler)
     assert got["calls"] == want["calls"] and got["steps"] == want["steps"]
     for k in ("a", "e", "s"):
         assert np.array_equal(common.bits(got[k]), common.bits(want[k])), k
@@ -45,3 +46,30 @@ def test_nan_direction_maps_to_texel_zero():
     px = (C.c_uint8 * 4)()
     O.lib().cvo_sky_pixel(O.CV, C.byref(s), O._dp(O.vec(np.nan, np.nan, np.nan)), px)
     assert list(px) == list(img[0, 0])
+
+
+def test_device_sampler_control_flow_equals_the_host_sampler_on_hard_settings():
+    """cv_sampler_dev.h (plan / store / consume over fixed arrays: what lane 0 of sampler_kernel runs) against cv_sampler.h on
+    settings that stress the control flow: few initial points, thresholds that refine everywhere / nowhere, a cap that leaves
+    NaN samples to be cleaned out (not escaped), max_iterations 0 / 1 / 3 (the warned path), a camera deep in the throat"""
+    sp, sn = common.make_skies(64, 32, "check")
+    cases = [("ellis", 5.0, 4096, 100, 100, 1e-5, 1e-5), ("ellis", 5.0, 4096, 3, 50, 1e-5, 1e-5), ("ellis", 5.0, 4096, 7, 100, 1e-9, 1e-9),
+             ("ellis", 5.0, 4096, 100, 100, 10.0, 10.0), ("ellis", 5.0, 2000, 100, 100, 1e-5, 1e-5), ("ellis", 0.3, 4096, 100, 3, 1e-5, 1e-5),
+             ("ellis", 5.0, 4096, 100, 0, 1e-5, 1e-5), ("ellis", 5.0, 4096, 100, 1, 1e-5, 1e-5), ("interstellar", 0.01, 8192, 100, 100, 1e-5, 2e-5),
+             ("interstellar", -3.0, 8192, 50, 100, 1e-6, 1e-5), ("ellis", 40.0, 4096, 100, 100, 1e-5, 1e-5)]
+    overflowed = 0
+    for metric, l, cap, n0, maxit, t1, t2 in cases:
+        _, _, pm, pc = common.scene(metric, res=(6, 4), pos=(0.0, l, common.HALF_PI, 0.3))
+        res = []
+        for dev in (0, 1):
+            try:
+                rgb, got = common.twin_render_efficient(pm, pc, sp, sn, cap, 100.0, 0.05, n0, maxit, t1, t2, fast=1, dev_sampler=dev)
+                res.append((rgb.tobytes(), got["calls"], got["steps"]) + tuple(got[k].tobytes() for k in "aes"))
+            except RuntimeError as exc:
+                res.append(str(exc))
+        if res[1] == "twin efficient render failed: -4":   # the fixed arrays ran out (the product then falls back to the host sampler)
+            assert len(res[0][3]) // 8 > 700, (metric, l, n0, t1)     # ... which may only happen to tables that really are large
+            overflowed += 1
+            continue
+        assert res[0] == res[1], (metric, l, cap, n0, maxit, t1, t2)
+    assert overflowed == 1

@@ -947,3 +947,77 @@ def test_single_frame_of_half_a_billion_rays(gpu_ctx):
     big = curvis_amd.Camera((0.0, 5.0, common.HALF_PI, 0.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 1.0), 15.0, 43.0, 65536, 65536)
     with pytest.raises(curvis_amd.CurvisError):
         gpu_ctx.render_brute(pm, big, CAP, R, 0.05, download=False)
+
+
+def _efficient_call(ctx, pm, cams, cap, n0, maxit, t1, t2):
+    rgb, st = ctx.render_efficient(pm, cams, cap, 100.0, 0.05, n0, maxit, t1, t2)
+    per = []
+    for f in range(len(cams)):
+        si = ctx.sampling_info(f)
+        a, e, s = ctx.samples(f)
+        fs = ctx.frame_stats(f)
+        per.append((si.n_samples, si.rounds, si.calls, si.steps, si.warned_max_iterations, a.tobytes(), e.tobytes(), s.tobytes(),
+                    fs.rays, fs.steps, fs.n_pos, fs.n_neg, fs.n_none, fs.n_oob))
+    return np.asarray(rgb).tobytes(), (st.rays, st.steps, st.n_pos, st.n_neg, st.n_none, st.n_oob), per
+
+
+def test_device_resident_sampler_equals_the_host_paced_sampler(gpu_ctx):
+    """sampler_kernel (one workgroup runs the reference's whole adaptive sampler in LDS: kernels_efficient.h, cv_sampler_dev.h)
+    against the host-paced sampler with speculation (cv_sampler.h, efficient_host.h): frames, sample tables (every alpha, escape
+    angle and escape space, bit for bit), rounds, integrator calls and steps as the reference would count them per frame, per-frame
+    pixel statistics.  Batches mix camera radii -- equal radii share a job on the device --, both metrics, both sides of the throat,
+    a camera inside the Interstellar throat, few initial points, a cap that leaves not-escaped (NaN) samples to be cleaned out,
+    max_iterations 0 / 1 (the warned path), a refine-nothing threshold, the strict (non-fast) Euler step."""
+    sp, sn = common.make_skies(512, 256, "check")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    res = (96, 54)
+
+    def cams_of(ls):
+        return [curvis_amd.Camera((0.0, l, common.HALF_PI + 0.05 * k, 0.3 * k), (-1.0 if l > 0 else 1.0, 0.1 * k, 0.02 * k), (0.0, 0.0, 1.0), 15.0, 43.0,
+                                  res[0], res[1]) for k, l in enumerate(ls)]
+    ellis, inter = curvis_amd.EllisMetric(1.0), curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0)
+    cases = [(ellis, [5.0, 3.0, 3.0, 5.0, -2.5, 3.0, 0.3, 40.0, 5.0], 4096, 100, 100, 1e-5, 1e-5, 1),
+             (inter, [5.0, -4.0, 0.01, 0.00005, 2.0, 2.0, -0.5], 8192, 100, 100, 1e-5, 2e-5, 1),
+             (ellis, [5.0, 3.0], 4096, 3, 50, 1e-5, 1e-5, 1), (ellis, [5.0, 1.0, 7.0], 2000, 100, 100, 1e-5, 1e-5, 1),
+             (ellis, [5.0, 2.0], 4096, 100, 0, 1e-5, 1e-5, 1), (ellis, [5.0, 2.0], 4096, 100, 1, 1e-5, 1e-5, 1),
+             (ellis, [5.0, 2.0], 4096, 100, 100, 10.0, 10.0, 1), (inter, [3.0, -3.0, 0.2], 8192, 60, 100, 1e-5, 1e-5, 0),
+             (curvis_amd.FlatSphericalMetric(), [5.0, 2.0], 4096, 100, 100, 1e-5, 1e-5, 1)]
+    try:
+        for pm, ls, cap, n0, maxit, t1, t2, fast in cases:
+            gpu_ctx.set_option("fast_math", fast)
+            cams = cams_of(ls)
+            gpu_ctx.set_option("device_sampler", 0)
+            host = _efficient_call(gpu_ctx, pm, cams, cap, n0, maxit, t1, t2)
+            assert gpu_ctx.get_option("last_sampler_path") == 0
+            gpu_ctx.set_option("device_sampler", 1)
+            dev = _efficient_call(gpu_ctx, pm, cams, cap, n0, maxit, t1, t2)
+            assert gpu_ctx.get_option("last_sampler_path") == 1 and gpu_ctx.get_option("last_sampling_launches") == 1
+            assert dev[1] == host[1], (ls, dev[1], host[1])
+            for f, (d, h) in enumerate(zip(dev[2], host[2])):
+                assert d[:5] == h[:5], ("sampling info", ls, f, d[:5], h[:5])
+                assert d[5:8] == h[5:8], ("sample table", ls, f)
+                assert d[8:] == h[8:], ("frame statistics", ls, f, d[8:], h[8:])
+            assert dev[0] == host[0], ls
+        # a table that outgrows the kernel's fixed arrays (everything refined): the call falls back to the host-paced sampler
+        cams = cams_of([5.0, 3.0])
+        gpu_ctx.set_option("device_sampler", 0)
+        host = _efficient_call(gpu_ctx, ellis, cams, 4096, 7, 100, 1e-9, 1e-9)
+        gpu_ctx.set_option("device_sampler", 1)
+        dev = _efficient_call(gpu_ctx, ellis, cams, 4096, 7, 100, 1e-9, 1e-9)
+        assert gpu_ctx.get_option("last_sampler_path") == 2 and dev == host and host[2][0][0] > 1536
+        # the reference's panic (fewer than three finite samples: nothing escapes within 10 steps) is the same error on both paths
+        for flag in (0, 1):
+            gpu_ctx.set_option("device_sampler", flag)
+            with pytest.raises(curvis_amd.CurvisError) as e:
+                gpu_ctx.render_efficient(ellis, cams, 10, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+            assert e.value.code == curvis_amd._abi.E_SAMPLING
+        # automatic choice: the device from device_sampler_min_frames frames on
+        gpu_ctx.set_option("device_sampler", -1)
+        gpu_ctx.render_efficient(ellis, cams_of([5.0] * 3), 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+        assert gpu_ctx.get_option("last_sampler_path") == 0
+        gpu_ctx.render_efficient(ellis, cams_of([5.0] * 8), 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+        assert gpu_ctx.get_option("last_sampler_path") == 1
+    finally:
+        gpu_ctx.set_option("device_sampler", -1)
+        gpu_ctx.set_option("fast_math", 1)
