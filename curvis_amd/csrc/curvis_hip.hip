@@ -48,6 +48,9 @@
 #include <map>
 #include <set>
 #include <string>
+#include <atomic>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -993,6 +996,8 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->device_sampler_min_frames;
   else if (k == "last_sampler_path")
     *value = ctx->last_sampler_path;
+  else if (k == "last_sampling_chains")
+    *value = ctx->last_sampling_chains;
   else if (k == "last_sampling_launches")
     *value = ctx->last_sampling_launches;
   else if (k == "last_sampling_evaluated")

@@ -153,6 +153,10 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   const size_t o_tn = carve(sizeof(unsigned) * n_frames), o_res = carve(sizeof(cvk::SamplerResult) * n_jobs);
   size_t o_tab[7];
   for (size_t &o : o_tab) o = carve(sizeof(double) * T);
+  /* the jobs' evaluation caches (cv_sampler_dev.h SpecTable): 256 KB each */
+  const size_t SS = (size_t)n_jobs * cvk::kSpecSlots;
+  const size_t o_sk = carve(sizeof(unsigned long long) * SS), o_se = carve(sizeof(double) * SS), o_ss = carve(sizeof(double) * SS),
+               o_st = carve(sizeof(unsigned) * SS), o_su = carve(sizeof(int) * SS);
   int rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, off);
   if (rc) return rc;
   const size_t res_bytes = sizeof(cvk::SamplerResult) * n_jobs;
@@ -179,6 +183,7 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   if (rc) return rc;
   ctx->fb_bytes = fb_bytes;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eff, stage, staged, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_eff + o_sk, 0xFF, sizeof(unsigned long long) * SS, ctx->stream)); /* every key = kSpecEmpty */
   SamplerParams SP;
   SP.metric = MP;
   SP.l_cam = (const double *)(ctx->d_eff + o_l);
@@ -204,6 +209,12 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   SP.m_s = (double *)(ctx->d_eff + o_tab[5]);
   SP.c_s = (double *)(ctx->d_eff + o_tab[6]);
   SP.res = (cvk::SamplerResult *)(ctx->d_eff + o_res);
+  SP.spec_key = (unsigned long long *)(ctx->d_eff + o_sk);
+  SP.spec_e = (double *)(ctx->d_eff + o_se);
+  SP.spec_s = (double *)(ctx->d_eff + o_ss);
+  SP.spec_steps = (unsigned *)(ctx->d_eff + o_st);
+  SP.spec_status = (int *)(ctx->d_eff + o_su);
+  SP.speculate = ctx->sampling_speculation != 0 ? 1 : 0; /* option "sampling_speculation" = 0 switches it off here too */
   const bool fast = ctx->fast_math != 0;
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   switch (metric->kind) {
@@ -250,6 +261,11 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
     overflow = overflow || h_res[j].status == cvk::SAMPLER_OVERFLOW;
     panic = panic || h_res[j].status == cvk::SAMPLER_PANIC;
   }
+  if (getenv("CURVIS_DEBUG_TIMING"))
+    for (unsigned j = 0; j < n_jobs; ++j)
+      fprintf(stderr, "[curvis] device sampler job %u: l = %.17g -> %u samples, %u rounds, %llu calls, %llu steps, warned %d, status %d; "
+              "%u Euler chains, %u points integrated\n", j, l_job[j], h_res[j].n, h_res[j].rounds, (unsigned long long)h_res[j].calls,
+              (unsigned long long)h_res[j].steps, h_res[j].warned, h_res[j].status, h_res[j].eval_phases, h_res[j].evaluated);
   if (overflow) return kSamplerFallback;
   float sample_ms = 0.f, ms = 0.f;
   HIP_TRY(ctx, hipEventElapsedTime(&sample_ms, ctx->ev0, ctx->ev1));
@@ -268,8 +284,13 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
     si.warned_max_iterations = r.warned;
     total_steps += r.steps;
   }
-  for (unsigned j = 0; j < n_jobs; ++j) evaluated += h_res[j].calls;
+  uint32_t chains = 0;
+  for (unsigned j = 0; j < n_jobs; ++j) {
+    evaluated += h_res[j].evaluated;
+    chains = std::max(chains, h_res[j].eval_phases);
+  }
   ctx->last_sampling_evaluated = evaluated;
+  ctx->last_sampling_chains = chains; /* Euler chains the slowest job waited for: what the launch's latency is made of */
   ctx->dev_samples.valid = !panic;
   ctx->dev_samples.job_of_frame = job_of_frame;
   ctx->dev_samples.off_a = o_tab[0];
@@ -366,8 +387,8 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   ctx->dev_samples.valid = false;
   /* step 3 on the device (sampler_kernel: no host in the refinement loop) for calls of `device_sampler_min_frames` frames and
    * more -- its latency is rounds x one Euler chain, about three times the speculating host-paced sampler's below, and what it
-   * saves is host time and launches per frame, so single images stay on the host-paced path; option "device_sampler": 1 always,
-   * 0 never, -1 (default) by that threshold */
+   * saves is host time and launches per frame, so single images and small batches stay on the host-paced path (cross-over measured
+   * between 32 and 64 frames per call); option "device_sampler": 1 always, 0 never, -1 (default) by that threshold */
   const bool want_device = ctx->device_sampler > 0 || (ctx->device_sampler < 0 && n_frames >= (uint32_t)ctx->device_sampler_min_frames);
   if (want_device && alpha_nums <= cvk::kSamplerCap && alpha_nums <= cvk::kSamplerPendCap) {
     rc = render_efficient_device(ctx, metric, MP, cams, n_frames, eframes, max_iter, max_radius, delta, alpha_nums, max_iterations_sampling,

@@ -112,8 +112,15 @@ struct SamplerParams {
   int fast_ok;
   double *sx, *se, *ss, *m_e, *c_e, *m_s, *c_s; /* n_jobs x kSamplerCap each */
   cvk::SamplerResult *res;        /* n_jobs */
+  /* evaluation cache of every job (cv_sampler_dev.h SpecTable), n_jobs x kSpecSlots each; keys preset to kSpecEmpty by the host */
+  unsigned long long *spec_key;
+  double *spec_e, *spec_s;
+  unsigned *spec_steps;
+  int *spec_status;
+  int speculate;                  /* 0: every round integrates exactly its pending points (no subtree, table still used) */
 };
-constexpr unsigned kSamplerThreads = 256;
+constexpr unsigned kSamplerThreads = 512; /* two waves per SIMD: what a lone chain leaves idle anyway (a step is ~85 dependent FP64
+                                             instructions of ~8 cycles latency, issued in 4) */
 
 template <int KIND, bool FAST>
 __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(const SamplerParams P) {
@@ -128,25 +135,88 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(const SamplerP
   load_math_tables<KIND>(s_tab, M); /* ends with a barrier */
   const unsigned job = blockIdx.x;
   const double l_cam = P.l_cam[job];
+  cvk::SpecTable T;
+  {
+    const size_t so = (size_t)job * cvk::kSpecSlots;
+    T.key = P.spec_key + so;
+    T.e = P.spec_e + so;
+    T.s = P.spec_s + so;
+    T.steps = P.spec_steps + so;
+    T.status = P.spec_status + so;
+  }
   for (;;) {
-    if (threadIdx.x == 0u) S.go = cvk::sampler_plan(S, P.n0, P.max_iterations, P.a_min, P.a_max, P.thr1, P.thr2) ? 1 : 0;
-    __syncthreads();
-    if (!S.go) break; /* uniform: read between this barrier and the next, written only after the one that follows */
-    const unsigned np = S.n_pend;
-    for (unsigned base = 0; base < np; base += kSamplerThreads) {
-      const unsigned t = base + threadIdx.x;
-      if (t < np) {
-        double angle, space;
-        unsigned steps;
-        int status;
-        escape_angle_lane<KIND, FAST>(M, S.pend_a[t], l_cam, P.max_iter, P.max_radius, P.delta, P.fast_ok, angle, space, steps, status);
-        cvk::sampler_store(S, t, angle, space);
-        atomicAdd(&S.steps, (unsigned long long)steps);
-        if (status == cvk::ESC_PANIC) s_panic = 1;
-      }
+    /* plan the round: cv_sampler_dev.h -- only the walk over the triples is one lane's work */
+    if (threadIdx.x == 0u) {
+      S.go = cvk::sampler_plan_begin(S, P.n0, P.max_iterations);
+      S.n_miss = S.n_eval = 0u;
     }
     __syncthreads();
-    if (threadIdx.x == 0u) cvk::sampler_consume(S, P.max_iterations);
+    const int mode = S.go; /* uniform: read between this barrier and the next, written only after the one that follows */
+    if (mode == cvk::PLAN_STOP) break;
+    if (mode == cvk::PLAN_GRID) {
+      for (unsigned i = threadIdx.x; i < P.n0; i += kSamplerThreads) cvk::sampler_grid_point(S, i, P.n0, P.a_min, P.a_max);
+    } else {
+      for (unsigned i = threadIdx.x; i + 2u < S.n; i += kSamplerThreads) cvk::sampler_flag(S, i, P.thr1, P.thr2);
+      __syncthreads();
+      if (threadIdx.x == 0u) S.go = cvk::sampler_walk(S) ? cvk::PLAN_REFINE : cvk::PLAN_STOP;
+      __syncthreads();
+      if (S.go == cvk::PLAN_STOP) break; /* out of room: uniform */
+      for (unsigned v = threadIdx.x; v < S.n_vis; v += kSamplerThreads) cvk::sampler_place(S, v);
+    }
+    __syncthreads();
+    const unsigned np = S.n_pend;
+    /* phase 1: what the table already holds goes straight into the new table; the rest is noted */
+    for (unsigned t = threadIdx.x; t < np; t += kSamplerThreads) {
+      int panic = 0;
+      if (!cvk::sampler_take(S, T, t, panic)) S.miss[atomicAdd(&S.n_miss, 1u)] = (unsigned short)t;
+      if (panic) s_panic = 1;
+    }
+    __syncthreads();
+    const unsigned nm = S.n_miss;
+    if (nm) { /* uniform */
+      /* phase 2: queue the missing points (they always fit), then the subtrees below their intervals on the lanes one chain
+       * would leave idle */
+      for (unsigned m = threadIdx.x; m < nm; m += kSamplerThreads) cvk::sampler_want(S, T, S.pend_a[S.miss[m]], true);
+      __syncthreads();
+      if (P.speculate && !S.overflow) {
+        const unsigned depth = S.started ? cvk::sampler_spec_depth(nm, kSamplerThreads) : 0u;
+        const unsigned grid_depth = (!S.started && kSamplerThreads > nm) ? cvk::sampler_spec_depth(nm - 1u, kSamplerThreads - nm) : 0u;
+        for (unsigned m = threadIdx.x; m < nm; m += kSamplerThreads) cvk::sampler_speculate(S, T, m, depth, grid_depth);
+      }
+      __syncthreads();
+      /* phase 3: integrate */
+      const unsigned ne = S.n_eval < cvk::kSpecEvalCap ? S.n_eval : cvk::kSpecEvalCap;
+      for (unsigned base = 0; base < ne; base += kSamplerThreads) {
+        const unsigned k = base + threadIdx.x;
+        if (k < ne) {
+          double angle, space;
+          unsigned steps;
+          int status;
+          escape_angle_lane<KIND, FAST>(M, S.eval_a[k], l_cam, P.max_iter, P.max_radius, P.delta, P.fast_ok, angle, space, steps, status);
+          const unsigned slot = S.eval_slot[k];
+          CV_SPEC_ST(&T.e[slot], angle);
+          CV_SPEC_ST(&T.s[slot], space);
+          CV_SPEC_ST(&T.steps[slot], steps);
+          CV_SPEC_ST(&T.status[slot], status);
+        }
+      }
+      if (threadIdx.x == 0u) {
+        S.eval_phases += (ne + kSamplerThreads - 1u) / kSamplerThreads;
+        S.evaluated += ne;
+      }
+      __syncthreads();
+      /* phase 4: the missing points are in the table now */
+      for (unsigned m = threadIdx.x; m < nm; m += kSamplerThreads) {
+        int panic = 0;
+        if (!cvk::sampler_take(S, T, S.miss[m], panic)) S.overflow = 1; /* cannot happen unless phase 2 ran out of room */
+        if (panic) s_panic = 1;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0u) {
+      if (S.overflow) S.finished = 1;
+      cvk::sampler_consume(S, P.max_iterations);
+    }
     __syncthreads();
   }
   /* the finished table and the interpolation tables over it; slot max(n, 1) - 1 is padding (zeros), as on the host */
@@ -185,6 +255,8 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(const SamplerP
     r.steps = S.steps;
     r.warned = S.warned;
     r.status = S.overflow ? cvk::SAMPLER_OVERFLOW : (S.panicked || s_panic) ? cvk::SAMPLER_PANIC : cvk::SAMPLER_OK;
+    r.eval_phases = S.eval_phases;
+    r.evaluated = S.evaluated;
     P.res[job] = r;
   }
 }

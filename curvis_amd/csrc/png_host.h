@@ -125,6 +125,10 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   P.out_words = L.out_words;
   const dim3 grid(P.grid_x, n_frames), block(kPngBlock); /* the 8 XCDs take contiguous eighths of a frame: png_logical_block */
   float ms_a = 0.f, ms_b = 0.f;
+  const bool dbg_timing = getenv("CURVIS_DEBUG_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t_0 = tnow();
 
   /* pass 1: histograms + Adler sums */
   HIP_TRY(ctx, hipMemsetAsync(base + L.hist, 0, L.codes - L.hist, ctx->stream)); /* hist, adler and the CRC words are adjacent */
@@ -138,12 +142,13 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   HIP_TRY(ctx, hipMemcpyAsync(adler.data(), base + L.adler, adler.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipEventElapsedTime(&ms_a, ctx->ev0, ctx->ev1));
+  const auto t_1 = tnow();
 
   /* the frames' codes: lengths <= 12 bits over the 286 literal/length symbols (every symbol keeps a code: +1 on each count,
    * which also makes the block header the host writer's), one distance code */
   std::vector<unsigned> codes((size_t)n_frames * kPngCodes, 0u), start_bit(n_frames), sym_bits((size_t)n_frames * kPngBins, 0u);
   std::vector<std::array<uint8_t, 176>> header(n_frames); /* zlib header + block header: 16 + 1222 bits, + BitWriter slack */
-  for (uint32_t f = 0; f < n_frames; ++f) {
+  auto build_codes = [&](uint32_t f) {
     uint32_t freq[286];
     for (int i = 0; i < 286; ++i) freq[i] = hist[(size_t)f * kPngBins + i] + 1u;
     freq[256] += 1u; /* the end-of-block symbol */
@@ -170,7 +175,36 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
     pngio::put_dynamic_block_header(bw, ll_len);
     start_bit[f] = (unsigned)((bw.p - header[f].data()) * 8 + bw.nb);
     bw.finish();
+  };
+  /* 286-symbol length-limited Huffman codes, 60-80 us per frame on a host core: nothing next to a render call of a few frames, but a
+   * 128-frame call of the efficient renderer spent more time here (9.4 ms, the GPU idle) than in its kernels (profiles/
+   * round6_eff_device_sampler.txt) -- the frames are independent, so a large call spreads them over a few threads */
+  {
+    const unsigned T = n_frames >= 16 ? std::min<unsigned>(8u, n_frames / 8u) : 1u;
+    if (T <= 1u) {
+      for (uint32_t f = 0; f < n_frames; ++f) build_codes(f);
+    } else {
+      std::vector<std::thread> th;
+      std::atomic<int> failed{0};
+      auto work = [&](unsigned t) {
+        try {
+          for (uint32_t f = t; f < n_frames; f += T) build_codes(f);
+        } catch (...) {
+          failed = 1;
+        }
+      };
+      try {
+        for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+      } catch (const std::system_error &) { /* fewer threads than asked for: thread 0 below picks up what has no worker */
+      }
+      const unsigned started = (unsigned)th.size() + 1u;
+      work(0);
+      for (unsigned t = started; t < T; ++t) work(t); /* strides nobody was started for */
+      for (auto &x : th) x.join();
+      if (failed) return fail(ctx, CURVIS_E_INVALID, "out of memory while building the frames' Huffman codes");
+    }
   }
+  const auto t_2 = tnow();
   HIP_TRY(ctx, hipMemcpyAsync(base + L.codes, codes.data(), codes.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(base + L.start_bit, start_bit.data(), start_bit.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(base + L.sym_bits, sym_bits.data(), sym_bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
@@ -197,6 +231,7 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   HIP_TRY(ctx, hipMemcpyAsync(crc_state.data(), base + L.crc, crc_state.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipEventElapsedTime(&ms_b, ctx->ev0, ctx->ev1));
+  const auto t_3 = tnow();
 
   /* streams to the host: deflate bytes, then the Adler-32 of the filtered scanlines.  Sizes first, copies after: a call that
    * fails for want of room must not leave transfers into the caller's buffer in flight */
@@ -217,6 +252,7 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
     HIP_TRY(ctx, hipMemcpyAsync(out + offsets[f], (const uint8_t *)(P.out + (size_t)f * L.out_words), offsets[f + 1] - offsets[f] - 4,
                                 hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const auto t_4 = tnow();
   const unsigned long long n = (unsigned long long)H * ((unsigned long long)W * 3 + 1);
   for (uint32_t f = 0; f < n_frames; ++f) {
     uint8_t *z = out + offsets[f];
@@ -232,6 +268,9 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
     if (idat_crc) idat_crc[f] = (uint32_t)crc32((uLong)(crc_state[f] ^ 0xFFFFFFFFu), a, 4);
   }
   if (crc_valid) *crc_valid = 1;
+  if (dbg_timing)
+    fprintf(stderr, "[curvis] deflate %u frames (ms): histogram pass + sync %.3f (kernel %.3f), codes on the host %.3f, uploads + emit + sync %.3f (kernels %.3f), "
+            "streams to the host (%zu bytes) %.3f, trailers %.3f\n", n_frames, tms(t_0, t_1), ms_a, tms(t_1, t_2), tms(t_2, t_3), ms_b, off, tms(t_3, t_4), tms(t_4, tnow()));
   if (kernel_ms) *kernel_ms = (double)ms_a + (double)ms_b;
   ctx->last_png_ms = (double)ms_a + (double)ms_b;
   return CURVIS_OK;

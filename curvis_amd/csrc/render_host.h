@@ -111,13 +111,14 @@ struct curvis_ctx {
   int sampling_speculation_first = -1; /* the same for the first launch (below the uniform grid); -1 = automatic: 8 / 4 / 3 */
   int device_sampler = -1;           /* efficient renderer: 1 = sampler_kernel (device-resident refinement loop), 0 = host-paced sampler with
                                         speculation, -1 = automatic: the device for calls of device_sampler_min_frames frames and more */
-  int device_sampler_min_frames = 8;
+  int device_sampler_min_frames = 48; /* measured cross-over against the host-paced sampler: between 32 and 64 frames per call (profiles/round6_eff_device_sampler.txt) */
   int last_sampler_path = 0;         /* of the last render_efficient call: 0 host-paced, 1 device, 2 device -> fell back to the host (overflow) */
   struct DevSamples {                /* where the tables of the last device-sampled call sit in d_eff (curvis_ctx_samples fetches on demand) */
     bool valid = false;
     std::vector<unsigned> job_of_frame;
     size_t off_a = 0, off_e = 0, off_s = 0;
   } dev_samples;
+  uint32_t last_sampling_chains = 0; /* device sampler: Euler chains (rounds that had to integrate) of the slowest job of the last call */
   uint32_t last_sampling_launches = 0;
   uint64_t last_sampling_evaluated = 0;
   size_t max_store_bytes = (size_t)8 << 30; /* frames of a batch are rendered in chunks below this */

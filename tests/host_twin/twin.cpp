@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <cstring>
 
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <vector>
 
@@ -183,16 +185,49 @@ extern "C" int twin_render_efficient(const curvis_metric *m, const curvis_camera
      * evaluation; its result is poured into S so that everything downstream is shared */
     std::unique_ptr<cvk::SamplerState> D(new cvk::SamplerState);
     cvk::sampler_reset(*D);
-    while (cvk::sampler_plan(*D, alpha_nums, max_it_sampling, S.a_min, S.a_max, thr1, thr2)) {
-      for (unsigned t = 0; t < D->n_pend; ++t) {
-        double ee, sp_;
-        uint32_t stp;
-        if (escape_angle_any(m->kind, M, c->pos[1], D->pend_a[t], delta, max_iter, R, fast, ee, sp_, stp) == cvk::ESC_PANIC) panic = true;
-        D->steps += stp;
-        cvk::sampler_store(*D, t, ee, sp_);
+    /* the job's evaluation cache, and the phases of sampler_kernel with the lanes run one after the other (dev_sampler == 2:
+     * with speculation, as the kernel does by default) */
+    const unsigned LANES = 512;
+    std::vector<unsigned long long> hk(cvk::kSpecSlots, cvk::kSpecEmpty);
+    std::vector<double> he(cvk::kSpecSlots), hs(cvk::kSpecSlots);
+    std::vector<unsigned> hst(cvk::kSpecSlots);
+    std::vector<int> hu(cvk::kSpecSlots);
+    cvk::SpecTable T{hk.data(), he.data(), hs.data(), hst.data(), hu.data()};
+    int spanic = 0;
+    for (;;) {
+      const bool go = cvk::sampler_plan(*D, alpha_nums, max_it_sampling, S.a_min, S.a_max, thr1, thr2);
+      D->n_miss = D->n_eval = 0;
+      if (!go) break;
+      for (unsigned t = 0; t < D->n_pend; ++t)
+        if (!cvk::sampler_take(*D, T, t, spanic)) D->miss[D->n_miss++] = (unsigned short)t;
+      const unsigned nm = D->n_miss;
+      if (nm) {
+        for (unsigned mi = 0; mi < nm; ++mi) cvk::sampler_want(*D, T, D->pend_a[D->miss[mi]], true);
+        if (dev_sampler == 2 && !D->overflow) {
+          const unsigned depth = D->started ? cvk::sampler_spec_depth(nm, LANES) : 0u;
+          const unsigned grid_depth = (!D->started && LANES > nm) ? cvk::sampler_spec_depth(nm - 1u, LANES - nm) : 0u;
+          for (unsigned mi = 0; mi < nm; ++mi) cvk::sampler_speculate(*D, T, mi, depth, grid_depth);
+        }
+        const unsigned ne = D->n_eval < cvk::kSpecEvalCap ? D->n_eval : cvk::kSpecEvalCap;
+        for (unsigned k = 0; k < ne; ++k) {
+          double ee, sp_;
+          uint32_t stp;
+          const int status = escape_angle_any(m->kind, M, c->pos[1], D->eval_a[k], delta, max_iter, R, fast, ee, sp_, stp);
+          const unsigned slot = D->eval_slot[k];
+          he[slot] = ee; hs[slot] = sp_; hst[slot] = stp; hu[slot] = status;
+        }
+        D->eval_phases += (ne + LANES - 1) / LANES;
+        D->evaluated += ne;
+        for (unsigned mi = 0; mi < nm; ++mi)
+          if (!cvk::sampler_take(*D, T, D->miss[mi], spanic)) D->overflow = 1;
       }
+      if (D->overflow) D->finished = 1;
       cvk::sampler_consume(*D, max_it_sampling);
     }
+    if (spanic) panic = true;
+    if (getenv("TWIN_SAMPLER_DIAG"))
+      fprintf(stderr, "twin device sampler (speculation %d): l = %g: %u samples, %u rounds, %llu calls; %u Euler chains, %u points integrated, %u keys\n",
+              dev_sampler == 2, c->pos[1], D->n, D->rounds, (unsigned long long)D->calls, D->eval_phases, D->evaluated, D->n_cached);
     if (D->overflow) return -4;
     S.pts.resize(D->n);
     for (unsigned i = 0; i < D->n; ++i) S.pts[i] = cvs::BiPoint{D->a[D->cur][i], D->e[D->cur][i], D->s[D->cur][i]};

@@ -325,10 +325,13 @@ def test_video_config_every_frame_efficient_against_glibc(gpu_ctx, video):
         want = list(ex.map(work, poses))
     axis_pixel = (res[1] // 2, res[0] // 2)
     axis_texel_00 = 0       # frames whose optical-axis pixel is the 0/0 case (texel (0, 0) of the + sky)
+    # the fly-through (every frame its own camera radius) through the DEVICE-RESIDENT sampler, the orbit through the host-paced one
+    gpu_ctx.set_option("device_sampler", 1 if video == "through" else 0)
     for k0 in range(0, n_frames, 32):
         part = poses[k0:k0 + 32]
         cams = [curvis_amd.Camera(p[0], p[1], p[2], 15.0, 43.0, res[0], res[1]) for p in part]
         rgb, _ = gpu_ctx.render_efficient(pm, cams, cap, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+        assert gpu_ctx.get_option("last_sampler_path") == (1 if video == "through" else 0)
         for j in range(len(part)):
             a, e, sp_ = gpu_ctx.samples(j)
             for fl, (w_rgb, w_smp) in zip(O.GLIBC_FLAVOURS, want[k0 + j]):
@@ -337,6 +340,7 @@ def test_video_config_every_frame_efficient_against_glibc(gpu_ctx, video):
                 d = (rgb[j] != w_rgb).any(axis=2)
                 assert not d.any(), ("frame %d vs %s: pixels %s" % (k0 + j, O.FLAVOUR_NAMES[fl], np.argwhere(d)[:5].tolist()))
             axis_texel_00 += int(np.array_equal(rgb[j][axis_pixel], sp[0, 0, :3]))
+    gpu_ctx.set_option("device_sampler", -1)
     print("%s, efficient renderer, %d frames at %dx%d vs %s: sample tables and every pixel identical in every frame (optical-axis pixel "
           "included; it is texel (0, 0) of the + sky in %d frames)" % (
               video, n_frames, res[0], res[1], ", ".join(O.FLAVOUR_NAMES[fl] for fl in O.GLIBC_FLAVOURS), axis_texel_00))
