@@ -86,7 +86,7 @@ def parse():
     ap.add_argument("--cpu-row-step", type=int, default=8)
     ap.add_argument("--no-value-efficient", action="store_true",
                     help="N = 1: skip value_efficient (the reference's default renderer: kernels only + `curvis video --mode efficient`)")
-    ap.add_argument("--value-efficient-frames", type=int, default=960,
+    ap.add_argument("--value-efficient-frames", type=int, default=3840,
                     help="frames of the end-to-end leg of value_efficient (path_orbit.csv resampled to that many frames)")
     return ap.parse_args()
 
@@ -979,46 +979,60 @@ def rows_split_run(ctx, dist, torch, world, rank, metric, cam, args, R, DELTA, f
 
 def efficient_kernels(ctx, torch, args):
     """value_efficient, kernels only: RelativisticSystem::render_image_efficient (src/systems.rs:333-527) -- the renderer the
-    reference's CLI runs (src/rendering.rs:97-106, :299-307) -- on the 240 poses of configs[3] (the reference's own
-    path_orbit.csv at 4 fps, tests/golden/paths), args.width x args.height, cap args.max_iter, the CLI's sampler settings
-    (sampling_initial_nums = 100 for BOTH alphas_num and max_iterations_sampling, threshold_1 for both thresholds:
-    src/main.rs:91-110), ONE context, 32 frames per call, frames left in HBM.  GPU-idle share from the context's own HIP events."""
+    reference's CLI runs (src/rendering.rs:97-106, :299-307) -- with the CLI's sampler settings (sampling_initial_nums = 100 for
+    BOTH alphas_num and max_iterations_sampling, threshold_1 for both thresholds: src/main.rs:91-110), ONE context, frames left in
+    HBM, args.width x args.height:
+      kernels_only                 the 240 poses of configs[3] (the reference's own path_orbit.csv at 4 fps), cap args.max_iter, 120
+                                   frames per call -> the device-resident sampler (sampler_kernel; every pose has l = 3: ONE job per call)
+      kernels_only_distinct_radii  the first 240 poses of configs[4] (path_through.csv at 24 fps: every frame its own l), Interstellar
+                                   metric, cap 8192, 120 frames per call -> one sampler job per frame
+      host_paced_32                configs[3] again at 32 frames per call: the host-paced sampler (what round 5 measured)
+    GPU-idle share from the context's own HIP events."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import refpaths
     import curvis_amd
     from curvis_amd import rendering
-    it = rendering.Interpolator.from_file(refpaths.reference_path_file("path_orbit.csv"))
-    times = rendering.times_of_frames(it.min_time(), it.max_time(), 4.0)
-    cams = [curvis_amd.Camera(tuple(it.camera_position(t)), tuple(it.camera_forward(t)), tuple(it.camera_up(t)), 15.0, 43.0,
-                              args.width, args.height) for t in times]
-    metric = curvis_amd.EllisMetric(1.0)
-    per_call = 32
 
-    def run():
-        kernel_ms = call_ms = 0.0
-        steps = 0
-        for k in range(0, len(cams), per_call):
-            _, st = ctx.render_efficient(metric, cams[k:k + per_call], args.max_iter, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
-            kernel_ms += st.kernel_ms
-            call_ms += st.total_ms
-            steps += st.steps
-        return kernel_ms, call_ms, steps
-    run()                                   # allocations, first-launch checks
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kernel_ms, call_ms, steps = run()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    n = len(cams)
-    return {"unit": "%dx%d frames/s, reference's default renderer (render_image_efficient), configs[3] poses" % (args.width, args.height),
-            "kernels_only": {
-                "value": round(n / wall, 1), "frames": n, "frames_per_call": per_call, "contexts": 1,
+    def poses(csv, fps, n):
+        it = rendering.Interpolator.from_file(refpaths.reference_path_file(csv))
+        times = rendering.times_of_frames(it.min_time(), it.max_time(), fps)[:n]
+        return [curvis_amd.Camera(tuple(it.camera_position(t)), tuple(it.camera_forward(t)), tuple(it.camera_up(t)), 15.0, 43.0,
+                                  args.width, args.height) for t in times]
+
+    def leg(metric, cams, cap, per_call):
+        def run():
+            kernel_ms = steps = 0
+            paths, chains = set(), 0
+            for k in range(0, len(cams), per_call):
+                _, st = ctx.render_efficient(metric, cams[k:k + per_call], cap, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
+                kernel_ms += st.kernel_ms
+                steps += st.steps
+                paths.add(ctx.get_option("last_sampler_path"))
+                chains = max(chains, ctx.get_option("last_sampling_chains") if 1 in paths else 0)
+            return kernel_ms, steps, paths, chains
+        run()                                   # allocations, first-launch checks
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kernel_ms, steps, paths, chains = run()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        n = len(cams)
+        return {"value": round(n / wall, 1), "frames": n, "frames_per_call": per_call, "contexts": 1,
+                "sampler": {0: "host-paced (cv_sampler.h, speculating launches)", 1: "device-resident (sampler_kernel)",
+                            2: "device-resident, fell back to the host"}[max(paths)],
+                "euler_chains_per_call": chains or None,
                 "ms_per_frame": round(wall / n * 1e3, 4), "kernel_ms_per_frame": round(kernel_ms / n, 4),
-                "gpu_idle_share": round(max(0.0, 1.0 - kernel_ms / 1e3 / wall), 4),
-                "integrator_steps_per_frame": int(steps / n),
-                "note": "one context, frames stay in HBM; wall time includes the host side of the adaptive sampler "
-                        "(src/sampling.rs:46-195: the rounds are host-paced); gpu_idle_share = 1 - kernels' HIP-event time / wall; "
-                        "several contexts on host threads hide the idle share (end_to_end uses the binary's default of 4)"}}
+                "gpu_idle_share": round(max(0.0, 1.0 - kernel_ms / 1e3 / wall), 4), "integrator_steps_per_frame": int(steps / n)}
+    orbit = poses("path_orbit.csv", 4.0, 240)
+    through = poses("path_through.csv", 24.0, 240)
+    out = {"unit": "%dx%d frames/s, reference's default renderer (render_image_efficient)" % (args.width, args.height),
+           "kernels_only": leg(curvis_amd.EllisMetric(1.0), orbit, args.max_iter, 120),
+           "kernels_only_distinct_radii": leg(curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0), through, 8192, 120),
+           "host_paced_32": leg(curvis_amd.EllisMetric(1.0), orbit, args.max_iter, 32)}
+    out["kernels_only"]["note"] = ("configs[3] poses (Ellis, l = 3 in every frame: the frames of a call share ONE sampler job); one context, frames "
+                                   "stay in HBM; gpu_idle_share = 1 - kernels' HIP-event time / wall")
+    out["kernels_only_distinct_radii"]["note"] = "configs[4] poses (Interstellar, cap 8192): every frame its own camera radius, one sampler job per frame"
+    return out
 
 
 def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gpu=None):
@@ -1030,7 +1044,14 @@ def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gp
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import refpaths  # the reference's own path_orbit.csv, committed as a data fixture (tests/golden/paths)
     exe = os.path.join(ROOT, "curvis_amd", "bin", "curvis")
-    d = tempfile.mkdtemp(prefix="curvis_e2e_")
+    base = None  # a RAM file system when it has room (a 1080p frame of the smooth skies is a 0.6 MB PNG), else the default temporary directory
+    try:
+        stv = os.statvfs("/dev/shm")
+        if stv.f_bavail * stv.f_frsize > (8 << 30):
+            base = "/dev/shm"
+    except OSError:
+        pass
+    d = tempfile.mkdtemp(prefix="curvis_e2e_", dir=base)
     try:
         t_files = time.perf_counter()
         from curvis_amd import _abi

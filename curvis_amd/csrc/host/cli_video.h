@@ -102,14 +102,19 @@ int video_main(const Args &a_in) {
      * frames: 240 / 960 / 2 400 / 6 000 1080p frames on one GPU took 0.63 / 0.91 / 1.36 / 2.46 s with one context, 0.64 / 0.77 /
      * 1.11 / 1.76 s with two, 0.71 / 0.85 / 1.04 / 1.50 s with four (profiles/round5_cli_startup.txt) */
     const size_t per_device = (n_frames + (size_t)a.devices - 1) / (size_t)a.devices;
-    const int cap = per_device < 600 ? 1 : per_device < 2000 ? 2 : per_device < 12000 ? 4 : a.contexts;
+    /* round 6 (device-resident sampler, 128 frames per call): 3 / 4 / 6 contexts read 10 672 / 11 183 / 10 474 frames/s at 29 970
+     * frames -- four is the most that pays (profiles/round6_eff_contexts_sweep.txt) */
+    const int cap = per_device < 600 ? 1 : per_device < 2000 ? 2 : 4;
     a.contexts = std::min(a.contexts, cap);
   }
   if (batch_auto && a.mode == "efficient" && (n_frames + (size_t)a.devices - 1) / (size_t)a.devices >= 2000) {
-    /* long videos: 64 frames per launch -- with the batch buffers sized for streams their length no longer costs pinned memory, and at
-     * 29 970 frames 3 / 4 / 6 contexts read 6 953 / 8 169 / 8 956 frames/s at 32 per launch, 7 491 / 8 451 / 9 330 at 64
-     * (profiles/round5_eff_contexts_sweep_final.txt); the frames of a launch sit together in HBM: 512 MB at most */
-    a.batch = (int)std::max<size_t>(4, std::min<size_t>(64, ((size_t)512 << 20) / std::max<size_t>(1, fbytes)));
+    /* long videos: 128 frames per call.  From 48 frames on the library samples on the device (sampler_kernel: one launch per call,
+     * no host in the refinement loop), whose latency -- a handful of Euler chains, 5-10 ms -- is paid once per call however many
+     * frames share it: 29 970 frames at 64 / 128 / 256 per call read 3 949 / 6 352 / 7 188 frames/s with one context, 7 643 /
+     * 11 183 / 11 183 with four (round 5, host-paced sampler at 64 per call: 3 280 and 8 451).  The frames of a call sit together
+     * in HBM (128 x 6.2 MB at 1080p; 1 GB at most) next to the PNG front end's scratch (~10 MB per frame); the page-locked batch
+     * buffers are sized for streams, not pixels */
+    a.batch = (int)std::max<size_t>(4, std::min<size_t>(128, ((size_t)1 << 30) / std::max<size_t>(1, fbytes)));
   }
   const int n_workers = a.devices * a.contexts;
   auto device_of = [&](int rank) { return a.device + rank / a.contexts; };

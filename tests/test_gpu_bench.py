@@ -146,12 +146,16 @@ def test_default_line_clock_agrees_with_itself_and_carries_the_download_figure()
     # GPU-idle share from its own HIP events) and end to end through `curvis video --mode efficient` on the reference's path_orbit.csv
     ve = out["value_efficient"]
     assert "failed" not in ve, ve
-    ko = ve["kernels_only"]
-    assert ko["frames"] == 240 and ko["contexts"] == 1 and ko["value"] > 100 and 0 < ko["kernel_ms_per_frame"] < ko["ms_per_frame"] * 1.001
-    assert 0.0 <= ko["gpu_idle_share"] < 1.0 and abs(ko["gpu_idle_share"] - (1 - ko["kernel_ms_per_frame"] / ko["ms_per_frame"])) < 2e-3
+    for key, sampler in (("kernels_only", "device-resident (sampler_kernel)"), ("kernels_only_distinct_radii", "device-resident (sampler_kernel)"),
+                         ("host_paced_32", "host-paced")):
+        ko = ve[key]
+        assert ko["frames"] == 240 and ko["contexts"] == 1 and ko["value"] > 100 and 0 < ko["kernel_ms_per_frame"] < ko["ms_per_frame"] * 1.001
+        assert 0.0 <= ko["gpu_idle_share"] < 1.0 and abs(ko["gpu_idle_share"] - (1 - ko["kernel_ms_per_frame"] / ko["ms_per_frame"])) < 2e-3
+        assert ko["sampler"].startswith(sampler), (key, ko["sampler"])
+    assert ve["kernels_only"]["gpu_idle_share"] < 0.10 and ve["kernels_only"]["value"] > ve["host_paced_32"]["value"]   # < 10 % of the span without a kernel
     ee = ve["end_to_end"]
     assert "failed" not in ee, ee
-    assert ee["frames"] == ee["frames_on_disk"] == 960 and ee["frames_per_s"] > 100 and ee["gpu_png"] is True and 0.0 <= ee["gpu_idle_share"] < 1.0
+    assert ee["frames"] == ee["frames_on_disk"] == 3840 and ee["frames_per_s"] > 100 and ee["gpu_png"] is True and 0.0 <= ee["gpu_idle_share"] < 1.0
     assert "--mode efficient" in ee["command"] and "path_orbit.csv" in ee["command"]
 
 
