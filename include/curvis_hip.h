@@ -349,8 +349,14 @@ int curvis_ctx_download_wait(curvis_ctx *ctx);
  * "sampling_speculation" (efficient renderer: depth of the speculative dyadic subtree evaluated below every
  * refined interval; 0 = one launch per refinement round; default -1 = automatic, 10 for one or two frames, 6 for three to five and 4
  * for larger batches) and "sampling_speculation_first" (the same below the intervals of the initial uniform grid,
- * i.e. for the first launch; default -1 = automatic, 8 / 4 / 3; depths up to 11); read-only after an efficient render:
- * "last_sampling_launches", "last_sampling_evaluated"; after any render: "last_frames"; after a relay render: "last_relay_launches",
+ * i.e. for the first launch; default -1 = automatic, 8 / 4 / 3; depths up to 11), "device_sampler" (efficient renderer: 1 = the
+ * reference's whole adaptive sampler -- rounds, speculation and all -- runs on the device, ONE launch per call and a workgroup
+ * per distinct camera radius, no host in the refinement loop; 0 = the host-paced sampler, several launches per call; default -1 =
+ * automatic: the device from "device_sampler_min_frames" (default 48) frames per call on; identical sample tables and pixels either
+ * way; a table that outgrows the kernel's fixed arrays -- 1536 samples -- sends the call to the host-paced sampler;
+ * "sampling_speculation" = 0 switches speculation off on the device too); read-only after an efficient render:
+ * "last_sampling_launches", "last_sampling_evaluated", "last_sampler_path" (0 host-paced, 1 device, 2 device fell back to the
+ * host), "last_sampling_chains" (device: Euler chains the slowest job waited for); after any render: "last_frames"; after a relay render: "last_relay_launches",
  * "last_relay_parks".  Relay safety net: if a relay launch reports waves that gave up waiting (the kernel leans
  * on in-order workgroup dispatch, which HIP does not promise), the frame is rendered again by the static kernel and
  * "relay_disabled" becomes 1 for the context ("relay_fallbacks" counts such renders); "relay_verify" = 1 (debug)
