@@ -88,6 +88,8 @@ SYMBOLS = {
     "curvis_render_efficient_batch": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_uint32,
                                                 C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_double,
                                                 C.c_double, _vp, C.POINTER(Stats)]),
+    "curvis_ctx_prefetch_efficient": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_uint32,
+                                                C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_double, C.c_double]),
     "curvis_render_direct": (C.c_int, [_vp, C.POINTER(Metric), C.POINTER(CameraC), C.c_uint32, C.c_double, C.c_double, _vp,
                                        C.POINTER(Stats)]),
     "curvis_ctx_sampling_info": (C.c_int, [_vp, C.c_uint32, C.POINTER(SamplingInfo)]),

@@ -127,6 +127,15 @@ void curvis_ctx_destroy(curvis_ctx *ctx) {
   if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream); /* a download still in flight reads d_fb / d_fb_alt */
+  if (ctx->sampler_stream) (void)hipStreamSynchronize(ctx->sampler_stream); /* a prefetched sampler still writes its slot */
+  for (auto &S : ctx->samp) {
+    if (S.d) (void)hipFree(S.d);
+    if (S.h) (void)hipHostFree(S.h);
+    if (S.done) (void)hipEventDestroy(S.done);
+    if (S.t0) (void)hipEventDestroy(S.t0);
+    if (S.t1) (void)hipEventDestroy(S.t1);
+  }
+  if (ctx->sampler_stream) (void)hipStreamDestroy(ctx->sampler_stream);
   for (int s = 0; s < 2; ++s)
     if (ctx->d_sky[s] && ctx->sky_owned[s]) (void)hipFree(ctx->d_sky[s]);
   if (ctx->d_fb) (void)hipFree(ctx->d_fb);
@@ -628,6 +637,14 @@ int curvis_render_efficient_batch(curvis_ctx *ctx, const curvis_metric *metric, 
                                sampling_convergence_threshold_2, rgb_out, stats);
 }
 
+int curvis_ctx_prefetch_efficient(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cameras, uint32_t n_frames,
+                                  uint32_t max_iterations_propagation, double max_radius, double delta, uint32_t alpha_nums,
+                                  uint32_t max_iterations_sampling, double sampling_convergence_threshold_1,
+                                  double sampling_convergence_threshold_2) {
+  return prefetch_efficient_impl(ctx, metric, cameras, n_frames, max_iterations_propagation, max_radius, delta, alpha_nums,
+                                 max_iterations_sampling, sampling_convergence_threshold_1, sampling_convergence_threshold_2);
+}
+
 int curvis_render_direct(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *camera, uint32_t max_iterations,
                          double max_radius, double delta, uint8_t *rgb_out, curvis_stats *stats) {
   return render_direct_impl(ctx, metric, camera, max_iterations, max_radius, delta, rgb_out, stats);
@@ -998,6 +1015,12 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->last_sampler_path;
   else if (k == "last_sampling_chains")
     *value = ctx->last_sampling_chains;
+  else if (k == "last_sampling_prefetched")
+    *value = ctx->last_sampling_prefetched;
+  else if (k == "prefetches")
+    *value = (int64_t)ctx->prefetches;
+  else if (k == "prefetch_hits")
+    *value = (int64_t)ctx->prefetch_hits;
   else if (k == "last_sampling_launches")
     *value = ctx->last_sampling_launches;
   else if (k == "last_sampling_evaluated")

@@ -29,7 +29,6 @@ int eval_escape_batch(curvis_ctx *ctx, const curvis_metric *metric, const cvk::M
   steps.resize(n);
   status.resize(n);
   if (n == 0) return CURVIS_OK;
-  ctx->dev_samples.valid = false; /* the scratch is about to be reused */
   /* layout: alpha | l | angle | space (f64) | steps (u32) | status (i32) */
   const size_t bytes = n * (4 * sizeof(double) + sizeof(unsigned) + sizeof(int));
   int rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, bytes);
@@ -105,25 +104,43 @@ int eval_escape_batch(curvis_ctx *ctx, const curvis_metric *metric, const cvk::M
 constexpr int kSamplerFallback = 1;
 
 template <int KIND>
-int launch_sampler_kind(curvis_ctx *ctx, bool fast, const SamplerParams &P) {
+int launch_sampler_kind(curvis_ctx *ctx, hipStream_t stream, bool fast, const SamplerParams &P) {
   if (fast)
-    hipLaunchKernelGGL((sampler_kernel<KIND, true>), dim3(P.n_jobs), dim3(kSamplerThreads), 0, ctx->stream, P);
+    hipLaunchKernelGGL((sampler_kernel<KIND, true>), dim3(P.n_jobs), dim3(kSamplerThreads), 0, stream, P);
   else
-    hipLaunchKernelGGL((sampler_kernel<KIND, false>), dim3(P.n_jobs), dim3(kSamplerThreads), 0, ctx->stream, P);
+    hipLaunchKernelGGL((sampler_kernel<KIND, false>), dim3(P.n_jobs), dim3(kSamplerThreads), 0, stream, P);
   HIP_TRY(ctx, hipGetLastError());
   return CURVIS_OK;
 }
 
-int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const cvk::MetricParams &MP, const curvis_camera *cams,
-                            uint32_t n_frames, const std::vector<cvk::EfficientFrame> &eframes, uint32_t max_iter, double max_radius,
-                            double delta, uint32_t alpha_nums, uint32_t max_iterations_sampling, double thr1, double thr2,
-                            uint8_t *rgb_out, curvis_stats *stats, std::chrono::steady_clock::time_point t_begin) {
-  const uint32_t W = cams[0].res_x, H = cams[0].res_y;
-  const size_t npix = (size_t)W * H;
-  if (npix > 0xFFFFFFFFull || n_frames > 65535u) return fail(ctx, CURVIS_E_INVALID, "frame or batch too large");
+/* what a sampler launch depends on: two launches with equal keys produce equal tables */
+bool sampler_key_equal(const curvis_ctx::SamplerSlot &S, const curvis_metric &metric, const curvis_camera *cams, uint32_t n_frames, uint32_t max_iter,
+                       double max_radius, double delta, uint32_t alpha_nums, uint32_t max_iterations_sampling, double thr1, double thr2, int fast,
+                       int speculate) {
+  /* (field by field: the struct has padding, and a copy need not carry it) */
+  const bool same_metric = S.metric.kind == metric.kind && std::memcmp(&S.metric.rho, &metric.rho, sizeof(double)) == 0 &&
+                           std::memcmp(&S.metric.m, &metric.m, sizeof(double)) == 0 && std::memcmp(&S.metric.a, &metric.a, sizeof(double)) == 0;
+  if (!S.valid || S.n_frames != n_frames || !same_metric || S.max_iter != max_iter ||
+      S.alpha_nums != alpha_nums || S.max_iterations_sampling != max_iterations_sampling || S.fast != fast || S.speculate != speculate)
+    return false;
+  const double p[4] = {max_radius, delta, thr1, thr2};
+  if (std::memcmp(S.params, p, sizeof p) != 0) return false;
+  for (uint32_t f = 0; f < n_frames; ++f)
+    if (std::memcmp(&S.l_frame[f], &cams[f].pos[1], sizeof(double)) != 0) return false;
+  return true;
+}
+
+/* Sample the frames of a call on `stream` into slot `slot` of the context (device buffer + page-locked mirror of its own): jobs,
+ * staging, the sampler kernel, the jobs' results on their way back, an event when all of that is done.  Nothing waits here. */
+int sampler_submit(curvis_ctx *ctx, unsigned slot, hipStream_t stream, const curvis_metric *metric, const cvk::MetricParams &MP,
+                   const curvis_camera *cams, uint32_t n_frames, uint32_t max_iter, double max_radius, double delta, uint32_t alpha_nums,
+                   uint32_t max_iterations_sampling, double thr1, double thr2) {
+  curvis_ctx::SamplerSlot &S = ctx->samp[slot];
+  S.valid = false;
   /* jobs: one per distinct radial coordinate of the cameras (bit pattern) */
-  std::vector<unsigned> job_of_frame(n_frames);
-  std::vector<double> l_job;
+  S.job_of_frame.assign(n_frames, 0u);
+  S.l_job.clear();
+  S.l_frame.resize(n_frames);
   {
     std::map<uint64_t, unsigned> seen;
     for (uint32_t f = 0; f < n_frames; ++f) {
@@ -131,14 +148,15 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
       std::memcpy(&key, &cams[f].pos[1], sizeof key);
       auto it = seen.find(key);
       if (it == seen.end()) {
-        it = seen.emplace(key, (unsigned)l_job.size()).first;
-        l_job.push_back(cams[f].pos[1]);
+        it = seen.emplace(key, (unsigned)S.l_job.size()).first;
+        S.l_job.push_back(cams[f].pos[1]);
       }
-      job_of_frame[f] = it->second;
+      S.job_of_frame[f] = it->second;
+      S.l_frame[f] = cams[f].pos[1];
     }
   }
-  const unsigned n_jobs = (unsigned)l_job.size();
-  const size_t T = (size_t)n_jobs * cvk::kSamplerCap;
+  const unsigned n_jobs = (unsigned)S.l_job.size();
+  const size_t T = (size_t)n_jobs * cvk::kSamplerCap, SS = (size_t)n_jobs * cvk::kSpecSlots;
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     const size_t o = off;
@@ -146,51 +164,48 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
     return o;
   };
   /* staged from the host in one copy ... */
-  const size_t o_cams = carve(sizeof(cvk::CameraParams) * n_frames), o_fr = carve(sizeof(cvk::EfficientFrame) * n_frames),
-               o_to = carve(sizeof(unsigned) * n_frames), o_jf = carve(sizeof(unsigned) * n_frames), o_l = carve(sizeof(double) * n_jobs);
+  const size_t o_jf = carve(sizeof(unsigned) * n_frames), o_to = carve(sizeof(unsigned) * n_frames), o_l = carve(sizeof(double) * n_jobs);
   const size_t staged = off;
   /* ... written by the sampler kernel */
-  const size_t o_tn = carve(sizeof(unsigned) * n_frames), o_res = carve(sizeof(cvk::SamplerResult) * n_jobs);
-  size_t o_tab[7];
-  for (size_t &o : o_tab) o = carve(sizeof(double) * T);
+  S.o_tab_off = o_to;
+  S.o_tab_n = carve(sizeof(unsigned) * n_frames);
+  S.o_res = carve(sizeof(cvk::SamplerResult) * n_jobs);
+  for (size_t &o : S.o_tab) o = carve(sizeof(double) * T);
   /* the jobs' evaluation caches (cv_sampler_dev.h SpecTable): 256 KB each */
-  const size_t SS = (size_t)n_jobs * cvk::kSpecSlots;
   const size_t o_sk = carve(sizeof(unsigned long long) * SS), o_se = carve(sizeof(double) * SS), o_ss = carve(sizeof(double) * SS),
                o_st = carve(sizeof(unsigned) * SS), o_su = carve(sizeof(int) * SS);
-  int rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, off);
+  int rc = ensure_device(ctx, S.d, S.d_cap, off);
   if (rc) return rc;
-  const size_t res_bytes = sizeof(cvk::SamplerResult) * n_jobs;
-  const size_t pinned = staged + ((res_bytes + 255) & ~(size_t)255);
-  if (ctx->h_eff_cap < pinned) {
-    if (ctx->h_eff) HIP_TRY(ctx, hipHostFree(ctx->h_eff));
-    ctx->h_eff = nullptr;
-    ctx->h_eff_cap = 0;
-    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_eff, pinned + pinned / 2));
-    ctx->h_eff_cap = pinned + pinned / 2;
+  S.res_bytes = sizeof(cvk::SamplerResult) * n_jobs;
+  S.h_res_off = staged;
+  const size_t pinned = staged + ((S.res_bytes + 255) & ~(size_t)255);
+  if (S.h_cap < pinned) {
+    if (S.h) HIP_TRY(ctx, hipHostFree(S.h));
+    S.h = nullptr;
+    S.h_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void **)&S.h, pinned + pinned / 2));
+    S.h_cap = pinned + pinned / 2;
   }
-  unsigned char *stage = ctx->h_eff;
+  if (!S.done) HIP_TRY(ctx, hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+  if (!S.t0) {
+    HIP_TRY(ctx, hipEventCreate(&S.t0));
+    HIP_TRY(ctx, hipEventCreate(&S.t1));
+  }
+  std::memcpy(S.h + o_jf, S.job_of_frame.data(), sizeof(unsigned) * n_frames);
   {
-    auto *cp = reinterpret_cast<cvk::CameraParams *>(stage + o_cams);
-    for (uint32_t f = 0; f < n_frames; ++f) cp[f] = make_camera(cams[f]);
-    std::memcpy(stage + o_fr, eframes.data(), sizeof(cvk::EfficientFrame) * n_frames);
-    auto *to = reinterpret_cast<unsigned *>(stage + o_to);
-    for (uint32_t f = 0; f < n_frames; ++f) to[f] = job_of_frame[f] * cvk::kSamplerCap;
-    std::memcpy(stage + o_jf, job_of_frame.data(), sizeof(unsigned) * n_frames);
-    std::memcpy(stage + o_l, l_job.data(), sizeof(double) * n_jobs);
+    auto *to = reinterpret_cast<unsigned *>(S.h + o_to);
+    for (uint32_t f = 0; f < n_frames; ++f) to[f] = S.job_of_frame[f] * cvk::kSamplerCap;
   }
-  const size_t fb_bytes = npix * 3 * n_frames;
-  rc = fb_begin_write(ctx, fb_bytes);
-  if (rc) return rc;
-  ctx->fb_bytes = fb_bytes;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eff, stage, staged, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_eff + o_sk, 0xFF, sizeof(unsigned long long) * SS, ctx->stream)); /* every key = kSpecEmpty */
+  std::memcpy(S.h + o_l, S.l_job.data(), sizeof(double) * n_jobs);
+  HIP_TRY(ctx, hipMemcpyAsync(S.d, S.h, staged, hipMemcpyHostToDevice, stream));
+  HIP_TRY(ctx, hipMemsetAsync(S.d + o_sk, 0xFF, sizeof(unsigned long long) * SS, stream)); /* every key = kSpecEmpty */
   SamplerParams SP;
   SP.metric = MP;
-  SP.l_cam = (const double *)(ctx->d_eff + o_l);
+  SP.l_cam = (const double *)(S.d + o_l);
   SP.n_jobs = n_jobs;
   SP.n_frames = n_frames;
-  SP.job_of_frame = (const unsigned *)(ctx->d_eff + o_jf);
-  SP.tab_n = (unsigned *)(ctx->d_eff + o_tn);
+  SP.job_of_frame = (const unsigned *)(S.d + o_jf);
+  SP.tab_n = (unsigned *)(S.d + S.o_tab_n);
   SP.n0 = alpha_nums;
   SP.max_iterations = max_iterations_sampling;
   SP.max_iter = max_iter;
@@ -201,28 +216,131 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   SP.max_radius = max_radius;
   SP.delta = delta;
   SP.fast_ok = cvk::metric_fast_ok(metric->kind, MP, max_radius) ? 1 : 0;
-  SP.sx = (double *)(ctx->d_eff + o_tab[0]);
-  SP.se = (double *)(ctx->d_eff + o_tab[1]);
-  SP.ss = (double *)(ctx->d_eff + o_tab[2]);
-  SP.m_e = (double *)(ctx->d_eff + o_tab[3]);
-  SP.c_e = (double *)(ctx->d_eff + o_tab[4]);
-  SP.m_s = (double *)(ctx->d_eff + o_tab[5]);
-  SP.c_s = (double *)(ctx->d_eff + o_tab[6]);
-  SP.res = (cvk::SamplerResult *)(ctx->d_eff + o_res);
-  SP.spec_key = (unsigned long long *)(ctx->d_eff + o_sk);
-  SP.spec_e = (double *)(ctx->d_eff + o_se);
-  SP.spec_s = (double *)(ctx->d_eff + o_ss);
-  SP.spec_steps = (unsigned *)(ctx->d_eff + o_st);
-  SP.spec_status = (int *)(ctx->d_eff + o_su);
+  SP.sx = (double *)(S.d + S.o_tab[0]);
+  SP.se = (double *)(S.d + S.o_tab[1]);
+  SP.ss = (double *)(S.d + S.o_tab[2]);
+  SP.m_e = (double *)(S.d + S.o_tab[3]);
+  SP.c_e = (double *)(S.d + S.o_tab[4]);
+  SP.m_s = (double *)(S.d + S.o_tab[5]);
+  SP.c_s = (double *)(S.d + S.o_tab[6]);
+  SP.res = (cvk::SamplerResult *)(S.d + S.o_res);
+  SP.spec_key = (unsigned long long *)(S.d + o_sk);
+  SP.spec_e = (double *)(S.d + o_se);
+  SP.spec_s = (double *)(S.d + o_ss);
+  SP.spec_steps = (unsigned *)(S.d + o_st);
+  SP.spec_status = (int *)(S.d + o_su);
   SP.speculate = ctx->sampling_speculation != 0 ? 1 : 0; /* option "sampling_speculation" = 0 switches it off here too */
   const bool fast = ctx->fast_math != 0;
-  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(S.t0, stream));
   switch (metric->kind) {
-    case CURVIS_METRIC_ELLIS: rc = launch_sampler_kind<cvk::METRIC_ELLIS>(ctx, fast, SP); break;
-    case CURVIS_METRIC_INTERSTELLAR: rc = launch_sampler_kind<cvk::METRIC_INTERSTELLAR>(ctx, fast, SP); break;
-    default: rc = launch_sampler_kind<cvk::METRIC_FLAT>(ctx, fast, SP); break;
+    case CURVIS_METRIC_ELLIS: rc = launch_sampler_kind<cvk::METRIC_ELLIS>(ctx, stream, fast, SP); break;
+    case CURVIS_METRIC_INTERSTELLAR: rc = launch_sampler_kind<cvk::METRIC_INTERSTELLAR>(ctx, stream, fast, SP); break;
+    default: rc = launch_sampler_kind<cvk::METRIC_FLAT>(ctx, stream, fast, SP); break;
   }
   if (rc) return rc;
+  HIP_TRY(ctx, hipEventRecord(S.t1, stream));
+  HIP_TRY(ctx, hipMemcpyAsync(S.h + S.h_res_off, S.d + S.o_res, S.res_bytes, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(ctx, hipEventRecord(S.done, stream));
+  S.metric = *metric;
+  S.n_frames = n_frames;
+  S.max_iter = max_iter;
+  S.alpha_nums = alpha_nums;
+  S.max_iterations_sampling = max_iterations_sampling;
+  S.params[0] = max_radius, S.params[1] = delta, S.params[2] = thr1, S.params[3] = thr2;
+  S.fast = fast ? 1 : 0;
+  S.speculate = SP.speculate;
+  S.seq = ++ctx->samp_seq;
+  S.valid = true;
+  return CURVIS_OK;
+}
+
+/* curvis_ctx_prefetch_efficient: the sampler of a FUTURE curvis_render_efficient_batch call, launched now on a stream of its own.
+ * The sampler's cost is latency (a handful of Euler chains on a few compute units), the per-pixel kernel's and the PNG front end's
+ * is throughput, and between them a render call leaves the GPU to the host (stream download, hand-over): the next call's sampler
+ * fits into all of that.  The call with the same metric, settings and camera radii then waits for the event instead of sampling. */
+int prefetch_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cams, uint32_t n_frames, uint32_t max_iter,
+                            double max_radius, double delta, uint32_t alpha_nums, uint32_t max_iterations_sampling, double thr1, double thr2) {
+  if (!ctx) return CURVIS_E_INVALID;
+  if (!metric || !cams || n_frames == 0) return fail(ctx, CURVIS_E_INVALID, "null metric/camera or zero frames");
+  int rc = curvis_metric_validate(metric);
+  if (rc != CURVIS_OK) return fail(ctx, rc, "invalid metric parameters (src/metrics.rs:409-456)");
+  if (alpha_nums < 3 || alpha_nums > cvk::kSamplerCap || alpha_nums > cvk::kSamplerPendCap) return CURVIS_OK; /* not a case for the device sampler */
+  if (!(ctx->device_sampler > 0 || (ctx->device_sampler < 0 && n_frames >= (uint32_t)ctx->device_sampler_min_frames)))
+    return CURVIS_OK; /* the render call will take the host-paced sampler: nothing to run ahead */
+  for (uint32_t f = 0; f < n_frames; ++f)
+    if (std::fabs(cams[f].pos[1]) > max_radius) return CURVIS_OK; /* the render call will report it */
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->sampler_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->sampler_stream, hipStreamNonBlocking));
+  const cvk::MetricParams MP = make_metric(*metric);
+  const unsigned slot = ctx->samp_next;
+  rc = sampler_submit(ctx, slot, ctx->sampler_stream, metric, MP, cams, n_frames, max_iter, max_radius, delta, alpha_nums, max_iterations_sampling,
+                      thr1, thr2);
+  if (rc) return rc;
+  ctx->samp[slot].prefetched = true;
+  ctx->samp_next = slot ^ 1u;
+  ctx->prefetches++;
+  return CURVIS_OK;
+}
+
+int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const cvk::MetricParams &MP, const curvis_camera *cams,
+                            uint32_t n_frames, const std::vector<cvk::EfficientFrame> &eframes, uint32_t max_iter, double max_radius,
+                            double delta, uint32_t alpha_nums, uint32_t max_iterations_sampling, double thr1, double thr2,
+                            uint8_t *rgb_out, curvis_stats *stats, std::chrono::steady_clock::time_point t_begin) {
+  const uint32_t W = cams[0].res_x, H = cams[0].res_y;
+  const size_t npix = (size_t)W * H;
+  if (npix > 0xFFFFFFFFull || n_frames > 65535u) return fail(ctx, CURVIS_E_INVALID, "frame or batch too large");
+  /* the tables: prefetched by curvis_ctx_prefetch_efficient (either slot may hold them), or sampled now on this call's stream */
+  const int fast_i = ctx->fast_math != 0 ? 1 : 0, spec_i = ctx->sampling_speculation != 0 ? 1 : 0;
+  int slot = -1;
+  for (unsigned k = 0; k < 2u; ++k) /* both may match (every batch of an orbit has the same radii): the one submitted FIRST is the finished one */
+    if (ctx->samp[k].prefetched && sampler_key_equal(ctx->samp[k], *metric, cams, n_frames, max_iter, max_radius, delta, alpha_nums,
+                                                     max_iterations_sampling, thr1, thr2, fast_i, spec_i) &&
+        (slot < 0 || ctx->samp[k].seq < ctx->samp[slot].seq))
+      slot = (int)k;
+  const bool prefetched = slot >= 0;
+  int rc;
+  if (!prefetched) {
+    slot = (int)ctx->samp_next;
+    rc = sampler_submit(ctx, (unsigned)slot, ctx->stream, metric, MP, cams, n_frames, max_iter, max_radius, delta, alpha_nums,
+                        max_iterations_sampling, thr1, thr2);
+    if (rc) return rc;
+    ctx->samp[slot].prefetched = false;
+    ctx->samp_next = (unsigned)slot ^ 1u;
+  } else {
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->samp[slot].done, 0));
+    ctx->prefetch_hits++;
+  }
+  curvis_ctx::SamplerSlot &S = ctx->samp[slot];
+  S.prefetched = false; /* consumed (the tables stay readable until the slot is submitted to again) */
+  const unsigned n_jobs = (unsigned)S.l_job.size();
+  /* this call's own staging: cameras and per-frame constants */
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  const size_t o_cams = carve(sizeof(cvk::CameraParams) * n_frames), o_fr = carve(sizeof(cvk::EfficientFrame) * n_frames);
+  rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, off);
+  if (rc) return rc;
+  if (ctx->h_eff_cap < off) {
+    if (ctx->h_eff) HIP_TRY(ctx, hipHostFree(ctx->h_eff));
+    ctx->h_eff = nullptr;
+    ctx->h_eff_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_eff, off + off / 2));
+    ctx->h_eff_cap = off + off / 2;
+  }
+  unsigned char *stage = ctx->h_eff;
+  {
+    auto *cp = reinterpret_cast<cvk::CameraParams *>(stage + o_cams);
+    for (uint32_t f = 0; f < n_frames; ++f) cp[f] = make_camera(cams[f]);
+    std::memcpy(stage + o_fr, eframes.data(), sizeof(cvk::EfficientFrame) * n_frames);
+  }
+  const size_t fb_bytes = npix * 3 * n_frames;
+  rc = fb_begin_write(ctx, fb_bytes);
+  if (rc) return rc;
+  ctx->fb_bytes = fb_bytes;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_eff, stage, off, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   FrameCounters FC;
   rc = prepare_counters(ctx, n_frames, FC, 64u);
@@ -237,13 +355,13 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   }
   Q.cams = (const cvk::CameraParams *)(ctx->d_eff + o_cams);
   Q.frames = (const cvk::EfficientFrame *)(ctx->d_eff + o_fr);
-  Q.tab_off = (const unsigned *)(ctx->d_eff + o_to);
-  Q.tab_n = SP.tab_n;
-  Q.sx = SP.sx;
-  Q.m_e = SP.m_e;
-  Q.c_e = SP.c_e;
-  Q.m_s = SP.m_s;
-  Q.c_s = SP.c_s;
+  Q.tab_off = (const unsigned *)(S.d + S.o_tab_off);
+  Q.tab_n = (const unsigned *)(S.d + S.o_tab_n);
+  Q.sx = (const double *)(S.d + S.o_tab[0]);
+  Q.m_e = (const double *)(S.d + S.o_tab[3]);
+  Q.c_e = (const double *)(S.d + S.o_tab[4]);
+  Q.m_s = (const double *)(S.d + S.o_tab[5]);
+  Q.c_s = (const double *)(S.d + S.o_tab[6]);
   Q.n_frames = n_frames;
   Q.W = W;
   Q.H = H;
@@ -253,9 +371,8 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words, hipMemcpyDeviceToHost, ctx->stream));
-  auto *h_res = reinterpret_cast<const cvk::SamplerResult *>(stage + staged);
-  HIP_TRY(ctx, hipMemcpyAsync(stage + staged, ctx->d_eff + o_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* the statuses decide whether the frames may leave */
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* (behind the sampler's event: its results are in S.h) */
+  auto *h_res = reinterpret_cast<const cvk::SamplerResult *>(S.h + S.h_res_off);
   bool overflow = false, panic = false;
   for (unsigned j = 0; j < n_jobs; ++j) {
     overflow = overflow || h_res[j].status == cvk::SAMPLER_OVERFLOW;
@@ -264,18 +381,20 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   if (getenv("CURVIS_DEBUG_TIMING"))
     for (unsigned j = 0; j < n_jobs; ++j)
       fprintf(stderr, "[curvis] device sampler job %u: l = %.17g -> %u samples, %u rounds, %llu calls, %llu steps, warned %d, status %d; "
-              "%u Euler chains, %u points integrated\n", j, l_job[j], h_res[j].n, h_res[j].rounds, (unsigned long long)h_res[j].calls,
-              (unsigned long long)h_res[j].steps, h_res[j].warned, h_res[j].status, h_res[j].eval_phases, h_res[j].evaluated);
+              "%u Euler chains, %u points integrated%s\n", j, S.l_job[j], h_res[j].n, h_res[j].rounds, (unsigned long long)h_res[j].calls,
+              (unsigned long long)h_res[j].steps, h_res[j].warned, h_res[j].status, h_res[j].eval_phases, h_res[j].evaluated,
+              prefetched ? " (prefetched)" : "");
   if (overflow) return kSamplerFallback;
   float sample_ms = 0.f, ms = 0.f;
-  HIP_TRY(ctx, hipEventElapsedTime(&sample_ms, ctx->ev0, ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(&sample_ms, S.t0, S.t1)); /* the sampler kernel, wherever and whenever it ran */
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev1, ctx->ev2));
   ctx->last_sampling_launches = 1;
+  ctx->last_sampling_prefetched = prefetched ? 1 : 0;
   uint64_t total_steps = 0, evaluated = 0;
   ctx->last_samples.assign(n_frames, {});
   ctx->last_sampling_info.assign(n_frames, curvis_sampling_info{});
   for (uint32_t f = 0; f < n_frames; ++f) {
-    const cvk::SamplerResult &r = h_res[job_of_frame[f]];
+    const cvk::SamplerResult &r = h_res[S.job_of_frame[f]];
     curvis_sampling_info &si = ctx->last_sampling_info[f];
     si.n_samples = r.n;
     si.rounds = r.rounds;
@@ -292,10 +411,7 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   ctx->last_sampling_evaluated = evaluated;
   ctx->last_sampling_chains = chains; /* Euler chains the slowest job waited for: what the launch's latency is made of */
   ctx->dev_samples.valid = !panic;
-  ctx->dev_samples.job_of_frame = job_of_frame;
-  ctx->dev_samples.off_a = o_tab[0];
-  ctx->dev_samples.off_e = o_tab[1];
-  ctx->dev_samples.off_s = o_tab[2];
+  ctx->dev_samples.slot = (unsigned)slot;
   if (panic)
     return fail(ctx, CURVIS_E_SAMPLING,
                 "sampler panic: fewer than 3 finite samples (src/sampling.rs:155-157) or undefined tangent rotation "
@@ -340,14 +456,16 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
 /* the sample table of frame `frame` of the last render_efficient call that used the device-resident sampler: fetched from the
  * context's scratch on demand (curvis_ctx_samples), once per frame asked for */
 int fetch_device_samples(curvis_ctx *ctx, uint32_t frame) {
-  if (!ctx->dev_samples.valid || frame >= ctx->dev_samples.job_of_frame.size()) return CURVIS_OK;
+  if (!ctx->dev_samples.valid) return CURVIS_OK;
+  const curvis_ctx::SamplerSlot &S = ctx->samp[ctx->dev_samples.slot];
+  if (frame >= S.job_of_frame.size() || frame >= ctx->last_samples.size()) return CURVIS_OK;
   if (!ctx->last_samples[frame].empty() || ctx->last_sampling_info[frame].n_samples == 0) return CURVIS_OK;
-  const size_t n = ctx->last_sampling_info[frame].n_samples, o = (size_t)ctx->dev_samples.job_of_frame[frame] * cvk::kSamplerCap * sizeof(double);
+  const size_t n = ctx->last_sampling_info[frame].n_samples, o = (size_t)S.job_of_frame[frame] * cvk::kSamplerCap * sizeof(double);
   std::vector<double> a(n), e(n), s(n);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemcpy(a.data(), ctx->d_eff + ctx->dev_samples.off_a + o, n * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(e.data(), ctx->d_eff + ctx->dev_samples.off_e + o, n * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(s.data(), ctx->d_eff + ctx->dev_samples.off_s + o, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(a.data(), S.d + S.o_tab[0] + o, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(e.data(), S.d + S.o_tab[1] + o, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(s.data(), S.d + S.o_tab[2] + o, n * sizeof(double), hipMemcpyDeviceToHost));
   auto &pts = ctx->last_samples[frame];
   pts.resize(n);
   for (size_t i = 0; i < n; ++i) pts[i] = cvs::BiPoint{a[i], e[i], s[i]};

@@ -232,6 +232,15 @@ curvis_ctx *make_ctx(int device, const Common &c, const char *what) {
   return ctx;
 }
 
+/* the sampler of a batch that render_frames will render later, started now (efficient mode; curvis_ctx_prefetch_efficient is a
+ * no-op where the library would not sample on the device).  Failures are not fatal: the render call then samples itself. */
+void prefetch_frames(curvis_ctx *ctx, const Args &a, const Common &c, const curvis_camera *cams, uint32_t n, double thr2) {
+  if (a.mode != "efficient" || n == 0) return;
+  (void)curvis_ctx_prefetch_efficient(ctx, &c.metric, cams, n, c.sim.ray_integration_max_itarations, c.sim.escape_radius,
+                                      c.sim.ray_integration_step, c.sim.sampling_initial_nums, c.sim.sampling_initial_nums,
+                                      c.sim.sampling_convergence_threshold_1, thr2);
+}
+
 /* per-frame statistics of the last render_frames call of this thread in "direct" mode (one render call per frame there;
  * the batch calls of the other modes keep theirs inside the context: curvis_ctx_frame_stats) */
 thread_local std::vector<curvis_stats> g_direct_frame_stats;

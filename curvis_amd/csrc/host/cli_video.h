@@ -91,6 +91,7 @@ int video_main(const Args &a_in) {
     double render_s = 0, kernel_ms = 0, submit_s = 0, wait_s = 0, busy_s = 0, pool_wait_s = 0;
     double png_ms = 0; /* device PNG front end: HIP-event time of its kernels */
     size_t png_frames = 0, png_fallback_frames = 0, png_regrown = 0; /* png_regrown: batches whose streams needed a larger buffer */
+    long long prefetches = 0, prefetch_hits = 0; /* efficient mode: samplers started ahead of their render call / found ready by it */
     double sky_s = 0, sky_bcast_s = 0; /* skies into this device's HBM: all of it / the curvis_ctx_bcast_skies call alone */
     unsigned long long steps = 0;
   };
@@ -102,18 +103,20 @@ int video_main(const Args &a_in) {
      * frames: 240 / 960 / 2 400 / 6 000 1080p frames on one GPU took 0.63 / 0.91 / 1.36 / 2.46 s with one context, 0.64 / 0.77 /
      * 1.11 / 1.76 s with two, 0.71 / 0.85 / 1.04 / 1.50 s with four (profiles/round5_cli_startup.txt) */
     const size_t per_device = (n_frames + (size_t)a.devices - 1) / (size_t)a.devices;
-    /* round 6 (device-resident sampler, 128 frames per call): 3 / 4 / 6 contexts read 10 672 / 11 183 / 10 474 frames/s at 29 970
-     * frames -- four is the most that pays (profiles/round6_eff_contexts_sweep.txt) */
-    const int cap = per_device < 600 ? 1 : per_device < 2000 ? 2 : 4;
+    /* round 6 (device-resident sampler, 128 frames per call, the next call's sampler prefetched under this call's kernels): one
+     * context no longer waits for the host, and a second one is all that still pays -- 1 / 2 / 3 / 4 contexts read 8 605 / 11 632 /
+     * 10 509 / 11 343 frames/s on the orbit and 7 852 / 9 979 / - / 9 027 on the fly-through at 29 970 frames
+     * (profiles/round6_eff_contexts_sweep.txt) */
+    const int cap = per_device < 600 ? 1 : 2;
     a.contexts = std::min(a.contexts, cap);
   }
   if (batch_auto && a.mode == "efficient" && (n_frames + (size_t)a.devices - 1) / (size_t)a.devices >= 2000) {
     /* long videos: 128 frames per call.  From 48 frames on the library samples on the device (sampler_kernel: one launch per call,
-     * no host in the refinement loop), whose latency -- a handful of Euler chains, 5-10 ms -- is paid once per call however many
-     * frames share it: 29 970 frames at 64 / 128 / 256 per call read 3 949 / 6 352 / 7 188 frames/s with one context, 7 643 /
-     * 11 183 / 11 183 with four (round 5, host-paced sampler at 64 per call: 3 280 and 8 451).  The frames of a call sit together
-     * in HBM (128 x 6.2 MB at 1080p; 1 GB at most) next to the PNG front end's scratch (~10 MB per frame); the page-locked batch
-     * buffers are sized for streams, not pixels */
+     * no host in the refinement loop), whose latency -- a handful of Euler chains, 5-12 ms -- is paid once per call however many
+     * frames share it, and hidden altogether when the worker prefetches the next call's sampler (below): 29 970 frames at 64 / 128 /
+     * 256 per call read 5 809 / 7 852 / 7 906 frames/s on the fly-through and - / 8 605 / 8 644 on the orbit with one context
+     * (round 5, host-paced sampler at 64 per call: 3 280).  The frames of a call sit together in HBM (128 x 6.2 MB at 1080p; 1 GB at
+     * most) next to the PNG front end's scratch (~10 MB per frame); the page-locked batch buffers are sized for streams, not pixels */
     a.batch = (int)std::max<size_t>(4, std::min<size_t>(128, ((size_t)1 << 30) / std::max<size_t>(1, fbytes)));
   }
   const int n_workers = a.devices * a.contexts;
@@ -254,8 +257,11 @@ int video_main(const Args &a_in) {
     }
     wmark("page-locked buffers");
     int calls = 0;
+    size_t prefetched_first = (size_t)-1; /* first frame of the batch whose sampler is already in flight (curvis_ctx_prefetch_efficient) */
+    std::vector<curvis_camera> pc;
     for (;;) {
       Batch b;
+      pc.clear();
       {
         std::unique_lock<std::mutex> g(q_mu);
         for (;;) {
@@ -264,6 +270,11 @@ int video_main(const Args &a_in) {
             q_cv.notify_all(); /* nobody may sleep on while the others leave */
             ds.busy_s = pngio::now_s() - t_worker0;
             wmark("last batch done");
+            {
+              int64_t v = 0;
+              if (curvis_ctx_get_option(ctx, "prefetches", &v) == CURVIS_OK) ds.prefetches = v;
+              if (curvis_ctx_get_option(ctx, "prefetch_hits", &v) == CURVIS_OK) ds.prefetch_hits = v;
+            }
             curvis_ctx_destroy(ctx);
             wmark("context destroyed");
             return;
@@ -292,6 +303,22 @@ int video_main(const Args &a_in) {
       const size_t nb = b.frames.size();
       bc.clear();
       for (size_t j = 0; j < nb; ++j) bc.push_back(cams[b.frames[j]]);
+      /* efficient mode: the sampler of the batch this worker takes NEXT starts now, on a stream of its own -- it runs under this
+       * batch's per-pixel kernel, PNG front end, stream download and hand-over, and its render call finds the tables ready */
+      if (a.mode == "efficient") {
+        {
+          std::lock_guard<std::mutex> g(q_mu);
+          if (!own[(size_t)rank].empty() && own[(size_t)rank].front().frames[0] != prefetched_first) {
+            const Batch &nx = own[(size_t)rank].front();
+            for (size_t j = 0; j < nx.frames.size(); ++j) pc.push_back(cams[nx.frames[j]]);
+            prefetched_first = nx.frames[0];
+          }
+        }
+        /* the worker's very first batch goes first: batches whose cameras share their radii (an orbit) have equal keys, a render call
+         * takes the OLDEST matching prefetch, and only a pipeline primed this way keeps it one batch ahead of the one in flight */
+        if (calls == 0 && !pc.empty()) prefetch_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1);
+        if (!pc.empty()) prefetch_frames(ctx, a, c, pc.data(), (uint32_t)pc.size(), c.sim.sampling_convergence_threshold_1);
+      }
       std::shared_ptr<uint8_t> batch_buf;
       uint8_t *rgb_ptr = nullptr;
       if (pool.buffers() >= 2) batch_buf = pool.take(&ds.pool_wait_s);
@@ -529,10 +556,11 @@ int video_main(const Args &a_in) {
                     "%s{\"device\": %zu, \"pci_bus_id\": \"%s\", \"frames\": %zu, \"batches\": %zu, \"kernel_ms_per_frame\": %.4f, "
                     "\"render_call_ms_per_frame\": %.4f, \"frames_per_s\": %.2f, \"mray_steps_per_s\": %.1f, \"sclk_mhz\": %d, \"power_w\": %d, "
                     "\"wait_s\": %.3f, \"hand_over_s\": %.3f, \"buffer_wait_s\": %.3f, \"busy_s\": %.3f, \"gpu_png_frames\": %zu, "
-                    "\"gpu_png_kernel_ms_per_frame\": %.4f, \"gpu_png_fallback_frames\": %zu, \"gpu_png_buffer_regrown\": %zu}",
+                    "\"gpu_png_kernel_ms_per_frame\": %.4f, \"gpu_png_fallback_frames\": %zu, \"gpu_png_buffer_regrown\": %zu, "
+                    "\"sampler_prefetches\": %lld, \"sampler_prefetch_hits\": %lld}",
                     r ? ", " : "", (size_t)device_of((int)r), d.pci_bus_id.c_str(), d.frames, d.batches, kf, rf, d.busy_s > 0 ? d.frames / d.busy_s : 0.0,
                     d.kernel_ms > 0 ? (double)d.steps / d.kernel_ms / 1e3 : 0.0, d.sclk_mhz, d.power_w, d.wait_s, d.submit_s, d.pool_wait_s, d.busy_s,
-                    d.png_frames, d.png_frames ? d.png_ms / d.png_frames : 0.0, d.png_fallback_frames, d.png_regrown);
+                    d.png_frames, d.png_frames ? d.png_ms / d.png_frames : 0.0, d.png_fallback_frames, d.png_regrown, d.prefetches, d.prefetch_hits);
       js += buf;
     }
     js += "]";

@@ -113,10 +113,32 @@ struct curvis_ctx {
                                         speculation, -1 = automatic: the device for calls of device_sampler_min_frames frames and more */
   int device_sampler_min_frames = 48; /* measured cross-over against the host-paced sampler: between 32 and 64 frames per call (profiles/round6_eff_device_sampler.txt) */
   int last_sampler_path = 0;         /* of the last render_efficient call: 0 host-paced, 1 device, 2 device -> fell back to the host (overflow) */
-  struct DevSamples {                /* where the tables of the last device-sampled call sit in d_eff (curvis_ctx_samples fetches on demand) */
-    bool valid = false;
+  /* device-resident sampler: two slots (device buffer + page-locked mirror each) that take turns -- a call samples into one on its own
+   * stream, or finds one filled ahead of time by curvis_ctx_prefetch_efficient on `sampler_stream`; the tables of the last render
+   * stay readable in their slot (curvis_ctx_samples) until that slot is submitted to again, i.e. for one more submission */
+  struct SamplerSlot {
+    bool valid = false, prefetched = false;
+    unsigned char *d = nullptr, *h = nullptr;
+    size_t d_cap = 0, h_cap = 0, res_bytes = 0, h_res_off = 0;
+    size_t o_tab_off = 0, o_tab_n = 0, o_res = 0, o_tab[7] = {0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
     std::vector<unsigned> job_of_frame;
-    size_t off_a = 0, off_e = 0, off_s = 0;
+    std::vector<double> l_job, l_frame;
+    /* what the tables depend on */
+    curvis_metric metric{};
+    uint32_t n_frames = 0, max_iter = 0, alpha_nums = 0, max_iterations_sampling = 0;
+    double params[4] = {0, 0, 0, 0};
+    int fast = 0, speculate = 0;
+    uint64_t seq = 0; /* order of submission */
+  } samp[2];
+  unsigned samp_next = 0;
+  uint64_t samp_seq = 0;
+  hipStream_t sampler_stream = nullptr;
+  uint64_t prefetches = 0, prefetch_hits = 0;
+  int last_sampling_prefetched = 0;
+  struct DevSamples {                /* which slot holds the tables of the last device-sampled call (curvis_ctx_samples fetches on demand) */
+    bool valid = false;
+    unsigned slot = 0;
   } dev_samples;
   uint32_t last_sampling_chains = 0; /* device sampler: Euler chains (rounds that had to integrate) of the slowest job of the last call */
   uint32_t last_sampling_launches = 0;

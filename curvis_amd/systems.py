@@ -511,6 +511,16 @@ class Context:
             rgb = rgb[0]
         return rgb, st
 
+    def prefetch_efficient(self, metric, cameras, max_iterations_propagation, max_radius, delta, alpha_nums, max_iterations_sampling,
+                           thr1, thr2):
+        """curvis_ctx_prefetch_efficient: launch the sampler of a FUTURE render_efficient call (same metric, settings and camera
+        radii) now, on a stream of its own; returns at once.  The render call then finds its tables ready."""
+        cams = [cameras] if isinstance(cameras, Camera) else list(cameras)
+        arr = (CameraC * len(cams))(*[c._c for c in cams])
+        m = metric._c()
+        check(lib().curvis_ctx_prefetch_efficient(self._h, C.byref(m), arr, len(cams), max_iterations_propagation, max_radius, delta,
+                                                  alpha_nums, max_iterations_sampling, thr1, thr2), self._h)
+
     def render_direct(self, metric, camera, max_iterations, max_radius, delta, download=True, out=None):
         """"direct" mode (not in the reference): compute_escape_angle for the alpha of every pixel instead of sampling and
         interpolating (curvis_render_direct).  Returns (rgb or None, stats)."""

@@ -228,6 +228,22 @@ int curvis_render_efficient_batch(curvis_ctx *ctx, const curvis_metric *metric, 
                                   double delta, uint32_t alpha_nums, uint32_t max_iterations_sampling,
                                   double sampling_convergence_threshold_1, double sampling_convergence_threshold_2,
                                   uint8_t *rgb_out, curvis_stats *stats);
+/* The sampler of a FUTURE curvis_render_efficient_batch call, launched NOW on a stream of its own (device-resident sampler:
+ * option "device_sampler").  Returns at once.  The render call with the same metric, settings and camera radii (the l of every
+ * frame, in order) then finds its sample tables ready -- it waits for the sampler's event on its own stream instead of sampling --
+ * so that a caller rendering batch after batch hides the sampler's latency (a handful of ~2000-step Euler chains on a few
+ * compute units) under the previous batch's per-pixel kernel, PNG front end and host work:
+ *     prefetch(batch 0); for k: { prefetch(batch k + 1); render(batch k); deflate / download(batch k); }
+ * A prefetch nobody consumes costs its kernel and is overwritten by the second prefetch after it (two slots).  Settings the
+ * device sampler does not take (alpha_nums beyond its arrays, a camera beyond max_radius) make this a no-op: the render call
+ * deals with them.  Identical results with and without; read-only options "prefetches", "prefetch_hits",
+ * "last_sampling_prefetched".  Reference seam: none -- the reference samples inside render_image_efficient
+ * (src/systems.rs:437-486); this only moves WHEN the same sampling runs. */
+int curvis_ctx_prefetch_efficient(curvis_ctx *ctx, const curvis_metric *metric, const curvis_camera *cameras, uint32_t n_frames,
+                                  uint32_t max_iterations_propagation, double max_radius, double delta, uint32_t alpha_nums,
+                                  uint32_t max_iterations_sampling, double sampling_convergence_threshold_1,
+                                  double sampling_convergence_threshold_2);
+
 /* "direct" mode -- NOT a function of the reference (SURVEY.md 8f N1 names it as an option): the image that
  * render_image_efficient approximates by adaptive sampling + linear interpolation, computed without either:
  * compute_escape_angle (src/systems.rs:203-261) is evaluated for the alpha of EVERY pixel (:405-433) and step 5

@@ -1021,3 +1021,49 @@ def test_device_resident_sampler_equals_the_host_paced_sampler(gpu_ctx):
     finally:
         gpu_ctx.set_option("device_sampler", -1)
         gpu_ctx.set_option("fast_math", 1)
+
+
+def test_prefetched_sampler_gives_the_same_call(gpu_ctx):
+    """curvis_ctx_prefetch_efficient: the sampler of a future render call launched ahead of time on its own stream.  The call that
+    matches (metric, settings, the l of every frame) consumes the prefetched tables -- same frames, tables, counts as a call that
+    samples itself --; one that does not match samples itself; batches in flight take turns in two slots."""
+    sp, sn = common.make_skies(512, 256, "check")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    res = (96, 54)
+    inter = curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0)
+
+    def batch(k):
+        return [curvis_amd.Camera((0.0, -3.0 + 0.37 * (4 * k + j), common.HALF_PI, 0.2 * j), (1.0, 0.1, 0.0), (0.0, 0.0, 1.0), 15.0, 43.0, res[0], res[1])
+                for j in range(4)]
+    args = (8192, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+    gpu_ctx.set_option("device_sampler", 1)
+    try:
+        plain = [_efficient_call(gpu_ctx, inter, batch(k), 8192, 100, 100, 1e-5, 1e-5) for k in range(3)]
+        assert gpu_ctx.get_option("last_sampling_prefetched") == 0
+        hits0 = gpu_ctx.get_option("prefetch_hits")
+        # the loop of a video worker: the next batch's sampler is in flight while this batch renders
+        gpu_ctx.prefetch_efficient(inter, batch(0), *args)
+        got = []
+        for k in range(3):
+            if k + 1 < 3:
+                gpu_ctx.prefetch_efficient(inter, batch(k + 1), *args)
+            got.append(_efficient_call(gpu_ctx, inter, batch(k), 8192, 100, 100, 1e-5, 1e-5))
+            assert gpu_ctx.get_option("last_sampling_prefetched") == 1 and gpu_ctx.get_option("last_sampler_path") == 1
+        assert gpu_ctx.get_option("prefetch_hits") == hits0 + 3 and got == plain
+        # a prefetch for other cameras / other settings is not taken; the call samples itself and is still right
+        gpu_ctx.prefetch_efficient(inter, batch(1), *args)
+        assert _efficient_call(gpu_ctx, inter, batch(0), 8192, 100, 100, 1e-5, 1e-5) == plain[0] and gpu_ctx.get_option("last_sampling_prefetched") == 0
+        gpu_ctx.prefetch_efficient(inter, batch(2), 8192, 100.0, 0.05, 100, 100, 1e-5, 2e-5)
+        assert _efficient_call(gpu_ctx, inter, batch(2), 8192, 100, 100, 1e-5, 1e-5) == plain[2] and gpu_ctx.get_option("last_sampling_prefetched") == 0
+        # ... and the still-pending prefetch of batch 1 (two slots) is taken by its call
+        gpu_ctx.prefetch_efficient(inter, batch(1), *args)
+        assert _efficient_call(gpu_ctx, inter, batch(1), 8192, 100, 100, 1e-5, 1e-5) == plain[1] and gpu_ctx.get_option("last_sampling_prefetched") == 1
+        # a context destroyed with a prefetch in flight
+        c2 = curvis_amd.Context(0)
+        c2.set_sky(0, curvis_amd.SphericalImage(sp))
+        c2.set_sky(1, curvis_amd.SphericalImage(sn))
+        c2.prefetch_efficient(inter, batch(0), *args)
+        c2.close()
+    finally:
+        gpu_ctx.set_option("device_sampler", -1)

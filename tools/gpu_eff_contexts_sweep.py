@@ -46,23 +46,37 @@ def main():
     open(sim, "w").write("escape_radius = 100.0\nray_integration_max_itarations = 4096\nray_integration_step = 0.05\nsampling_initial_nums = 100\n"
                          "sampling_max_iterations = 50\nsampling_convergence_threshold_1 = 1e-5\nsampling_convergence_threshold_2 = 1e-5\n")
     open(cam, "w").write("resolution_x = 1920\nresolution_y = 1080\ndiagonal = 43.0\nfocal_length = 15.0\n")
-    open(vid, "w").write('video_name = "v"\nframe_rate = %r\nfilepath_to_camera_path = "%s"\n' % (fps, refpaths.reference_path_file("path_orbit.csv")))
-    print("# curvis video --mode %s, 1920x1080, path_orbit.csv at %g fps, ONE MI355X, device PNG front end, 16 writer threads, output in %s" % (mode, fps, d))
+    # SWEEP_PATH=through: configs[4]'s poses (path_through.csv, Interstellar metric, cap 8192: every frame its own camera radius, i.e. one
+    # sampler job per frame) instead of configs[3]'s orbit (every frame l = 3: the frames of a call share one job); 20 s of path
+    through = os.environ.get("SWEEP_PATH", "orbit") == "through"
+    extra = []
+    if through:
+        if "SWEEP_FPS" not in os.environ:
+            fps = 1500.0
+        met = os.path.join(d, "met.toml")
+        open(met, "w").write("m = 0.1\na = 0.0001\nrho = 1.0\n")
+        text = open(sim).read().replace("ray_integration_max_itarations = 4096", "ray_integration_max_itarations = 8192")
+        open(sim, "w").write(text)
+        extra = ["-m", met]
+    open(vid, "w").write('video_name = "v"\nframe_rate = %r\nfilepath_to_camera_path = "%s"\n' % (
+        fps, refpaths.reference_path_file("path_through.csv" if through else "path_orbit.csv")))
+    print("# curvis video --mode %s, 1920x1080, %s at %g fps, ONE MI355X, device PNG front end, 16 writer threads, output in %s" % (mode, "path_through.csv (Interstellar, cap 8192)" if through else "path_orbit.csv", fps, d))
     print("# host: %d logical CPUs visible, cgroup CPU quota %s; %d interleaved rounds over the %d cells" % (os.cpu_count(), V.cpu_quota(), rounds, len(CELLS)))
     res = {cell: [] for cell in CELLS}
     for rnd in range(rounds):
         for (c, b) in CELLS:
             s = V.run(d, "c%d_b%d_r%d" % (c, b, rnd), sky, vid, cam, sim,
-                      ["--gpu-png", "on", "--writers", os.environ.get("SWEEP_WRITERS", "16"), "--contexts-per-device", str(c), "--batch", str(b)], None, mode=mode)
+                      ["--gpu-png", "on", "--writers", os.environ.get("SWEEP_WRITERS", "16"), "--contexts-per-device", str(c), "--batch", str(b)] + extra, None, mode=mode)
             if not s:
                 continue
             dv = s["devices"]
             res[(c, b)].append(s["frames_per_s"])
             print("round %d  C=%d batch=%-3d %8.1f frames/s (wall %6.2f s, %d frames) | render kernels %.3f ms/frame + PNG kernels %.3f | render(+deflate) call %.3f | "
-                  "buffer waits %.2f s, writer drain %.2f s" % (
+                  "buffer waits %.2f s, writer drain %.2f s | samplers prefetched %d, found ready %d" % (
                       rnd, c, b, s["frames_per_s"], s["wall_s"], s["frames"], np.mean([x["kernel_ms_per_frame"] for x in dv]),
                       np.mean([x.get("gpu_png_kernel_ms_per_frame", 0.0) for x in dv]), np.mean([x["render_call_ms_per_frame"] for x in dv]),
-                      sum(x["buffer_wait_s"] for x in dv), s["writer_drain_s"]), flush=True)
+                      sum(x["buffer_wait_s"] for x in dv), s["writer_drain_s"], sum(x.get("sampler_prefetches", 0) for x in dv),
+                      sum(x.get("sampler_prefetch_hits", 0) for x in dv)), flush=True)
     print("\n| contexts per GPU | " + " | ".join("batch %d" % b for b in BS) + " |")
     print("|---|" + "---|" * len(BS))
     for c in CS:
