@@ -284,6 +284,14 @@ class VideoRenderingSystem:
                                              getattr(self, "max_iterations_sampling", self.sampling_initial_nums), thr1, thr1,
                                              download=download)
 
+    def _prefetch(self, cams):
+        """the sampler of a batch that _render_batch will render later, started now on a stream of its own (a no-op where the library
+        would not sample on the device: brute mode, small batches, contexts without the entry point such as the tests' stubs)"""
+        if cams and self.mode != "brute" and hasattr(self.context, "prefetch_efficient"):
+            thr1 = self.sampling_convergence_threshold_1
+            self.context.prefetch_efficient(self.metric, cams, self.max_iterations_propagation, self.escape_radius, self.ray_integration_step,
+                                            self.sampling_initial_nums, getattr(self, "max_iterations_sampling", self.sampling_initial_nums), thr1, thr1)
+
     def render(self, on_frame=None, download=True, streams=False):
         """Render this rank's shard, `batch` frames per launch.  on_frame(index, rgb_or_None, stats_dict) is
         called per frame in index order of the shard; with streams=True the frames stay in HBM and on_frame receives each
@@ -295,9 +303,14 @@ class VideoRenderingSystem:
         times = self.times_of_frames()
         mine = frames_of_rank(len(times), self.rank, self.world_size)
         out = []
-        for b0 in range(0, len(mine), self.batch):
-            idx = mine[b0:b0 + self.batch]
-            cams = [self.camera_at(times[k]) for k in idx]
+        batches = [mine[b0:b0 + self.batch] for b0 in range(0, len(mine), self.batch)]
+        cams_of = lambda idx: [self.camera_at(times[k]) for k in idx]  # noqa: E731
+        nxt = cams_of(batches[0]) if batches else None
+        self._prefetch(nxt)           # efficient mode: the first batch's sampler, then always one batch ahead (curvis_ctx_prefetch_efficient)
+        for bi, idx in enumerate(batches):
+            cams = nxt
+            nxt = cams_of(batches[bi + 1]) if bi + 1 < len(batches) else None
+            self._prefetch(nxt)
             rgb, st = self._render_batch(cams, download and not streams)
             frames = list(rgb) if (download and not streams) else [None] * len(cams)
             per = self.context.frame_stats()
