@@ -336,3 +336,46 @@ def test_fast_exit_drops_nothing_when_stdout_and_stats_are_pipes(scene_files, mo
         got[how] = (len(lines), [(x["frame"], x["rays"], x["steps"], x["n_pos"], x["n_neg"], x["n_none"]) for x in recs], frames)
     assert got["fast"][0] == got["slow"][0] and got["fast"][1] == got["slow"][1]
     assert all(np.array_equal(a, b) for a, b in zip(got["fast"][2], got["slow"][2]))
+
+
+@pytest.mark.parametrize("video", ["through", "orbit"])
+def test_video_efficient_with_the_device_sampler_prefetched(scene_files, video):
+    """`curvis video` in the reference's default mode at the operating point of a long video: 64 frames per call -> the device-resident
+    sampler (sampler_kernel), the next call's sampler prefetched under the current call (curvis_ctx_prefetch_efficient), one and two
+    worker contexts.  The fly-through (Interstellar: every frame its own camera radius, one sampler job per frame) and the orbit (all
+    frames l = 3: the batches have EQUAL keys, the oldest matching prefetch must be the one taken).  Every 8th frame against the
+    oracle's render_image_efficient; the binary's summary says that every call after a worker's first found its sampler ready."""
+    d, sp, sn = scene_files
+    csv = refpaths.reference_path_file("path_%s.csv" % video)
+    it = rendering.Interpolator.from_file(csv)
+    fps = 288 / (it.max_time() - it.min_time())
+    times = rendering.times_of_frames(it.min_time(), it.max_time(), fps)
+    n = len(times)
+    assert 286 <= n <= 289
+    om = O.interstellar(0.1, 1e-4, 1.0) if video == "through" else O.ellis(1.0)
+    cap = 8192 if video == "through" else 4096
+    (d / "vid_dev.toml").write_text('video_name = "v"\nframe_rate = %r\nfilepath_to_camera_path = "%s"\n' % (fps, csv))
+    (d / "sim_dev.toml").write_text(SIM.replace("ray_integration_max_itarations = 4096", "ray_integration_max_itarations = %d" % cap))
+    want = {}
+    for contexts in (1, 2):
+        out = d / ("out_dev_%s_%d" % (video, contexts))
+        out.mkdir()
+        args = ["video", d / "pos.png", d / "neg.png", out, "-v", d / "vid_dev.toml", "-s", d / "sim_dev.toml", "-c", d / "cam.toml",
+                "--batch", "64", "--contexts-per-device", contexts, "--stats", out / "st.jsonl"]
+        if video == "through":
+            args += ["-m", d / "met.toml"]
+        # (device_sampler = 1: the last, short batch of a worker would otherwise fall under the library's 48-frame threshold)
+        r = run(*args, env=dict(os.environ, CURVIS_CTX_OPTIONS="device_sampler=1"))
+        assert r.returncode in (0, 101), r.stderr[-2000:]       # 101: the reference's own off-by-one at the end of a path
+        files = [f for f in os.listdir(out / "tmp") if f.endswith(".png")]
+        assert len(files) >= n - 3
+        for k in range(0, len(files), 8):
+            if k not in want:
+                oc = O.camera(tuple(it.camera_position(times[k])), tuple(it.camera_forward(times[k])), tuple(it.camera_up(times[k])), 15.0, 43.0, (96, 54))
+                want[k] = O.render_image_efficient(O.CV, om, oc, O.sky(sp), O.sky(sn), cap, 100.0, 0.05, 100, 100, 1e-5, 1e-5)[0]
+            assert np.array_equal(pngio.read_png(out / "tmp" / ("frame_%d.png" % k)), want[k]), (video, contexts, k)
+        summ = json.loads((out / "st.jsonl.summary.json").read_text())
+        devs = summ["devices"]
+        assert len(devs) == contexts
+        for dv in devs:       # a worker with b batches prefetches its first and every following one (b), and every call finds one ready
+            assert dv["batches"] >= 2 and dv["sampler_prefetches"] == dv["batches"] and dv["sampler_prefetch_hits"] == dv["batches"], dv
