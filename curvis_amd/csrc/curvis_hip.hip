@@ -142,6 +142,7 @@ void curvis_ctx_destroy(curvis_ctx *ctx) {
   if (ctx->d_fb_alt) (void)hipFree(ctx->d_fb_alt);
   if (ctx->ev_fb) (void)hipEventDestroy(ctx->ev_fb);
   if (ctx->ev_dl) (void)hipEventDestroy(ctx->ev_dl);
+  if (ctx->ev_streams) (void)hipEventDestroy(ctx->ev_streams);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
   if (ctx->d_store) (void)hipFree(ctx->d_store);
@@ -910,6 +911,13 @@ int curvis_ctx_set_option(curvis_ctx *ctx, const char *key, int64_t value) {
       if (rc) return rc;
     }
     ctx->async_download = value ? 1 : 0;
+  } else if (k == "async_streams") { /* curvis_ctx_deflate_frames returns with its streams still on their way: png_host.h */
+    if (!value) {
+      HIP_TRY(ctx, hipSetDevice(ctx->device));
+      const int rc = download_wait(ctx);
+      if (rc) return rc;
+    }
+    ctx->async_streams = value ? 1 : 0;
   } else if (k == "relay_max_frames")
     ctx->relay_max_frames = (int)value;
   else if (k == "relay_min_blocks")
@@ -984,6 +992,10 @@ int curvis_ctx_get_option(const curvis_ctx *ctx, const char *key, int64_t *value
     *value = ctx->relay_recheck_every;
   else if (k == "async_download")
     *value = ctx->async_download;
+  else if (k == "async_streams")
+    *value = ctx->async_streams;
+  else if (k == "streams_pending")
+    *value = ctx->streams_pending ? 1 : 0;
   else if (k == "downloads_overlapped")
     *value = (int64_t)ctx->downloads_overlapped;
   else if (k == "download_pending")

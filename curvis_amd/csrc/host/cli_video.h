@@ -256,6 +256,23 @@ int video_main(const Args &a_in) {
       std::fprintf(stderr, "warning: device %d: no page-locked host memory for the frame buffers, using pageable memory\n", device_of(rank));
     }
     wmark("page-locked buffers");
+    /* the zlib streams of a batch travel to its (page-locked) buffer while the NEXT batch renders (option "async_streams"): the
+     * writer jobs of that batch are held back here and handed to the pool once the copy engine is done -- right after the next
+     * render call has returned, or before this thread leaves.  (Held back, not submitted to wait on a flag: the pool's queue is
+     * bounded, and a queue full of waiting jobs would block the very thread that has to raise the flag.) */
+    const bool async_streams = gpu_png && pool.buffers() >= 2 && !std::getenv("CURVIS_NO_ASYNC_STREAMS") &&
+                               curvis_ctx_set_option(ctx, "async_streams", 1) == CURVIS_OK;
+    std::vector<std::function<void()>> deferred;
+    auto settle = [&] {
+      if (deferred.empty()) return;
+      if (curvis_ctx_download_wait(ctx) != CURVIS_OK) {
+        std::lock_guard<std::mutex> gi(io_mu);
+        std::fprintf(stderr, "Error in rendering video: device %d: the frames' streams did not arrive: %s\n", device_of(rank), curvis_last_error(ctx));
+        failed = 1;
+      }
+      for (auto &job : deferred) writers.submit(std::move(job));
+      deferred.clear();
+    };
     int calls = 0;
     size_t prefetched_first = (size_t)-1; /* first frame of the batch whose sampler is already in flight (curvis_ctx_prefetch_efficient) */
     std::vector<curvis_camera> pc;
@@ -269,6 +286,7 @@ int video_main(const Args &a_in) {
             g.unlock();
             q_cv.notify_all(); /* nobody may sleep on while the others leave */
             ds.busy_s = pngio::now_s() - t_worker0;
+            settle();
             wmark("last batch done");
             {
               int64_t v = 0;
@@ -338,6 +356,7 @@ int video_main(const Args &a_in) {
       std::vector<uint32_t> zcrc;
       bool streams = false, have_crc = false; /* have_crc: the device also computed the PNG chunks' CRC-32 (two-pass front end) */
       int rc = render_frames(ctx, a, c, bc.data(), (uint32_t)nb, c.sim.sampling_convergence_threshold_1, gpu_png ? nullptr : rgb_ptr, &st);
+      settle(); /* the previous batch's streams had this call to arrive under */
       if (rc == CURVIS_OK && gpu_png) {
         zoff.resize(nb + 1);
         double pms = 0.0;
@@ -422,6 +441,8 @@ int video_main(const Args &a_in) {
         if (pw > 0) ds.power_w = pw;
       }
       const double t_s0 = pngio::now_s();
+      const bool hold_back = streams && async_streams && batch_buf; /* the streams are still on their way: see `deferred` above */
+      if (streams && async_streams && !batch_buf) (void)curvis_ctx_download_wait(ctx); /* pageable fall-back buffer: the jobs own copies made right here */
       for (size_t j = 0; j < nb; ++j) {
         const size_t k = b.frames[j];
         /* the writer job keeps the batch buffer alive and reads its frame in place; with pageable memory it owns a copy */
@@ -438,7 +459,7 @@ int video_main(const Args &a_in) {
         const double batch_ms = st.kernel_ms;
         const uint32_t frame_crc = streams && have_crc ? zcrc[j] : 0u;
         const bool frame_has_crc = streams && have_crc;
-        writers.submit([&, k, frame, f_len, streams, batch_buf, copy, fs, nb, rank, batch_ms, batch_call_ms, frame_crc, frame_has_crc] {
+        auto job = [&, k, frame, f_len, streams, batch_buf, copy, fs, nb, rank, batch_ms, batch_call_ms, frame_crc, frame_has_crc] {
           const std::string file = tmp + "/frame_" + std::to_string(k) + ".png";
           const std::string part = file + ".part"; /* written under another name, then renamed: --resume never sees half a file */
           std::string e;
@@ -480,7 +501,11 @@ int video_main(const Args &a_in) {
                          (unsigned long long)fs.n_pos, (unsigned long long)fs.n_neg, (unsigned long long)fs.n_none,
                          (unsigned long long)fs.n_oob, fs.kernel_ms, fs.kernel_ms > 0.0 ? (double)fs.steps / fs.kernel_ms / 1e3 : 0.0, nb,
                          batch_ms, batch_call_ms);
-        });
+        };
+        if (hold_back)
+          deferred.emplace_back(std::move(job));
+        else
+          writers.submit(std::move(job));
       }
       ds.submit_s += pngio::now_s() - t_s0; /* frame copies + time blocked on a full writer queue */
       {

@@ -48,6 +48,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <future>
 #include <thread>
 #include <vector>
 

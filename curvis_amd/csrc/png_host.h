@@ -91,6 +91,10 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   if (!ctx->d_fb || frame_bytes * n_frames > ctx->fb_bytes)
     return fail(ctx, CURVIS_E_INVALID, "the context's framebuffer does not hold that many frames of that size (render first)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->streams_pending) { /* the last call's streams are still being read out of the scratch this call is about to overwrite */
+    const int rcw = download_wait(ctx);
+    if (rcw) return rcw;
+  }
   PngParams P{};
   P.fb = ctx->d_fb;
   P.frame_bytes = frame_bytes;
@@ -248,16 +252,29 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
    * was too small can come back with a larger one instead of giving up on the device front end */
   ctx->last_png_stream_bytes = fits_scratch ? off : 0;
   if (!fits_scratch || off > out_cap) return fail(ctx, CURVIS_E_INVALID, "output buffer too small for the compressed frames");
+  /* option "async_streams": the copies go to the copy stream and this call returns without waiting for them -- everything the host
+   * still adds (the Adler-32 trailers behind the streams, the CRC-32 over them) needs the sums, not the bytes; the kernels are done
+   * (the stream was synchronised for the sizes above).  The bytes are there after curvis_ctx_download_wait. */
+  const bool async_out = ctx->async_streams != 0;
+  hipStream_t out_stream = ctx->stream;
+  if (async_out) {
+    const int rcs = ensure_copy_stream(ctx);
+    if (rcs) return rcs;
+    out_stream = ctx->copy_stream;
+  }
   for (uint32_t f = 0; f < n_frames; ++f)
     HIP_TRY(ctx, hipMemcpyAsync(out + offsets[f], (const uint8_t *)(P.out + (size_t)f * L.out_words), offsets[f + 1] - offsets[f] - 4,
-                                hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                                hipMemcpyDeviceToHost, out_stream));
+  if (async_out) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_streams, ctx->copy_stream));
+    ctx->streams_pending = true;
+  } else {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   const auto t_4 = tnow();
   const unsigned long long n = (unsigned long long)H * ((unsigned long long)W * 3 + 1);
   for (uint32_t f = 0; f < n_frames; ++f) {
-    uint8_t *z = out + offsets[f];
-    const size_t hb = (start_bit[f] + 7) / 8;
-    for (size_t k = 0; k < hb; ++k) z[k] |= header[f][k]; /* (png_offsets_kernel wrote them already; idempotent) */
+    /* (the zlib and block headers are already in the stream: png_offsets_kernel wrote them) */
     const unsigned long long s1 = (1ull + adler[(size_t)f * 2]) % 65521ull, s2 = (n % 65521ull + adler[(size_t)f * 2 + 1]) % 65521ull;
     uint8_t *a = out + offsets[f + 1] - 4;
     a[0] = (uint8_t)(s2 >> 8);

@@ -35,6 +35,11 @@ struct curvis_ctx {
   bool dl_pending = false;
   const unsigned char *dl_src = nullptr;       /* the device buffer the pending download reads */
   uint64_t downloads_overlapped = 0;           /* downloads queued behind the caller's back so far (option, read-only) */
+  /* option "async_streams": curvis_ctx_deflate_frames returns while its streams are still on their way to the caller's buffer (copy
+   * stream); they are there after curvis_ctx_download_wait, and before the next deflate call touches the scratch they are read from */
+  int async_streams = 0;
+  bool streams_pending = false;
+  hipEvent_t ev_streams = nullptr;
   curvis_ray_debug *d_dbg = nullptr;
   size_t dbg_cap = 0;
   unsigned char *d_store = nullptr; /* RayStore arrays, carved from one allocation */
@@ -185,10 +190,23 @@ int ensure_device(curvis_ctx *ctx, T *&ptr, size_t &cap, size_t need) {
  * after curvis_ctx_download_wait.  ctx->d_fb is always the buffer of the LAST render (what curvis_ctx_deflate_frames,
  * curvis_ctx_download and the seat belt read); only a call that is about to WRITE frames steps aside. */
 int download_wait(curvis_ctx *ctx) {
+  if (ctx->streams_pending) { /* option "async_streams": the zlib streams of the last deflate call */
+    ctx->streams_pending = false;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_streams));
+  }
   if (!ctx->dl_pending) return CURVIS_OK;
   ctx->dl_pending = false;
   ctx->dl_src = nullptr;
   HIP_TRY(ctx, hipEventSynchronize(ctx->ev_dl));
+  return CURVIS_OK;
+}
+int ensure_copy_stream(curvis_ctx *ctx) {
+  if (!ctx->copy_stream) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fb, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_dl, hipEventDisableTiming));
+  }
+  if (!ctx->ev_streams) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_streams, hipEventDisableTiming));
   return CURVIS_OK;
 }
 /* call before anything writes `bytes` of frames into ctx->d_fb */
@@ -207,10 +225,9 @@ int fb_download(curvis_ctx *ctx, unsigned char *rgb_out, size_t bytes) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CURVIS_OK;
   }
-  if (!ctx->copy_stream) {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fb, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_dl, hipEventDisableTiming));
+  {
+    const int rcs = ensure_copy_stream(ctx);
+    if (rcs) return rcs;
   }
   const int rc = download_wait(ctx); /* the previous call's: it had this call's kernels to hide under */
   if (rc) return rc;
