@@ -379,7 +379,20 @@ class Context:
         ms = C.c_double(0.0)
         check(lib().curvis_ctx_deflate_frames(self._h, int(width), int(height), int(n_frames), out.ctypes.data, out.size, offs,
                                               C.byref(ms)), self._h)
+        self.download_wait()  # option "async_streams": this wrapper hands out COPIES of the streams, which have to be there first
         return [out[offs[k]:offs[k + 1]].tobytes() for k in range(int(n_frames))], ms.value
+
+    def deflate_frames_into(self, width, height, n_frames, out):
+        """curvis_ctx_deflate_frames_crc straight into the caller's uint8 array (a HostBuffer's: page-locked), nothing copied: returns
+        (offsets [n_frames + 1], kernel ms, [crc, ...]).  With option "async_streams" = 1 the bytes may still be on their way when this
+        returns -- offsets, trailers' values and CRCs are final --; they are there after download_wait()."""
+        offs = (C.c_size_t * (int(n_frames) + 1))()
+        ms, valid = C.c_double(0.0), C.c_int(0)
+        crc = (C.c_uint32 * int(n_frames))()
+        check(lib().curvis_ctx_deflate_frames_crc(self._h, int(width), int(height), int(n_frames), out.ctypes.data, out.size, offs,
+                                                  C.byref(ms), crc, C.byref(valid)), self._h)
+        self._dl_keep = out
+        return list(offs), ms.value, list(crc)
 
     def deflate_frames_crc(self, width, height, n_frames=1, out=None):
         """curvis_ctx_deflate_frames_crc: as deflate_frames, plus the PNG chunk CRC-32 ("IDAT" + stream) of every frame computed
@@ -391,6 +404,7 @@ class Context:
         crc = (C.c_uint32 * int(n_frames))()
         check(lib().curvis_ctx_deflate_frames_crc(self._h, int(width), int(height), int(n_frames), out.ctypes.data, out.size, offs,
                                                   C.byref(ms), crc, C.byref(valid)), self._h)
+        self.download_wait()  # (option "async_streams": see deflate_frames)
         return [out[offs[k]:offs[k + 1]].tobytes() for k in range(int(n_frames))], ms.value, (list(crc) if valid.value else None)
 
     def set_option(self, key, value):

@@ -337,6 +337,15 @@ int curvis_ctx_download(curvis_ctx *ctx, uint8_t *rgb_out, size_t bytes);
  * curvis_ctx_deflate_frames then compresses */
 int curvis_ctx_upload(curvis_ctx *ctx, const uint8_t *rgb, size_t bytes);
 int curvis_ctx_synchronize(curvis_ctx *ctx);
+/* Overlapped stream download (option "async_streams" = 1, default 0): curvis_ctx_deflate_frames[_crc] returns while the frames'
+ * zlib streams are still travelling to `zlib_out` on the context's copy stream.  Offsets, the Adler-32 trailers (written by the
+ * host behind every stream: they need the sums, not the bytes) and the chunk CRCs are final on return; the stream bytes are
+ * there after curvis_ctx_download_wait -- call it before anything reads `zlib_out`, e.g. after the NEXT render call has
+ * returned, which is what the copy hides under (`curvis video`: one context 8 600 -> 10 600 frames/s).  The next deflate call
+ * waits by itself before it reuses the scratch the streams are read from; so does switching the option off and
+ * curvis_ctx_destroy.  `zlib_out` must stay valid until then (page-locked memory from curvis_host_alloc for a real overlap).
+ * Read-only option "streams_pending". */
+
 /* Overlapped download (option "async_download" = 1, default 0).  The reference's render_image returns an owned host
  * image (src/systems.rs:314-329), so a host that renders frame after frame pays the PCIe copy behind every kernel
  * (+0.25 ms on a 10.2 ms 1080p frame).  With the option set, a render call given `rgb_out` (brute, rows, batch, efficient,

@@ -276,3 +276,45 @@ def test_tokeniser_on_synthetic_contents(gpu_ctx, tmp_path, w, h):
         gpu_ctx.upload_frames(batch)
         again, _ = gpu_ctx.deflate_frames(w, h, len(frames))
         assert again == first
+
+
+def test_async_streams_option(gpu_ctx):
+    """option "async_streams": a deflate call returns with its streams still travelling to the caller's (page-locked) buffer -- offsets,
+    Adler-32 trailers and chunk CRCs are final on return, the bytes after curvis_ctx_download_wait --; the next deflate call waits
+    for them by itself before it reuses the scratch they are read from, and switching the option off waits too.  Same bytes as the
+    synchronous call."""
+    sp, sn = common.make_skies(2048, 1024, "smooth")
+    gpu_ctx.set_sky(0, curvis_amd.SphericalImage(sp))
+    gpu_ctx.set_sky(1, curvis_amd.SphericalImage(sn))
+    w, h, n = 1280, 720, 6
+    cams = []
+    for k in range(n):
+        _, _, pm, pc = common.scene("ellis", res=(w, h), pos=(0.0, 3.0 + k, common.HALF_PI, 0.4 * k))
+        cams.append(pc)
+    gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
+    want, _, want_crc = gpu_ctx.deflate_frames_crc(w, h, n)
+    buf = curvis_amd.HostBuffer(n * w * h * 3)
+    try:
+        gpu_ctx.set_option("async_streams", 1)
+        for rep in range(3):
+            buf.array[:] = 0xAB
+            offs, ms, crc = gpu_ctx.deflate_frames_into(w, h, n, buf.array)
+            assert gpu_ctx.get_option("streams_pending") == 1 and crc == want_crc and ms > 0
+            if rep == 0:
+                gpu_ctx.download_wait()
+            elif rep == 1:
+                gpu_ctx.render_efficient(pm, cams, 4096, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)   # a render call does not wait for them ...
+                assert gpu_ctx.get_option("streams_pending") == 1
+                other = curvis_amd.HostBuffer(n * w * h * 3)     # (kept alive until its own streams have arrived)
+                gpu_ctx.deflate_frames_into(w, h, n, other.array)                                               # ... the next deflate call does, before its own
+                gpu_ctx.download_wait()
+                other.close()
+            else:
+                gpu_ctx.set_option("async_streams", 0)                                                          # switching it off waits
+            assert gpu_ctx.get_option("streams_pending") == 0
+            got = [bytes(buf.array[offs[k]:offs[k + 1]]) for k in range(n)]
+            assert got == want, rep
+            assert all(zlib.crc32(b"IDAT" + z) == c for z, c in zip(got, crc))
+    finally:
+        gpu_ctx.set_option("async_streams", 0)
+        buf.close()
