@@ -287,6 +287,7 @@ class Context:
         self.device = device
         self._sky_objs = [None, None]  # strong refs: identity check must not suffer id() reuse
         self._async_download = False
+        self._async_streams = False
         self._dl_keep = None  # the array the last download went (or is still going) into: see _downloaded
 
     def close(self):
@@ -379,7 +380,8 @@ class Context:
         ms = C.c_double(0.0)
         check(lib().curvis_ctx_deflate_frames(self._h, int(width), int(height), int(n_frames), out.ctypes.data, out.size, offs,
                                               C.byref(ms)), self._h)
-        self.download_wait()  # option "async_streams": this wrapper hands out COPIES of the streams, which have to be there first
+        if self._async_streams:  # this wrapper hands out COPIES of the streams, which have to be there first
+            self.download_wait()
         return [out[offs[k]:offs[k + 1]].tobytes() for k in range(int(n_frames))], ms.value
 
     def deflate_frames_into(self, width, height, n_frames, out):
@@ -404,11 +406,14 @@ class Context:
         crc = (C.c_uint32 * int(n_frames))()
         check(lib().curvis_ctx_deflate_frames_crc(self._h, int(width), int(height), int(n_frames), out.ctypes.data, out.size, offs,
                                                   C.byref(ms), crc, C.byref(valid)), self._h)
-        self.download_wait()  # (option "async_streams": see deflate_frames)
+        if self._async_streams:  # (see deflate_frames)
+            self.download_wait()
         return [out[offs[k]:offs[k + 1]].tobytes() for k in range(int(n_frames))], ms.value, (list(crc) if valid.value else None)
 
     def set_option(self, key, value):
         check(lib().curvis_ctx_set_option(self._h, key.encode(), int(value)), self._h)
+        if key == "async_streams":
+            self._async_streams = bool(int(value))
         if key == "async_download":
             self._async_download = bool(int(value))
             if not self._async_download:
