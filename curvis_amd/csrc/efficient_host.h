@@ -136,6 +136,11 @@ int sampler_submit(curvis_ctx *ctx, unsigned slot, hipStream_t stream, const cur
                    const curvis_camera *cams, uint32_t n_frames, uint32_t max_iter, double max_radius, double delta, uint32_t alpha_nums,
                    uint32_t max_iterations_sampling, double thr1, double thr2) {
   curvis_ctx::SamplerSlot &S = ctx->samp[slot];
+  /* the slot's previous occupant may have been submitted on the OTHER stream (a prefetch nobody consumed, then a call that samples
+   * itself, or the reverse): its kernel, its staging copy and its read-back must be over before the buffers are touched again.  It
+   * was submitted two submissions ago, so this wait is over before it starts. */
+  if (S.seq != 0 && S.done) HIP_TRY(ctx, hipEventSynchronize(S.done));
+  if (ctx->dev_samples.valid && ctx->dev_samples.slot == slot) ctx->dev_samples.overwritten = true; /* curvis_ctx_samples: see fetch_device_samples */
   S.valid = false;
   /* jobs: one per distinct radial coordinate of the cameras (bit pattern) */
   S.job_of_frame.assign(n_frames, 0u);
@@ -411,6 +416,7 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   ctx->last_sampling_evaluated = evaluated;
   ctx->last_sampling_chains = chains; /* Euler chains the slowest job waited for: what the launch's latency is made of */
   ctx->dev_samples.valid = !panic;
+  ctx->dev_samples.overwritten = false;
   ctx->dev_samples.slot = (unsigned)slot;
   if (panic)
     return fail(ctx, CURVIS_E_SAMPLING,
@@ -460,6 +466,9 @@ int fetch_device_samples(curvis_ctx *ctx, uint32_t frame) {
   const curvis_ctx::SamplerSlot &S = ctx->samp[ctx->dev_samples.slot];
   if (frame >= S.job_of_frame.size() || frame >= ctx->last_samples.size()) return CURVIS_OK;
   if (!ctx->last_samples[frame].empty() || ctx->last_sampling_info[frame].n_samples == 0) return CURVIS_OK;
+  if (ctx->dev_samples.overwritten)
+    return fail(ctx, CURVIS_E_INVALID, "the sample tables of that render call are gone: a later curvis_ctx_prefetch_efficient has taken their slot "
+                                       "(ask for them before the second prefetch after the call)");
   const size_t n = ctx->last_sampling_info[frame].n_samples, o = (size_t)S.job_of_frame[frame] * cvk::kSamplerCap * sizeof(double);
   std::vector<double> a(n), e(n), s(n);
   HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -142,7 +142,7 @@ struct curvis_ctx {
   uint64_t prefetches = 0, prefetch_hits = 0;
   int last_sampling_prefetched = 0;
   struct DevSamples {                /* which slot holds the tables of the last device-sampled call (curvis_ctx_samples fetches on demand) */
-    bool valid = false;
+    bool valid = false, overwritten = false;
     unsigned slot = 0;
   } dev_samples;
   uint32_t last_sampling_chains = 0; /* device sampler: Euler chains (rounds that had to integrate) of the slowest job of the last call */

@@ -1059,6 +1059,19 @@ def test_prefetched_sampler_gives_the_same_call(gpu_ctx):
         # ... and the still-pending prefetch of batch 1 (two slots) is taken by its call
         gpu_ctx.prefetch_efficient(inter, batch(1), *args)
         assert _efficient_call(gpu_ctx, inter, batch(1), 8192, 100, 100, 1e-5, 1e-5) == plain[1] and gpu_ctx.get_option("last_sampling_prefetched") == 1
+        # the tables of a call stay readable for ONE more submission into the other slot; the second one takes their slot: an error, not stale data
+        gpu_ctx.render_efficient(inter, batch(0), *args)
+        gpu_ctx.prefetch_efficient(inter, batch(1), *args)
+        assert gpu_ctx.samples(1)[0].tobytes() == plain[0][2][1][5]
+        gpu_ctx.prefetch_efficient(inter, batch(2), *args)
+        assert gpu_ctx.samples(1)[0].tobytes() == plain[0][2][1][5]          # (already fetched: kept)
+        with pytest.raises(curvis_amd.CurvisError) as e:
+            gpu_ctx.samples(2)
+        assert "prefetch" in str(e.value)
+        # prefetches nobody consumes, then calls that sample themselves into the same slots (other stream): still right
+        for k in range(3):
+            assert _efficient_call(gpu_ctx, inter, [batch(k)[0]] * 4, 8192, 100, 100, 1e-5, 1e-5)[2][0][5:8] == plain[k][2][0][5:8]
+            gpu_ctx.prefetch_efficient(inter, batch((k + 1) % 3), 8192, 100.0, 0.05, 100, 100, 1e-5, 3e-5)
         # a context destroyed with a prefetch in flight
         c2 = curvis_amd.Context(0)
         c2.set_sky(0, curvis_amd.SphericalImage(sp))
