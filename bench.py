@@ -986,6 +986,8 @@ def efficient_kernels(ctx, torch, args):
                                    frames per call -> the device-resident sampler (sampler_kernel; every pose has l = 3: ONE job per call)
       kernels_only_distinct_radii  the first 240 poses of configs[4] (path_through.csv at 24 fps: every frame its own l), Interstellar
                                    metric, cap 8192, 120 frames per call -> one sampler job per frame
+      ..._prefetched               the same two with the next call's sampler started before the current call renders
+                                   (curvis_ctx_prefetch_efficient: what `curvis video` does)
       host_paced_32                configs[3] again at 32 frames per call: the host-paced sampler (what round 5 measured)
     GPU-idle share from the context's own HIP events."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -999,12 +1001,18 @@ def efficient_kernels(ctx, torch, args):
         return [curvis_amd.Camera(tuple(it.camera_position(t)), tuple(it.camera_forward(t)), tuple(it.camera_up(t)), 15.0, 43.0,
                                   args.width, args.height) for t in times]
 
-    def leg(metric, cams, cap, per_call):
+    def leg(metric, cams, cap, per_call, prefetch=False):
+        sets = (cap, 100.0, 0.05, 100, 100, 1e-5, 1e-5)
+
         def run():
             kernel_ms = steps = 0
             paths, chains = set(), 0
+            if prefetch:
+                ctx.prefetch_efficient(metric, cams[:per_call], *sets)
             for k in range(0, len(cams), per_call):
-                _, st = ctx.render_efficient(metric, cams[k:k + per_call], cap, 100.0, 0.05, 100, 100, 1e-5, 1e-5, download=False)
+                if prefetch and k + per_call < len(cams):  # the next call's sampler starts before this call renders
+                    ctx.prefetch_efficient(metric, cams[k + per_call:k + 2 * per_call], *sets)
+                _, st = ctx.render_efficient(metric, cams[k:k + per_call], *sets, download=False)
                 kernel_ms += st.kernel_ms
                 steps += st.steps
                 paths.add(ctx.get_option("last_sampler_path"))
@@ -1017,17 +1025,20 @@ def efficient_kernels(ctx, torch, args):
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         n = len(cams)
-        return {"value": round(n / wall, 1), "frames": n, "frames_per_call": per_call, "contexts": 1,
+        return {"value": round(n / wall, 1), "frames": n, "frames_per_call": per_call, "contexts": 1, "sampler_prefetched": bool(prefetch),
                 "sampler": {0: "host-paced (cv_sampler.h, speculating launches)", 1: "device-resident (sampler_kernel)",
                             2: "device-resident, fell back to the host"}[max(paths)],
                 "euler_chains_per_call": chains or None,
                 "ms_per_frame": round(wall / n * 1e3, 4), "kernel_ms_per_frame": round(kernel_ms / n, 4),
+                # with the prefetch the sampler's kernel runs BESIDE the previous call's per-pixel kernel: summed kernel time can exceed the wall time
                 "gpu_idle_share": round(max(0.0, 1.0 - kernel_ms / 1e3 / wall), 4), "integrator_steps_per_frame": int(steps / n)}
     orbit = poses("path_orbit.csv", 4.0, 240)
     through = poses("path_through.csv", 24.0, 240)
     out = {"unit": "%dx%d frames/s, reference's default renderer (render_image_efficient)" % (args.width, args.height),
            "kernels_only": leg(curvis_amd.EllisMetric(1.0), orbit, args.max_iter, 120),
            "kernels_only_distinct_radii": leg(curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0), through, 8192, 120),
+           "kernels_only_prefetched": leg(curvis_amd.EllisMetric(1.0), orbit, args.max_iter, 120, prefetch=True),
+           "kernels_only_distinct_radii_prefetched": leg(curvis_amd.InterstellarMetric(0.1, 1e-4, 1.0), through, 8192, 120, prefetch=True),
            "host_paced_32": leg(curvis_amd.EllisMetric(1.0), orbit, args.max_iter, 32)}
     out["kernels_only"]["note"] = ("configs[3] poses (Ellis, l = 3 in every frame: the frames of a call share ONE sampler job); one context, frames "
                                    "stay in HBM; gpu_idle_share = 1 - kernels' HIP-event time / wall")

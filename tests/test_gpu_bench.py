@@ -152,6 +152,8 @@ def test_default_line_clock_agrees_with_itself_and_carries_the_download_figure()
         assert ko["frames"] == 240 and ko["contexts"] == 1 and ko["value"] > 100 and 0 < ko["kernel_ms_per_frame"] < ko["ms_per_frame"] * 1.001
         assert 0.0 <= ko["gpu_idle_share"] < 1.0 and abs(ko["gpu_idle_share"] - (1 - ko["kernel_ms_per_frame"] / ko["ms_per_frame"])) < 2e-3
         assert ko["sampler"].startswith(sampler), (key, ko["sampler"])
+    assert ve["kernels_only_prefetched"]["sampler_prefetched"] and ve["kernels_only_prefetched"]["value"] > ve["kernels_only"]["value"]
+    assert ve["kernels_only_distinct_radii_prefetched"]["value"] > ve["kernels_only_distinct_radii"]["value"]
     assert ve["kernels_only"]["gpu_idle_share"] < 0.10 and ve["kernels_only"]["value"] > ve["host_paced_32"]["value"]   # < 10 % of the span without a kernel
     ee = ve["end_to_end"]
     assert "failed" not in ee, ee
