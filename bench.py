@@ -86,8 +86,10 @@ def parse():
     ap.add_argument("--cpu-row-step", type=int, default=8)
     ap.add_argument("--no-value-efficient", action="store_true",
                     help="N = 1: skip value_efficient (the reference's default renderer: kernels only + `curvis video --mode efficient`)")
-    ap.add_argument("--value-efficient-frames", type=int, default=3840,
-                    help="frames of the end-to-end leg of value_efficient (path_orbit.csv resampled to that many frames)")
+    ap.add_argument("--value-efficient-frames", type=int, default=0,
+                    help="frames of the end-to-end leg of value_efficient (path_orbit.csv resampled to that many frames); 0 = 15 360 "
+                         "when /dev/shm has 32 GB free for the 9.5 GB of PNG files and the container's memory limit is above 64 GB (about 1.3 s of rendering: long enough for the binary's fixed "
+                         "start-up costs, ~0.15 s, to stop dominating), else 3 840")
     return ap.parse_args()
 
 
@@ -608,10 +610,22 @@ def main():
             phase("video_e2e_both_modes")
     if dist is None and rank == 0 and isinstance(out.get("value_efficient"), dict) and "failed" not in out["value_efficient"]:
         # ... and end to end through the binary: `curvis video --mode efficient` on the reference's path_orbit.csv, files in -> PNG
-        # frames out (the context above is closed: the binary makes its own, 4 per GPU by default)
+        # frames out (the context above is closed: the binary makes its own, two per GPU for a video of this length)
         try:
-            e2e = video_e2e(args, 1, host_skies, False, mode="efficient", frames_per_gpu=args.value_efficient_frames)
+            n_eff = args.value_efficient_frames
+            if n_eff <= 0:
+                n_eff = 3840
+                try:  # 15 360 frames are 9.5 GB of PNG files in /dev/shm, which counts against the container's memory limit
+                    stv = os.statvfs("/dev/shm")
+                    if stv.f_bavail * stv.f_frsize > (32 << 30) and cgroup_memory_limit() > (64 << 30):
+                        n_eff = 15360
+                except OSError:
+                    pass
+            e2e = video_e2e(args, 1, host_skies, False, mode="efficient", frames_per_gpu=n_eff)
             if "failed" not in e2e:
+                e2e["frames_requested"] = n_eff
+                e2e["frames_note"] = ("times_of_frames stops at t < 60 s of a path whose last row is short of 60 s, so a few frames fewer than "
+                                      "requested are rendered, as with the reference (src/rendering.rs:224-238)")
                 dev = e2e["per_device"][0]
                 kern_s = e2e["frames"] * (dev["kernel_ms_per_frame"] + dev["gpu_png_kernel_ms_per_frame"]) / 1e3
                 e2e["gpu_idle_share"] = round(max(0.0, 1.0 - kern_s / e2e["wall_s"]), 4) if e2e["wall_s"] > 0 else None
@@ -1046,6 +1060,18 @@ def efficient_kernels(ctx, torch, args):
     return out
 
 
+def cgroup_memory_limit():
+    """bytes this container may use (cgroup v2 memory.max or v1 memory.limit_in_bytes); a very large number when unlimited or unknown"""
+    for p in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            with open(p) as f:
+                t = f.read().strip()
+            return (1 << 62) if t == "max" else int(t)
+        except (OSError, ValueError):
+            continue
+    return 1 << 62
+
+
 def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gpu=None):
     """`curvis video --mode brute --devices N --stats` on a 16N-frame rendition of configs[3] (Ellis, path_orbit.csv,
     1920x1080, cap 4096): files in, PNG frames out, the binary's own per-device table back."""
@@ -1083,7 +1109,7 @@ def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gp
         t_files = time.perf_counter() - t_files
         cmd = [exe, "video", os.path.join(d, "pos.png"), os.path.join(d, "neg.png"), os.path.join(d, "out"),
                "-v", os.path.join(d, "vid.toml"), "-s", os.path.join(d, "sim.toml"), "-c", os.path.join(d, "cam.toml"),
-               "--mode", mode, "--devices", str(world), "--stats", os.path.join(d, "st.jsonl")] + (["--batch", "4"] if mode == "brute" else [])  # efficient: the binary's defaults (4 contexts per GPU, up to 32 frames per launch)
+               "--mode", mode, "--devices", str(world), "--stats", os.path.join(d, "st.jsonl")] + (["--batch", "4"] if mode == "brute" else [])  # efficient: the binary's defaults (two contexts per GPU and 128 frames per call for a long video)
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
         if world > 1 and not share_device:  # a per-rank device mask is the launcher's, not the binary's: it drives all N GPUs itself
             for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
@@ -1116,7 +1142,7 @@ def video_e2e(args, world, host_skies, share_device, mode="brute", frames_per_gp
                 "per_device": summ["devices"], "encode": summ.get("encode"),
                 "distinct_gpus": len(set(dv["pci_bus_id"] for dv in summ["devices"])),
                 "input_files_s": round(t_files, 2),
-                "note": "one process, one host thread + context per GPU (four per GPU in --mode efficient), frames k mod workers, skies decoded once and broadcast from "
+                "note": "one process, one host thread + context per GPU (in --mode efficient one or two per GPU by the length of the video, each taking up to 128 consecutive frames per call), frames k mod workers, skies decoded once and broadcast from "
                         "device 0 (ncclCommInitAll + curvis_ctx_bcast_skies), PNG frames written by the writer pool; wall_s "
                         "includes context creation, sky decode/upload/broadcast and the first-launch check of the relay kernel"}
     finally:
