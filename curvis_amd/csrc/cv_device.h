@@ -196,6 +196,71 @@ CV_HD double div_with_recip(double n, double d, double y) {
   const double rem = CV_FMA(-d, q0, n);
   return CV_FMA(rem, y, q0);
 }
+/* ---- quotients that share their reciprocal (the per-pixel kernel of the efficient renderer; device only) -------------------------
+ * The AMDGPU expansion of an f64 quotient n/d is  y = v_rcp_f64(d) refined by two Newton steps;  q0 = n y;  rem = fma(-d, q0, n);
+ * q = fma(rem, y, q0)  -- wrapped in v_div_scale / v_div_fmas / v_div_fixup, which only act when an operand or the quotient is zero,
+ * subnormal, infinite, NaN or within 2^-/+768 of the exponent limits, and pass their operands through otherwise.  A pixel forms
+ * twelve such quotients, nine of them in groups that share the denominator (v / |v| twice) or divide by a constant of the call (the
+ * resolution, pi, 2 pi).  recip_chain is the FIRST HALF of that very sequence -- same instructions, same operand -- and
+ * div_with_recip (cv_device.h) its second half, so a quotient formed from a shared y is the quotient the compiler's own expansion
+ * returns, operation for operation: nothing is assumed about how close y is to 1/d (unlike the fast Euler step, whose
+ * reciprocals are products).  The guards keep every operand inside [2^-300, 2^300), where none of the wrappers acts; a lane outside
+ * takes the `/` operator.  The x86 build keeps the operator throughout (its quotients are IEEE by construction); device == twin ==
+ * oracle is what the parity tests assert, and tests/test_gpu_fast_step.py puts the helpers themselves on operands whose quotient sits
+ * within 2^-106 of a rounding boundary and on every class of special value.  Measured: 914 -> 887 VALU instructions per wave (the
+ * guards and their joins give back more than half of what the 36 + 31 + 8 wrapper, Newton and seed instructions save), 0.0559 ->
+ * 0.0534 ms per 1080p frame = -4.4 % on one box, interleaved (profiles/round6_eff_pixel_shared_div.txt). */
+CV_HD double recip_chain(double d) {
+  double y = rcp_seed(d);
+  y = CV_FMA(y, CV_FMA(-d, y, 1.0), y);
+  return CV_FMA(y, CV_FMA(-d, y, 1.0), y);
+}
+/* y of the call's constant denominators, formed once per context and resolution by recip_chain ON THE DEVICE (recip_chain_kernel)
+ * and handed to the pixel kernel as arguments */
+struct PixelRecips {
+  double y_res_x, y_res_y, y_pi, y_two_pi;
+};
+/* v / n for the three components of a vector and its Euclidean norm n (so |v_i| <= n up to rounding: one bound per operand) */
+template <bool SHARED>
+CV_HD void unit3(const double *v, double n, double *u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (SHARED) {
+    if (n >= 0x1p-300 && n < 0x1p300 && CV_FABS(v[0]) >= 0x1p-300 && CV_FABS(v[1]) >= 0x1p-300 && CV_FABS(v[2]) >= 0x1p-300) {
+      const double y = recip_chain(n);
+      u[0] = div_with_recip(v[0], n, y);
+      u[1] = div_with_recip(v[1], n, y);
+      u[2] = div_with_recip(v[2], n, y);
+      return;
+    }
+  }
+#endif
+  u[0] = v[0] / n;
+  u[1] = v[1] / n;
+  u[2] = v[2] / n;
+}
+/* a / d for a constant d of the call, 2^-300 <= d < 2^300, with y = recip_chain(d):
+ * div_index: a is an integer-valued 0 <= a < 2^32 (a pixel index) -- always inside the range, no guard.  (+0: 0 y = +0,
+ *            fma(-d, +0, +0) = +0, fma(+0, y, +0) = +0, the IEEE quotient.)
+ * div_angle: a is an angle, 0 <= a < 8 or NaN by construction; zero (of either sign), anything below 2^-300 and NaN take the operator. */
+template <bool SHARED>
+CV_HD double div_index(double a, double d, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (SHARED) return div_with_recip(a, d, y);
+#endif
+  (void)y;
+  return a / d;
+}
+template <bool SHARED>
+CV_HD double div_angle(double a, double d, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (SHARED) {
+    if (a >= 0x1p-300 && a < 8.0) return div_with_recip(a, d, y);
+  }
+#endif
+  (void)y;
+  return a / d;
+}
+
 /* root = sqrt(x) correctly rounded, y ~ 1/sqrt(x) to about an ulp (Goldschmidt on the hardware seed, no
  * scaling).  With g0 = x y0 and E = 1 - g0 y0 (= 1 - x y0^2):  sqrt(x) = g0 (1 - E)^(-1/2) = g0 (1 + E/2 + 3/8 E^2
  * + 5/16 E^3 ...), and the same factor takes y0 to 1/sqrt(x).  One third-order step p = E/2 + 3/8 E^2 brings BOTH
@@ -507,7 +572,10 @@ struct SkyParams {
 
 /* direction -> texel indices: src/images.rs:132-142 -> src/algebra.rs:128-134 -> :106-116 ->
  * src/images.rs:115-121.  Returns raw `as u32` indices (may equal w / h: reference panics). */
-CV_HD void sky_indices(const SkyParams &S, double d0, double d1, double d2, unsigned &tx, unsigned &ty) {
+template <bool SHARED = false> /* SHARED (device, the efficient renderer's pixel kernel): theta / pi and phi / 2 pi through the call's
+                                  precomputed reciprocals -- div_angle above */
+CV_HD void sky_indices(const SkyParams &S, double d0, double d1, double d2, unsigned &tx, unsigned &ty, double y_pi = 0.0,
+                       double y_two_pi = 0.0) {
   double w0, w1, w2;
   mat3_vec(S.inv_rot, d0, d1, d2, w0, w1, w2);
   const double rn = CV_SQRT(w0 * w0 + w1 * w1 + w2 * w2);
@@ -522,8 +590,8 @@ CV_HD void sky_indices(const SkyParams &S, double d0, double d1, double d2, unsi
     }
     phi = rem_euclid_pos(phi, TWO_PI);
   }
-  ty = rust_as_u32((theta / CV_PI) * (double)S.h);
-  tx = rust_as_u32(rem_euclid_pos(0.5 - phi / TWO_PI, 1.0) * (double)S.w);
+  ty = rust_as_u32(div_angle<SHARED>(theta, CV_PI, y_pi) * (double)S.h);
+  tx = rust_as_u32(rem_euclid_pos(0.5 - div_angle<SHARED>(phi, TWO_PI, y_two_pi), 1.0) * (double)S.w);
 }
 
 }  // namespace cvk

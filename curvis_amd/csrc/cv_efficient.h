@@ -173,16 +173,16 @@ CV_HD unsigned interp_index(const double *x, unsigned n, double xp) {
 
 /* step 2 of render_image_efficient for one pixel (src/systems.rs:405-433): the angle alpha between the pixel's
  * outward direction and the radial direction, and the rotation axis cam_bg x out_bg */
+template <bool SHARED = false>
 CV_HD void efficient_pixel_geometry(const CameraParams &C, const EfficientFrame &F, unsigned px, unsigned py, double &alpha,
-                                    double *axis) {
+                                    double *axis, const PixelRecips *R = nullptr) {
   /* outward_vector_on_world_space_from_x_y (src/cameras.rs:150-172) */
-  const double h = 0.5 - ((double)py / C.res_y);
-  const double w = ((double)px / C.res_x) - 0.5;
-  double v[3] = {C.focal * 1.0, -C.sensor_w * w, C.sensor_h * h};
-  const double n = norm3(v);
-  v[0] = v[0] / n;
-  v[1] = v[1] / n;
-  v[2] = v[2] / n;
+  const double h = 0.5 - (SHARED ? div_index<SHARED>((double)py, C.res_y, R->y_res_y) : (double)py / C.res_y);
+  const double w = (SHARED ? div_index<SHARED>((double)px, C.res_x, R->y_res_x) : (double)px / C.res_x) - 0.5;
+  const double v0[3] = {C.focal * 1.0, -C.sensor_w * w, C.sensor_h * h};
+  const double n = norm3(v0);
+  double v[3];
+  unit3<SHARED>(v0, n, v);
   double out_tan[3], out_bg[3];
   mat3_vec(C.rot, v[0], v[1], v[2], out_tan[0], out_tan[1], out_tan[2]);
   mat3_vec(F.rot_bg, out_tan[0], out_tan[1], out_tan[2], out_bg[0], out_bg[1], out_bg[2]);
@@ -191,9 +191,11 @@ CV_HD void efficient_pixel_geometry(const CameraParams &C, const EfficientFrame 
   alpha = cv_acos(dot3(out_tan, ex)); /* :431 */
 }
 /* step 5 (src/systems.rs:498-506): final = from_axis_angle(normalize(axis), escape angle) * cam_bg */
+template <bool SHARED = false>
 CV_HD void efficient_final_direction(const EfficientFrame &F, const double *axis, double esc, double *fin) {
   const double an = norm3(axis); /* Unit::new_normalize: 0/0 -> NaN for the centre pixel */
-  const double u[3] = {axis[0] / an, axis[1] / an, axis[2] / an};
+  double u[3];
+  unit3<SHARED>(axis, an, u);
   double rot[9];
   from_axis_angle(u, esc, rot);
   mat3_vec(rot, F.cam_bg[0], F.cam_bg[1], F.cam_bg[2], fin[0], fin[1], fin[2]);
@@ -201,11 +203,12 @@ CV_HD void efficient_final_direction(const EfficientFrame &F, const double *axis
 
 /* steps 2 + 4 + 5 of render_image_efficient for one pixel: returns the final direction on the background
  * space and the interpolated escape space (1.0 / -1.0 / anything else = black). */
+template <bool SHARED = false>
 CV_HD void efficient_pixel(const CameraParams &C, const EfficientFrame &F, unsigned px, unsigned py,
                            const double *sx, const double *m_e, const double *c_e, const double *m_s,
-                           const double *c_s, unsigned n_samples, double *fin, double &space) {
+                           const double *c_s, unsigned n_samples, double *fin, double &space, const PixelRecips *R = nullptr) {
   double alpha, axis[3];
-  efficient_pixel_geometry(C, F, px, py, alpha, axis);
+  efficient_pixel_geometry<SHARED>(C, F, px, py, alpha, axis, R);
   double esc;
   if (n_samples == 0) { /* interp_slice on empty tables returns zeros */
     esc = 0.0;
@@ -218,7 +221,7 @@ CV_HD void efficient_pixel(const CameraParams &C, const EfficientFrame &F, unsig
     esc = m_e[i] * alpha + c_e[i];
     space = m_s[i] * alpha + c_s[i];
   }
-  efficient_final_direction(F, axis, esc, fin);
+  efficient_final_direction<SHARED>(F, axis, esc, fin);
 }
 
 }  // namespace cvk

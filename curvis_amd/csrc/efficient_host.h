@@ -94,6 +94,39 @@ int eval_escape_batch(curvis_ctx *ctx, const curvis_metric *metric, const cvk::M
 }
 
 
+/* The per-pixel kernel divides by four constants of the call -- the resolution (twice), pi and 2 pi -- and takes the first half of
+ * those divisions, y = v_rcp_f64 + two Newton steps, from here: formed ONCE per context and resolution, on the device, by the same
+ * instructions the compiler's own expansion of `/` uses (cv_device.h recip_chain), so that the kernel's quotients stay that expansion's
+ * quotients bit for bit.  ~50 us, once. */
+int ensure_pixel_recips(curvis_ctx *ctx, double res_x, double res_y, cvk::PixelRecips &out) {
+  curvis_ctx::PixRecips &R = ctx->pix_recips;
+  if (!R.valid || std::memcmp(&R.res_x, &res_x, sizeof res_x) != 0 || std::memcmp(&R.res_y, &res_y, sizeof res_y) != 0) {
+    const double d[4] = {res_x, res_y, CV_PI, 2.0 * CV_PI};
+    double y[4] = {0, 0, 0, 0}, *dev = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&dev, sizeof d + sizeof y));
+    hipError_t e = hipMemcpyAsync(dev, d, sizeof d, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(recip_chain_kernel, dim3(1), dim3(64), 0, ctx->stream, dev, dev + 4, 4u);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(y, dev + 4, sizeof y, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(ctx, CURVIS_E_HIP, std::string("reciprocals of the pixel kernel's constants: ") + hipGetErrorString(e));
+    for (int k = 0; k < 4; ++k) /* a resolution of 1 .. 2^32 and pi: nothing else can come out */
+      if (!(y[k] > 0.0) || !std::isfinite(y[k])) return fail(ctx, CURVIS_E_HIP, "reciprocals of the pixel kernel's constants: not finite");
+    R.res_x = res_x;
+    R.res_y = res_y;
+    R.y.y_res_x = y[0];
+    R.y.y_res_y = y[1];
+    R.y.y_pi = y[2];
+    R.y.y_two_pi = y[3];
+    R.valid = true;
+  }
+  out = R.y;
+  return CURVIS_OK;
+}
+
 /* ---- efficient mode with the DEVICE-RESIDENT sampler (kernels_efficient.h sampler_kernel) ------------------------------------
  * One launch samples every frame of the call -- a workgroup per distinct camera radius, rounds and all --, the per-pixel kernel
  * follows on the same stream and reads the tables where the sampler left them: no host round trip per refinement round, no
@@ -372,6 +405,8 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   Q.H = H;
   Q.fb = ctx->d_fb;
   Q.counters = FC;
+  rc = ensure_pixel_recips(ctx, (double)W, (double)H, Q.recips);
+  if (rc) return rc;
   hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)((npix + 255) / 256), n_frames), dim3(256), 0, ctx->stream, Q);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
@@ -824,6 +859,8 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   Q.H = H;
   Q.fb = ctx->d_fb;
   Q.counters = FC;
+  rc = ensure_pixel_recips(ctx, (double)W, (double)H, Q.recips);
+  if (rc) return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)((npix + 255) / 256), n_frames), dim3(256), 0, ctx->stream, Q);
   HIP_TRY(ctx, hipGetLastError());

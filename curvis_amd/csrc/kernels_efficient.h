@@ -271,7 +271,14 @@ struct EfficientPixelParams {
   unsigned n_frames, W, H;
   unsigned char *fb;
   FrameCounters counters;
+  cvk::PixelRecips recips;            /* cv_device.h: reciprocals of the call's constant denominators (ensure_pixel_recips) */
 };
+
+/* y = recip_chain(d) for a handful of constants: the first half of the device's own f64 division, run ON the device so that the
+ * pixel kernel's shared quotients are the compiler's quotients operation for operation (cv_device.h) */
+__global__ void recip_chain_kernel(const double *d, double *y, unsigned n) {
+  if (threadIdx.x < n) y[threadIdx.x] = cvk::recip_chain(d[threadIdx.x]);
+}
 
 /* K3: steps 2, 4, 5 of render_image_efficient + sky lookup, one thread per pixel.
  *
@@ -298,11 +305,12 @@ __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPix
     const unsigned py = pix / P.W, px = pix - py * P.W;
     const unsigned off = P.tab_off[f], n = P.tab_n[f];
     double fin[3], space;
-    cvk::efficient_pixel(P.cams[f], P.frames[f], px, py, P.sx + off, P.m_e + off, P.c_e + off, P.m_s + off, P.c_s + off, n, fin, space);
+    cvk::efficient_pixel<true>(P.cams[f], P.frames[f], px, py, P.sx + off, P.m_e + off, P.c_e + off, P.m_s + off, P.c_s + off, n, fin, space,
+                               &P.recips);
     if (space == 1.0 || space == -1.0) { /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black } */
       const cvk::SkyParams &S = P.sky[space == 1.0 ? 0 : 1];
       unsigned tx, ty;
-      cvk::sky_indices(S, fin[0], fin[1], fin[2], tx, ty);
+      cvk::sky_indices<true>(S, fin[0], fin[1], fin[2], tx, ty, P.recips.y_pi, P.recips.y_two_pi);
       if (tx >= S.w || ty >= S.h) oob = true;
       if (tx >= S.w) tx = S.w - 1;
       if (ty >= S.h) ty = S.h - 1;
@@ -521,7 +529,8 @@ __global__ void selftest_math_kernel(int op, const double *a, const double *b, d
 /* Directed cases for the primitives of the fast step (tests/test_gpu_fast_step.py): three inputs per element.
  * op 0 div_with_recip(a, b, c)   1 root of sqrt_and_rsqrt(a)   2 its y ~ 1/sqrt(a)
  *    3 the square root's last residual step for given (x, g, y) = (a, b, c): fma(fma(-g, g, x), 0.5 y, g)
- *    4 recip_refined(a)   5 cv_div_nr(a, b)   6 recip_newton(a, b) */
+ *    4 recip_refined(a)   5 cv_div_nr(a, b)   6 recip_newton(a, b)
+ *    7 / 8 / 9 component 0 / 1 / 2 of unit3<true>(v = (a, b, c), |v|)   10 div_index<true>(a, b, recip_chain(b))   11 div_angle<true>(a, b, recip_chain(b)) */
 __global__ void selftest_math3_kernel(int op, const double *a, const double *b, const double *c, double *out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -546,8 +555,23 @@ __global__ void selftest_math3_kernel(int op, const double *a, const double *b, 
     case 5:
       r = cv_div_nr(x, y);
       break;
-    default:
+    case 6:
       r = cvk::recip_newton(x, y);
+      break;
+    case 7: /* 7, 8, 9: component 0, 1, 2 of unit3<true>((a, b, c), |(a, b, c)|) */
+    case 8:
+    case 9: {
+      const double v[3] = {x, y, z};
+      double u[3];
+      cvk::unit3<true>(v, cvk::norm3(v), u);
+      r = u[op - 7];
+      break;
+    }
+    case 10: /* an index by a constant */
+      r = cvk::div_index<true>(x, y, cvk::recip_chain(y));
+      break;
+    default: /* 11: an angle by a constant */
+      r = cvk::div_angle<true>(x, y, cvk::recip_chain(y));
       break;
   }
   out[i] = r;

@@ -145,6 +145,12 @@ struct curvis_ctx {
     bool valid = false, overwritten = false;
     unsigned slot = 0;
   } dev_samples;
+  struct PixRecips {                 /* efficient pixel kernel: reciprocals of the call's constant denominators, formed on the device once
+                                        per resolution (efficient_host.h ensure_pixel_recips) */
+    bool valid = false;
+    double res_x = 0.0, res_y = 0.0;
+    cvk::PixelRecips y{};
+  } pix_recips;
   uint32_t last_sampling_chains = 0; /* device sampler: Euler chains (rounds that had to integrate) of the slowest job of the last call */
   uint32_t last_sampling_launches = 0;
   uint64_t last_sampling_evaluated = 0;

@@ -134,3 +134,49 @@ def test_shared_reciprocals_of_real_steps(gpu_ctx, metric, l_cam):
     # THE documented rate: < 2^-49 per step Ellis, < 2^-48 Interstellar, i.e. ~4e-6 per 1080p frame and
     # ~1.5e-2 per full configs[4] render -- the exact gap of every recorded quotient over the spacing of the boundaries
     assert per_step < (2.0 ** -49 if metric == "ellis" else 2.0 ** -48), per_step
+
+
+def _same(a, b):
+    """bit-equal where both are numbers (signed zeros included), NaN where either is"""
+    a, b = np.asarray(a), np.asarray(b)
+    nan = np.isnan(a) | np.isnan(b)
+    return bool(np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a.view(np.uint64)[~nan], b.view(np.uint64)[~nan]))
+
+
+def test_shared_quotients_of_the_pixel_kernel(gpu_ctx):
+    """The efficient renderer's per-pixel kernel forms nine of its twelve quotients from shared reciprocals (cv_device.h
+    recip_chain / unit3 / div_const; reference operations: src/cameras.rs:150-172, src/systems.rs:498-506, src/images.rs:115-121).
+    The shared y is the first half of the device's own division, so every quotient must BE the IEEE quotient: on operands
+    whose exact quotient sits within a few quanta of 2^-106 of a rounding boundary, on ordinary ones, and -- through the guards --
+    on zeros of either sign, subnormals, the exponent limits, infinities and NaN."""
+    rng = np.random.default_rng(611)
+    n, d, j, expect, quanta = H.division_hard_cases(rng, 20000)
+    n, d = np.abs(n), np.abs(d)
+    assert np.array_equal(gpu_ctx.selftest_math3(10, n, d), n / d)          # hard cases: numerator, denominator > 0
+    a = rng.uniform(1.0, 2.0, 2_000_000) * 2.0 ** rng.integers(-299, 299, 2_000_000)
+    b = rng.uniform(1.0, 2.0, 2_000_000) * 2.0 ** rng.integers(-299, 299, 2_000_000)
+    assert np.array_equal(gpu_ctx.selftest_math3(10, a, b), a / b)          # the whole guarded range (and quotients far outside it)
+    # what the kernel really divides: pixel indices by resolutions (no guard: an index is +0 or 1 .. 2^32) ...
+    for res in (1.0, 2.0, 3.0, 144.0, 256.0, 1080.0, 1920.0, 2160.0, 3840.0, 4097.0, 65535.0, 4294967295.0):
+        px = np.concatenate([np.arange(0.0, min(res, 8192.0)), np.floor(rng.uniform(0.0, res, 4096))])
+        assert _same(gpu_ctx.selftest_math3(10, px, np.full_like(px, res)), px / res)
+    # ... and angles by pi and 2 pi; zeros, tiny values, NaN and whatever else is no angle go to the `/` operator: results unchanged
+    special = np.array([0.0, -0.0, 5e-324, -5e-324, 2.2250738585072014e-308, 1e-310, 2.0 ** -301, 2.0 ** -300, 2.0 ** 299, 2.0 ** 300,
+                        1.7976931348623157e308, -1.0, -3.5, np.inf, -np.inf, np.nan, 1.0, 3.0, 8.0, np.nextafter(8.0, 0.0)])
+    ang = np.concatenate([rng.uniform(0.0, 2.0 * np.pi, 1_000_000), np.arccos(1.0 - 2.0 ** -np.arange(1.0, 54.0)), [np.pi, 2.0 * np.pi],
+                          2.0 ** -rng.uniform(0.0, 320.0, 100000), special])
+    with np.errstate(all="ignore"):
+        for c in (np.pi, 2.0 * np.pi):
+            assert _same(gpu_ctx.selftest_math3(11, ang, np.full_like(ang, c)), ang / c)
+    # v / |v|: ordinary vectors over the exponent range, components that are zeros of either sign or tiny, norms that leave the range
+    m = 1_000_000
+    v = [rng.uniform(-2.0, 2.0, m) * 2.0 ** rng.integers(-8, 8, m) * 2.0 ** rng.integers(-140, 141) for _ in range(3)]
+    vs = [np.concatenate([v[k], rng.choice(special, 40000), rng.uniform(-1, 1, 40000) * 2.0 ** rng.integers(-1074, 1024, 40000).astype(float)])
+          for k in range(3)]
+    for k in range(3):                                                      # a third of the first block: one exact zero (the centre row / column of a frame)
+        vs[k][k * 100000:(k + 1) * 100000:3] = 0.0
+        vs[k][k * 100000 + 1:(k + 1) * 100000:3] = -0.0
+    with np.errstate(all="ignore"):
+        norm = np.sqrt((vs[0] * vs[0] + vs[1] * vs[1]) + vs[2] * vs[2])
+        for k in range(3):
+            assert _same(gpu_ctx.selftest_math3(7 + k, vs[0], vs[1], vs[2]), vs[k] / norm), k
