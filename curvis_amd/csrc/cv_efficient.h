@@ -171,6 +171,43 @@ CV_HD unsigned interp_index(const double *x, unsigned n, double xp) {
   return i;
 }
 
+/* The same index through a bucket grid over the abscissae (the per-pixel kernel: a table has 300 .. 1500 samples, and eleven
+ * dependent loads and compares per pixel were 7 % of its instructions).  interp_bucket is monotone non-decreasing in its argument
+ * -- a rounded subtraction, a rounded product, a clamp and a truncation all are -- so for a query xp in bucket b every sample in a
+ * lower bucket is < xp and every sample in a higher one is > xp: the index sought, #{i : x[i] < xp}, lies between
+ * G[b] = #{i : bucket(x[i]) < b} and G[b + 1], and the binary search runs over that span only -- EXACTLY the index of the full
+ * search, whatever the rounding of the bucket arithmetic (it only has to be the same function for samples and queries; NaN
+ * queries fall into bucket 0 and come out as index 0 like before).  1024 buckets over [-0.1 pi, 1.1 pi], the interval the
+ * reference samples (src/systems.rs:437-438); G has kInterpGrid + 1 entries, G[kInterpGrid] = n. */
+constexpr unsigned kInterpGrid = 1024;
+CV_HD unsigned interp_bucket(double x) {
+  const double t = (x - (-0.1 * CV_PI)) * ((double)kInterpGrid / (1.2 * CV_PI));
+  if (!(t > 0.0)) return 0u; /* below the interval, NaN */
+  if (t >= (double)(kInterpGrid - 1u)) return kInterpGrid - 1u;
+  return (unsigned)t;
+}
+/* the grid entries that sample index i (0 .. n inclusive; x has n entries, strictly increasing) is responsible for:
+ * G[b] = i for every b with bucket(x[i - 1]) < b <= bucket(x[i]) (from 0 for i = 0, up to kInterpGrid for i = n) */
+CV_HD void interp_grid_fill(const double *x, unsigned n, unsigned i, unsigned *G) {
+  const unsigned b0 = i ? interp_bucket(x[i - 1u]) + 1u : 0u;
+  const unsigned b1 = i < n ? interp_bucket(x[i]) : kInterpGrid;
+  for (unsigned b = b0; b <= b1; ++b) G[b] = i;
+}
+CV_HD unsigned interp_index_grid(const double *x, unsigned n, double xp, const unsigned *G) {
+  const unsigned b = interp_bucket(xp);
+  unsigned lo = G[b], hi = G[b + 1u];
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (x[mid] < xp)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  unsigned i = lo ? lo - 1 : 0;
+  if (i > n - 2) i = n - 2;
+  return i;
+}
+
 /* step 2 of render_image_efficient for one pixel (src/systems.rs:405-433): the angle alpha between the pixel's
  * outward direction and the radial direction, and the rotation axis cam_bg x out_bg */
 template <bool SHARED = false>
@@ -206,7 +243,8 @@ CV_HD void efficient_final_direction(const EfficientFrame &F, const double *axis
 template <bool SHARED = false>
 CV_HD void efficient_pixel(const CameraParams &C, const EfficientFrame &F, unsigned px, unsigned py,
                            const double *sx, const double *m_e, const double *c_e, const double *m_s,
-                           const double *c_s, unsigned n_samples, double *fin, double &space, const PixelRecips *R = nullptr) {
+                           const double *c_s, unsigned n_samples, double *fin, double &space, const PixelRecips *R = nullptr,
+                           const unsigned *grid = nullptr) {
   double alpha, axis[3];
   efficient_pixel_geometry<SHARED>(C, F, px, py, alpha, axis, R);
   double esc;
@@ -217,7 +255,7 @@ CV_HD void efficient_pixel(const CameraParams &C, const EfficientFrame &F, unsig
     esc = c_e[0]; /* y[0] */
     space = c_s[0];
   } else {
-    const unsigned i = interp_index(sx, n_samples, alpha); /* both tables share the abscissae */
+    const unsigned i = grid ? interp_index_grid(sx, n_samples, alpha, grid) : interp_index(sx, n_samples, alpha); /* both tables share the abscissae */
     esc = m_e[i] * alpha + c_e[i];
     space = m_s[i] * alpha + c_s[i];
   }

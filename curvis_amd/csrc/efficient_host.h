@@ -202,10 +202,13 @@ int sampler_submit(curvis_ctx *ctx, unsigned slot, hipStream_t stream, const cur
     return o;
   };
   /* staged from the host in one copy ... */
-  const size_t o_jf = carve(sizeof(unsigned) * n_frames), o_to = carve(sizeof(unsigned) * n_frames), o_l = carve(sizeof(double) * n_jobs);
+  const size_t o_jf = carve(sizeof(unsigned) * n_frames), o_to = carve(sizeof(unsigned) * n_frames), o_go = carve(sizeof(unsigned) * n_frames),
+               o_l = carve(sizeof(double) * n_jobs);
   const size_t staged = off;
   /* ... written by the sampler kernel */
   S.o_tab_off = o_to;
+  S.o_grid_off = o_go;
+  S.o_grid = carve(sizeof(unsigned) * n_jobs * (cvk::kInterpGrid + 1u));
   S.o_tab_n = carve(sizeof(unsigned) * n_frames);
   S.o_res = carve(sizeof(cvk::SamplerResult) * n_jobs);
   for (size_t &o : S.o_tab) o = carve(sizeof(double) * T);
@@ -232,7 +235,11 @@ int sampler_submit(curvis_ctx *ctx, unsigned slot, hipStream_t stream, const cur
   std::memcpy(S.h + o_jf, S.job_of_frame.data(), sizeof(unsigned) * n_frames);
   {
     auto *to = reinterpret_cast<unsigned *>(S.h + o_to);
-    for (uint32_t f = 0; f < n_frames; ++f) to[f] = S.job_of_frame[f] * cvk::kSamplerCap;
+    auto *go = reinterpret_cast<unsigned *>(S.h + o_go);
+    for (uint32_t f = 0; f < n_frames; ++f) {
+      to[f] = S.job_of_frame[f] * cvk::kSamplerCap;
+      go[f] = S.job_of_frame[f] * (cvk::kInterpGrid + 1u);
+    }
   }
   std::memcpy(S.h + o_l, S.l_job.data(), sizeof(double) * n_jobs);
   HIP_TRY(ctx, hipMemcpyAsync(S.d, S.h, staged, hipMemcpyHostToDevice, stream));
@@ -261,6 +268,7 @@ int sampler_submit(curvis_ctx *ctx, unsigned slot, hipStream_t stream, const cur
   SP.c_e = (double *)(S.d + S.o_tab[4]);
   SP.m_s = (double *)(S.d + S.o_tab[5]);
   SP.c_s = (double *)(S.d + S.o_tab[6]);
+  SP.grid = (unsigned *)(S.d + S.o_grid);
   SP.res = (cvk::SamplerResult *)(S.d + S.o_res);
   SP.spec_key = (unsigned long long *)(S.d + o_sk);
   SP.spec_e = (double *)(S.d + o_se);
@@ -395,6 +403,8 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   Q.frames = (const cvk::EfficientFrame *)(ctx->d_eff + o_fr);
   Q.tab_off = (const unsigned *)(S.d + S.o_tab_off);
   Q.tab_n = (const unsigned *)(S.d + S.o_tab_n);
+  Q.grid_off = (const unsigned *)(S.d + S.o_grid_off);
+  Q.grid = (const unsigned *)(S.d + S.o_grid);
   Q.sx = (const double *)(S.d + S.o_tab[0]);
   Q.m_e = (const double *)(S.d + S.o_tab[3]);
   Q.c_e = (const double *)(S.d + S.o_tab[4]);
@@ -773,7 +783,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
 
   /* step 4 tables (interp 1.0.3) */
   std::vector<double> sx, m_e, c_e, m_s, c_s, x, ye, ys, m, c;
-  std::vector<unsigned> tab_off(n_frames), tab_n(n_frames);
+  std::vector<unsigned> tab_off(n_frames), tab_n(n_frames), grid_off(n_frames), grid; /* grid: cv_efficient.h interp_index_grid */
   for (uint32_t f = 0; f < n_frames; ++f) {
     const auto &pts = smp[f].pts;
     x.clear();
@@ -797,6 +807,9 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
     c.resize(slots, 0.0);
     m_s.insert(m_s.end(), m.begin(), m.end());
     c_s.insert(c_s.end(), c.begin(), c.end());
+    grid_off[f] = (unsigned)grid.size();
+    grid.resize(grid.size() + cvk::kInterpGrid + 1u, 0u);
+    for (unsigned i = 0; i <= (unsigned)pts.size(); ++i) cvk::interp_grid_fill(x.data(), (unsigned)pts.size(), i, grid.data() + grid_off[f]);
     x.resize(slots, 0.0);
     sx.insert(sx.end(), x.begin(), x.end());
   }
@@ -817,6 +830,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   };
   const size_t o_cams = carve(sizeof(cvk::CameraParams) * n_frames), o_fr = carve(sizeof(cvk::EfficientFrame) * n_frames),
                o_to = carve(sizeof(unsigned) * n_frames), o_tn = carve(sizeof(unsigned) * n_frames),
+               o_go = carve(sizeof(unsigned) * n_frames), o_gr = carve(sizeof(unsigned) * grid.size()),
                o_sx = carve(sizeof(double) * T), o_me = carve(sizeof(double) * T), o_ce = carve(sizeof(double) * T),
                o_ms = carve(sizeof(double) * T), o_cs = carve(sizeof(double) * T);
   rc = ensure_device(ctx, ctx->d_eff, ctx->eff_cap, off);
@@ -828,6 +842,8 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   std::memcpy(stage.data() + o_fr, eframes.data(), sizeof(cvk::EfficientFrame) * n_frames);
   std::memcpy(stage.data() + o_to, tab_off.data(), sizeof(unsigned) * n_frames);
   std::memcpy(stage.data() + o_tn, tab_n.data(), sizeof(unsigned) * n_frames);
+  std::memcpy(stage.data() + o_go, grid_off.data(), sizeof(unsigned) * n_frames);
+  std::memcpy(stage.data() + o_gr, grid.data(), sizeof(unsigned) * grid.size());
   std::memcpy(stage.data() + o_sx, sx.data(), sizeof(double) * T);
   std::memcpy(stage.data() + o_me, m_e.data(), sizeof(double) * T);
   std::memcpy(stage.data() + o_ce, c_e.data(), sizeof(double) * T);
@@ -849,6 +865,8 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   Q.frames = (const cvk::EfficientFrame *)(ctx->d_eff + o_fr);
   Q.tab_off = (const unsigned *)(ctx->d_eff + o_to);
   Q.tab_n = (const unsigned *)(ctx->d_eff + o_tn);
+  Q.grid_off = (const unsigned *)(ctx->d_eff + o_go);
+  Q.grid = (const unsigned *)(ctx->d_eff + o_gr);
   Q.sx = (const double *)(ctx->d_eff + o_sx);
   Q.m_e = (const double *)(ctx->d_eff + o_me);
   Q.c_e = (const double *)(ctx->d_eff + o_ce);

@@ -111,6 +111,7 @@ struct SamplerParams {
   double a_min, a_max, thr1, thr2, max_radius, delta;
   int fast_ok;
   double *sx, *se, *ss, *m_e, *c_e, *m_s, *c_s; /* n_jobs x kSamplerCap each */
+  unsigned *grid;                 /* n_jobs x (kInterpGrid + 1): bucket grid over sx (cv_efficient.h interp_index_grid) */
   cvk::SamplerResult *res;        /* n_jobs */
   /* evaluation cache of every job (cv_sampler_dev.h SpecTable), n_jobs x kSpecSlots each; keys preset to kSpecEmpty by the host */
   unsigned long long *spec_key;
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(kSamplerThreads) void sampler_kernel(const SamplerP
     P.m_s[o + i] = ms;
     P.c_s[o + i] = cs;
   }
+  for (unsigned i = threadIdx.x; i <= n; i += kSamplerThreads) cvk::interp_grid_fill(A, n, i, P.grid + (size_t)job * (cvk::kInterpGrid + 1u));
   for (unsigned f = threadIdx.x; f < P.n_frames; f += kSamplerThreads)
     if (P.job_of_frame[f] == job) P.tab_n[f] = n;
   if (threadIdx.x == 0u) {
@@ -267,6 +269,8 @@ struct EfficientPixelParams {
   const cvk::EfficientFrame *frames;  /* n_frames */
   const unsigned *tab_off;            /* n_frames: offset of the frame's tables in sx/m/c */
   const unsigned *tab_n;              /* n_frames: number of samples */
+  const unsigned *grid_off;           /* n_frames: offset of the frame's bucket grid in `grid` */
+  const unsigned *grid;               /* kInterpGrid + 1 entries per table */
   const double *sx, *m_e, *c_e, *m_s, *c_s;
   unsigned n_frames, W, H;
   unsigned char *fb;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPix
     const unsigned off = P.tab_off[f], n = P.tab_n[f];
     double fin[3], space;
     cvk::efficient_pixel<true>(P.cams[f], P.frames[f], px, py, P.sx + off, P.m_e + off, P.c_e + off, P.m_s + off, P.c_s + off, n, fin, space,
-                               &P.recips);
+                               &P.recips, P.grid + P.grid_off[f]);
     if (space == 1.0 || space == -1.0) { /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black } */
       const cvk::SkyParams &S = P.sky[space == 1.0 ? 0 : 1];
       unsigned tx, ty;

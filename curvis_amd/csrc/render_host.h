@@ -125,7 +125,7 @@ struct curvis_ctx {
     bool valid = false, prefetched = false;
     unsigned char *d = nullptr, *h = nullptr;
     size_t d_cap = 0, h_cap = 0, res_bytes = 0, h_res_off = 0;
-    size_t o_tab_off = 0, o_tab_n = 0, o_res = 0, o_tab[7] = {0, 0, 0, 0, 0, 0, 0};
+    size_t o_tab_off = 0, o_tab_n = 0, o_grid_off = 0, o_grid = 0, o_res = 0, o_tab[7] = {0, 0, 0, 0, 0, 0, 0};
     hipEvent_t done = nullptr, t0 = nullptr, t1 = nullptr;
     std::vector<unsigned> job_of_frame;
     std::vector<double> l_job, l_frame;

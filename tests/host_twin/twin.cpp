@@ -285,3 +285,15 @@ extern "C" int twin_inflate_zlib(const uint8_t *in, size_t in_len, uint8_t *out,
   return cvinflate::inflate_zlib(buf.get(), in_len, out, out_cap, out_len, adler);
 }
 
+
+/* cv_efficient.h interp_index_grid against interp_index: the grid is built over x[0..n) the way the kernels build it (one call of
+ * interp_grid_fill per index 0..n), then every query is looked up both ways; returns the number of queries whose indices differ
+ * and leaves the grid in G (kInterpGrid + 1 entries) */
+extern "C" size_t twin_interp_grid_check(const double *x, unsigned n, const double *q, size_t m, unsigned *G) {
+  for (unsigned b = 0; b <= cvk::kInterpGrid; ++b) G[b] = 0xFFFFFFFFu; /* every entry must be written */
+  for (unsigned i = 0; i <= n; ++i) cvk::interp_grid_fill(x, n, i, G);
+  size_t bad = 0;
+  for (size_t k = 0; k < m; ++k)
+    if (cvk::interp_index_grid(x, n, q[k], G) != cvk::interp_index(x, n, q[k])) ++bad;
+  return bad;
+}

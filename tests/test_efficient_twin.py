@@ -73,3 +73,35 @@ def test_device_sampler_control_flow_equals_the_host_sampler_on_hard_settings():
             continue
         assert res[0] == res[1] == res[2], (metric, l, cap, n0, maxit, t1, t2)
     assert overflowed == 1
+
+
+def test_bucket_grid_lookup_equals_the_full_search():
+    """cv_efficient.h interp_index_grid (what the per-pixel kernel uses) == interp_index (interp 1.0.3's prev_index, what the
+    reference's interp_slice does per pixel, src/systems.rs:491-497 via src/interpolation.rs) for every query: tables spread over
+    the sampled interval, clustered inside ONE bucket, reaching outside the interval, with two and three entries; queries on the
+    abscissae themselves, one ulp either side of them, on bucket edges, outside the interval, infinities and NaN."""
+    import ctypes as C
+    lib = common.twin()
+    lib.twin_interp_grid_check.restype = C.c_size_t
+    lib.twin_interp_grid_check.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(77)
+    a0, a1 = -0.1 * np.pi, 1.1 * np.pi
+    edges = a0 + (a1 - a0) * np.arange(0, 1025) / 1024.0
+    tables = []
+    for n in (2, 3, 17, 100, 700, 1536):
+        tables.append(np.sort(rng.uniform(a0, a1, n)))                                  # spread
+        tables.append(np.sort(1.3 + rng.uniform(0.0, 1e-4, n)))                          # inside one bucket
+        tables.append(np.sort(np.concatenate([rng.uniform(a0 - 1.0, a1 + 1.0, n - 2), [a0, a1]])))   # beyond both ends
+        x = np.sort(rng.uniform(1.0, 1.2, n)); x[: n // 2] = np.sort(rng.uniform(a0, a0 + 1e-9, n // 2)); tables.append(np.sort(x))
+    x = edges[100:140].copy(); tables.append(x)                                        # abscissae ON bucket edges
+    x = np.nextafter(edges[100:140], 10.0); tables.append(x)
+    for x in tables:
+        x = np.unique(x)                                                                 # strictly increasing, as the sampler's tables are
+        q = np.concatenate([x, np.nextafter(x, -10.0), np.nextafter(x, 10.0), edges, np.nextafter(edges, -10.0), np.nextafter(edges, 10.0),
+                            rng.uniform(a0 - 0.5, a1 + 0.5, 20000), rng.uniform(x[0], x[-1], 20000),
+                            [0.0, -0.0, np.pi, a0, a1, -1e300, 1e300, np.inf, -np.inf, np.nan, 5e-324]])
+        G = np.zeros(1025, np.uint32)
+        x = np.ascontiguousarray(x); q = np.ascontiguousarray(q)
+        bad = lib.twin_interp_grid_check(x.ctypes.data, x.size, q.ctypes.data, q.size, G.ctypes.data)
+        assert bad == 0, (x.size, bad)
+        assert G[0] == 0 and G[1024] == x.size and np.all(np.diff(G.astype(np.int64)) >= 0)
