@@ -311,18 +311,23 @@ __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPix
     double fin[3], space;
     cvk::efficient_pixel<true>(P.cams[f], P.frames[f], px, py, P.sx + off, P.m_e + off, P.c_e + off, P.m_s + off, P.c_s + off, n, fin, space,
                                &P.recips, P.grid + P.grid_off[f]);
-    if (space == 1.0 || space == -1.0) { /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black } */
-      const cvk::SkyParams &S = P.sky[space == 1.0 ? 0 : 1];
-      unsigned tx, ty;
-      cvk::sky_indices<true>(S, fin[0], fin[1], fin[2], tx, ty, P.recips.y_pi, P.recips.y_two_pi);
-      if (tx >= S.w || ty >= S.h) oob = true;
-      if (tx >= S.w) tx = S.w - 1;
-      if (ty >= S.h) ty = S.h - 1;
-      texel = S.texels[(size_t)ty * S.w + tx];
-      pos = (space == 1.0);
-      neg = (space == -1.0);
-    } else {
-      none = true;
+    /* match escape_space { 1.0 => ..., -1.0 => ..., _ => black }.  One sky after the other, each under its own branch: the lanes of
+     * a wave nearly always look at the same sky, and then its rotation, size and texel pointer are scalar operands of that one
+     * pass -- selecting them per lane cost 22 v_cndmask and the VGPRs to hold the result */
+    pos = (space == 1.0);
+    neg = (space == -1.0);
+    none = !(pos || neg);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k == 0 ? pos : neg) {
+        const cvk::SkyParams &S = P.sky[k];
+        unsigned tx, ty;
+        cvk::sky_indices<true>(S, fin[0], fin[1], fin[2], tx, ty, P.recips.y_pi, P.recips.y_two_pi);
+        if (tx >= S.w || ty >= S.h) oob = true;
+        if (tx >= S.w) tx = S.w - 1;
+        if (ty >= S.h) ty = S.h - 1;
+        texel = S.texels[(size_t)ty * S.w + tx];
+      }
     }
   }
   unsigned char *fb = P.fb + (size_t)f * npix * 3u;
