@@ -70,6 +70,7 @@
 #include "kernels_efficient.h"
 #include "render_host.h"
 #include "efficient_host.h"
+#include "png_codes.h"
 #include "kernels_png.h"
 #include "png_host.h"
 

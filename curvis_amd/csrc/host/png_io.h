@@ -12,6 +12,7 @@
 #define CURVIS_PNG_IO_H
 #include <zlib.h>
 #include "inflate_fast.h"
+#include "../png_codes.h"
 
 #include <time.h>
 #if defined(__linux__)
@@ -621,56 +622,23 @@ inline double now_s() {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-/* code lengths (<= maxlen) of a Huffman code for freq[0..n): plain Huffman by repeated minimum extraction (n <= 286),
- * frequencies halved and the tree rebuilt while it is too deep */
-inline void huffman_lengths(const uint32_t *freq_in, int n, int maxlen, uint8_t *len) {
-  /* Huffman by the two-queue method: leaves sorted once, merged nodes come out in non-decreasing weight, so the two smallest
-   * are always at the heads of the two queues -- O(n log n) for the sort, O(n) for the tree (this runs once per frame on the
-   * thread that feeds a GPU).  Too deep for `maxlen`: weights halved (rounding up) and again, as zlib's fast strategies do. */
-  std::vector<uint32_t> freq(freq_in, freq_in + n);
-  std::vector<int> order, parent, depth;
-  std::vector<uint64_t> w;
-  for (;;) {
-    order.clear();
-    for (int i = 0; i < n; ++i) {
-      len[i] = 0;
-      if (freq[i]) order.push_back(i);
-    }
-    const int m = (int)order.size();
-    if (m == 0) return;
-    if (m == 1) {
-      len[order[0]] = 1;
-      return;
-    }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return freq[a] < freq[b]; });
-    /* nodes [0, m): leaves in weight order; [m, 2m - 1): internal nodes in creation order */
-    w.assign((size_t)2 * m - 1, 0);
-    parent.assign((size_t)2 * m - 1, -1);
-    for (int k = 0; k < m; ++k) w[(size_t)k] = freq[order[(size_t)k]];
-    int leaf = 0, inner = m, next = m;
-    auto take = [&]() {
-      if (leaf < m && (inner >= next || w[(size_t)leaf] <= w[(size_t)inner])) return leaf++;
-      return inner++;
-    };
-    while (next < 2 * m - 1) {
-      const int a = take(), b = take();
-      w[(size_t)next] = w[(size_t)a] + w[(size_t)b];
-      parent[(size_t)a] = parent[(size_t)b] = next;
-      ++next;
-    }
-    depth.assign((size_t)2 * m - 1, 0);
-    int deepest = 0;
-    for (int k = 2 * m - 3; k >= 0; --k) { /* a parent is created after its children: one backward pass */
-      depth[(size_t)k] = depth[(size_t)parent[(size_t)k]] + 1;
-      if (k < m) {
-        len[order[(size_t)k]] = (uint8_t)std::min(depth[(size_t)k], 255);
-        deepest = std::max(deepest, depth[(size_t)k]);
-      }
-    }
-    if (deepest <= maxlen) return;
-    for (int i = 0; i < n; ++i)
-      if (freq[i]) freq[i] = (freq[i] + 1) >> 1;
+/* code lengths (<= maxlen) of a Huffman code for freq[0..n), n <= 288; symbols with a zero count get no code.  The method is
+ * png_codes.h's (shared with the device's png_codes_kernel): package-merge over the symbols in (count, index) order -- the optimal
+ * code under the limit. */
+inline void huffman_lengths(const uint32_t *freq, int n, int maxlen, uint8_t *len) {
+  uint64_t key[pngcodes::kMaxLeaves];
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    len[i] = 0;
+    if (freq[i]) key[m++] = ((uint64_t)freq[i] << 9) | (uint64_t)i; /* n <= 288 < 512 */
   }
+  if (m == 0) return;
+  std::sort(key, key + m);
+  uint32_t w[pngcodes::kMaxLeaves];
+  uint8_t ls[pngcodes::kMaxLeaves];
+  for (int k = 0; k < m; ++k) w[k] = (uint32_t)(key[k] >> 9);
+  pngcodes::pm_lengths_sorted(w, m, maxlen, ls);
+  for (int k = 0; k < m; ++k) len[key[k] & 511u] = ls[k];
 }
 
 /* canonical codes (RFC 1951 3.2.2), bit-reversed for an LSB-first bit writer; entry = code | len << 16 */
@@ -714,15 +682,7 @@ struct BitWriter { /* LSB-first, branch-free: an unaligned 8-byte store per put,
 };
 
 /* length -> (symbol 257.., extra bits, extra value) of RFC 1951 3.2.5 */
-inline void length_symbol(int length, int &sym, int &ebits, int &eval) {
-  static const int base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-  static const int extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-  int k = 28;
-  while (base[k] > length) --k;
-  sym = 257 + k;
-  ebits = extra[k];
-  eval = length - base[k];
-}
+inline void length_symbol(int length, int &sym, int &ebits, int &eval) { pngcodes::length_symbol(length, sym, ebits, eval); }
 
 inline uint32_t load32(const uint8_t *p) {
   uint32_t v;

@@ -8,7 +8,9 @@
  * difference: a thread tokenises 64 image bytes, so a zero run is cut every 64 bytes (matches of 3..63 instead of 3..258).
  *
  *   png_hist2_kernel      pass 1: token histogram (286 symbols) per frame AND per workgroup, Adler-32 partial sums
- *   (host)                code lengths (<= 12 bits) and canonical codes from the histograms: 286 symbols per frame, microseconds
+ *   png_codes_kernel      code lengths (<= 12 bits), canonical codes and the block header from the frame's histogram: a workgroup
+ *                         per frame (png_codes.h: the host writer's functions).  Rounds 3-6 did this on the host, between two
+ *                         synchronisations: 1.1-1.5 ms of a 128-frame call with the GPU idle
  *   png_blockbits_kernel  bits per workgroup = its token counts . bits per symbol (no pass over the pixels)
  *   png_offsets_kernel    exclusive scan of the workgroup totals of every frame, total stream length; headers; the few words
  *                         the emit pass ORs into are cleared
@@ -51,13 +53,13 @@ struct PngParams {
   unsigned grid_x;                /* 8 * ceil(blocks_per_frame / 8): see png_logical_block */
   unsigned *hist;                 /* [n_frames][kPngBins] */
   unsigned long long *adler;      /* [n_frames][2]: sum of the filtered bytes; sum of (n - i) * byte_i; both mod 65521 per workgroup */
-  const unsigned *codes;          /* [n_frames][kPngCodes]: bits | n_bits << 24 */
+  unsigned *codes;                /* [n_frames][kPngCodes]: bits | n_bits << 24 (png_codes_kernel) */
   unsigned long long *block_bits; /* [n_frames][blocks_per_frame]: bits per workgroup, then (in place) exclusive prefix */
-  const unsigned *start_bit;      /* [n_frames]: where the token stream starts (after the zlib and the block header) */
+  unsigned *start_bit;            /* [n_frames]: where the token stream starts (after the zlib and the block header) */
   unsigned long long *frame_bits; /* [n_frames]: end of the stream in bits (start offset, tokens, end-of-block code) */
   unsigned short *block_hist;     /* [n_frames][blocks_per_frame][kPngBins] token counts per workgroup (<= 16 641 each) */
-  const unsigned *sym_bits;       /* [n_frames][kPngBins] bits a token of each symbol takes (code + extra + distance) */
-  const unsigned *header;         /* [n_frames][kPngHeaderWords] zlib + block header bits (zero from start_bit on) */
+  unsigned *sym_bits;             /* [n_frames][kPngBins] bits a token of each symbol takes (code + extra + distance) */
+  unsigned *header;               /* [n_frames][kPngHeaderWords] zlib + block header bits (zero from start_bit on) */
   const unsigned *crc_tables;     /* [4][256] slice-by-4 tables of CRC-32 (reflected 0xEDB88320), then x^(8 d 16^i) mod p, [i = 0..7][d = 0..15] */
   unsigned *crc;                  /* [n_frames]: XOR of the threads' contributions = CRC state after "IDAT" + the frame's stream */
   unsigned *out;                  /* [n_frames][out_words] */
@@ -322,6 +324,143 @@ __global__ __launch_bounds__(kPngBlock) void png_hist2_kernel(const PngParams P)
     if (v) atomicAdd(&P.hist[(size_t)frame * kPngBins + k], v);
   }
   if (threadIdx.x < 2u) atomicAdd(&P.adler[(size_t)frame * 2 + threadIdx.x], s_sum[threadIdx.x] % 65521ull);
+}
+
+/* The frame's code: lengths from the histogram (every symbol keeps a code: +1 on each count, +1 more for the end-of-block symbol --
+ * which also makes the block header the host writer's fixed-size one), canonical codes, the table the emit pass indexes (literals,
+ * end of block, matches of length 3..63 with extra bits and the one-bit distance code folded in), bits per token of every symbol for
+ * png_blockbits_kernel, and the zlib + dynamic block header (16 + 1222 bits, RFC 1951 3.2.7: HLIT = 29, HDIST = 0, all 19
+ * code-length codes of 3 bits declaring "4 bits" for lengths 0..15 and nothing for the repeat codes, then the 286 + 1 lengths raw).
+ * One workgroup per frame, a lane per item: the symbols are ranked by (count, index), the eleven merges of package-merge
+ * (png_codes.h) are rank computations by binary search, one lane walks the twelve levels back, the rest is per symbol again. */
+constexpr unsigned kPngStartBit = 16u + 1222u;
+__global__ __launch_bounds__(kPngBlock) void png_codes_kernel(const PngParams P) {
+  constexpr unsigned kStride = 2u * pngcodes::kMaxLeaves;
+  __shared__ unsigned s_freq[kPngBins], s_wl[kPngBins];
+  __shared__ unsigned long long s_list[2][kStride];
+  __shared__ unsigned short s_src[(kPngCodeBits + 1u) * kStride], s_order[kPngBins];
+  __shared__ unsigned char s_len[kPngBins];
+  __shared__ unsigned s_taken[16], s_count[16], s_first[16], s_code[kPngBins], s_hdr[kPngHeaderWords];
+  const unsigned frame = blockIdx.x;
+  constexpr unsigned n = 286u;
+  for (unsigned i = threadIdx.x; i < n; i += kPngBlock) s_freq[i] = P.hist[(size_t)frame * kPngBins + i] + (i == 256u ? 2u : 1u);
+  if (threadIdx.x < 16u) s_count[threadIdx.x] = 0u;
+  for (unsigned i = threadIdx.x; i < kPngHeaderWords; i += kPngBlock) s_hdr[i] = 0u;
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < n; i += kPngBlock) { /* rank by (count, index): the keys are distinct */
+    const unsigned fi = s_freq[i];
+    unsigned rank = 0u;
+    for (unsigned j = 0; j < n; ++j) {
+      const unsigned fj = s_freq[j];
+      rank += (fj < fi || (fj == fi && j < i)) ? 1u : 0u;
+    }
+    s_order[rank] = (unsigned short)i;
+    s_wl[rank] = fi;
+    s_list[0][rank] = fi; /* list 1: the leaves */
+  }
+  __syncthreads();
+  /* lists 2 .. limit: the leaves merged with the packages of the list below, a leaf before a package of equal weight */
+  unsigned size = n, cur = 0u;
+  for (unsigned j = 2u; j <= kPngCodeBits; ++j) {
+    const unsigned long long *A = s_list[cur];
+    unsigned long long *B = s_list[cur ^ 1u];
+    unsigned short *src = s_src + j * kStride;
+    const unsigned q = size >> 1;
+    for (unsigned t = threadIdx.x; t < n + q; t += kPngBlock) {
+      if (t < n) { /* leaf t: behind the packages that are strictly cheaper */
+        const unsigned long long w = s_wl[t];
+        unsigned lo = 0u, hi = q;
+        while (lo < hi) {
+          const unsigned mid = (lo + hi) >> 1;
+          if (A[2u * mid] + A[2u * mid + 1u] < w)
+            lo = mid + 1u;
+          else
+            hi = mid;
+        }
+        B[t + lo] = w;
+        src[t + lo] = (unsigned short)t;
+      } else { /* package i: behind the leaves that are no dearer */
+        const unsigned i = t - n;
+        const unsigned long long w = A[2u * i] + A[2u * i + 1u];
+        unsigned lo = 0u, hi = n;
+        while (lo < hi) {
+          const unsigned mid = (lo + hi) >> 1;
+          if ((unsigned long long)s_wl[mid] <= w)
+            lo = mid + 1u;
+          else
+            hi = mid;
+        }
+        B[i + lo] = w;
+        src[i + lo] = (unsigned short)(pngcodes::kPmPackage | i);
+      }
+    }
+    size = n + q;
+    cur ^= 1u;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0u) pngcodes::pm_backtrack(s_src, kStride, (int)n, (int)kPngCodeBits, s_taken);
+  __syncthreads();
+  for (unsigned k = threadIdx.x; k < n; k += kPngBlock) {
+    const unsigned l = pngcodes::pm_length(k, s_taken, (int)kPngCodeBits);
+    s_len[s_order[k]] = (unsigned char)l;
+    atomicAdd(&s_count[l], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0u) pngcodes::canonical_first(s_count, (int)kPngCodeBits, s_first);
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < n; i += kPngBlock) { /* code = first of its length + earlier symbols of that length */
+    const unsigned l = s_len[i];
+    unsigned before = 0u;
+    for (unsigned j = 0; j < i; ++j) before += s_len[j] == l ? 1u : 0u;
+    s_code[i] = pngcodes::reverse_bits(s_first[l] + before, (int)l);
+  }
+  __syncthreads();
+  unsigned *c = P.codes + (size_t)frame * kPngCodes;
+  unsigned *sb = P.sym_bits + (size_t)frame * kPngBins;
+  for (unsigned k = threadIdx.x; k < kPngCodes; k += kPngBlock) {
+    unsigned e = 0u;
+    if (k <= 256u) { /* literals; 256: end of block, in the slot of the impossible "match of length 0" */
+      e = s_code[k] | ((unsigned)s_len[k] << 24);
+    } else if (k >= 256u + 3u) { /* a match of length k - 256 = 3..63: code, extra bits, the distance code (one zero bit) */
+      int sym, eb, ev;
+      pngcodes::length_symbol((int)(k - 256u), sym, eb, ev);
+      const unsigned cl = s_len[sym];
+      e = (s_code[sym] | ((unsigned)ev << cl)) | ((cl + (unsigned)eb + 1u) << 24);
+    }
+    c[k] = e;
+  }
+  for (unsigned i = threadIdx.x; i < kPngBins; i += kPngBlock) {
+    unsigned bits = 0u;
+    if (i <= 256u) {
+      bits = s_len[i];
+    } else if (i < n) { /* length symbols 257..285: code + extra bits + distance code (those beyond length 63 never occur) */
+      const unsigned g = i < 265u ? 0u : (i - 261u) / 4u;
+      bits = (unsigned)s_len[i] + (i == 285u ? 0u : g) + 1u;
+    }
+    sb[i] = bits;
+  }
+  /* header: 0x78 0x01, then LSB first BFINAL = 1, BTYPE = 2, HLIT = 29, HDIST = 0, HCLEN = 15, the 19 three-bit code-length-code
+   * lengths in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (0 for the three repeat codes, 4 for the rest), then
+   * every symbol's length as a bit-reversed nibble (the canonical 4-bit code of the value), then the distance code's length 1 */
+  auto put = [&](unsigned pos, unsigned v, unsigned nb) {
+    atomicOr(&s_hdr[pos >> 5], v << (pos & 31u));
+    if ((pos & 31u) + nb > 32u) atomicOr(&s_hdr[(pos >> 5) + 1u], v >> (32u - (pos & 31u)));
+  };
+  auto rev4 = [](unsigned v) { return ((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3); };
+  if (threadIdx.x == 0u) {
+    put(0u, 0x0178u, 16u);
+    put(16u, 1u, 1u);
+    put(17u, 2u, 2u);
+    put(19u, 29u, 5u);
+    put(24u, 0u, 5u);
+    put(29u, 15u, 4u);
+    for (unsigned k = 0; k < 19u; ++k) put(33u + 3u * k, k < 3u ? 0u : 4u, 3u);
+    put(90u + 4u * n, rev4(1u), 4u);
+  }
+  for (unsigned i = threadIdx.x; i < n; i += kPngBlock) put(90u + 4u * i, rev4(s_len[i]), 4u);
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < kPngHeaderWords; i += kPngBlock) P.header[(size_t)frame * kPngHeaderWords + i] = s_hdr[i];
+  if (threadIdx.x == 0u) P.start_bit[frame] = kPngStartBit;
 }
 
 /* bits per workgroup = its token counts . bits per symbol (+ the end-of-block code after the last one): one WAVE per

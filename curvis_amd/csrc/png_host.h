@@ -1,5 +1,6 @@
-/* png_host.h -- host side of the device PNG front end (kernels_png.h): scratch layout, the launches around the host's
- * Huffman-code construction, assembly of one zlib stream per frame in the caller's buffer.
+/* png_host.h -- host side of the device PNG front end (kernels_png.h): scratch
+ * layout, the launches (histogram, codes, offsets, emit, CRC: one synchronisation, at the end), assembly of one zlib stream per frame
+ * in the caller's buffer.
  * Part of the ONE translation unit curvis_hip.hip (included there, nowhere else). */
 #pragma once
 
@@ -81,8 +82,7 @@ const std::array<unsigned, 1024 + 128> &png_crc_tables() {
 }
 
 /* frames [0, n_frames) of W x H RGB8 in ctx->d_fb -> zlib streams, back to back in `out`; offsets[f] .. offsets[f + 1] is
- * frame f's stream.  kernel_ms: HIP-event time of the five launches (histogram; workgroup bits, offsets, emit, CRC), the
- * host's code construction between the first and the rest excluded. */
+ * frame f's stream.  kernel_ms: HIP-event time of the six launches (histogram, codes, workgroup bits, offsets, emit, CRC). */
 int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_frames, uint8_t *out, size_t out_cap, size_t *offsets,
                         double *kernel_ms, uint32_t *idat_crc = nullptr, int *crc_valid = nullptr) {
   if (crc_valid) *crc_valid = 0;
@@ -116,125 +116,48 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   unsigned char *base = ctx->d_png;
   P.hist = (unsigned *)(base + L.hist);
   P.adler = (unsigned long long *)(base + L.adler);
-  P.codes = (const unsigned *)(base + L.codes);
+  P.codes = (unsigned *)(base + L.codes);
   P.block_bits = (unsigned long long *)(base + L.block_bits);
-  P.start_bit = (const unsigned *)(base + L.start_bit);
+  P.start_bit = (unsigned *)(base + L.start_bit);
   P.frame_bits = (unsigned long long *)(base + L.frame_bits);
   P.block_hist = (unsigned short *)(base + L.block_hist);
-  P.sym_bits = (const unsigned *)(base + L.sym_bits);
-  P.header = (const unsigned *)(base + L.header);
+  P.sym_bits = (unsigned *)(base + L.sym_bits);
+  P.header = (unsigned *)(base + L.header);
   P.crc_tables = (const unsigned *)(base + L.crc_tables);
   P.crc = (unsigned *)(base + L.crc);
   P.out = (unsigned *)(base + L.out);
   P.out_words = L.out_words;
   const dim3 grid(P.grid_x, n_frames), block(kPngBlock); /* the 8 XCDs take contiguous eighths of a frame: png_logical_block */
-  float ms_a = 0.f, ms_b = 0.f;
+  float ms_a = 0.f;
   const bool dbg_timing = getenv("CURVIS_DEBUG_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t_0 = tnow();
 
-  /* pass 1: histograms + Adler sums */
+  /* pass 1: histograms + Adler sums; the frames' codes and headers from the histograms (png_codes_kernel: a workgroup per frame --
+   * rounds 3-6 built them on the host, between two synchronisations, with the GPU idle for 1.1-1.5 ms of a 128-frame call);
+   * offsets from the workgroups' token counts; ONE more pass over the pixels; the chunk's CRC over the stream.  Nothing comes back
+   * before the end. */
   HIP_TRY(ctx, hipMemsetAsync(base + L.hist, 0, L.codes - L.hist, ctx->stream)); /* hist, adler and the CRC words are adjacent */
+  HIP_TRY(ctx, hipMemcpyAsync(base + L.crc_tables, png_crc_tables().data(), sizeof(unsigned) * (1024 + 128), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(png_hist2_kernel, grid, block, 0, ctx->stream, P);
-  HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  std::vector<unsigned> hist((size_t)n_frames * kPngBins);
-  std::vector<unsigned long long> adler((size_t)n_frames * 2);
-  HIP_TRY(ctx, hipMemcpyAsync(hist.data(), base + L.hist, hist.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(adler.data(), base + L.adler, adler.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, hipEventElapsedTime(&ms_a, ctx->ev0, ctx->ev1));
-  const auto t_1 = tnow();
-
-  /* the frames' codes: lengths <= 12 bits over the 286 literal/length symbols (every symbol keeps a code: +1 on each count,
-   * which also makes the block header the host writer's), one distance code */
-  std::vector<unsigned> codes((size_t)n_frames * kPngCodes, 0u), start_bit(n_frames), sym_bits((size_t)n_frames * kPngBins, 0u);
-  std::vector<std::array<uint8_t, 176>> header(n_frames); /* zlib header + block header: 16 + 1222 bits, + BitWriter slack */
-  auto build_codes = [&](uint32_t f) {
-    uint32_t freq[286];
-    for (int i = 0; i < 286; ++i) freq[i] = hist[(size_t)f * kPngBins + i] + 1u;
-    freq[256] += 1u; /* the end-of-block symbol */
-    uint8_t ll_len[286];
-    uint32_t ll[286];
-    pngio::huffman_lengths(freq, 286, (int)kPngCodeBits, ll_len);
-    pngio::canonical_codes(ll_len, 286, ll);
-    unsigned *c = codes.data() + (size_t)f * kPngCodes;
-    for (int v = 0; v < 256; ++v) c[v] = (ll[v] & 0xffffu) | ((ll[v] >> 16) << 24);
-    c[256] = (ll[256] & 0xffffu) | ((ll[256] >> 16) << 24); /* end of block, in the slot of the impossible "match of length 0" */
-    for (int len = 3; len < (int)kPngChunk; ++len) {
-      int sym, eb, ev;
-      pngio::length_symbol(len, sym, eb, ev);
-      const unsigned cl = ll[sym] >> 16;
-      const unsigned bits = (ll[sym] & 0xffffu) | ((unsigned)ev << cl); /* + the distance code: one zero bit */
-      c[256 + len] = bits | ((cl + (unsigned)eb + 1u) << 24);
-      sym_bits[(size_t)f * kPngBins + (size_t)sym] = cl + (unsigned)eb + 1u; /* a match of this symbol: code + extra bits + distance code */
-    }
-    for (int v = 0; v <= 256; ++v) sym_bits[(size_t)f * kPngBins + (size_t)v] = ll[v] >> 16; /* literals and end of block: the code */
-    header[f].fill(0);
-    header[f][0] = 0x78;
-    header[f][1] = 0x01;
-    pngio::BitWriter bw(header[f].data() + 2);
-    pngio::put_dynamic_block_header(bw, ll_len);
-    start_bit[f] = (unsigned)((bw.p - header[f].data()) * 8 + bw.nb);
-    bw.finish();
-  };
-  /* 286-symbol length-limited Huffman codes, 60-80 us per frame on a host core: nothing next to a render call of a few frames, but a
-   * 128-frame call of the efficient renderer spent more time here (9.4 ms, the GPU idle) than in its kernels (profiles/
-   * round6_eff_device_sampler.txt) -- the frames are independent, so a large call spreads them over a few threads */
-  {
-    const unsigned T = n_frames >= 16 ? std::min<unsigned>(8u, n_frames / 8u) : 1u;
-    if (T <= 1u) {
-      for (uint32_t f = 0; f < n_frames; ++f) build_codes(f);
-    } else {
-      std::vector<std::thread> th;
-      std::atomic<int> failed{0};
-      auto work = [&](unsigned t) {
-        try {
-          for (uint32_t f = t; f < n_frames; f += T) build_codes(f);
-        } catch (...) {
-          failed = 1;
-        }
-      };
-      try {
-        for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
-      } catch (const std::system_error &) { /* fewer threads than asked for: thread 0 below picks up what has no worker */
-      }
-      const unsigned started = (unsigned)th.size() + 1u;
-      work(0);
-      for (unsigned t = started; t < T; ++t) work(t); /* strides nobody was started for */
-      for (auto &x : th) x.join();
-      if (failed) return fail(ctx, CURVIS_E_INVALID, "out of memory while building the frames' Huffman codes");
-    }
-  }
-  const auto t_2 = tnow();
-  HIP_TRY(ctx, hipMemcpyAsync(base + L.codes, codes.data(), codes.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(base + L.start_bit, start_bit.data(), start_bit.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(base + L.sym_bits, sym_bits.data(), sym_bits.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-  /* the headers go to the device too: the stream it leaves is then complete (but for the Adler-32 trailer), which is what
-   * lets it compute the PNG chunk's CRC-32 as well */
-  std::vector<unsigned> header_words((size_t)n_frames * kPngHeaderWords, 0u);
-  for (uint32_t f = 0; f < n_frames; ++f) std::memcpy(header_words.data() + (size_t)f * kPngHeaderWords, header[f].data(), sizeof header[f]);
-  static_assert(sizeof(std::array<uint8_t, 176>) == kPngHeaderWords * sizeof(unsigned), "header staging");
-  HIP_TRY(ctx, hipMemcpyAsync(base + L.header, header_words.data(), header_words.size() * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(base + L.crc_tables, png_crc_tables().data(), sizeof(unsigned) * (1024 + 128), hipMemcpyHostToDevice, ctx->stream));
-
-  /* offsets from the workgroups' token counts, then ONE more pass over the pixels, then the chunk's CRC over the stream */
-  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(png_codes_kernel, dim3(n_frames), block, 0, ctx->stream, P);
   hipLaunchKernelGGL(png_blockbits_kernel, dim3((P.blocks_per_frame + 3u) / 4u, n_frames), block, 0, ctx->stream, P);
   hipLaunchKernelGGL(png_offsets_kernel, dim3(n_frames), block, 0, ctx->stream, P);
   hipLaunchKernelGGL(png_emit2_kernel, grid, block, 0, ctx->stream, P);
   hipLaunchKernelGGL(png_crc_kernel, dim3((unsigned)((P.out_words * 4 + kPngBlock * 64 - 1) / (kPngBlock * 64)), n_frames), block, 0, ctx->stream, P);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  std::vector<unsigned long long> adler((size_t)n_frames * 2);
+  HIP_TRY(ctx, hipMemcpyAsync(adler.data(), base + L.adler, adler.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   std::vector<unsigned long long> frame_bits(n_frames);
   HIP_TRY(ctx, hipMemcpyAsync(frame_bits.data(), base + L.frame_bits, frame_bits.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ctx->stream));
   std::vector<unsigned> crc_state(n_frames, 0u);
   HIP_TRY(ctx, hipMemcpyAsync(crc_state.data(), base + L.crc, crc_state.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, hipEventElapsedTime(&ms_b, ctx->ev0, ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(&ms_a, ctx->ev0, ctx->ev1));
   const auto t_3 = tnow();
 
   /* streams to the host: deflate bytes, then the Adler-32 of the filtered scanlines.  Sizes first, copies after: a call that
@@ -286,10 +209,10 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   }
   if (crc_valid) *crc_valid = 1;
   if (dbg_timing)
-    fprintf(stderr, "[curvis] deflate %u frames (ms): histogram pass + sync %.3f (kernel %.3f), codes on the host %.3f, uploads + emit + sync %.3f (kernels %.3f), "
-            "streams to the host (%zu bytes) %.3f, trailers %.3f\n", n_frames, tms(t_0, t_1), ms_a, tms(t_1, t_2), tms(t_2, t_3), ms_b, off, tms(t_3, t_4), tms(t_4, tnow()));
-  if (kernel_ms) *kernel_ms = (double)ms_a + (double)ms_b;
-  ctx->last_png_ms = (double)ms_a + (double)ms_b;
+    fprintf(stderr, "[curvis] deflate %u frames (ms): launches + sync %.3f (the six kernels %.3f), streams to the host (%zu bytes) %.3f, trailers %.3f\n",
+            n_frames, tms(t_0, t_3), ms_a, off, tms(t_3, t_4), tms(t_4, tnow()));
+  if (kernel_ms) *kernel_ms = (double)ms_a;
+  ctx->last_png_ms = (double)ms_a;
   return CURVIS_OK;
 }
 

@@ -297,3 +297,24 @@ extern "C" size_t twin_interp_grid_check(const double *x, unsigned n, const doub
     if (cvk::interp_index_grid(x, n, q[k], G) != cvk::interp_index(x, n, q[k])) ++bad;
   return bad;
 }
+
+/* png_codes.h, the code construction shared by the host PNG writer and the device's png_codes_kernel: lengths for freq[0..n)
+ * exactly the way pngio::huffman_lengths wraps it (symbols in (count, index) order, zero counts get no code) */
+#include "../../curvis_amd/csrc/png_codes.h"
+#include <algorithm>
+extern "C" void twin_huffman_lengths(const uint32_t *freq, int n, int maxlen, uint8_t *len) {
+  uint64_t key[pngcodes::kMaxLeaves];
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    len[i] = 0;
+    if (freq[i]) key[m++] = ((uint64_t)freq[i] << 9) | (uint64_t)i;
+  }
+  if (m == 0) return;
+  std::sort(key, key + m);
+  uint32_t w[pngcodes::kMaxLeaves];
+  uint8_t ls[pngcodes::kMaxLeaves];
+  for (int k = 0; k < m; ++k) w[k] = (uint32_t)(key[k] >> 9);
+  pngcodes::pm_lengths_sorted(w, m, maxlen, ls);
+  for (int k = 0; k < m; ++k) len[key[k] & 511u] = ls[k];
+}
+extern "C" void twin_length_symbol(int length, int *sym, int *ebits, int *eval) { pngcodes::length_symbol(length, *sym, *ebits, *eval); }

@@ -36,7 +36,7 @@ _LEN_EXTRA = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 
 _CL_ORDER = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
 
 
-def deflate_tokens(z):
+def deflate_tokens(z, lengths_out=None):
     """The TOKENS of a zlib stream holding one final dynamic-Huffman block (RFC 1951), read by a decoder written for this test:
     literal v -> v, match of length L at distance 1 -> 1000 + L (any other distance fails).  The independent checker of WHAT the
     device emitted, not only of what it decodes to (until round 5 the three-pass kernels played that part)."""
@@ -83,6 +83,8 @@ def deflate_tokens(z):
         else:
             lens += [0] * (11 + bits(7))
     lt, dt = table(lens[:hlit]), table(lens[hlit:])
+    if lengths_out is not None:
+        lengths_out.extend(lens[:hlit])
     toks = []
     while True:
         sy = symbol(lt)
@@ -96,6 +98,30 @@ def deflate_tokens(z):
             toks.append(1000 + ln)
     assert (len(z) - 6) * 8 - pos < 8, "the stream ends with the end-of-block code"
     return toks
+
+
+def assert_code_is_the_cheapest(toks, lens, what):
+    """the code in the block header is what png_codes_kernel is meant to build: the cheapest one of at most 12 bits for the
+    stream's own token counts + 1 (+ 1 more for the end-of-block symbol) -- compared with the host's construction (png_codes.h
+    through the x86 twin; tests/test_png_stream_host.py checks THAT against an independent package-merge).  Ties may be broken
+    differently; the cost cannot differ."""
+    import ctypes as C
+    lib = common.twin()
+    lib.twin_huffman_lengths.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.twin_huffman_lengths.restype = None
+    freq = np.ones(286, np.uint32)
+    freq[256] += 1
+    for t in toks:
+        if t < 1000:
+            freq[t] += 1
+        else:
+            ln = t - 1000
+            freq[257 + max(i for i in range(29) if _LEN_BASE[i] <= ln)] += 1
+    best = np.zeros(286, np.uint8)
+    lib.twin_huffman_lengths(freq.ctypes.data, 286, 12, best.ctypes.data)
+    got = np.array(lens[:286], np.int64)
+    assert got.size == 286 and got.min() >= 1 and got.max() <= 12, what
+    assert int((freq * got).sum()) == int((freq.astype(np.int64) * best).sum()), what
 
 
 def model_tokens(frame):
@@ -142,7 +168,10 @@ def check_streams(ctx, tmp_path, frames, w, h, tag):
     # ragged rows chunk by chunk); until then the three-pass kernels were compared bit for bit here.
     if w * h * 3 <= 160_000:
         for k, (z, want) in enumerate(zip(streams, frames)):
-            assert deflate_tokens(z) == model_tokens(want), (tag, k)
+            lens = []
+            toks = deflate_tokens(z, lens)
+            assert toks == model_tokens(want), (tag, k)
+            assert_code_is_the_cheapest(toks, lens, (tag, k))
     # the PNG chunk's CRC-32 ("IDAT" + stream) from the device: equal to zlib's over the same bytes, for every frame; the file
     # written with it is byte-identical to the one whose CRC the host computed
     s2, _, crcs = ctx.deflate_frames_crc(w, h, len(frames))
