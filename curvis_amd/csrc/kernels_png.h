@@ -334,29 +334,30 @@ __global__ __launch_bounds__(kPngBlock) void png_hist2_kernel(const PngParams P)
  * One workgroup per frame, a lane per item: the symbols are ranked by (count, index), the eleven merges of package-merge
  * (png_codes.h) are rank computations by binary search, one lane walks the twelve levels back, the rest is per symbol again. */
 constexpr unsigned kPngStartBit = 16u + 1222u;
-__global__ __launch_bounds__(kPngBlock) void png_codes_kernel(const PngParams P) {
+constexpr unsigned kPngCodesThreads = 576; /* a lane per item of the longest list (286 leaves + 285 packages): one binary search per lane and level */
+__global__ __launch_bounds__(kPngCodesThreads) void png_codes_kernel(const PngParams P) {
   constexpr unsigned kStride = 2u * pngcodes::kMaxLeaves;
   __shared__ unsigned s_freq[kPngBins], s_wl[kPngBins];
   __shared__ unsigned long long s_list[2][kStride];
   __shared__ unsigned short s_src[(kPngCodeBits + 1u) * kStride], s_order[kPngBins];
-  __shared__ unsigned char s_len[kPngBins];
+  __shared__ __attribute__((aligned(4))) unsigned char s_len[kPngBins];
   __shared__ unsigned s_taken[16], s_count[16], s_first[16], s_code[kPngBins], s_hdr[kPngHeaderWords];
   const unsigned frame = blockIdx.x;
   constexpr unsigned n = 286u;
-  for (unsigned i = threadIdx.x; i < n; i += kPngBlock) s_freq[i] = P.hist[(size_t)frame * kPngBins + i] + (i == 256u ? 2u : 1u);
+  for (unsigned i = threadIdx.x; i < n; i += kPngCodesThreads) s_freq[i] = P.hist[(size_t)frame * kPngBins + i] + (i == 256u ? 2u : 1u);
   if (threadIdx.x < 16u) s_count[threadIdx.x] = 0u;
-  for (unsigned i = threadIdx.x; i < kPngHeaderWords; i += kPngBlock) s_hdr[i] = 0u;
+  for (unsigned i = threadIdx.x; i < kPngHeaderWords; i += kPngCodesThreads) s_hdr[i] = 0u;
   __syncthreads();
-  for (unsigned i = threadIdx.x; i < n; i += kPngBlock) { /* rank by (count, index): the keys are distinct */
-    const unsigned fi = s_freq[i];
+  for (unsigned i = threadIdx.x; i < n; i += kPngCodesThreads) s_list[1][i] = ((unsigned long long)s_freq[i] << 9) | i; /* (count, index) as one key */
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < n; i += kPngCodesThreads) { /* rank among the keys: they are distinct */
+    const unsigned long long ki = s_list[1][i];
     unsigned rank = 0u;
-    for (unsigned j = 0; j < n; ++j) {
-      const unsigned fj = s_freq[j];
-      rank += (fj < fi || (fj == fi && j < i)) ? 1u : 0u;
-    }
+#pragma unroll 2
+    for (unsigned j = 0; j < n; ++j) rank += s_list[1][j] < ki ? 1u : 0u;
     s_order[rank] = (unsigned short)i;
-    s_wl[rank] = fi;
-    s_list[0][rank] = fi; /* list 1: the leaves */
+    s_wl[rank] = s_freq[i];
+    s_list[0][rank] = s_freq[i]; /* list 1: the leaves */
   }
   __syncthreads();
   /* lists 2 .. limit: the leaves merged with the packages of the list below, a leaf before a package of equal weight */
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(kPngBlock) void png_codes_kernel(const PngParams P)
     unsigned long long *B = s_list[cur ^ 1u];
     unsigned short *src = s_src + j * kStride;
     const unsigned q = size >> 1;
-    for (unsigned t = threadIdx.x; t < n + q; t += kPngBlock) {
+    for (unsigned t = threadIdx.x; t < n + q; t += kPngCodesThreads) {
       if (t < n) { /* leaf t: behind the packages that are strictly cheaper */
         const unsigned long long w = s_wl[t];
         unsigned lo = 0u, hi = q;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(kPngBlock) void png_codes_kernel(const PngParams P)
   }
   if (threadIdx.x == 0u) pngcodes::pm_backtrack(s_src, kStride, (int)n, (int)kPngCodeBits, s_taken);
   __syncthreads();
-  for (unsigned k = threadIdx.x; k < n; k += kPngBlock) {
+  for (unsigned k = threadIdx.x; k < n; k += kPngCodesThreads) {
     const unsigned l = pngcodes::pm_length(k, s_taken, (int)kPngCodeBits);
     s_len[s_order[k]] = (unsigned char)l;
     atomicAdd(&s_count[l], 1u);
@@ -408,16 +409,19 @@ __global__ __launch_bounds__(kPngBlock) void png_codes_kernel(const PngParams P)
   __syncthreads();
   if (threadIdx.x == 0u) pngcodes::canonical_first(s_count, (int)kPngCodeBits, s_first);
   __syncthreads();
-  for (unsigned i = threadIdx.x; i < n; i += kPngBlock) { /* code = first of its length + earlier symbols of that length */
+  for (unsigned i = threadIdx.x; i < n; i += kPngCodesThreads) { /* code = first of its length + earlier symbols of that length */
     const unsigned l = s_len[i];
     unsigned before = 0u;
-    for (unsigned j = 0; j < i; ++j) before += s_len[j] == l ? 1u : 0u;
+    const unsigned *lw = reinterpret_cast<const unsigned *>(s_len); /* four lengths per word */
+    const unsigned pat = l * 0x01010101u;
+    for (unsigned j = 0; j < (i >> 2); ++j) before += (unsigned)__popc(png_zero_flags(lw[j] ^ pat));
+    for (unsigned j = i & ~3u; j < i; ++j) before += s_len[j] == l ? 1u : 0u;
     s_code[i] = pngcodes::reverse_bits(s_first[l] + before, (int)l);
   }
   __syncthreads();
   unsigned *c = P.codes + (size_t)frame * kPngCodes;
   unsigned *sb = P.sym_bits + (size_t)frame * kPngBins;
-  for (unsigned k = threadIdx.x; k < kPngCodes; k += kPngBlock) {
+  for (unsigned k = threadIdx.x; k < kPngCodes; k += kPngCodesThreads) {
     unsigned e = 0u;
     if (k <= 256u) { /* literals; 256: end of block, in the slot of the impossible "match of length 0" */
       e = s_code[k] | ((unsigned)s_len[k] << 24);
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(kPngBlock) void png_codes_kernel(const PngParams P)
     }
     c[k] = e;
   }
-  for (unsigned i = threadIdx.x; i < kPngBins; i += kPngBlock) {
+  for (unsigned i = threadIdx.x; i < kPngBins; i += kPngCodesThreads) {
     unsigned bits = 0u;
     if (i <= 256u) {
       bits = s_len[i];
@@ -457,9 +461,9 @@ __global__ __launch_bounds__(kPngBlock) void png_codes_kernel(const PngParams P)
     for (unsigned k = 0; k < 19u; ++k) put(33u + 3u * k, k < 3u ? 0u : 4u, 3u);
     put(90u + 4u * n, rev4(1u), 4u);
   }
-  for (unsigned i = threadIdx.x; i < n; i += kPngBlock) put(90u + 4u * i, rev4(s_len[i]), 4u);
+  for (unsigned i = threadIdx.x; i < n; i += kPngCodesThreads) put(90u + 4u * i, rev4(s_len[i]), 4u);
   __syncthreads();
-  for (unsigned i = threadIdx.x; i < kPngHeaderWords; i += kPngBlock) P.header[(size_t)frame * kPngHeaderWords + i] = s_hdr[i];
+  for (unsigned i = threadIdx.x; i < kPngHeaderWords; i += kPngCodesThreads) P.header[(size_t)frame * kPngHeaderWords + i] = s_hdr[i];
   if (threadIdx.x == 0u) P.start_bit[frame] = kPngStartBit;
 }
 

@@ -142,7 +142,7 @@ int deflate_frames_impl(curvis_ctx *ctx, uint32_t W, uint32_t H, uint32_t n_fram
   HIP_TRY(ctx, hipMemcpyAsync(base + L.crc_tables, png_crc_tables().data(), sizeof(unsigned) * (1024 + 128), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(png_hist2_kernel, grid, block, 0, ctx->stream, P);
-  hipLaunchKernelGGL(png_codes_kernel, dim3(n_frames), block, 0, ctx->stream, P);
+  hipLaunchKernelGGL(png_codes_kernel, dim3(n_frames), dim3(kPngCodesThreads), 0, ctx->stream, P);
   hipLaunchKernelGGL(png_blockbits_kernel, dim3((P.blocks_per_frame + 3u) / 4u, n_frames), block, 0, ctx->stream, P);
   hipLaunchKernelGGL(png_offsets_kernel, dim3(n_frames), block, 0, ctx->stream, P);
   hipLaunchKernelGGL(png_emit2_kernel, grid, block, 0, ctx->stream, P);
