@@ -421,7 +421,16 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long) * cnt_words, hipMemcpyDeviceToHost, ctx->stream));
+  const auto t_launched = std::chrono::steady_clock::now();
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* (behind the sampler's event: its results are in S.h) */
+  if (getenv("CURVIS_DEBUG_TIMING")) {
+    float k_ms = 0.f;
+    (void)hipEventElapsedTime(&k_ms, ctx->ev1, ctx->ev2);
+    const auto t_now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[curvis] efficient call, %u frames (ms): host before the sync %.3f, in the sync %.3f (staging copy -> end of the per-pixel kernel: %.3f)\n",
+            n_frames, std::chrono::duration<double, std::milli>(t_launched - t_begin).count(),
+            std::chrono::duration<double, std::milli>(t_now - t_launched).count(), k_ms);
+  }
   auto *h_res = reinterpret_cast<const cvk::SamplerResult *>(S.h + S.h_res_off);
   bool overflow = false, panic = false;
   for (unsigned j = 0; j < n_jobs; ++j) {

@@ -256,6 +256,18 @@ int video_main(const Args &a_in) {
       std::fprintf(stderr, "warning: device %d: no page-locked host memory for the frame buffers, using pageable memory\n", device_of(rank));
     }
     wmark("page-locked buffers");
+    /* The writer queue holds 64 jobs; a worker hands over a whole batch at once (128 frames in efficient mode) and waited ~1.2 ms per
+     * batch for room, GPU idle.  With ONE context per GPU the bound goes up to two batches (the jobs of pooled batches own no memory:
+     * cli_writers.h): 13 300 -> 14 400 frames/s.  With two contexts it stays: measured, the stall is what keeps the two workers out of
+     * phase -- 15 600 frames/s with it, 13 400-13 700 without, 14 600 with the render calls taking explicit turns instead
+     * (profiles/round6_png_codes_kernel.txt).  CURVIS_WRITER_QUEUE=<n> sets the bound for experiments. */
+    if (pool.buffers() >= 2) {
+      const char *qe = std::getenv("CURVIS_WRITER_QUEUE");
+      if (qe)
+        writers.raise_bound((size_t)std::max(1, std::atoi(qe)));
+      else if (a.contexts == 1)
+        writers.raise_bound((size_t)2 * (size_t)n_workers * (size_t)std::max(1, a.batch));
+    }
     /* the zlib streams of a batch travel to its (page-locked) buffer while the NEXT batch renders (option "async_streams"): the
      * writer jobs of that batch are held back here and handed to the pool once the copy engine is done -- right after the next
      * render call has returned, or before this thread leaves.  (Held back, not submitted to wait on a flag: the pool's queue is

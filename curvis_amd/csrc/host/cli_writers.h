@@ -22,9 +22,17 @@ class WriterPool {
   ~WriterPool() { finish(); }
   void submit(std::function<void()> job) {
     std::unique_lock<std::mutex> g(mu_);
-    cv_space_.wait(g, [this] { return q_.size() < 64; }); /* bound the frames held in host memory */
+    cv_space_.wait(g, [this] { return q_.size() < bound_; }); /* bound the frames held in host memory */
     q_.push_back(std::move(job));
     cv_work_.notify_one();
+  }
+  /* Jobs that share page-locked BATCH buffers hold no memory of their own -- the buffer pool bounds that --, and a worker hands over
+   * a whole batch at once: with the queue shorter than a batch (128 frames in efficient mode) it waits here for the writers to
+   * make room.  Raised by such callers (cli_video.h says when); never lowered. */
+  void raise_bound(size_t n) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (n > bound_) bound_ = n;
+    cv_space_.notify_all();
   }
   void finish() {
     {
@@ -52,6 +60,7 @@ class WriterPool {
     }
   }
   std::mutex mu_;
+  size_t bound_ = 64;
   std::condition_variable cv_work_, cv_space_;
   std::deque<std::function<void()>> q_;
   std::vector<std::thread> th_;

@@ -20,7 +20,7 @@ PY
 mkdir -p "$D/out"
 CURVIS_DEBUG_TIMING=1 "$ROOT/curvis_amd/bin/curvis" video "$D/pos.png" "$D/neg.png" "$D/out" -v "$D/vid.toml" -s "$D/sim.toml" -c "$D/cam.toml" \
   --mode efficient --contexts-per-device "$C" --batch "$B" --writers 16 --stats "$D/st.jsonl" > "$D/run.txt" 2>&1
-grep "deflate" "$D/run.txt" | sed -n '5,12p'
+grep -E "deflate|efficient call" "$D/run.txt" | sed -n "9,20p"
 python - "$D" <<'PY'
 import json, sys, re
 d = sys.argv[1]
