@@ -238,6 +238,30 @@ CV_HD void unit3(const double *v, double n, double *u) {
   u[1] = v[1] / n;
   u[2] = v[2] / n;
 }
+/* sqrt(x) the same way: the AMDGPU expansion of an f64 square root is v_rsq_f64 and a Goldschmidt / Newton chain of nine
+ * operations, wrapped in a scaling by 2^256 for arguments below 2^-767 and a class test that passes zeros and infinities through
+ * (v_cmp, v_cndmask, v_ldexp twice, v_cmp_class, two v_cndmask).  Inside [2^-700, 2^700) the wrappers do nothing; the chain below is
+ * the compiler's, operation for operation, and a lane outside the range (zero, negative, NaN, ...) takes the operator. */
+template <bool SHARED>
+CV_HD double sqrt_plain(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (SHARED) {
+    if (x >= 0x1p-700 && x < 0x1p700) {
+      const double y = rsq_seed(x);
+      double g = x * y, h = y * 0.5;
+      const double e = CV_FMA(-h, g, 0.5);
+      g = CV_FMA(g, e, g);
+      h = CV_FMA(h, e, h);
+      double d = CV_FMA(-g, g, x);
+      g = CV_FMA(d, h, g);
+      d = CV_FMA(-g, g, x);
+      return CV_FMA(d, h, g);
+    }
+  }
+#endif
+  return CV_SQRT(x);
+}
+
 /* a / d for a constant d of the call, 2^-300 <= d < 2^300, with y = recip_chain(d):
  * div_index: a is an integer-valued 0 <= a < 2^32 (a pixel index) -- always inside the range, no guard.  (+0: 0 y = +0,
  *            fma(-d, +0, +0) = +0, fma(+0, y, +0) = +0, the IEEE quotient.)
@@ -578,7 +602,7 @@ CV_HD void sky_indices(const SkyParams &S, double d0, double d1, double d2, unsi
                        double y_two_pi = 0.0) {
   double w0, w1, w2;
   mat3_vec(S.inv_rot, d0, d1, d2, w0, w1, w2);
-  const double rn = CV_SQRT(w0 * w0 + w1 * w1 + w2 * w2);
+  const double rn = sqrt_plain<SHARED>(w0 * w0 + w1 * w1 + w2 * w2);
   double theta = cv_acos(w2 / rn);
   double phi = cv_atan2(w1, w0);
   const double TWO_PI = 2.0 * CV_PI;

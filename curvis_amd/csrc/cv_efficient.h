@@ -217,7 +217,7 @@ CV_HD void efficient_pixel_geometry(const CameraParams &C, const EfficientFrame 
   const double h = 0.5 - (SHARED ? div_index<SHARED>((double)py, C.res_y, R->y_res_y) : (double)py / C.res_y);
   const double w = (SHARED ? div_index<SHARED>((double)px, C.res_x, R->y_res_x) : (double)px / C.res_x) - 0.5;
   const double v0[3] = {C.focal * 1.0, -C.sensor_w * w, C.sensor_h * h};
-  const double n = norm3(v0);
+  const double n = sqrt_plain<SHARED>(dot3(v0, v0)); /* norm3 */
   double v[3];
   unit3<SHARED>(v0, n, v);
   double out_tan[3], out_bg[3];
@@ -230,7 +230,7 @@ CV_HD void efficient_pixel_geometry(const CameraParams &C, const EfficientFrame 
 /* step 5 (src/systems.rs:498-506): final = from_axis_angle(normalize(axis), escape angle) * cam_bg */
 template <bool SHARED = false>
 CV_HD void efficient_final_direction(const EfficientFrame &F, const double *axis, double esc, double *fin) {
-  const double an = norm3(axis); /* Unit::new_normalize: 0/0 -> NaN for the centre pixel */
+  const double an = sqrt_plain<SHARED>(dot3(axis, axis)); /* norm3; Unit::new_normalize: 0/0 -> NaN for the centre pixel */
   double u[3];
   unit3<SHARED>(axis, an, u);
   double rot[9];

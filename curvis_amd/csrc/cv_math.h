@@ -611,48 +611,53 @@ CV_HD double cv_atan2(double y, double x) {
   const double TINY = 1.0e-300;
   const uint32_t hx = cv_hi(x), lx = cv_lo(x), hy = cv_hi(y), ly = cv_lo(y);
   const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
-  if (ix > 0x7ff00000u || (ix == 0x7ff00000u && lx != 0) || iy > 0x7ff00000u || (iy == 0x7ff00000u && ly != 0))
+  /* both operands finite, non-zero and not subnormal (exponent field 1 .. 0x7fe): none of fdlibm's special cases below can apply,
+   * and the per-pixel caller's lanes skip their dozen compares with two */
+  const int plain = (ix - 0x00100000u) < 0x7fe00000u && (iy - 0x00100000u) < 0x7fe00000u;
+  if (!plain && (ix > 0x7ff00000u || (ix == 0x7ff00000u && lx != 0) || iy > 0x7ff00000u || (iy == 0x7ff00000u && ly != 0)))
     return x + y;                                        /* nan */
   if (hx == 0x3ff00000u && lx == 0) return cv_atan(y);   /* x == 1 */
   const int m = (int)((hy >> 31) & 1) | (int)((hx >> 30) & 2); /* 2*sign(x) + sign(y) */
-  if ((iy | ly) == 0) { /* y == 0 */
-    switch (m) {
-      case 0:
-      case 1:
-        return y;
-      case 2:
-        return CV_PI + TINY;
-      default:
-        return -CV_PI - TINY;
-    }
-  }
-  if ((ix | lx) == 0) return (hy >> 31) ? -PI_O_2 - TINY : PI_O_2 + TINY; /* x == 0 */
-  if (ix == 0x7ff00000u) { /* x inf */
-    if (iy == 0x7ff00000u) {
+  if (!plain) {
+    if ((iy | ly) == 0) { /* y == 0 */
       switch (m) {
         case 0:
-          return PI_O_4 + TINY;
         case 1:
-          return -PI_O_4 - TINY;
-        case 2:
-          return 3.0 * PI_O_4 + TINY;
-        default:
-          return -3.0 * PI_O_4 - TINY;
-      }
-    } else {
-      switch (m) {
-        case 0:
-          return 0.0;
-        case 1:
-          return -0.0;
+          return y;
         case 2:
           return CV_PI + TINY;
         default:
           return -CV_PI - TINY;
       }
     }
+    if ((ix | lx) == 0) return (hy >> 31) ? -PI_O_2 - TINY : PI_O_2 + TINY; /* x == 0 */
+    if (ix == 0x7ff00000u) { /* x inf */
+      if (iy == 0x7ff00000u) {
+        switch (m) {
+          case 0:
+            return PI_O_4 + TINY;
+          case 1:
+            return -PI_O_4 - TINY;
+          case 2:
+            return 3.0 * PI_O_4 + TINY;
+          default:
+            return -3.0 * PI_O_4 - TINY;
+        }
+      } else {
+        switch (m) {
+          case 0:
+            return 0.0;
+          case 1:
+            return -0.0;
+          case 2:
+            return CV_PI + TINY;
+          default:
+            return -CV_PI - TINY;
+        }
+      }
+    }
+    if (iy == 0x7ff00000u) return (hy >> 31) ? -PI_O_2 - TINY : PI_O_2 + TINY; /* y inf */
   }
-  if (iy == 0x7ff00000u) return (hy >> 31) ? -PI_O_2 - TINY : PI_O_2 + TINY; /* y inf */
   const int k = (int)(iy >> 20) - (int)(ix >> 20);
   double zh, zl; /* atan(|y/x|) = zh + zl, unrounded */
   if (k > 60) { /* |y/x| > 2^60 */

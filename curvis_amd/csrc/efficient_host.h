@@ -417,6 +417,7 @@ int render_efficient_device(curvis_ctx *ctx, const curvis_metric *metric, const 
   Q.counters = FC;
   rc = ensure_pixel_recips(ctx, (double)W, (double)H, Q.recips);
   if (rc) return rc;
+  Q.w_magic = W > 1u ? ~0ull / W + 1ull : 0ull; /* floor((2^64 - 1) / W) + 1 = floor(2^64 / W) + 1 unless W divides 2^64, where it is 2^64 / W: exact too */
   hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)((npix + 255) / 256), n_frames), dim3(256), 0, ctx->stream, Q);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
@@ -888,6 +889,7 @@ int render_efficient_impl(curvis_ctx *ctx, const curvis_metric *metric, const cu
   Q.counters = FC;
   rc = ensure_pixel_recips(ctx, (double)W, (double)H, Q.recips);
   if (rc) return rc;
+  Q.w_magic = W > 1u ? ~0ull / W + 1ull : 0ull; /* floor((2^64 - 1) / W) + 1 = floor(2^64 / W) + 1 unless W divides 2^64, where it is 2^64 / W: exact too */
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(efficient_pixel_kernel, dim3((unsigned)((npix + 255) / 256), n_frames), dim3(256), 0, ctx->stream, Q);
   HIP_TRY(ctx, hipGetLastError());

@@ -276,6 +276,8 @@ struct EfficientPixelParams {
   unsigned char *fb;
   FrameCounters counters;
   cvk::PixelRecips recips;            /* cv_device.h: reciprocals of the call's constant denominators (ensure_pixel_recips) */
+  unsigned long long w_magic;         /* floor(2^64 / W) + 1: pixel index / W = the high 64 bits of index x w_magic, exactly, for every
+                                         index < 2^32 (index e / (W 2^64) < 1 / W with e = w_magic W - 2^64 <= W); 0 for W = 1 */
 };
 
 /* y = recip_chain(d) for a handful of constants: the first half of the device's own f64 division, run ON the device so that the
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void efficient_pixel_kernel(const EfficientPix
   bool pos = false, neg = false, none = false, oob = false;
   unsigned texel = 0xFF000000u;
   if (valid) {
-    const unsigned py = pix / P.W, px = pix - py * P.W;
+    const unsigned py = P.w_magic ? (unsigned)__umul64hi((unsigned long long)pix, P.w_magic) : pix / P.W, px = pix - py * P.W;
     const unsigned off = P.tab_off[f], n = P.tab_n[f];
     double fin[3], space;
     cvk::efficient_pixel<true>(P.cams[f], P.frames[f], px, py, P.sx + off, P.m_e + off, P.c_e + off, P.m_s + off, P.c_s + off, n, fin, space,
@@ -539,7 +541,7 @@ __global__ void selftest_math_kernel(int op, const double *a, const double *b, d
  * op 0 div_with_recip(a, b, c)   1 root of sqrt_and_rsqrt(a)   2 its y ~ 1/sqrt(a)
  *    3 the square root's last residual step for given (x, g, y) = (a, b, c): fma(fma(-g, g, x), 0.5 y, g)
  *    4 recip_refined(a)   5 cv_div_nr(a, b)   6 recip_newton(a, b)
- *    7 / 8 / 9 component 0 / 1 / 2 of unit3<true>(v = (a, b, c), |v|)   10 div_index<true>(a, b, recip_chain(b))   11 div_angle<true>(a, b, recip_chain(b)) */
+ *    7 / 8 / 9 component 0 / 1 / 2 of unit3<true>(v = (a, b, c), |v|)   10 div_index<true>(a, b, recip_chain(b))   11 div_angle<true>(a, b, recip_chain(b))   12 sqrt_plain<true>(a) */
 __global__ void selftest_math3_kernel(int op, const double *a, const double *b, const double *c, double *out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -579,8 +581,11 @@ __global__ void selftest_math3_kernel(int op, const double *a, const double *b, 
     case 10: /* an index by a constant */
       r = cvk::div_index<true>(x, y, cvk::recip_chain(y));
       break;
-    default: /* 11: an angle by a constant */
+    case 11: /* an angle by a constant */
       r = cvk::div_angle<true>(x, y, cvk::recip_chain(y));
+      break;
+    default: /* 12: the square root without the expansion's range wrappers */
+      r = cvk::sqrt_plain<true>(x);
       break;
   }
   out[i] = r;

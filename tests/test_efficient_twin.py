@@ -105,3 +105,19 @@ def test_bucket_grid_lookup_equals_the_full_search():
         bad = lib.twin_interp_grid_check(x.ctypes.data, x.size, q.ctypes.data, q.size, G.ctypes.data)
         assert bad == 0, (x.size, bad)
         assert G[0] == 0 and G[1024] == x.size and np.all(np.diff(G.astype(np.int64)) >= 0)
+
+
+def test_pixel_row_by_magic_multiplication_is_the_division():
+    """efficient_pixel_kernel takes the pixel's row as the high 64 bits of index x (floor((2^64 - 1) / W) + 1) (efficient_host.h
+    w_magic) instead of dividing: exact for every index below 2^32 and every width from 2 up"""
+    rng = np.random.default_rng(5)
+    widths = [2, 3, 4, 5, 7, 64, 96, 100, 255, 256, 257, 1000, 1080, 1920, 2160, 3840, 4096, 65535, 65536, 65537, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1]
+    widths += [int(w) for w in rng.integers(2, 2 ** 32, 200)]
+    for W in widths:
+        M = (2 ** 64 - 1) // W + 1
+        assert M < 2 ** 64
+        idx = [0, 1, W - 1, W, W + 1, 2 * W - 1, 2 * W, 2 ** 32 - 1, 2 ** 32 - W, (2 ** 32 - 1) // W * W, (2 ** 32 - 1) // W * W - 1]
+        idx += [int(v) for v in rng.integers(0, 2 ** 32, 300)]
+        for n in idx:
+            if 0 <= n < 2 ** 32:
+                assert (n * M) >> 64 == n // W, (W, n)

@@ -180,3 +180,19 @@ def test_shared_quotients_of_the_pixel_kernel(gpu_ctx):
         norm = np.sqrt((vs[0] * vs[0] + vs[1] * vs[1]) + vs[2] * vs[2])
         for k in range(3):
             assert _same(gpu_ctx.selftest_math3(7 + k, vs[0], vs[1], vs[2]), vs[k] / norm), k
+
+
+def test_square_root_without_the_range_wrappers(gpu_ctx):
+    """cv_device.h sqrt_plain (the efficient pixel kernel's three norms): the compiler's own chain without its scaling and class
+    wrappers inside [2^-700, 2^700), the operator outside -- the IEEE root everywhere: on arguments whose root lies within 2^-106 of
+    a rounding boundary, over the whole guarded range and beyond it, on zeros, negatives, infinities and NaN."""
+    rng = np.random.default_rng(612)
+    x, _, expect = H.sqrt_hard_cases(2000)
+    assert np.array_equal(np.sqrt(x), expect)
+    assert np.array_equal(gpu_ctx.selftest_math3(12, x), expect)
+    a = rng.uniform(1.0, 4.0, 2_000_000) * 4.0 ** rng.integers(-500, 500, 2_000_000)
+    assert np.array_equal(gpu_ctx.selftest_math3(12, a), np.sqrt(a))
+    special = np.array([0.0, -0.0, 5e-324, 2.2250738585072014e-308, 1e-310, 2.0 ** -701, 2.0 ** -700, np.nextafter(2.0 ** -700, 0.0), 2.0 ** 699,
+                        2.0 ** 700, np.nextafter(2.0 ** 700, 0.0), 1.7976931348623157e308, -1.0, -1e-320, np.inf, -np.inf, np.nan, 1.0, 2.0, 3.0, 4.0])
+    with np.errstate(all="ignore"):
+        assert _same(gpu_ctx.selftest_math3(12, special), np.sqrt(special))
