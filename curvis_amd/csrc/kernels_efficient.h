@@ -541,7 +541,7 @@ __global__ void selftest_math_kernel(int op, const double *a, const double *b, d
  * op 0 div_with_recip(a, b, c)   1 root of sqrt_and_rsqrt(a)   2 its y ~ 1/sqrt(a)
  *    3 the square root's last residual step for given (x, g, y) = (a, b, c): fma(fma(-g, g, x), 0.5 y, g)
  *    4 recip_refined(a)   5 cv_div_nr(a, b)   6 recip_newton(a, b)
- *    7 / 8 / 9 component 0 / 1 / 2 of unit3<true>(v = (a, b, c), |v|)   10 div_index<true>(a, b, recip_chain(b))   11 div_angle<true>(a, b, recip_chain(b))   12 sqrt_plain<true>(a) */
+ *    7 / 8 / 9 component 0 / 1 / 2 of unit3<true>(v = (a, b, c), |v|)   10 div_index<true>(a, b, recip_chain(b))   11 div_angle<true>(a, b, recip_chain(b))   12 sqrt_plain<true>(a)   13 (double)rust_as_u32(a) */
 __global__ void selftest_math3_kernel(int op, const double *a, const double *b, const double *c, double *out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -584,8 +584,11 @@ __global__ void selftest_math3_kernel(int op, const double *a, const double *b, 
     case 11: /* an angle by a constant */
       r = cvk::div_angle<true>(x, y, cvk::recip_chain(y));
       break;
-    default: /* 12: the square root without the expansion's range wrappers */
+    case 12: /* the square root without the expansion's range wrappers */
       r = cvk::sqrt_plain<true>(x);
+      break;
+    default: /* 13: Rust's `as u32` */
+      r = (double)cvk::rust_as_u32(x);
       break;
   }
   out[i] = r;

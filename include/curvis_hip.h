@@ -402,6 +402,7 @@ int curvis_selftest_math(curvis_ctx *ctx, int op, const double *a, const double 
  *    7 / 8 / 9 component 0 / 1 / 2 of v / |v| for v = (a, b, c) through the efficient pixel kernel's shared reciprocal (unit3)
  *    10 a / b as the pixel kernel divides an index by a constant (div_index, y = recip_chain(b))    11 ... an angle (div_angle)
  *    12 sqrt(a) through the pixel kernel's sqrt_plain (the compiler's chain without its range wrappers)
+ *    13 Rust's `a as u32` (saturating, NaN -> 0) as the sky lookup converts its texel coordinates
  * -- the directed hard cases of tests/test_gpu_fast_step.py go through here. */
 int curvis_selftest_math3(curvis_ctx *ctx, int op, const double *a, const double *b, const double *c, double *out, size_t n);
 

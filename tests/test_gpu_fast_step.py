@@ -196,3 +196,15 @@ def test_square_root_without_the_range_wrappers(gpu_ctx):
                         2.0 ** 700, np.nextafter(2.0 ** 700, 0.0), 1.7976931348623157e308, -1.0, -1e-320, np.inf, -np.inf, np.nan, 1.0, 2.0, 3.0, 4.0])
     with np.errstate(all="ignore"):
         assert _same(gpu_ctx.selftest_math3(12, special), np.sqrt(special))
+
+
+def test_saturating_conversion_to_u32(gpu_ctx):
+    """cv_device.h rust_as_u32 on the device is one v_cvt_u32_f64: it must be Rust's `as u32` (src/images.rs:115-121: truncation
+    toward zero, NaN -> 0, negatives -> 0, 2^32 and above -> u32::MAX) on every class of value"""
+    rng = np.random.default_rng(613)
+    v = np.concatenate([rng.uniform(-10.0, 5000.0, 200000), rng.uniform(0.0, 2.0 ** 33, 200000), 2.0 ** rng.uniform(-1074, 1023, 100000),
+                        -(2.0 ** rng.uniform(-1074, 1023, 100000)), np.arange(0.0, 4097.0), np.nextafter(np.arange(1.0, 4097.0), 0.0),
+                        [0.0, -0.0, 0.5, 0.9999999999999999, 1.0, 4294967294.5, 4294967295.0, 4294967295.5, 4294967296.0, 1e300, -1e300,
+                         np.inf, -np.inf, np.nan, 5e-324, -5e-324]])
+    want = np.where(np.isnan(v), 0.0, np.clip(np.trunc(np.nan_to_num(v, nan=0.0, posinf=1e308, neginf=-1e308)), 0.0, 4294967295.0))
+    assert np.array_equal(gpu_ctx.selftest_math3(13, v), want)
