@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
@@ -626,6 +627,8 @@ inline double now_s() {
  * png_codes.h's (shared with the device's png_codes_kernel): package-merge over the symbols in (count, index) order -- the optimal
  * code under the limit. */
 inline void huffman_lengths(const uint32_t *freq, int n, int maxlen, uint8_t *len) {
+  if (n < 0 || n > pngcodes::kMaxLeaves || maxlen < 1 || maxlen > pngcodes::kMaxLimit || (n > 1 && (1 << maxlen) < n))
+    throw std::length_error("huffman_lengths: not an alphabet / code length of the deflate format"); /* (the callers pass 286 and 12) */
   uint64_t key[pngcodes::kMaxLeaves];
   int m = 0;
   for (int i = 0; i < n; ++i) {
