@@ -624,6 +624,9 @@ def main():
             e2e = video_e2e(args, 1, host_skies, False, mode="efficient", frames_per_gpu=n_eff)
             if "failed" not in e2e:
                 e2e["frames_requested"] = n_eff
+                e2e["frames_per_s_workers"] = round(sum(float(dv.get("frames_per_s", 0.0)) for dv in e2e["per_device"]), 1)
+                e2e["frames_per_s_workers_note"] = ("sum over the binary's workers of frames / the worker's own busy time: the run without its start-up "
+                                                    "(context creation, sky decode and upload: ~0.1 s of this ~1 s run); `frames_per_s` is the whole run")
                 e2e["frames_note"] = ("times_of_frames stops at t < 60 s of a path whose last row is short of 60 s, so a few frames fewer than "
                                       "requested are rendered, as with the reference (src/rendering.rs:224-238)")
                 dev = e2e["per_device"][0]
