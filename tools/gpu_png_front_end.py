@@ -53,7 +53,7 @@ for mode, kind, res, sky, batches in CASES:
             hb += os.path.getsize(p)
         host_ms = (time.perf_counter() - t0) * 1e3 / min(nf, 4)
         raw_b = nf * W * H * 3
-        print("%s %s %dx%d %s sky, %2d frames/call: kernels %.3f ms/frame (call %.3f ms/frame incl. host code construction, 2 syncs, D2H of the streams) | "
+        print("%s %s %dx%d %s sky, %2d frames/call: kernels %.3f ms/frame (call %.3f ms/frame incl. the six launches, one synchronisation, D2H of the streams) | "
               "stream %.3f MB/frame (%.1fx; host writer's file %.3f MB) | algorithmic %.2f MB/frame -> %.0f GB/s of 8000 | host fast writer %.2f ms/frame" % (
                   mode, kind, W, H, sky, nf, ms / nf, wall / nf, zbytes / nf / 1e6, raw_b / zbytes, hb / min(nf, 4) / 1e6,
                   (raw_b + zbytes) / nf / 1e6, (raw_b + zbytes) / (ms * 1e-3) / 1e9, host_ms), flush=True)
